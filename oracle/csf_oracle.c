@@ -1,0 +1,1056 @@
+/*
+ * csf_oracle.c — CPU restatement (fp64, plain C) of the reference's per-tick hot path.
+ *
+ * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product (cyclistsocialforce_amd/, include/csf.h) never links, imports or
+ * falls back to it.
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference/src/cyclistsocialforce/).  The restatement is deliberately literal — polar
+ * coordinates, arccos/atan2/sin/cos exactly where the reference has them — so that it is an
+ * independent check of the trig-free HIP kernels.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file against every golden vector in
+ * tests/golden/ (captured by running the literal reference, see tests/golden/make_golden.py).
+ * The InvPendulum rows are pinned against the reference's matrix assembly + state machine running
+ * on a scipy.linalg.expm shim of python-control (absent here): "parity unpinned against
+ * python-control" for that row.
+ *
+ * Documented deviations from the literal reference (all in places where the reference yields NaN or
+ * raises):
+ *   D1  vehicle.py:1644-1646  P*Fx/F is evaluated as P*unit(g) with g P-free: identical where the
+ *       reference is finite, 0 where exp() underflow makes the reference 0/0 = NaN (SURVEY finding 4).
+ *   D2  coincident agents (rho == 0): 0 instead of NaN.
+ *   D3  vehicle.py:1062-1064  v < 0 makes pow() NaN in the reference; here e := 0 for v <= 0.
+ *   D4  vehicle.py:1496       splprep raises ValueError on duplicate consecutive points; here the
+ *       agent gets status bit CSFO_ST_SPLINE and a zero destination force for that tick.
+ *   D5  vehicle.py:320-321    Vehicle.step (PlanarPoint) never wraps i (IndexError at tick 3000);
+ *       here i wraps like Bicycle.step (vehicle.py:1279-1280).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define CSFO_BICYCLE 0
+#define CSFO_TWOD 1
+#define CSFO_INVPEND 2
+#define CSFO_PLANARPOINT 3
+
+#define CSFO_ST_SPLINE 1u
+#define CSFO_ST_NAN 2u
+#define CSFO_ST_NAVSTATE 4u
+
+#define PI 3.141592653589793238462643383279502884
+
+/* Field order mirrors csf_params of include/csf.h so that the test harness fills both from one table. */
+typedef struct csfo_params {
+    /* VehicleParameters — parameters.py:430-508 */
+    double t_s, d_arrived_inter, d_arrived_stop, v_max_stop, v_max_harddecel, hfov;
+    double f_0, e_0, e_1, sigma_0, sigma_1, sigma_2, sigma_3;
+    /* BicycleParameters — parameters.py:780-800 */
+    double v_max_riding[2], p_decay, p_0, l, l_2, delta_max, a_max[2], a_desired_default[2];
+    double k_p_v, k_p_delta, g;
+    /* InvPendulumBicycleParameters — parameters.py:1429-1472, 1641-1643 */
+    double h, m, i_bike_longlong, i_steer_vertvert, c_steer, v_max_walk, delta_max_walk;
+    /* PlanarPointBicycleParameters — parameters.py:1180-1201 (gain = -Re(pole), dynamics.py:933-940) */
+    double k_psi;
+    int32_t model, priority_rule /* 0 unregulated, 1 p2r */, traj_len /* int(30/t_s) */, reserved;
+} csfo_params;
+
+typedef struct csfo {
+    csfo_params p;
+    int n, ns;
+    double *s;        /* [n][6] */
+    double *vdes;     /* [n]  params.v_desired_default per agent (demoCSFstandalone.py:104-113) */
+    int64_t *qoff;    /* [n+1] CSR offsets into dq */
+    double *dq;       /* [sum][3] x, y, stop */
+    int32_t *ptr;     /* destpointer */
+    uint8_t *znav;    /* [n][3] */
+    double *znavp;    /* [n][4] v0, d0, d1, i */
+    int32_t *i;       /* ring-buffer column */
+    double *traj;     /* [n][3][L]: x, y, delta */
+    double *xlti;     /* [n][5] delta, ddelta, theta, dtheta, psi (InvPendulum) */
+    uint8_t *zrid;    /* [n][2] */
+    double *xdyn;     /* [n][3] psi (unwrapped), x, y (PlanarPoint) */
+    double *vdyn;     /* [n] */
+    double *sx, *sy, *spsi, *sv; /* snapshot: intersection.py:660-677 (+ source speed for A2') */
+    double *Fx, *Fy, *Fdx, *Fdy, *Frx, *Fry;
+    int64_t nv;       /* road vertices, per-vertex F0 / sigma */
+    double *vx, *vy, *vF0, *vsig;
+    uint32_t *status;
+    int64_t tick;
+} csfo_t;
+
+/* ------------------------------------------------------------------ utils.py ---- */
+
+/* utils.py:124-139 */
+double csfo_limit_angle(double th) {
+    th = floor(th / (2 * PI)) * (-2 * PI) + th;
+    if (th > PI) th = th - 2 * PI;
+    else if (th < -PI) th = th + 2 * PI;
+    return th;
+}
+
+/* utils.py:151-182 (scalar branch) */
+double csfo_angle_difference(double a1, double a2) {
+    double da = (a1 > a2) ? a1 - a2 : a2 - a1;
+    if (da > PI) da = 2 * PI - da;
+    double t1 = fabs(csfo_limit_angle(a1 - da) - a2);
+    double t2 = fabs(csfo_limit_angle(a1 + da) - a2);
+    return (t1 < t2) ? -da : da;
+}
+
+/* utils.py:204-227 */
+static double thresh(double x, double lo, double hi) { return fmax(fmin(x, hi), lo); }
+
+/* utils.py:56-86, one vector */
+void csfo_limit_magnitude(double *x, double *y, double r) {
+    double rin = sqrt(*x * *x + *y * *y);
+    if (rin > r) {
+        *x = *x * r / rin;
+        *y = *y * r / rin;
+    }
+}
+
+/* utils.py:185-194 */
+static void cart2polar(double x, double y, double *rho, double *phi) {
+    *rho = sqrt(x * x + y * y);
+    double p = acos(x / *rho);
+    if (y < 0) p = -p;
+    *phi = p;
+}
+
+/* ------------------------------------------------------- the force fields (A2, A2') ---- */
+
+/* vehicle.py:1560-1648 — field of source (x0,y0,psi0) at one receiver (x,y,psi). Deviations D1, D2. */
+void csfo_pair_twod(const csfo_params *p, double x0, double y0, double psi0, double x, double y,
+                    double psi, double *Fx, double *Fy) {
+    *Fx = 0.0;
+    *Fy = 0.0;
+    if (p->f_0 == 0.0) return;                                     /* :1592-1593 */
+    double psi_rel = psi0 - psi;                                   /* :1595 */
+    double s2 = sin(psi_rel) * sin(psi_rel);
+    double sig_a = p->sigma_0 + p->sigma_1 * s2;                   /* :1604-1606 */
+    double sig_b = p->sigma_2 + p->sigma_3 * s2;                   /* :1607-1609 */
+    double e = p->e_0 - p->e_1 * s2;                               /* :1612 */
+    double dx = x - x0, dy = y - y0;                               /* :1615-1616 */
+    double rho, phi1;
+    cart2polar(dx, dy, &rho, &phi1);                               /* :1617 */
+    if (!(rho > 0.0)) return;                                      /* D2 */
+    double phi = csfo_limit_angle(phi1 - psi0);                    /* :1618 */
+    double cosphi = cos(phi), sinphi = sin(phi);
+    double sgn = (phi > 0) - (phi < 0);
+    double sigma = sig_a - sig_b * sqrt((1 - cosphi) / 2);         /* :1624 */
+    double dsigm = -sig_b * sqrt((1 + cosphi) / 2) * sgn / 2;      /* :1625 */
+    double q2 = 1 - (e * cosphi) * (e * cosphi);
+    double q = sqrt(q2);
+    double P = p->f_0 * exp(-rho * q / sigma);                     /* :1628 */
+    /* :1631-1639 with the common factor P taken out (D1) */
+    double frho = q / sigma;
+    double fphi = -(q2 * dsigm - e * e * sinphi * cosphi * sigma) / (sigma * sigma * q);
+    double gx = frho * cos(phi1) - fphi * sin(phi1);               /* :1641 */
+    double gy = frho * sin(phi1) + fphi * cos(phi1);               /* :1642 */
+    double G = sqrt(gx * gx + gy * gy);                            /* :1644 */
+    if (!(G > 0.0)) return;
+    *Fx = P * gx / G;                                              /* :1645 */
+    *Fy = P * gy / G;                                              /* :1646 */
+}
+
+/* vehicle.py:1054-1147 — older elliptic field of base Bicycle; needs the source's speed. D2, D3. */
+void csfo_pair_bicycle(const csfo_params *p, double x0, double y0, double psi0, double v0, double x,
+                       double y, double *Fx, double *Fy) {
+    *Fx = 0.0;
+    *Fy = 0.0;
+    double dx = x - x0, dy = y - y0;                               /* :1123-1124 */
+    double rho, phi;
+    cart2polar(dx, dy, &rho, &phi);                                /* :1126 */
+    if (!(rho > 0.0)) return;                                      /* D2 */
+    double phi0 = phi - psi0;                                      /* :1129 */
+    double e = 0.0;                                                /* :1062-1064, D3 */
+    if (v0 > 0.0) {
+        double pw = pow(v0 / p->v_max_riding[1], 0.1);
+        e = (0.7 < pw) ? 0.7 : pw;
+    }
+    double se = sqrt(1 - e * e);
+    double b = (1 / (se * p->p_decay)) * rho * (1 - e * cos(phi0));   /* :1095-1099 */
+    double P = p->p_0 * exp(-b) / p->p_decay;                      /* :1101, :1132 */
+    double Frho0 = P * ((1 - e * cos(phi0)) / se);                 /* :1135-1137 */
+    double Fphi0 = P * ((e * sin(phi0)) / se);                     /* :1138-1140 */
+    *Fx = Frho0 * cos(phi) - Fphi0 * sin(phi);                     /* :1144 */
+    *Fy = Frho0 * sin(phi) + Fphi0 * cos(phi);                     /* :1145 */
+}
+
+/* intersection.py:690-745 — is source i ignored by receiver j?  (row = source, column = receiver) */
+int csfo_untracked(double hfov_i, int rule, int i, int j, double xi, double yi, double xj, double yj,
+                   double psij) {
+    if (i == j) return 1;                                          /* :729-730 */
+    double az = csfo_limit_angle(atan2(yi - yj, xi - xj));         /* :711-718 */
+    double rel = csfo_angle_difference(psij, az);                  /* :724-726 */
+    if (fabs(rel) > hfov_i / 2) return 1;                          /* :733-736 */
+    if (rule == 1 && rel > 0) return 1;                            /* :739-741 */
+    return 0;
+}
+
+/* intersection.py:226-242 — one vertex list with per-vertex F0 and sigma (summed over edges: 36-48, 81-94) */
+void csfo_road_force(int64_t nv, const double *vx, const double *vy, const double *vF0,
+                     const double *vsig, double x, double y, double *Fx, double *Fy) {
+    double fx = 0, fy = 0;
+    for (int64_t k = 0; k < nv; k++) {
+        double ex = vx[k] - x, ey = vy[k] - y;
+        double r = sqrt(ex * ex + ey * ey);                        /* :231-234 */
+        double F = -vF0[k] * pow(r, -vsig[k]);                     /* :238 */
+        fx += F * (ex / r);                                        /* :235, :239 */
+        fy += F * (ey / r);                                        /* :236, :240 */
+    }
+    *Fx = fx;
+    *Fy = fy;
+}
+
+/* ----------------------------------------------- destination queue + nav state machine ---- */
+
+static inline double *S(csfo_t *o, int a) { return o->s + 6 * (size_t)a; }
+static inline int qlen(csfo_t *o, int a) { return (int)(o->qoff[a + 1] - o->qoff[a]); }
+static inline double *qrow(csfo_t *o, int a, int k) { return o->dq + 3 * (o->qoff[a] + k); }
+static inline double *trj(csfo_t *o, int a, int row) {
+    return o->traj + ((size_t)a * 3 + row) * (size_t)o->p.traj_len;
+}
+
+/* vehicle.py:596-604 */
+static double dest_distance(csfo_t *o, int a) {
+    double *d = qrow(o, a, o->ptr[a]), *s = S(o, a);
+    return sqrt(pow(d[0] - s[0], 2) + pow(d[1] - s[1], 2));
+}
+
+/* vehicle.py:537-543 */
+static int is_last_dest(csfo_t *o, int a) { return o->ptr[a] + 1 >= qlen(o, a); }
+
+/* vehicle.py:545-594 */
+static void update_destination(csfo_t *o, int a) {
+    double dnext = dest_distance(o, a);                            /* :560 */
+    uint8_t *z = o->znav + 3 * a;
+    if (z[1] || z[2]) return;                                      /* :567-568 */
+    int K = qlen(o, a);
+    if (dnext <= o->p.d_arrived_inter) {                           /* :571-574 */
+        int np1 = o->ptr[a] + 1;
+        o->ptr[a] = np1 < K - 1 ? np1 : K - 1;
+    }
+    if (o->ptr[a] < K - 1) {                                       /* :577-583 */
+        double *d = qrow(o, a, o->ptr[a] + 1), *s = S(o, a);
+        double dnn = sqrt((d[0] - s[0]) * (d[0] - s[0]) + (d[1] - s[1]) * (d[1] - s[1]));
+        if (dnn < dnext) o->ptr[a] += 1;
+    }
+}
+
+/* vehicle.py:354-457 */
+static void update_nav_state(csfo_t *o, int a, double *vd_out, double *ddest_out) {
+    const csfo_params *p = &o->p;
+    uint8_t *zn = o->znav + 3 * a;
+    double *zp = o->znavp + 4 * a, *s = S(o, a);
+    int stop = qrow(o, a, o->ptr[a])[2] != 0.0;
+    const double k = 1.5;                                          /* :377 */
+    double d0, d1;
+    if (zn[0]) {                                                   /* :379-386 */
+        d0 = 0.5 * (p->v_max_harddecel * p->v_max_harddecel - s[3] * s[3]) / p->a_desired_default[0];
+        d1 = 0.5 * -(p->v_max_harddecel * p->v_max_harddecel) / p->a_max[0];
+    } else {                                                       /* :388-389 */
+        d0 = zp[1];
+        d1 = zp[2];
+    }
+    double ddest = dest_distance(o, a);                            /* :392 */
+    int x0 = stop, x1 = ddest <= k * (d0 + d1), x2 = ddest <= p->d_arrived_stop,
+        x3 = s[3] <= p->v_max_stop;                                /* :397-400 */
+    int z0 = zn[0], z1 = zn[1], z2 = zn[2];
+    int n0 = (!x0) || (x0 && !x1 && ((z0 && !x2) || z1));          /* :404-406 */
+    int n1 = x0 && ((z0 && ((!x2 && x1) || (x2 && !x3))) || (z1 && x1 && (!x2 || !x3))); /* :407-413 */
+    int n2 = x0 && (((z0 || z1) && x2 && x3) || z2);               /* :414 */
+    zn[0] = (uint8_t)n0;
+    zn[1] = (uint8_t)n1;
+    zn[2] = (uint8_t)n2;
+    if (n0 + n1 + n2 != 1) o->status[a] |= CSFO_ST_NAVSTATE;      /* :416-425 only prints */
+    if (z0 && n1) {                                                /* :428-430 */
+        zp[0] = s[3];
+        zp[1] = d0;
+        zp[2] = d1;
+        zp[3] = (double)o->i[a];
+    }
+    double vd;
+    if (n0) vd = o->vdes[a];                                       /* :434-435 */
+    else if (n1) {                                                 /* :436-450 */
+        if (ddest < k * zp[2]) vd = p->v_max_harddecel / zp[2] * ddest * 1 / k;
+        else vd = (zp[0] - p->v_max_harddecel) / zp[1] * (ddest - zp[2]) * 1 / k + p->v_max_harddecel;
+    } else vd = 0;                                                 /* :452-453 (invalid state: reference raises) */
+    *vd_out = vd;
+    *ddest_out = ddest;
+}
+
+/* vehicle.py:1150-1194 and 2078-2108 — straight-line destination force */
+static void direct_approach(csfo_t *o, int a, double *Fx, double *Fy) {
+    update_destination(o, a);                                      /* :1168-1169 */
+    double vd, ddest;
+    update_nav_state(o, a, &vd, &ddest);                           /* :1171 */
+    double *d = qrow(o, a, o->ptr[a]), *s = S(o, a);
+    if (ddest > 0) {                                               /* :1173-1178 */
+        *Fx = -vd * (s[0] - d[0]) / ddest;
+        *Fy = -vd * (s[1] - d[1]) / ddest;
+    } else {
+        *Fx = 0;
+        *Fy = 0;
+    }
+}
+
+/* ------------------------------------------------------------------ cubic B-spline ---- */
+/* scipy.interpolate.splprep(s=0, k=3) / splev (FITPACK parcur, fpbspl, splev, splder; SciPy 1.15.3
+ * here, reference requires >= 1.10).  Published algorithm: chord-length parameter u in [0,1];
+ * knots = 4 x 0, u[2..m-3], 4 x 1; interpolation conditions B(u_r) c = p_r; de Boor evaluation. */
+
+static int find_span(const double *t, int n, int k, double u) {
+    int l = k;
+    while (u >= t[l + 1] && l != n - 1) l++;
+    return l;
+}
+
+/* values of the k+1 non-zero degree-k B-splines at u (Cox–de Boor), span l */
+static void basis_funs(const double *t, int l, int k, double u, double *N) {
+    double left[4], right[4];
+    N[0] = 1.0;
+    for (int j = 1; j <= k; j++) {
+        left[j] = u - t[l + 1 - j];
+        right[j] = t[l + j] - u;
+        double saved = 0.0;
+        for (int r = 0; r < j; r++) {
+            double tmp = N[r] / (right[r + 1] + left[j - r]);
+            N[r] = saved + right[r + 1] * tmp;
+            saved = left[j - r] * tmp;
+        }
+        N[j] = saved;
+    }
+}
+
+static double bspl_eval(const double *t, const double *c, int n, int k, double u) {
+    double N[4];
+    int l = find_span(t, n, k, u);
+    basis_funs(t, l, k, u, N);
+    double v = 0;
+    for (int j = 0; j <= k; j++) v += N[j] * c[l - k + j];
+    return v;
+}
+
+/* returns 0 on success, 1 if the input is rejected (duplicate consecutive points) */
+int csfo_spline20(int m, const double *px, const double *py, double out[20][6]) {
+    double u[6], t[10], A[6][6], cx[6], cy[6];
+    u[0] = 0;
+    for (int r = 1; r < m; r++) {
+        double d = sqrt((px[r] - px[r - 1]) * (px[r] - px[r - 1]) + (py[r] - py[r - 1]) * (py[r] - py[r - 1]));
+        if (!(d > 0.0)) return 1;
+        u[r] = u[r - 1] + d;
+    }
+    for (int r = 1; r < m; r++) u[r] /= u[m - 1];
+    u[m - 1] = 1.0;
+    int n = m, k = 3;
+    for (int j = 0; j < 4; j++) {
+        t[j] = 0.0;
+        t[n + j] = 1.0;
+    }
+    for (int j = 0; j < m - 4; j++) t[4 + j] = u[2 + j];
+    memset(A, 0, sizeof A);
+    for (int r = 0; r < m; r++) {
+        double N[4];
+        int l = find_span(t, n, k, u[r]);
+        basis_funs(t, l, k, u[r], N);
+        for (int j = 0; j <= k; j++) A[r][l - k + j] = N[j];
+        cx[r] = px[r];
+        cy[r] = py[r];
+    }
+    for (int c = 0; c < m; c++) { /* Gaussian elimination, partial pivoting */
+        int piv = c;
+        for (int r = c + 1; r < m; r++)
+            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        if (A[piv][c] == 0.0) return 1;
+        if (piv != c) {
+            for (int j = 0; j < m; j++) {
+                double tmp = A[c][j];
+                A[c][j] = A[piv][j];
+                A[piv][j] = tmp;
+            }
+            double tmp = cx[c];
+            cx[c] = cx[piv];
+            cx[piv] = tmp;
+            tmp = cy[c];
+            cy[c] = cy[piv];
+            cy[piv] = tmp;
+        }
+        for (int r = c + 1; r < m; r++) {
+            double f = A[r][c] / A[c][c];
+            if (f == 0.0) continue;
+            for (int j = c; j < m; j++) A[r][j] -= f * A[c][j];
+            cx[r] -= f * cx[c];
+            cy[r] -= f * cy[c];
+        }
+    }
+    for (int r = m - 1; r >= 0; r--) {
+        double sx = cx[r], sy = cy[r];
+        for (int j = r + 1; j < m; j++) {
+            sx -= A[r][j] * cx[j];
+            sy -= A[r][j] * cy[j];
+        }
+        cx[r] = sx / A[r][r];
+        cy[r] = sy / A[r][r];
+    }
+    /* derivative splines: c'_j = k (c_{j+1}-c_j)/(t_{j+k+1}-t_{j+1}) on knots t[1..] */
+    double c1x[6], c1y[6], c2x[6], c2y[6];
+    for (int j = 0; j < n - 1; j++) {
+        double den = t[j + 4] - t[j + 1];
+        c1x[j] = den > 0 ? 3 * (cx[j + 1] - cx[j]) / den : 0.0;
+        c1y[j] = den > 0 ? 3 * (cy[j + 1] - cy[j]) / den : 0.0;
+    }
+    const double *t1 = t + 1; /* degree 2, n-1 coefficients */
+    for (int j = 0; j < n - 2; j++) {
+        double den = t1[j + 3] - t1[j + 1];
+        c2x[j] = den > 0 ? 2 * (c1x[j + 1] - c1x[j]) / den : 0.0;
+        c2y[j] = den > 0 ? 2 * (c1y[j + 1] - c1y[j]) / den : 0.0;
+    }
+    const double *t2 = t + 2; /* degree 1, n-2 coefficients */
+    for (int q = 0; q < 20; q++) {
+        double uu = (double)q / 19.0; /* np.linspace(0,1,20) — vehicle.py:1508 */
+        if (q == 19) uu = 1.0;
+        out[q][0] = bspl_eval(t, cx, n, 3, uu);
+        out[q][1] = bspl_eval(t, cy, n, 3, uu);
+        out[q][2] = bspl_eval(t1, c1x, n - 1, 2, uu);
+        out[q][3] = bspl_eval(t1, c1y, n - 1, 2, uu);
+        out[q][4] = bspl_eval(t2, c2x, n - 2, 1, uu);
+        out[q][5] = bspl_eval(t2, c2y, n - 2, 1, uu);
+    }
+    return 0;
+}
+
+/* vehicle.py:1416-1558 */
+static void twod_dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
+    const csfo_params *p = &o->p;
+    const int nSplV = 4, nSplpnts = 20, ipred = 3, ipredlast = 5;  /* :1444-1448 */
+    double *s = S(o, a);
+    update_destination(o, a);                                      /* :1451 */
+    double vd, ddest;
+    update_nav_state(o, a, &vd, &ddest);                           /* :1452 */
+    int i = o->i[a];
+    if (i == 0) {                                                  /* :1455-1458 */
+        *Fx = vd * cos(s[2]);
+        *Fy = vd * sin(s[2]);
+        return;
+    }
+    if (o->znav[3 * a + 2]) {                                      /* :1461-1462 */
+        *Fx = 0;
+        *Fy = 0;
+        return;
+    }
+    double px[6], py[6];
+    int m;
+    double *tx = trj(o, a, 0), *ty = trj(o, a, 1);
+    int last = is_last_dest(o, a);
+    double *dest = qrow(o, a, o->ptr[a]);
+    if (!last) {                                                   /* :1465-1479 */
+        int K = qlen(o, a), hi = o->ptr[a] + nSplV;
+        if (hi > K) hi = K;
+        px[0] = tx[i - 1];
+        py[0] = ty[i - 1];
+        px[1] = tx[i];
+        py[1] = ty[i];
+        m = 2;
+        for (int k = o->ptr[a]; k < hi; k++, m++) {
+            px[m] = qrow(o, a, k)[0];
+            py[m] = qrow(o, a, k)[1];
+        }
+    } else {                                                       /* :1486-1492 */
+        int back = i - (int)(1 / p->t_s);
+        if (back < 0) back = 0;
+        px[0] = tx[back];
+        py[0] = ty[back];
+        px[1] = tx[i - 1];
+        py[1] = ty[i - 1];
+        px[2] = tx[i];
+        py[2] = ty[i];
+        px[3] = dest[0];
+        py[3] = dest[1];
+        m = 4;
+    }
+    double sp[20][6];
+    if (csfo_spline20(m, px, py, sp)) {                            /* :1495-1507, D4 */
+        o->status[a] |= CSFO_ST_SPLINE;
+        *Fx = 0;
+        *Fy = 0;
+        return;
+    }
+    int ii = 1;                                                    /* :1516-1522 */
+    if (last) {
+        double best = INFINITY;
+        for (int q = 0; q < nSplpnts; q++) {
+            double d = (sp[q][0] - s[0]) * (sp[q][0] - s[0]) + (sp[q][1] - s[1]) * (sp[q][1] - s[1]);
+            if (d < best) {
+                best = d;
+                ii = q;
+            }
+        }
+    }
+    int iprev = ii + (dest[2] != 0.0 ? ipredlast : ipred);         /* :1523-1526 */
+    if (iprev < nSplpnts) {                                        /* :1529-1553 */
+        double R = pow(sqrt(sp[ii][2] * sp[ii][2] + sp[ii][3] * sp[ii][3]), 3) /
+                   fabs(sp[ii][2] * sp[ii][5] - sp[ii][3] * sp[ii][4]);
+        double thetacomf = 10 * (2 * PI / 360);
+        double v = fmax(2.5, sqrt(thetacomf * p->g * R));
+        v = fmin(v, vd);
+        double ex = sp[iprev][0] - sp[ii][0], ey = sp[iprev][1] - sp[ii][1];
+        double tmp = v / sqrt(ex * ex + ey * ey);
+        *Fx = tmp * ex;
+        *Fy = tmp * ey;
+    } else {
+        direct_approach(o, a, Fx, Fy);                             /* :1555-1556 */
+    }
+}
+
+static void dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
+    switch (o->p.model) {
+    case CSFO_BICYCLE:
+        direct_approach(o, a, Fx, Fy);                             /* vehicle.py:1189-1194 */
+        break;
+    case CSFO_PLANARPOINT:
+        update_destination(o, a);                                  /* vehicle.py:295-297 */
+        twod_dest_force(o, a, Fx, Fy);                             /* vehicle.py:2025 */
+        break;
+    default:
+        twod_dest_force(o, a, Fx, Fy);
+    }
+}
+
+/* --------------------------------------------------------- controllers + integrators ---- */
+
+/* vehicle.py:1218-1245 with dynamics.py:33-54 (ki = kd = 0) */
+static void bike_control(csfo_t *o, int a, double Fx, double Fy, double *acc, double *omega) {
+    const csfo_params *p = &o->p;
+    double *s = S(o, a), *dest = qrow(o, a, o->ptr[a]);
+    double theta = atan2(Fy, Fx);                                  /* :1223 */
+    double v = sqrt(pow(Fx, 2) + pow(Fy, 2));                      /* :1224 */
+    double ddest = sqrt(pow(dest[0] - s[0], 2) + pow(dest[1] - s[1], 2)); /* :1226-1229 */
+    if (ddest < 3 && is_last_dest(o, a)) v = (v / 3) * ddest;      /* :1231-1232 */
+    double target = csfo_angle_difference(s[2], theta);            /* :1235 */
+    double ddelta = csfo_angle_difference(s[4], target);           /* :1239 */
+    double dv = v - s[3];                                          /* :1240 */
+    *omega = p->k_p_delta * ddelta;                                /* :1242 */
+    *acc = p->k_p_v * dv;                                          /* :1243 */
+}
+
+/* vehicle.py:1247-1272 */
+static void bike_move(csfo_t *o, int a, double acc, double omega) {
+    const csfo_params *p = &o->p;
+    double *s = S(o, a);
+    acc = thresh(acc, p->a_max[0], p->a_max[1]);                   /* :1249 */
+    double delta = csfo_limit_angle(s[4] + p->t_s * omega);        /* :1254 */
+    double v = s[3] + p->t_s * acc;                                /* :1255 */
+    delta = thresh(delta, -p->delta_max, p->delta_max);            /* :1257 */
+    v = thresh(v, p->v_max_riding[0], p->v_max_riding[1]);         /* :1258 */
+    double theta = s[2] + p->t_s * v * tan(delta) / p->l;          /* :1260 */
+    theta = csfo_limit_angle(theta);                               /* :1262 */
+    s[1] = s[1] + p->t_s * v * sin(theta);                         /* :1264 */
+    s[0] = s[0] + p->t_s * v * cos(theta);                         /* :1265 */
+    s[2] = theta;
+    s[3] = v;
+    s[4] = delta;
+}
+
+/* single-vehicle entry for known-answer tests: Bicycle.step / TwoDBicycle.step on a free agent */
+void csfo_control_move(const csfo_params *p, const double *s_in, const double *dest, int is_last,
+                       double Fx, double Fy, double *s_out) {
+    csfo_t o;
+    memset(&o, 0, sizeof o);
+    o.p = *p;
+    double s[6] = {0}, dq[6];
+    int64_t qoff[2] = {0, is_last ? 1 : 2};
+    int32_t ptr = 0;
+    memcpy(s, s_in, 5 * sizeof(double));
+    memcpy(dq, dest, 3 * sizeof(double));
+    memcpy(dq + 3, dest, 3 * sizeof(double));
+    o.s = s;
+    o.dq = dq;
+    o.qoff = qoff;
+    o.ptr = &ptr;
+    double acc, om;
+    bike_control(&o, 0, Fx, Fy, &acc, &om);
+    bike_move(&o, 0, acc, om);
+    memcpy(s_out, s, 5 * sizeof(double));
+}
+
+/* ---- small dense matrix exponential: scaling and squaring with the [13/13] Pade approximant
+ * (Higham 2005), the published algorithm behind scipy.linalg.expm which the python-control shim of
+ * the golden generator uses.  n <= 6. */
+#define MN 6
+static void mmul(int n, const double *A, const double *B, double *C) {
+    double T[MN * MN];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double acc = 0;
+            for (int k = 0; k < n; k++) acc += A[i * n + k] * B[k * n + j];
+            T[i * n + j] = acc;
+        }
+    memcpy(C, T, sizeof(double) * n * n);
+}
+
+static int lu_solve(int n, double *A, double *B) { /* A X = B, in place, B is n x n */
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        for (int r = c + 1; r < n; r++)
+            if (fabs(A[r * n + c]) > fabs(A[piv * n + c])) piv = r;
+        if (A[piv * n + c] == 0.0) return 1;
+        if (piv != c)
+            for (int j = 0; j < n; j++) {
+                double t = A[c * n + j];
+                A[c * n + j] = A[piv * n + j];
+                A[piv * n + j] = t;
+                t = B[c * n + j];
+                B[c * n + j] = B[piv * n + j];
+                B[piv * n + j] = t;
+            }
+        for (int r = c + 1; r < n; r++) {
+            double f = A[r * n + c] / A[c * n + c];
+            for (int j = c; j < n; j++) A[r * n + j] -= f * A[c * n + j];
+            for (int j = 0; j < n; j++) B[r * n + j] -= f * B[c * n + j];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--)
+        for (int j = 0; j < n; j++) {
+            double acc = B[r * n + j];
+            for (int k = r + 1; k < n; k++) acc -= A[r * n + k] * B[k * n + j];
+            B[r * n + j] = acc / A[r * n + r];
+        }
+    return 0;
+}
+
+void csfo_expm(int n, const double *Ain, double *E) {
+    static const double b[14] = {64764752532480000., 32382376266240000., 7771770303897600.,
+                                 1187353796428800.,  129060195264000.,   10559470521600.,
+                                 670442572800.,      33522128640.,       1323241920.,
+                                 40840800.,          960960.,            16380.,
+                                 182.,               1.};
+    double A[MN * MN], A2[MN * MN], A4[MN * MN], A6[MN * MN], U[MN * MN], V[MN * MN], T[MN * MN];
+    double nrm = 0;
+    for (int j = 0; j < n; j++) {
+        double c = 0;
+        for (int i = 0; i < n; i++) c += fabs(Ain[i * n + j]);
+        if (c > nrm) nrm = c;
+    }
+    int sq = 0;
+    if (nrm > 5.371920351148152) {
+        sq = (int)ceil(log2(nrm / 5.371920351148152));
+        if (sq < 0) sq = 0;
+    }
+    double sc = ldexp(1.0, -sq);
+    for (int i = 0; i < n * n; i++) A[i] = Ain[i] * sc;
+    mmul(n, A, A, A2);
+    mmul(n, A2, A2, A4);
+    mmul(n, A4, A2, A6);
+    for (int i = 0; i < n * n; i++) T[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
+    mmul(n, A6, T, T);
+    for (int i = 0; i < n * n; i++) T[i] += b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
+    for (int i = 0; i < n; i++) T[i * n + i] += b[1];
+    mmul(n, A, T, U);
+    for (int i = 0; i < n * n; i++) T[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
+    mmul(n, A6, T, V);
+    for (int i = 0; i < n * n; i++) V[i] += b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
+    for (int i = 0; i < n; i++) V[i * n + i] += b[0];
+    double P[MN * MN], Q[MN * MN];
+    for (int i = 0; i < n * n; i++) {
+        P[i] = V[i] + U[i];
+        Q[i] = V[i] - U[i];
+    }
+    lu_solve(n, Q, P);
+    for (int k = 0; k < sq; k++) mmul(n, P, P, P);
+    memcpy(E, P, sizeof(double) * n * n);
+}
+
+/* vehicle.py:1738-1786 + parameters.py:1832-1892: closed loop A - B K_x, K_u B at speed v */
+static void invpend_closed_loop(const csfo_params *p, double v, double A[25], double B[5]) {
+    static const double kx[5][4] = {
+        {3.48203226e02, -5.12057324e03, 1.58364873e04, -1.98073306e04},
+        {-4.51700000e01, 0.0, 0.0, 0.0},
+        {-9.16379250e02, 1.31769807e04, -6.57341643e04, 8.22163589e04},
+        {3.20214069e02, -4.69953797e03, 1.66378680e04, -2.43114309e04},
+        {2.87549256e-08, -2.27913445e03, 0.0, 0.0}};
+    static const double ku[4] = {-3.38638984e-09, -2.27913445e+03, 0.0, 0.0};
+    double vd[4] = {1, pow(v, -1), pow(v, -2), pow(v, -3)};        /* parameters.py:1885 */
+    double Kx[5], Ku = 0;
+    for (int r = 0; r < 5; r++) {
+        Kx[r] = 0;
+        for (int c = 0; c < 4; c++) Kx[r] += kx[r][c] * vd[c];
+    }
+    for (int c = 0; c < 4; c++) Ku += ku[c] * vd[c];
+    double Ktau2 = (v * p->l_2) / (p->g * p->l);                   /* parameters.py:1850 */
+    double K = (v * v) / (p->g * p->l);                            /* :1851 */
+    double tau3 = p->l / v;                                        /* :1853 */
+    double tau1sq = (p->i_bike_longlong + p->m * p->h * p->h) / (p->m * p->g * p->h); /* :1641-1643 */
+    memset(A, 0, 25 * sizeof(double));
+    A[0 * 5 + 1] = 1;                                              /* vehicle.py:1740-1760 */
+    A[1 * 5 + 1] = -p->c_steer / p->i_steer_vertvert;
+    A[2 * 5 + 3] = 1;
+    A[3 * 5 + 0] = -K / tau1sq;
+    A[3 * 5 + 1] = -Ktau2 / tau1sq;
+    A[3 * 5 + 2] = 1 / tau1sq;
+    A[4 * 5 + 0] = 1 / tau3;
+    double Bo[5] = {0, 1 / p->i_steer_vertvert, 0, 0, 0};          /* :1762 */
+    for (int r = 0; r < 5; r++)
+        for (int c = 0; c < 5; c++) A[r * 5 + c] -= Bo[r] * Kx[c]; /* :1785 */
+    for (int r = 0; r < 5; r++) B[r] = Ku * Bo[r];                 /* :1786 */
+}
+
+/* vehicle.py:1810-1848: one exact zero-order-hold step (control.forced_response over [0, t_s] with
+ * constant input = the block matrix exponential [[A h, B h], [0, 0]]) */
+static void invpend_step_yaw(csfo_t *o, int a, double Fx, double Fy, double *psi, double *delta,
+                             double *theta) {
+    const csfo_params *p = &o->p;
+    double A[25], B[5], M[36], E[36];
+    invpend_closed_loop(p, S(o, a)[3], A, B);                      /* :1829 (speed already updated) */
+    double psi_d = atan2(Fy, Fx);                                  /* :1832 */
+    memset(M, 0, sizeof M);
+    for (int r = 0; r < 5; r++) {
+        for (int c = 0; c < 5; c++) M[r * 6 + c] = A[r * 5 + c] * p->t_s;
+        M[r * 6 + 5] = B[r] * p->t_s;
+    }
+    csfo_expm(6, M, E);
+    double *x = o->xlti + 5 * a, xn[5];
+    for (int r = 0; r < 5; r++) {
+        double acc = E[r * 6 + 5] * psi_d;
+        for (int c = 0; c < 5; c++) acc += E[r * 6 + c] * x[c];
+        xn[r] = acc;
+    }
+    memcpy(x, xn, sizeof xn);                                      /* :1843 */
+    *psi = csfo_limit_angle(xn[4]);                                /* :1844 (C = [0,0,0,0,1]) */
+    *delta = csfo_limit_angle(xn[0]);                              /* :1845 */
+    *theta = csfo_limit_angle(xn[2]);                              /* :1846 */
+}
+
+/* vehicle.py:1932-1950 */
+static void invpend_update_riding_state(csfo_t *o, int a) {
+    const csfo_params *p = &o->p;
+    double *s = S(o, a);
+    uint8_t *zr = o->zrid + 2 * a;
+    int cvwalk = s[3] < p->v_max_walk;                             /* :1939 */
+    int i = o->i[a];
+    int imin = (int)(i - 1 / p->t_s);                              /* :1941 */
+    if (imin < 0) imin = 0;
+    int cdelta = 1;
+    double *td = trj(o, a, 2);
+    for (int k = imin; k <= i; k++)                                /* :1943-1947 */
+        if (!(-p->delta_max_walk < td[k] && p->delta_max_walk > td[k])) cdelta = 0;
+    int z0 = !cvwalk && ((zr[1] && cdelta) || zr[0]);              /* :1949 */
+    zr[0] = (uint8_t)z0;
+    zr[1] = (uint8_t)!z0;                                          /* :1950 */
+}
+
+/* dynamics.py:996-1079; the implicit-midpoint system is solved in closed form (yaw equation linear,
+ * position explicit given yaw) where the reference runs MINPACK lm to ~1.5e-8 */
+static void planarpoint_step(csfo_t *o, int a, double Fx, double Fy) {
+    const csfo_params *p = &o->p;
+    double *s = S(o, a), *x = o->xdyn + 3 * a;
+    double vd = sqrt(Fx * Fx + Fy * Fy);                           /* :1018 */
+    double acc = thresh(p->k_p_v * (vd - o->vdyn[a]), p->a_max[0], p->a_max[1]); /* :1021-1022 */
+    double v = thresh(o->vdyn[a] + p->t_s * acc, p->v_max_riding[0], p->v_max_riding[1]); /* :1025 */
+    double psi_c = csfo_limit_angle(atan2(Fy, Fx));                /* dynamics.py:115 */
+    double vbar = (v + s[3]) / 2;                                  /* :1065 */
+    double h = p->t_s, k = p->k_psi;
+    double psi_n = (x[0] * (1 - h * k / 2) + h * k * psi_c) / (1 + h * k / 2);
+    double pm = (x[0] + psi_n) / 2;
+    x[1] = x[1] + h * vbar * cos(pm);
+    x[2] = x[2] + h * vbar * sin(pm);
+    x[0] = psi_n;
+    o->vdyn[a] = v;                                                /* :1075-1076 */
+    s[0] = x[1];                                                   /* :959-964 */
+    s[1] = x[2];
+    s[2] = csfo_limit_angle(x[0]);
+    s[3] = v;
+}
+
+/* --------------------------------------------------------------- population tick ---- */
+
+/* intersection.py:747-864 for receivers [lo, hi) */
+void csfo_calc_forces_range(csfo_t *o, int lo, int hi) {
+    const csfo_params *p = &o->p;
+    int n = o->n;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int j = lo; j < hi; j++) {
+        double fdx, fdy;
+        dest_force(o, j, &fdx, &fdy);                              /* :799 */
+        double fx = fdx, fy = fdy;
+        double rx = 0, ry = 0;
+        if (n > 1) {                                               /* :813, :825 */
+            for (int i = 0; i < n; i++) {
+                if (csfo_untracked(p->hfov, p->priority_rule, i, j, o->sx[i], o->sy[i], o->sx[j],
+                                   o->sy[j], o->spsi[j]))
+                    continue;                                      /* :815-823 */
+                double gx, gy;
+                if (p->model == CSFO_BICYCLE)
+                    csfo_pair_bicycle(p, o->sx[i], o->sy[i], o->spsi[i], o->sv[i], o->sx[j], o->sy[j], &gx, &gy);
+                else
+                    csfo_pair_twod(p, o->sx[i], o->sy[i], o->spsi[i], o->sx[j], o->sy[j], o->spsi[j], &gx, &gy);
+                rx += gx;                                          /* :842-843 column sum */
+                ry += gy;
+            }
+            csfo_limit_magnitude(&rx, &ry, sqrt(fdx * fdx + fdy * fdy)); /* :841-845 */
+            fx = rx + fdx;                                         /* :847-848 */
+            fy = ry + fdy;
+        }
+        if (o->nv > 0) {                                           /* :854-857 */
+            double ex, ey;
+            csfo_road_force(o->nv, o->vx, o->vy, o->vF0, o->vsig, o->sx[j], o->sy[j], &ex, &ey);
+            fx += ex;
+            fy += ey;
+        }
+        o->Fdx[j] = fdx;
+        o->Fdy[j] = fdy;
+        o->Frx[j] = rx;
+        o->Fry[j] = ry;
+        o->Fx[j] = fx;                                             /* :860-861 */
+        o->Fy[j] = fy;
+        if (isnan(fx) || isnan(fy)) o->status[j] |= CSFO_ST_NAN;
+    }
+}
+
+/* vehicle.*.step for agents [lo, hi) with the forces of csfo_calc_forces_range — intersection.py:891-892 */
+void csfo_integrate_range(csfo_t *o, int lo, int hi) {
+    const csfo_params *p = &o->p;
+    int L = p->traj_len;
+#pragma omp parallel for schedule(static)
+    for (int a = lo; a < hi; a++) {
+        double *s = S(o, a), Fx = o->Fx[a], Fy = o->Fy[a];
+        double acc, om;
+        switch (p->model) {
+        case CSFO_BICYCLE:                                         /* vehicle.py:1274-1289 */
+            bike_control(o, a, Fx, Fy, &acc, &om);
+            bike_move(o, a, acc, om);
+            break;
+        case CSFO_TWOD:                                            /* vehicle.py:1386-1414 */
+            if (o->znav[3 * a + 2]) {
+                s[3] = 0;
+                s[4] = 0;
+            } else {
+                bike_control(o, a, Fx, Fy, &acc, &om);
+                bike_move(o, a, acc, om);
+            }
+            break;
+        case CSFO_INVPEND:                                         /* vehicle.py:1883-1930 */
+            invpend_update_riding_state(o, a);
+            if (o->znav[3 * a + 2]) {
+                s[3] = 0;
+                s[4] = 0;
+                s[5] = 0;
+            } else if (o->zrid[2 * a]) {
+                /* step_pos — vehicle.py:1850-1881 (old psi) */
+                double vd = sqrt(Fx * Fx + Fy * Fy);
+                double a_ = thresh(p->k_p_v * (vd - s[3]), p->a_max[0], p->a_max[1]);
+                double v = thresh(s[3] + p->t_s * a_, p->v_max_riding[0], p->v_max_riding[1]);
+                s[1] = s[1] + p->t_s * v * sin(s[2]);
+                s[0] = s[0] + p->t_s * v * cos(s[2]);
+                s[3] = v;
+                double psi, de, th;
+                invpend_step_yaw(o, a, Fx, Fy, &psi, &de, &th);
+                s[2] = psi;
+                s[4] = de;
+                s[5] = th;
+            } else {                                               /* :1905-1916 walking */
+                s[3] = p->v_max_walk;
+                s[5] = 0;
+                bike_control(o, a, Fx, Fy, &acc, &om);
+                bike_move(o, a, acc, om);
+                double *x = o->xlti + 5 * a;
+                x[0] = s[4];
+                x[1] = 0;
+                x[2] = s[5];
+                x[3] = 0;
+                x[4] = s[2];
+            }
+            break;
+        case CSFO_PLANARPOINT:                                     /* vehicle.py:301-328 */
+            planarpoint_step(o, a, Fx, Fy);
+            break;
+        }
+        int i = (o->i[a] + 1) % L;                                 /* vehicle.py:1279-1282, D5 */
+        o->i[a] = i;
+        trj(o, a, 0)[i] = s[0];
+        trj(o, a, 1)[i] = s[1];
+        trj(o, a, 2)[i] = s[4];
+    }
+}
+
+/* intersection.py:660-677 */
+void csfo_update_snapshot_range(csfo_t *o, int lo, int hi) {
+    for (int a = lo; a < hi; a++) {
+        o->sx[a] = S(o, a)[0];
+        o->sy[a] = S(o, a)[1];
+        o->spsi[a] = S(o, a)[2];
+        o->sv[a] = S(o, a)[3];
+    }
+}
+
+/* intersection.py:866-896 */
+void csfo_step(csfo_t *o, int nticks) {
+    for (int t = 0; t < nticks; t++) {
+        if (o->n > 0) {
+            csfo_calc_forces_range(o, 0, o->n);
+            csfo_integrate_range(o, 0, o->n);
+            csfo_update_snapshot_range(o, 0, o->n);
+        }
+        o->tick++;
+    }
+}
+
+/* ----------------------------------------------------------------- construction ---- */
+
+csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double *vdes,
+                    const int64_t *qoff, const double *dq) {
+    csfo_t *o = (csfo_t *)calloc(1, sizeof *o);
+    o->p = *p;
+    o->n = n;
+    static const int NS[4] = {5, 5, 6, 4};
+    o->ns = NS[p->model];
+    size_t N = (size_t)(n > 0 ? n : 1), L = (size_t)p->traj_len;
+    o->s = (double *)calloc(N * 6, sizeof(double));
+    o->vdes = (double *)calloc(N, sizeof(double));
+    o->qoff = (int64_t *)calloc(N + 1, sizeof(int64_t));
+    memcpy(o->qoff, qoff, sizeof(int64_t) * (size_t)(n + 1));
+    size_t Q = (size_t)qoff[n];
+    o->dq = (double *)calloc((Q ? Q : 1) * 3, sizeof(double));
+    memcpy(o->dq, dq, sizeof(double) * Q * 3);
+    o->ptr = (int32_t *)calloc(N, sizeof(int32_t));
+    o->znav = (uint8_t *)calloc(N * 3, 1);
+    o->znavp = (double *)calloc(N * 4, sizeof(double));
+    o->i = (int32_t *)calloc(N, sizeof(int32_t));
+    o->traj = (double *)calloc(N * 3 * L, sizeof(double));
+    o->xlti = (double *)calloc(N * 5, sizeof(double));
+    o->zrid = (uint8_t *)calloc(N * 2, 1);
+    o->xdyn = (double *)calloc(N * 3, sizeof(double));
+    o->vdyn = (double *)calloc(N, sizeof(double));
+    o->sx = (double *)calloc(N, sizeof(double));
+    o->sy = (double *)calloc(N, sizeof(double));
+    o->spsi = (double *)calloc(N, sizeof(double));
+    o->sv = (double *)calloc(N, sizeof(double));
+    o->Fx = (double *)calloc(N, sizeof(double));
+    o->Fy = (double *)calloc(N, sizeof(double));
+    o->Fdx = (double *)calloc(N, sizeof(double));
+    o->Fdy = (double *)calloc(N, sizeof(double));
+    o->Frx = (double *)calloc(N, sizeof(double));
+    o->Fry = (double *)calloc(N, sizeof(double));
+    o->status = (uint32_t *)calloc(N, sizeof(uint32_t));
+    for (int a = 0; a < n; a++) {
+        double *s = S(o, a);
+        for (int k = 0; k < o->ns; k++) s[k] = s0[(size_t)a * o->ns + k];
+        s[2] = csfo_limit_angle(s[2]);                             /* vehicle.py:154-155 */
+        o->vdes[a] = vdes[a];
+        o->znav[3 * a] = 1;                                        /* vehicle.py:188 */
+        trj(o, a, 0)[0] = s[0];                                    /* vehicle.py:159-160 */
+        trj(o, a, 1)[0] = s[1];
+        trj(o, a, 2)[0] = s[4];
+        if (p->model == CSFO_INVPEND) {                            /* vehicle.py:1728-1736 */
+            double *x = o->xlti + 5 * a;
+            x[0] = s[4];
+            x[2] = s[5];
+            x[4] = s[2];
+            if (s[3] < p->v_max_walk) o->zrid[2 * a + 1] = 1;
+            else o->zrid[2 * a] = 1;
+        }
+        if (p->model == CSFO_PLANARPOINT) {                        /* dynamics.py:828, 987-993 */
+            o->xdyn[3 * a] = s[2];
+            o->xdyn[3 * a + 1] = s[0];
+            o->xdyn[3 * a + 2] = s[1];
+            o->vdyn[a] = s[3];
+        }
+    }
+    csfo_update_snapshot_range(o, 0, n);                           /* intersection.py:320 */
+    return o;
+}
+
+void csfo_destroy(csfo_t *o) {
+    if (!o) return;
+    free(o->s); free(o->vdes); free(o->qoff); free(o->dq); free(o->ptr); free(o->znav);
+    free(o->znavp); free(o->i); free(o->traj); free(o->xlti); free(o->zrid); free(o->xdyn);
+    free(o->vdyn); free(o->sx); free(o->sy); free(o->spsi); free(o->sv); free(o->Fx); free(o->Fy);
+    free(o->Fdx); free(o->Fdy); free(o->Frx); free(o->Fry); free(o->status);
+    free(o->vx); free(o->vy); free(o->vF0); free(o->vsig);
+    free(o);
+}
+
+/* edges as CSR over vertices with one (F0, sigma) per edge — intersection.py:222-224 */
+void csfo_set_road(csfo_t *o, int n_edges, const int64_t *off, const double *xy, const double *F0,
+                   const double *sigma) {
+    free(o->vx); free(o->vy); free(o->vF0); free(o->vsig);
+    int64_t nv = n_edges > 0 ? off[n_edges] : 0;
+    o->nv = nv;
+    o->vx = (double *)calloc((size_t)(nv ? nv : 1), sizeof(double));
+    o->vy = (double *)calloc((size_t)(nv ? nv : 1), sizeof(double));
+    o->vF0 = (double *)calloc((size_t)(nv ? nv : 1), sizeof(double));
+    o->vsig = (double *)calloc((size_t)(nv ? nv : 1), sizeof(double));
+    for (int e = 0; e < n_edges; e++)
+        for (int64_t k = off[e]; k < off[e + 1]; k++) {
+            o->vx[k] = xy[2 * k];
+            o->vy[k] = xy[2 * k + 1];
+            o->vF0[k] = F0[e];
+            o->vsig[k] = sigma[e];
+        }
+}
+
+/* --------------------------------------------------------------------- accessors ---- */
+
+void csfo_get_state(csfo_t *o, double *s_out) {
+    for (int a = 0; a < o->n; a++)
+        for (int k = 0; k < o->ns; k++) s_out[(size_t)a * o->ns + k] = S(o, a)[k];
+}
+void csfo_get_forces(csfo_t *o, double *Fx, double *Fy) {
+    memcpy(Fx, o->Fx, sizeof(double) * (size_t)o->n);
+    memcpy(Fy, o->Fy, sizeof(double) * (size_t)o->n);
+}
+void csfo_get_force_parts(csfo_t *o, double *Fdx, double *Fdy, double *Frx, double *Fry) {
+    memcpy(Fdx, o->Fdx, sizeof(double) * (size_t)o->n);
+    memcpy(Fdy, o->Fdy, sizeof(double) * (size_t)o->n);
+    memcpy(Frx, o->Frx, sizeof(double) * (size_t)o->n);
+    memcpy(Fry, o->Fry, sizeof(double) * (size_t)o->n);
+}
+void csfo_get_nav(csfo_t *o, int32_t *ptr, uint8_t *znav, int32_t *i, uint32_t *status) {
+    memcpy(ptr, o->ptr, sizeof(int32_t) * (size_t)o->n);
+    memcpy(znav, o->znav, 3 * (size_t)o->n);
+    memcpy(i, o->i, sizeof(int32_t) * (size_t)o->n);
+    memcpy(status, o->status, sizeof(uint32_t) * (size_t)o->n);
+}
+/* snapshot exchange for sharded (multi-rank) tests: (x, y, psi, v) per agent */
+void csfo_get_snapshot(csfo_t *o, int lo, int hi, double *out) {
+    for (int a = lo; a < hi; a++) {
+        out[4 * (a - lo) + 0] = o->sx[a];
+        out[4 * (a - lo) + 1] = o->sy[a];
+        out[4 * (a - lo) + 2] = o->spsi[a];
+        out[4 * (a - lo) + 3] = o->sv[a];
+    }
+}
+void csfo_set_snapshot(csfo_t *o, int lo, int hi, const double *in) {
+    for (int a = lo; a < hi; a++) {
+        o->sx[a] = in[4 * (a - lo) + 0];
+        o->sy[a] = in[4 * (a - lo) + 1];
+        o->spsi[a] = in[4 * (a - lo) + 2];
+        o->sv[a] = in[4 * (a - lo) + 3];
+    }
+}
+/* destination force of one agent from its current state (mutates queue pointer + nav state) */
+void csfo_dest_force(csfo_t *o, int a, double *Fx, double *Fy) { dest_force(o, a, Fx, Fy); }
+/* apply given forces to all agents (single-vehicle closed-loop tests: vehicle.step(Fx, Fy)) */
+void csfo_apply_forces(csfo_t *o, const double *Fx, const double *Fy) {
+    memcpy(o->Fx, Fx, sizeof(double) * (size_t)o->n);
+    memcpy(o->Fy, Fy, sizeof(double) * (size_t)o->n);
+    csfo_integrate_range(o, 0, o->n);
+    csfo_update_snapshot_range(o, 0, o->n);
+    o->tick++;
+}
+int csfo_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+size_t csfo_sizeof_params(void) { return sizeof(csfo_params); }

@@ -1,0 +1,294 @@
+"""ctypes front-end of the CPU oracle (oracle/csf_oracle.c).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libcsf_oracle.so")
+
+BICYCLE, TWOD, INVPEND, PLANARPOINT = 0, 1, 2, 3
+MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT}
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4}
+
+ST_SPLINE, ST_NAN, ST_NAVSTATE = 1, 2, 4
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("t_s", C.c_double), ("d_arrived_inter", C.c_double), ("d_arrived_stop", C.c_double),
+        ("v_max_stop", C.c_double), ("v_max_harddecel", C.c_double), ("hfov", C.c_double),
+        ("f_0", C.c_double), ("e_0", C.c_double), ("e_1", C.c_double),
+        ("sigma_0", C.c_double), ("sigma_1", C.c_double), ("sigma_2", C.c_double), ("sigma_3", C.c_double),
+        ("v_max_riding", C.c_double * 2), ("p_decay", C.c_double), ("p_0", C.c_double),
+        ("l", C.c_double), ("l_2", C.c_double), ("delta_max", C.c_double),
+        ("a_max", C.c_double * 2), ("a_desired_default", C.c_double * 2),
+        ("k_p_v", C.c_double), ("k_p_delta", C.c_double), ("g", C.c_double),
+        ("h", C.c_double), ("m", C.c_double), ("i_bike_longlong", C.c_double),
+        ("i_steer_vertvert", C.c_double), ("c_steer", C.c_double),
+        ("v_max_walk", C.c_double), ("delta_max_walk", C.c_double),
+        ("k_psi", C.c_double),
+        ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# Defaults of the reference parameter classes.
+#   VehicleParameters parameters.py:430-451; BicycleParameters :780-800;
+#   InvPendulumBicycleParameters :1429-1472; PlanarPointBicycleParameters :1180-1201.
+_VEHICLE = dict(t_s=0.01, d_arrived_inter=2.0, d_arrived_stop=2.0, v_max_stop=0.1, v_max_harddecel=2.5,
+                hfov=2 * np.pi, f_0=7.0, e_0=0.995, e_1=0.7, sigma_0=0.5, sigma_1=5.0, sigma_2=0.3,
+                sigma_3=4.9)
+_BICYCLE = dict(_VEHICLE, v_max_riding=(-1.0, 10.0), p_decay=5.0, p_0=30.0, hfov=np.pi * 2 / 3,
+                v_max_stop=0.6, l=1.0, l_2=0.5, delta_max=1.4, a_max=(-10.0, 10.0),
+                a_desired_default=(-5.0, 5.0), k_p_v=10.0, k_p_delta=10.0, g=9.81,
+                h=0.0, m=0.0, i_bike_longlong=0.0, i_steer_vertvert=1.0, c_steer=0.0,
+                v_max_walk=0.0, delta_max_walk=0.0, k_psi=0.0)
+_INVPEND = dict(_BICYCLE, v_max_riding=(-1.0, 7.0), a_max=(-3.0, 1.0), a_desired_default=(-1.0, 0.5),
+                l=1.0, l_2=0.5, h=1.0, m=87.0, i_bike_longlong=3.28, i_steer_vertvert=0.07,
+                c_steer=50.0, v_max_walk=1.5, delta_max_walk=0.174)
+_PLANARPOINT = dict(_BICYCLE, k_psi=2.0)
+DEFAULTS = {BICYCLE: _BICYCLE, TWOD: _INVPEND, INVPEND: _INVPEND, PLANARPOINT: _PLANARPOINT}
+
+
+def default_params(model, priority_rule=0, **overrides):
+    if isinstance(model, str):
+        model = MODEL_IDS[model]
+    d = dict(DEFAULTS[model], **overrides)
+    p = Params()
+    for k, v in d.items():
+        if isinstance(v, (tuple, list)):
+            setattr(p, k, (C.c_double * 2)(*v))
+        else:
+            setattr(p, k, v)
+    p.model = model
+    p.priority_rule = priority_rule
+    p.traj_len = int(30 / p.t_s)
+    return p
+
+
+def build(force=False):
+    src = os.path.join(HERE, "csf_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libcsf_oracle.so"])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB)
+        dp = C.POINTER(C.c_double)
+        L.csfo_limit_angle.restype = C.c_double
+        L.csfo_limit_angle.argtypes = [C.c_double]
+        L.csfo_angle_difference.restype = C.c_double
+        L.csfo_angle_difference.argtypes = [C.c_double, C.c_double]
+        L.csfo_limit_magnitude.argtypes = [dp, dp, C.c_double]
+        L.csfo_pair_twod.argtypes = [C.POINTER(Params)] + [C.c_double] * 6 + [dp, dp]
+        L.csfo_pair_bicycle.argtypes = [C.POINTER(Params)] + [C.c_double] * 6 + [dp, dp]
+        L.csfo_untracked.restype = C.c_int
+        L.csfo_untracked.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_double] * 5
+        L.csfo_road_force.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_double, C.c_double, dp, dp]
+        L.csfo_spline20.restype = C.c_int
+        L.csfo_spline20.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_control_move.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                        C.c_double, C.c_void_p]
+        L.csfo_expm.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.csfo_create.restype = C.c_void_p
+        L.csfo_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_destroy.argtypes = [C.c_void_p]
+        L.csfo_set_road.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_step.argtypes = [C.c_void_p, C.c_int]
+        for f in ("csfo_calc_forces_range", "csfo_integrate_range", "csfo_update_snapshot_range"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.csfo_get_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.csfo_get_forces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_get_force_parts.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.csfo_get_nav.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.csfo_get_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.csfo_set_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.csfo_dest_force.argtypes = [C.c_void_p, C.c_int, dp, dp]
+        L.csfo_apply_forces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_num_threads.restype = C.c_int
+        L.csfo_sizeof_params.restype = C.c_size_t
+        assert L.csfo_sizeof_params() == C.sizeof(Params)
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def limit_angle(t):
+    return lib().csfo_limit_angle(float(t))
+
+
+def angle_difference(a1, a2):
+    return lib().csfo_angle_difference(float(a1), float(a2))
+
+
+def limit_magnitude(x, y, r):
+    x = np.array(x, dtype=np.float64)
+    y = np.array(y, dtype=np.float64)
+    for k in range(x.size):
+        cx, cy = C.c_double(x[k]), C.c_double(y[k])
+        lib().csfo_limit_magnitude(C.byref(cx), C.byref(cy), float(r[k]))
+        x[k], y[k] = cx.value, cy.value
+    return x, y
+
+
+def pair_twod(params, src, x, y, psi):
+    fx = np.zeros(len(x)); fy = np.zeros(len(x))
+    a, b = C.c_double(), C.c_double()
+    for k in range(len(x)):
+        lib().csfo_pair_twod(C.byref(params), src[0], src[1], src[2], x[k], y[k], psi[k], C.byref(a), C.byref(b))
+        fx[k], fy[k] = a.value, b.value
+    return fx, fy
+
+
+def pair_bicycle(params, src, v, x, y):
+    fx = np.zeros(len(x)); fy = np.zeros(len(x))
+    a, b = C.c_double(), C.c_double()
+    for k in range(len(x)):
+        lib().csfo_pair_bicycle(C.byref(params), src[0], src[1], src[2], v, x[k], y[k], C.byref(a), C.byref(b))
+        fx[k], fy[k] = a.value, b.value
+    return fx, fy
+
+
+def untracked_matrix(hfov, rule, x, y, psi):
+    n = len(x)
+    U = np.zeros((n, n), dtype=bool)
+    for i in range(n):
+        for j in range(n):
+            U[i, j] = bool(lib().csfo_untracked(hfov, rule, i, j, x[i], y[i], x[j], y[j], psi[j]))
+    return U
+
+
+def road_force(verts, off, F0, sigma, x, y):
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    vF0 = np.zeros(len(verts)); vsg = np.zeros(len(verts))
+    for e in range(len(off) - 1):
+        vF0[off[e]:off[e + 1]] = F0[e]
+        vsg[off[e]:off[e + 1]] = sigma[e]
+    vx = np.ascontiguousarray(verts[:, 0]); vy = np.ascontiguousarray(verts[:, 1])
+    fx = np.zeros(len(x)); fy = np.zeros(len(x))
+    a, b = C.c_double(), C.c_double()
+    for k in range(len(x)):
+        lib().csfo_road_force(len(verts), _p(vx), _p(vy), _p(vF0), _p(vsg), x[k], y[k], C.byref(a), C.byref(b))
+        fx[k], fy[k] = a.value, b.value
+    return fx, fy
+
+
+def spline20(px, py):
+    px = np.ascontiguousarray(px, dtype=np.float64); py = np.ascontiguousarray(py, dtype=np.float64)
+    out = np.zeros((20, 6))
+    rc = lib().csfo_spline20(len(px), _p(px), _p(py), _p(out))
+    return rc, out
+
+
+def control_move(params, s, dest, is_last, Fx, Fy):
+    s = np.ascontiguousarray(s, dtype=np.float64); dest = np.ascontiguousarray(dest, dtype=np.float64)
+    out = np.zeros(5)
+    lib().csfo_control_move(C.byref(params), _p(s), _p(dest), int(is_last), float(Fx), float(Fy), _p(out))
+    return out
+
+
+def expm(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    E = np.zeros_like(A)
+    lib().csfo_expm(A.shape[0], _p(A), _p(E))
+    return E
+
+
+class Population:
+    """Population of one vehicle class stepped by the CPU oracle (SocialForceIntersection.step)."""
+
+    def __init__(self, params, s0, vdes, qoff, dq):
+        self.params = params
+        self.ns = N_STATES[params.model]
+        s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float64)[:, :self.ns])
+        self.n = s0.shape[0]
+        vdes = np.ascontiguousarray(np.broadcast_to(np.asarray(vdes, dtype=np.float64), (self.n,)))
+        qoff = np.ascontiguousarray(qoff, dtype=np.int64)
+        dq = np.ascontiguousarray(dq, dtype=np.float64).reshape(-1, 3)
+        assert qoff.shape == (self.n + 1,) and qoff[-1] == dq.shape[0]
+        self.h = C.c_void_p(lib().csfo_create(C.byref(params), self.n, _p(s0), _p(vdes), _p(qoff), _p(dq)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().csfo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_road(self, off, verts, F0, sigma):
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        verts = np.ascontiguousarray(verts, dtype=np.float64)
+        F0 = np.ascontiguousarray(F0, dtype=np.float64); sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+        lib().csfo_set_road(self.h, len(off) - 1, _p(off), _p(verts), _p(F0), _p(sigma))
+
+    def step(self, nticks=1):
+        lib().csfo_step(self.h, int(nticks))
+
+    def calc_forces_range(self, lo, hi):
+        lib().csfo_calc_forces_range(self.h, lo, hi)
+
+    def integrate_range(self, lo, hi):
+        lib().csfo_integrate_range(self.h, lo, hi)
+
+    def update_snapshot_range(self, lo, hi):
+        lib().csfo_update_snapshot_range(self.h, lo, hi)
+
+    def state(self):
+        out = np.zeros((self.n, self.ns))
+        lib().csfo_get_state(self.h, _p(out))
+        return out
+
+    def forces(self):
+        fx = np.zeros(self.n); fy = np.zeros(self.n)
+        lib().csfo_get_forces(self.h, _p(fx), _p(fy))
+        return fx, fy
+
+    def force_parts(self):
+        a = [np.zeros(self.n) for _ in range(4)]
+        lib().csfo_get_force_parts(self.h, *[_p(x) for x in a])
+        return a
+
+    def nav(self):
+        ptr = np.zeros(self.n, dtype=np.int32); zn = np.zeros((self.n, 3), dtype=np.uint8)
+        i = np.zeros(self.n, dtype=np.int32); st = np.zeros(self.n, dtype=np.uint32)
+        lib().csfo_get_nav(self.h, _p(ptr), _p(zn), _p(i), _p(st))
+        return ptr, zn.astype(bool), i, st
+
+    def snapshot(self, lo, hi):
+        out = np.zeros((hi - lo, 4))
+        lib().csfo_get_snapshot(self.h, lo, hi, _p(out))
+        return out
+
+    def set_snapshot(self, lo, hi, snap):
+        snap = np.ascontiguousarray(snap, dtype=np.float64)
+        lib().csfo_set_snapshot(self.h, lo, hi, _p(snap))
+
+    def dest_force(self, a):
+        fx, fy = C.c_double(), C.c_double()
+        lib().csfo_dest_force(self.h, a, C.byref(fx), C.byref(fy))
+        return fx.value, fy.value
+
+    def apply_forces(self, Fx, Fy):
+        Fx = np.ascontiguousarray(Fx, dtype=np.float64); Fy = np.ascontiguousarray(Fy, dtype=np.float64)
+        lib().csfo_apply_forces(self.h, _p(Fx), _p(Fy))
+
+
+def num_threads():
+    return lib().csfo_num_threads()

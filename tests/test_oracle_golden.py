@@ -1,0 +1,175 @@
+"""Pins the CPU oracle (oracle/csf_oracle.c) to the golden vectors captured from the literal reference.
+
+Every case cites the reference function it pins.  Tolerances: 1e-12 relative where the oracle follows
+the same arithmetic; 2e-7 on single calls where the reference itself goes through an iterative solver (MINPACK lm,
+dynamics.py:1070) or FITPACK (vehicle.py:1496-1510).  Measured: population trajectories agree with the
+literal reference to <= 1.1e-11 absolute over 150-3100 ticks (1e-9 asserted).
+"""
+import numpy as np
+import pytest
+
+from oracle import csf_oracle as orc
+
+
+def test_limit_angle_and_angle_difference(golden):
+    g = golden("utils")
+    got = np.array([orc.limit_angle(t) for t in g["a"]])
+    np.testing.assert_allclose(got, g["limitAngle"], rtol=0, atol=1e-15)         # utils.py:124-139
+    got = np.array([orc.angle_difference(p, q) for p, q in zip(g["a1"], g["a2"])])
+    np.testing.assert_allclose(got, g["angleDifference"], rtol=0, atol=1e-15)    # utils.py:151-182
+    lx, ly = orc.limit_magnitude(g["x"], g["y"], g["r"])
+    np.testing.assert_allclose(lx, g["lx"], rtol=1e-15)                          # utils.py:56-86
+    np.testing.assert_allclose(ly, g["ly"], rtol=1e-15)
+
+
+def test_pair_field_twod(golden):
+    """vehicle.py:1560-1648 (TwoDBicycle.calcRepulsiveForce)."""
+    g = golden("pair_fields")
+    p = orc.default_params("twod")
+    fx = np.zeros(g["x"].size); fy = np.zeros(g["x"].size)
+    for k in range(g["x"].size):
+        a, b = orc.pair_twod(p, g["src"][k], g["x"][k:k + 1], g["y"][k:k + 1], g["psi"][k:k + 1])
+        fx[k], fy[k] = a[0], b[0]
+    scale = np.hypot(g["twod_fx"], g["twod_fy"])
+    np.testing.assert_allclose(fx, g["twod_fx"], rtol=1e-11, atol=1e-13 * scale.max())
+    np.testing.assert_allclose(fy, g["twod_fy"], rtol=1e-11, atol=1e-13 * scale.max())
+    # survey known answers
+    np.testing.assert_allclose(fx[:4], [1.4335766673611808e-01, -5.5699677693686585e-03,
+                                        -3.6663914817607920e-03, 6.3346542039922857e+00], rtol=1e-12)
+
+
+def test_pair_field_bicycle(golden):
+    """vehicle.py:1054-1147 (Bicycle.calcRepulsiveForce / calcPotential / updateExcentricity)."""
+    g = golden("pair_fields")
+    p = orc.default_params("bicycle")
+    fx = np.zeros(g["x"].size); fy = np.zeros(g["x"].size)
+    for k in range(g["x"].size):
+        a, b = orc.pair_bicycle(p, g["src"][k], g["src_v"][k], g["x"][k:k + 1], g["y"][k:k + 1])
+        fx[k], fy[k] = a[0], b[0]
+    np.testing.assert_allclose(fx, g["bicycle_fx"], rtol=1e-11, atol=1e-14)
+    np.testing.assert_allclose(fy, g["bicycle_fy"], rtol=1e-11, atol=1e-14)
+
+
+def test_pair_field_guard_far_apart():
+    """Deviation D1: where the reference underflows to 0/0 the oracle returns exactly 0 (SURVEY finding 4)."""
+    p = orc.default_params("twod")
+    fx, fy = orc.pair_twod(p, (0.0, 0.0, 0.0), np.array([-3000.0, 0.0]), np.array([8000.0, 0.0]),
+                           np.array([0.0, 0.3]))
+    assert fx[0] == 0.0 and fy[0] == 0.0          # underflow
+    assert fx[1] == 0.0 and fy[1] == 0.0          # coincident (D2)
+    assert np.isfinite(fx).all() and np.isfinite(fy).all()
+
+
+@pytest.mark.parametrize("tag", ["n2", "n3", "n16", "n32", "n16_p2r"])
+def test_untracked_masks_and_totals(golden, tag):
+    """intersection.py:690-745 (get_untracked_foes) and 747-864 (calc_forces)."""
+    g = golden("masks_totals")
+    rule = int(g[f"{tag}_p2r"])
+    p = orc.default_params("twod", priority_rule=rule)
+    s0 = g[f"{tag}_s0"]
+    U = orc.untracked_matrix(p.hfov, rule, s0[:, 0], s0[:, 1], s0[:, 2])
+    np.testing.assert_array_equal(U, g[f"{tag}_untracked0"])
+    pop = orc.Population(p, s0, g[f"{tag}_vdes"], g[f"{tag}_off"], g[f"{tag}_dq"])
+    pop.step(1)
+    s1 = pop.state()
+    np.testing.assert_allclose(s1, g[f"{tag}_s1"], rtol=1e-11, atol=1e-12)
+    U1 = orc.untracked_matrix(p.hfov, rule, s1[:, 0], s1[:, 1], s1[:, 2])
+    np.testing.assert_array_equal(U1, g[f"{tag}_untracked1"])
+    pop.calc_forces_range(0, pop.n)
+    fx, fy = pop.forces()
+    np.testing.assert_allclose(fx, g[f"{tag}_Fx1"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(fy, g[f"{tag}_Fy1"], rtol=1e-7, atol=1e-9)
+
+
+def test_control_move(golden):
+    """vehicle.py:1218-1272 (Bicycle.control + Bicycle.move) incl. the survey's known answer."""
+    g = golden("control_move")
+    for k in range(g["s"].shape[0]):
+        p = orc.default_params("bicycle" if g["is_bicycle"][k] else "twod")
+        out = orc.control_move(p, g["s"][k], np.r_[g["dest"][k, :2], 0.0], g["dest"][k, 2] != 0,
+                               g["F"][k, 0], g["F"][k, 1])
+        np.testing.assert_allclose(out, g["s_next"][k], rtol=1e-12, atol=1e-13, err_msg=f"case {k}")
+    np.testing.assert_allclose(g["s_next"][0], [1.0378922590640614, 2.011843424463476, 0.3029352011084877,
+                                                3.97, 0.07380026035475676], rtol=1e-14)
+
+
+@pytest.mark.parametrize("tag", ["demo_a", "turn", "stop_last", "stop_mid", "pp_turn"])
+def test_dest_force_runs(golden, tag):
+    """vehicle.py:354-457, 545-594, 1416-1558: single agent driven by its own destination force."""
+    g = golden("dest_force_runs")
+    model = str(g[f"{tag}_model"])
+    p = orc.default_params(model)
+    S = g[f"{tag}_s"]
+    dq = g[f"{tag}_dq"]
+    pop = orc.Population(p, S[:1], float(g[f"{tag}_vdes"]), np.array([0, dq.shape[0]]), dq)
+    T = g[f"{tag}_Fdest"].shape[0]
+    tol = 2e-7
+    for t in range(T):
+        fx, fy = pop.dest_force(0)
+        ptr, zn, i, st = pop.nav()
+        assert st[0] == 0
+        np.testing.assert_allclose([fx, fy], g[f"{tag}_Fdest"][t], rtol=tol, atol=tol, err_msg=f"tick {t}")
+        assert ptr[0] == g[f"{tag}_ptr"][t], f"tick {t}"
+        np.testing.assert_array_equal(zn[0], g[f"{tag}_znav"][t], err_msg=f"tick {t}")
+        pop.apply_forces([fx], [fy])
+        np.testing.assert_allclose(pop.state()[0], S[t + 1], rtol=tol, atol=tol, err_msg=f"tick {t}")
+
+
+def test_planarpoint_steps(golden):
+    """dynamics.py:996-1079 (closed-form implicit midpoint vs the reference's lm solve)."""
+    g = golden("planarpoint_steps")
+    p = orc.default_params("planarpoint")
+    for k in range(g["s01"].shape[0]):
+        s0 = g["s01"][k, :4]
+        pop = orc.Population(p, s0[None, :], 5.0, np.array([0, 1]), np.array([[s0[0], s0[1], 0.0]]))
+        pop.apply_forces([g["F01"][k, 0]], [g["F01"][k, 1]])
+        np.testing.assert_allclose(pop.state()[0], g["s01"][k, 4:], rtol=1e-7, atol=1e-8)
+        pop.apply_forces([g["F01"][k, 2]], [g["F01"][k, 3]])
+        np.testing.assert_allclose(pop.state()[0], g["s2"][k], rtol=1e-7, atol=1e-8)
+
+
+def test_road_edges(golden):
+    """intersection.py:118-242 on the scenarios/curve-scenario.py:63-81 geometry."""
+    g = golden("road_edges")
+    fx, fy = orc.road_force(g["verts"], g["off"], g["F0"], g["sigma"], g["x"], g["y"])
+    np.testing.assert_allclose(fx, g["Fx"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(fy, g["Fy"], rtol=1e-11, atol=1e-13)
+
+
+def test_expm_against_scipy():
+    from scipy.linalg import expm
+    rng = np.random.default_rng(0)
+    for scale in (0.01, 1.0, 30.0, 400.0):
+        A = rng.normal(size=(6, 6)) * scale / 6
+        A -= np.eye(6) * scale * 0.5
+        np.testing.assert_allclose(orc.expm(A), expm(A), rtol=1e-9, atol=1e-12)
+
+
+TRAJ = [
+    # (prefix, model, rule, rtol on positions) — intersection.py:866-896 end to end
+    ("demo_twod", "twod", 0, 1e-9), ("demo_bicycle", "bicycle", 0, 1e-9),
+    ("demo_planarpoint", "planarpoint", 0, 1e-9), ("demo_invpend", "invpend", 0, 1e-9),
+    ("dense_twod", "twod", 0, 1e-9), ("dense_bicycle", "bicycle", 0, 1e-9),
+    ("dense_planarpoint", "planarpoint", 0, 1e-9), ("dense_invpend", "invpend", 0, 1e-9),
+    ("p2r_twod", "twod", 1, 1e-9), ("road_pp", "planarpoint", 0, 1e-9), ("lap_twod", "twod", 0, 1e-9),
+]
+
+
+@pytest.mark.parametrize("prefix,model,rule,tol", TRAJ)
+def test_population_trajectories(golden, prefix, model, rule, tol):
+    g = golden("trajectories")
+    p = orc.default_params(model, priority_rule=rule)
+    pop = orc.Population(p, g[f"{prefix}_s0"], g[f"{prefix}_vdes"], g[f"{prefix}_off"], g[f"{prefix}_dq"])
+    if f"{prefix}_verts" in g.files:
+        pop.set_road(g[f"{prefix}_roff"], g[f"{prefix}_verts"], g[f"{prefix}_F0"], g[f"{prefix}_sigma"])
+    S = g[f"{prefix}_S"]
+    F = g[f"{prefix}_F"]
+    every = {"lap_twod": 50}.get(prefix, 10)
+    for k in range(1, S.shape[0]):
+        pop.step(every)
+        got = pop.state()
+        np.testing.assert_allclose(got, S[k], rtol=tol, atol=tol * 10, err_msg=f"{prefix} sample {k}")
+        fx, fy = pop.forces()
+        np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=100 * tol, atol=100 * tol,
+                                   err_msg=f"{prefix} forces sample {k}")
+    assert (pop.nav()[3] == 0).all()
