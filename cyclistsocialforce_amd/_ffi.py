@@ -1,0 +1,113 @@
+"""ctypes binding of libcsf_hip.so (include/csf.h).
+
+The library is the only compute path of this package: if it is missing or cannot be loaded the import of
+the engine fails loudly — there is no NumPy/CPU fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcsf_hip.so")
+
+BICYCLE, TWOD, INVPEND, PLANARPOINT = 0, 1, 2, 3
+UNREGULATED, P2R = 0, 1
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4}
+UNIQUE_ID_BYTES = 128
+ST_SPLINE, ST_NAN, ST_NAVSTATE = 1, 2, 4
+
+# every symbol include/csf.h declares (tests check that the library exports all of them)
+SYMBOLS = (
+    "csf_create", "csf_destroy", "csf_last_error", "csf_abi_version", "csf_add_agents", "csf_remove_agents",
+    "csf_set_dest_queue", "csf_set_road_vertices", "csf_set_params", "csf_set_v_desired",
+    "csf_set_priority_rule", "csf_push_state", "csf_num_agents", "csf_num_states", "csf_step", "csf_sync",
+    "csf_calc_forces", "csf_apply_forces", "csf_dest_force", "csf_get_state", "csf_get_forces",
+    "csf_get_force_parts", "csf_status", "csf_enable_history", "csf_get_history", "csf_pair_force",
+    "csf_comm_unique_id", "csf_comm_init", "csf_shard_range", "csf_profile_enable", "csf_profile_read",
+)
+
+
+class Params(C.Structure):
+    """csf_params of include/csf.h (field order is ABI)."""
+
+    _fields_ = [
+        ("t_s", C.c_double), ("d_arrived_inter", C.c_double), ("d_arrived_stop", C.c_double),
+        ("v_max_stop", C.c_double), ("v_max_harddecel", C.c_double), ("hfov", C.c_double),
+        ("f_0", C.c_double), ("e_0", C.c_double), ("e_1", C.c_double),
+        ("sigma_0", C.c_double), ("sigma_1", C.c_double), ("sigma_2", C.c_double), ("sigma_3", C.c_double),
+        ("v_max_riding", C.c_double * 2), ("p_decay", C.c_double), ("p_0", C.c_double),
+        ("l", C.c_double), ("l_2", C.c_double), ("delta_max", C.c_double),
+        ("a_max", C.c_double * 2), ("a_desired_default", C.c_double * 2),
+        ("k_p_v", C.c_double), ("k_p_delta", C.c_double), ("g", C.c_double),
+        ("h", C.c_double), ("m", C.c_double), ("i_bike_longlong", C.c_double),
+        ("i_steer_vertvert", C.c_double), ("c_steer", C.c_double),
+        ("v_max_walk", C.c_double), ("delta_max_walk", C.c_double),
+        ("k_psi", C.c_double),
+        ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libcsf_hip.so; raises EngineError if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cyclistsocialforce_amd/csrc`). This package has no CPU fallback."
+        )
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the machine
+        raise EngineError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+    L.csf_create.restype = vp
+    L.csf_create.argtypes = [C.POINTER(Params), i64, i32]
+    L.csf_destroy.argtypes = [vp]
+    L.csf_last_error.restype = C.c_char_p
+    L.csf_last_error.argtypes = [vp]
+    L.csf_abi_version.restype = i32
+    L.csf_add_agents.argtypes = [vp, i64, dp, dp]
+    L.csf_remove_agents.argtypes = [vp, i64, vp]
+    L.csf_set_dest_queue.argtypes = [vp, i64, vp, vp, dp, i32]
+    L.csf_set_road_vertices.argtypes = [vp, i32, vp, dp, dp, dp]
+    L.csf_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.csf_set_v_desired.argtypes = [vp, i64, vp, dp]
+    L.csf_set_priority_rule.argtypes = [vp, i32]
+    L.csf_push_state.argtypes = [vp, i64, vp, dp]
+    L.csf_num_agents.restype = i64
+    L.csf_num_agents.argtypes = [vp]
+    L.csf_num_states.restype = i32
+    L.csf_num_states.argtypes = [vp]
+    L.csf_step.argtypes = [vp, i64]
+    L.csf_sync.argtypes = [vp]
+    L.csf_calc_forces.argtypes = [vp]
+    L.csf_apply_forces.argtypes = [vp, dp, dp]
+    L.csf_dest_force.argtypes = [vp, dp, dp]
+    L.csf_get_state.argtypes = [vp, dp, vp, vp, C.POINTER(i64)]
+    L.csf_get_forces.argtypes = [vp, dp, dp]
+    L.csf_get_force_parts.argtypes = [vp, dp, dp, dp, dp]
+    L.csf_status.argtypes = [vp, vp]
+    L.csf_enable_history.argtypes = [vp, i32, i32]
+    L.csf_get_history.argtypes = [vp, i64, i64, dp]
+    L.csf_pair_force.argtypes = [vp, dp, i64, dp, dp, dp, i32, dp, dp]
+    L.csf_comm_unique_id.argtypes = [vp]
+    L.csf_comm_init.argtypes = [vp, vp, i32, i32]
+    L.csf_shard_range.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.csf_profile_enable.argtypes = [vp, i32]
+    L.csf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:  # default: status code
+            fn.restype = C.c_int
+    if L.csf_abi_version() != 1:
+        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 1")
+    _lib = L
+    return L

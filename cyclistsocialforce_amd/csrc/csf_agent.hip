@@ -1,0 +1,699 @@
+// csf_agent.hip — fused per-agent tick (fp64, one lane per agent, SoA state => coalesced).
+//
+// Replaces, per tick and per agent:
+//   PH_DEST       vehicle.calcDestinationForce: destination queue (vehicle.py:545-594), navigation state
+//                 machine (:354-457), straight-line force (:1150-1194, 2078-2108) or spline path planner
+//                 (:1416-1558; scipy splprep/splev restated as a closed 4..6-point cubic B-spline);
+//   PH_COMBINE    column-sum tail of calc_forces: limitMagnitude clamp to |F_dest|, + F_dest, + road
+//                 edges, store vehicle.force (intersection.py:841-862; utils.py:56-86);
+//   PH_INTEGRATE  vehicle.step: controller + kinematics (vehicle.py:1218-1289, 1386-1414, 1810-1950;
+//                 dynamics.py:996-1079), ring-buffer bookkeeping, and the refreshed (x, y, psi) snapshot
+//                 (intersection.py:660-677) written as the fp32 source record of the next tick.
+// The O(N) work is done in fp64 so that the only fp32 rounding in a tick is the pair sum.
+#include "csf_dev.h"
+
+namespace csf {
+
+constexpr double PI = 3.141592653589793238462643383279502884;
+
+// utils.py:124-139
+__device__ __forceinline__ double limit_angle(double th) {
+    th = floor(th / (2 * PI)) * (-2 * PI) + th;
+    if (th > PI) th -= 2 * PI;
+    else if (th < -PI) th += 2 * PI;
+    return th;
+}
+
+// utils.py:167-182: signed shortest rotation a1 -> a2 (ties resolve to +)
+__device__ __forceinline__ double angle_diff(double a1, double a2) {
+    double da = fabs(a1 - a2);
+    if (da > PI) da = 2 * PI - da;
+    double t1 = fabs(limit_angle(a1 - da) - a2), t2 = fabs(limit_angle(a1 + da) - a2);
+    return t1 < t2 ? -da : da;
+}
+
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmax(fmin(x, hi), lo); }
+
+// Registers of one agent while it is being ticked.
+struct Agent {
+    int64_t a;
+    double x, y, psi, v, delta, theta;
+    double vdes;
+    int64_t qb;   // first row of the destination queue
+    int32_t K;    // rows
+    int32_t ptr;
+    int32_t zn;   // 0 cruise, 1 brake, 2 arrived
+    double zv0, zd0, zd1;
+    int32_t ti;
+    uint32_t st;
+};
+
+__device__ __forceinline__ double qx(const Dev &d, const Agent &g, int k) { return d.q[g.qb + k]; }
+__device__ __forceinline__ double qy(const Dev &d, const Agent &g, int k) { return d.q[d.qcap + g.qb + k]; }
+__device__ __forceinline__ bool qstop(const Dev &d, const Agent &g, int k) {
+    return d.q[2 * d.qcap + g.qb + k] != 0.0;
+}
+
+// vehicle.py:596-604
+__device__ __forceinline__ double dest_dist(const Dev &d, const Agent &g) {
+    double ex = qx(d, g, g.ptr) - g.x, ey = qy(d, g, g.ptr) - g.y;
+    return sqrt(ex * ex + ey * ey);
+}
+
+// vehicle.py:545-594
+__device__ void update_destination(const Dev &d, Agent &g) {
+    if (g.zn != 0) return;                                    // :567-568
+    double dnext = dest_dist(d, g);
+    if (dnext <= d.p.d_arrived_inter) g.ptr = min(g.ptr + 1, g.K - 1);   // :571-574
+    if (g.ptr < g.K - 1) {                                    // :577-583
+        double ex = qx(d, g, g.ptr + 1) - g.x, ey = qy(d, g, g.ptr + 1) - g.y;
+        if (sqrt(ex * ex + ey * ey) < dnext) g.ptr += 1;
+    }
+}
+
+// vehicle.py:354-457.  Returns the desired speed; ddest through the reference argument.
+__device__ double update_nav(const Dev &d, Agent &g, double &ddest) {
+    const csf_params &p = d.p;
+    const double k = 1.5;                                     // :377
+    double d0, d1;
+    if (g.zn == 0) {                                          // :379-386
+        d0 = 0.5 * (p.v_max_harddecel * p.v_max_harddecel - g.v * g.v) / p.a_desired_default[0];
+        d1 = 0.5 * -(p.v_max_harddecel * p.v_max_harddecel) / p.a_max[0];
+    } else {
+        d0 = g.zd0;
+        d1 = g.zd1;
+    }
+    ddest = dest_dist(d, g);
+    bool x0 = qstop(d, g, g.ptr);                             // :397-400
+    bool x1 = ddest <= k * (d0 + d1), x2 = ddest <= p.d_arrived_stop, x3 = g.v <= p.v_max_stop;
+    bool z0 = g.zn == 0, z1 = g.zn == 1, z2 = g.zn == 2;
+    bool n0 = !x0 || (x0 && !x1 && ((z0 && !x2) || z1));      // :404-406
+    bool n1 = x0 && ((z0 && ((!x2 && x1) || (x2 && !x3))) || (z1 && x1 && (!x2 || !x3)));
+    bool n2 = x0 && (((z0 || z1) && x2 && x3) || z2);         // :414
+    if ((int)n0 + (int)n1 + (int)n2 != 1) g.st |= CSF_ST_NAVSTATE;  // reference only prints (:416-425)
+    if (z0 && n1) {                                           // :428-430
+        g.zv0 = g.v;
+        g.zd0 = d0;
+        g.zd1 = d1;
+    }
+    g.zn = n0 ? 0 : (n1 ? 1 : 2);
+    if (n0) return g.vdes;                                    // :434-435
+    if (n1) {                                                 // :436-450
+        if (ddest < k * g.zd1) return p.v_max_harddecel / g.zd1 * ddest * 1 / k;
+        return (g.zv0 - p.v_max_harddecel) / g.zd0 * (ddest - g.zd1) * 1 / k + p.v_max_harddecel;
+    }
+    return 0.0;                                               // :452-453
+}
+
+// vehicle.py:1150-1194 / 2078-2108
+__device__ void direct_approach(const Dev &d, Agent &g, double &fx, double &fy) {
+    update_destination(d, g);
+    double ddest, vd = update_nav(d, g, ddest);
+    if (ddest > 0) {
+        fx = -vd * (g.x - qx(d, g, g.ptr)) / ddest;
+        fy = -vd * (g.y - qy(d, g, g.ptr)) / ddest;
+    } else {
+        fx = 0;
+        fy = 0;
+    }
+}
+
+// ---- cubic B-spline through m in {4,5,6} points (scipy splprep(s=0) + splev, vehicle.py:1496-1510) ----
+// Chord-length parameter u, clamped knots with interior knots u[2..m-3].  The end conditions make the first
+// and last coefficient equal the end points, so only an (m-2)x(m-2) totally positive system remains; it is
+// eliminated without pivoting.  Evaluation returns position, first and second derivative at one parameter.
+struct Spline {
+    double t[10];
+    double cx[6], cy[6];
+    int n;
+};
+
+__device__ __forceinline__ int span_of(const Spline &s, double u) {
+    int l = 3;
+    while (l < s.n - 1 && u >= s.t[l + 1]) l++;
+    return l;
+}
+
+// non-zero cubic basis values N[0..3] at u in span l, plus the quadratic (N2[0..2]) and linear (N1[0..1]) ones
+__device__ __forceinline__ void basis(const Spline &s, int l, double u, double N3[4], double N2[3], double N1[2]) {
+    double a1 = u - s.t[l], b1 = s.t[l + 1] - u;
+    double w = 1.0 / (s.t[l + 1] - s.t[l]);
+    N1[0] = b1 * w;
+    N1[1] = a1 * w;
+    double a2 = u - s.t[l - 1], b2 = s.t[l + 2] - u;
+    double w0 = N1[0] / (s.t[l + 1] - s.t[l - 1]), w1 = N1[1] / (s.t[l + 2] - s.t[l]);
+    N2[0] = b1 * w0;
+    N2[1] = a2 * w0 + b2 * w1;
+    N2[2] = a1 * w1;
+    double a3 = u - s.t[l - 2], b3 = s.t[l + 3] - u;
+    double v0 = N2[0] / (s.t[l + 1] - s.t[l - 2]), v1 = N2[1] / (s.t[l + 2] - s.t[l - 1]),
+           v2 = N2[2] / (s.t[l + 3] - s.t[l]);
+    N3[0] = b1 * v0;
+    N3[1] = a3 * v0 + b2 * v1;
+    N3[2] = a2 * v1 + b3 * v2;
+    N3[3] = a1 * v2;
+}
+
+__device__ bool spline_fit(Spline &s, int m, const double *px, const double *py) {
+    double u[6];
+    u[0] = 0;
+    for (int r = 1; r < m; r++) {
+        double ex = px[r] - px[r - 1], ey = py[r] - py[r - 1];
+        double dd = sqrt(ex * ex + ey * ey);
+        if (!(dd > 0.0)) return false;  // splprep raises ValueError here
+        u[r] = u[r - 1] + dd;
+    }
+    double tot = u[m - 1];
+    for (int r = 1; r < m - 1; r++) u[r] /= tot;
+    u[m - 1] = 1.0;
+    s.n = m;
+    for (int j = 0; j < 4; j++) {
+        s.t[j] = 0.0;
+        s.t[m + j] = 1.0;
+    }
+    for (int j = 0; j < m - 4; j++) s.t[4 + j] = u[2 + j];
+    // interior unknowns c_1 .. c_{m-2}
+    const int q = m - 2;
+    double A[4][4], bx[4], by[4];
+    for (int r = 0; r < q; r++) {
+        for (int c = 0; c < q; c++) A[r][c] = 0.0;
+        double N3[4], N2[3], N1[2];
+        double ur = u[r + 1];
+        int l = span_of(s, ur);
+        basis(s, l, ur, N3, N2, N1);
+        double rx = px[r + 1], ry = py[r + 1];
+        for (int j = 0; j < 4; j++) {
+            int c = l - 3 + j;  // coefficient index
+            if (c == 0) {
+                rx -= N3[j] * px[0];
+                ry -= N3[j] * py[0];
+            } else if (c == m - 1) {
+                rx -= N3[j] * px[m - 1];
+                ry -= N3[j] * py[m - 1];
+            } else A[r][c - 1] = N3[j];
+        }
+        bx[r] = rx;
+        by[r] = ry;
+    }
+    for (int c = 0; c < q; c++) {
+        double piv = A[c][c];
+        if (piv == 0.0) return false;
+        for (int r = c + 1; r < q; r++) {
+            double f = A[r][c] / piv;
+            if (f != 0.0) {
+                for (int j = c; j < q; j++) A[r][j] -= f * A[c][j];
+                bx[r] -= f * bx[c];
+                by[r] -= f * by[c];
+            }
+        }
+    }
+    for (int r = q - 1; r >= 0; r--) {
+        double sx = bx[r], sy = by[r];
+        for (int j = r + 1; j < q; j++) {
+            sx -= A[r][j] * bx[j];
+            sy -= A[r][j] * by[j];
+        }
+        bx[r] = sx / A[r][r];
+        by[r] = sy / A[r][r];
+    }
+    s.cx[0] = px[0];
+    s.cy[0] = py[0];
+    for (int r = 0; r < q; r++) {
+        s.cx[r + 1] = bx[r];
+        s.cy[r + 1] = by[r];
+    }
+    s.cx[m - 1] = px[m - 1];
+    s.cy[m - 1] = py[m - 1];
+    return true;
+}
+
+__device__ void spline_pos(const Spline &s, double u, double &X, double &Y) {
+    double N3[4], N2[3], N1[2];
+    int l = span_of(s, u);
+    basis(s, l, u, N3, N2, N1);
+    X = 0;
+    Y = 0;
+    for (int j = 0; j < 4; j++) {
+        X += N3[j] * s.cx[l - 3 + j];
+        Y += N3[j] * s.cy[l - 3 + j];
+    }
+}
+
+__device__ void spline_der(const Spline &s, double u, double &dX, double &dY, double &ddX, double &ddY) {
+    double N3[4], N2[3], N1[2];
+    int l = span_of(s, u);
+    basis(s, l, u, N3, N2, N1);
+    double ex[3], ey[3];
+    for (int k = 0; k < 3; k++) {
+        double w = 3.0 / (s.t[l + k + 1] - s.t[l + k - 2]);
+        ex[k] = w * (s.cx[l - 2 + k] - s.cx[l - 3 + k]);
+        ey[k] = w * (s.cy[l - 2 + k] - s.cy[l - 3 + k]);
+    }
+    dX = N2[0] * ex[0] + N2[1] * ex[1] + N2[2] * ex[2];
+    dY = N2[0] * ey[0] + N2[1] * ey[1] + N2[2] * ey[2];
+    double gx[2], gy[2];
+    for (int k = 0; k < 2; k++) {
+        double w = 2.0 / (s.t[l + k + 1] - s.t[l + k - 1]);
+        gx[k] = w * (ex[k + 1] - ex[k]);
+        gy[k] = w * (ey[k + 1] - ey[k]);
+    }
+    ddX = N1[0] * gx[0] + N1[1] * gx[1];
+    ddY = N1[0] * gy[0] + N1[1] * gy[1];
+}
+
+// vehicle.py:1416-1558
+__device__ void twod_dest(const Dev &d, Agent &g, double &fx, double &fy) {
+    const int nSplV = 4, nS = 20, ipred = 3, ipredlast = 5;   // :1444-1448
+    update_destination(d, g);                                 // :1451
+    double ddest, vd = update_nav(d, g, ddest);               // :1452
+    if (g.ti == 0) {                                          // :1455-1458
+        fx = vd * cos(g.psi);
+        fy = vd * sin(g.psi);
+        return;
+    }
+    if (g.zn == 2) {                                          // :1461-1462
+        fx = 0;
+        fy = 0;
+        return;
+    }
+    const int hm = d.hist_len - 1;
+    double px[6], py[6];
+    int m;
+    bool last = g.ptr + 1 >= g.K;                             // :537-543
+    if (!last) {                                              // :1465-1479
+        px[0] = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
+        py[0] = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
+        px[1] = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a];
+        py[1] = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
+        int hi = min(g.ptr + nSplV, g.K);
+        m = 2;
+        for (int k = g.ptr; k < hi; k++, m++) {
+            px[m] = qx(d, g, k);
+            py[m] = qy(d, g, k);
+        }
+    } else {                                                  // :1486-1492
+        int back = max(0, g.ti - d.back);
+        px[0] = d.hx[(int64_t)(back & hm) * d.cap + g.a];
+        py[0] = d.hy[(int64_t)(back & hm) * d.cap + g.a];
+        px[1] = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
+        py[1] = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
+        px[2] = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a];
+        py[2] = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
+        px[3] = qx(d, g, g.ptr);
+        py[3] = qy(d, g, g.ptr);
+        m = 4;
+    }
+    Spline s;
+    if (!spline_fit(s, m, px, py)) {                          // :1495-1507 raises in the reference
+        g.st |= CSF_ST_SPLINE;
+        fx = 0;
+        fy = 0;
+        return;
+    }
+    int i = 1;                                                // :1516-1522
+    if (last) {
+        double best = INFINITY;
+        for (int k = 0; k < nS; k++) {
+            double X, Y;
+            spline_pos(s, k == nS - 1 ? 1.0 : (double)k / (nS - 1), X, Y);
+            double dd = (X - g.x) * (X - g.x) + (Y - g.y) * (Y - g.y);
+            if (dd < best) {
+                best = dd;
+                i = k;
+            }
+        }
+    }
+    int iprev = i + (qstop(d, g, g.ptr) ? ipredlast : ipred); // :1523-1526
+    if (iprev < nS) {                                         // :1529-1553
+        double ui = i == nS - 1 ? 1.0 : (double)i / (nS - 1);
+        double up = iprev == nS - 1 ? 1.0 : (double)iprev / (nS - 1);
+        double X0, Y0, X1, Y1, dX, dY, ddX, ddY;
+        spline_pos(s, ui, X0, Y0);
+        spline_pos(s, up, X1, Y1);
+        spline_der(s, ui, dX, dY, ddX, ddY);
+        double sp = sqrt(dX * dX + dY * dY);
+        double R = sp * sp * sp / fabs(dX * ddY - dY * ddX);  // :1532-1537
+        const double thetacomf = 10 * (2 * PI / 360);         // :1541
+        double v = fmax(2.5, sqrt(thetacomf * d.p.g * R));    // :1542-1544
+        v = fmin(v, vd);                                      // :1545
+        double ex = X1 - X0, ey = Y1 - Y0;
+        double tmp = v / sqrt(ex * ex + ey * ey);             // :1548-1553
+        fx = tmp * ex;
+        fy = tmp * ey;
+    } else {
+        direct_approach(d, g, fx, fy);                        // :1555-1556 (second queue + nav update)
+    }
+}
+
+template <int MODEL>
+__device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, double &fy) {
+    if (MODEL == CSF_BICYCLE) direct_approach(d, g, fx, fy);  // vehicle.py:1189-1194
+    else {
+        if (MODEL == CSF_PLANARPOINT) update_destination(d, g);  // Vehicle.calcDestinationForce :295-297
+        twod_dest(d, g, fx, fy);
+    }
+}
+
+// vehicle.py:1218-1272 (Bicycle.control + Bicycle.move; PIDcontroller with ki = kd = 0, dynamics.py:33-54)
+__device__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) {
+    const csf_params &p = d.p;
+    double theta = atan2(Fy, Fx);                             // :1223
+    double vd = sqrt(Fx * Fx + Fy * Fy);                      // :1224
+    double ddest = dest_dist(d, g);                           // :1226-1229
+    if (ddest < 3 && g.ptr + 1 >= g.K) vd = (vd / 3) * ddest; // :1231-1232
+    double target = angle_diff(g.psi, theta);                 // :1235
+    double om = p.k_p_delta * angle_diff(g.delta, target);    // :1239-1242
+    double acc = p.k_p_v * (vd - g.v);                        // :1240-1243
+    acc = clampd(acc, p.a_max[0], p.a_max[1]);                // :1249
+    double delta = limit_angle(g.delta + p.t_s * om);         // :1254
+    double v = g.v + p.t_s * acc;                             // :1255
+    delta = clampd(delta, -p.delta_max, p.delta_max);         // :1257
+    v = clampd(v, p.v_max_riding[0], p.v_max_riding[1]);      // :1258
+    double psi = limit_angle(g.psi + p.t_s * v * tan(delta) / p.l);  // :1260-1262
+    g.y += p.t_s * v * sin(psi);                              // :1264
+    g.x += p.t_s * v * cos(psi);                              // :1265
+    g.psi = psi;
+    g.v = v;
+    g.delta = delta;
+}
+
+// ---- InvPendulum: exact zero-order-hold step of the speed-dependent closed loop -------------------------
+// vehicle.py:1738-1786, 1810-1848; parameters.py:1832-1892.  control.forced_response over [0, t_s] with
+// constant input equals x+ = E11 x + E12 u with E = exp([[A h, B h],[0, 0]]).  E is formed by scaling and
+// squaring of a degree-12 Taylor polynomial (||M/2^s||_1 <= 1/2); only the 5 non-trivial rows are carried.
+__device__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, double Fy) {
+    const csf_params &p = d.p;
+    const double v = g.v;
+    const double iv = 1.0 / v, iv2 = iv * iv, iv3 = iv2 * iv;
+    const double kx0 = 3.48203226e02 - 5.12057324e03 * iv + 1.58364873e04 * iv2 - 1.98073306e04 * iv3;
+    const double kx1 = -4.51700000e01;
+    const double kx2 = -9.16379250e02 + 1.31769807e04 * iv - 6.57341643e04 * iv2 + 8.22163589e04 * iv3;
+    const double kx3 = 3.20214069e02 - 4.69953797e03 * iv + 1.66378680e04 * iv2 - 2.43114309e04 * iv3;
+    const double kx4 = 2.87549256e-08 - 2.27913445e03 * iv;
+    const double ku = -3.38638984e-09 - 2.27913445e+03 * iv;
+    const double Ktau2 = (v * p.l_2) / (p.g * p.l), K = (v * v) / (p.g * p.l), tau3 = p.l / v;
+    const double tau1sq = (p.i_bike_longlong + p.m * p.h * p.h) / (p.m * p.g * p.h);
+    const double bI = 1.0 / p.i_steer_vertvert, h = p.t_s;
+    double M[5][6];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) M[r][c] = 0.0;
+    M[0][1] = h;
+    M[1][0] = -bI * kx0 * h;
+    M[1][1] = (-p.c_steer * bI - bI * kx1) * h;
+    M[1][2] = -bI * kx2 * h;
+    M[1][3] = -bI * kx3 * h;
+    M[1][4] = -bI * kx4 * h;
+    M[1][5] = ku * bI * h;
+    M[2][3] = h;
+    M[3][0] = -K / tau1sq * h;
+    M[3][1] = -Ktau2 / tau1sq * h;
+    M[3][2] = 1 / tau1sq * h;
+    M[4][0] = 1 / tau3 * h;
+    double nrm = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double col = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) col += fabs(M[r][c]);
+        nrm = fmax(nrm, col);
+    }
+    int sq = 0;
+    while (nrm > 0.5 && sq < 40) {
+        nrm *= 0.5;
+        sq++;
+    }
+    const double sc = ldexp(1.0, -sq);
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) M[r][c] *= sc;
+    // Horner: E = I + M (I + M/2 (I + M/3 (... (I + M/12))))   — rows 0..4; row 5 of every term is e5
+    double E[5][6];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) E[r][c] = (r == c ? 1.0 : 0.0) + M[r][c] * (1.0 / 12);
+    for (int k = 11; k >= 1; k--) {
+        double T[5][6];
+        const double ik = 1.0 / k;
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double acc = (c == 5) ? M[r][5] : 0.0;  // M[:,5] * E[5][c], E row 5 = e5
+#pragma unroll
+                for (int q = 0; q < 5; q++) acc += M[r][q] * E[q][c];
+                T[r][c] = (r == c ? 1.0 : 0.0) + acc * ik;
+            }
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) E[r][c] = T[r][c];
+    }
+    for (int it = 0; it < sq; it++) {
+        double T[5][6];
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double acc = (c == 5) ? E[r][5] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 5; q++) acc += E[r][q] * E[q][c];
+                T[r][c] = acc;
+            }
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) E[r][c] = T[r][c];
+    }
+    const double psi_d = atan2(Fy, Fx);                       // :1832
+    double xn[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        double acc = E[r][5] * psi_d;
+#pragma unroll
+        for (int c = 0; c < 5; c++) acc += E[r][c] * xl[c];
+        xn[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < 5; r++) xl[r] = xn[r];                // :1843
+    g.psi = limit_angle(xn[4]);                               // :1844
+    g.delta = limit_angle(xn[0]);                             // :1845
+    g.theta = limit_angle(xn[2]);                             // :1846
+}
+
+template <int MODEL>
+__device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
+    const csf_params &p = d.p;
+    const int64_t a = g.a, cap = d.cap;
+    if (MODEL == CSF_BICYCLE) {                               // vehicle.py:1274-1289
+        bike_control_move(d, g, Fx, Fy);
+    } else if (MODEL == CSF_TWOD) {                           // vehicle.py:1386-1414
+        if (g.zn == 2) {
+            g.v = 0;
+            g.delta = 0;
+        } else bike_control_move(d, g, Fx, Fy);
+    } else if (MODEL == CSF_INVPEND) {                        // vehicle.py:1883-1950
+        bool riding = d.zrid[a] != 0;
+        // updateRidingState (:1932-1950): the slice traj[4, imin:i+1] is all inside +-delta_max_walk iff the
+        // run of good samples ending at column i is at least as long as the slice
+        bool cvwalk = g.v < p.v_max_walk;
+        int imin = max(0, (int)((double)g.ti - 1.0 / p.t_s));
+        bool cdelta = d.dgood[a] >= (g.ti - imin + 1);
+        riding = !cvwalk && ((!riding && cdelta) || riding);
+        d.zrid[a] = riding ? 1 : 0;
+        double xl[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) xl[k] = d.lti[k * cap + a];
+        if (g.zn == 2) {                                      // :1898-1899
+            g.v = 0;
+            g.delta = 0;
+            g.theta = 0;
+        } else if (riding) {
+            double vd = sqrt(Fx * Fx + Fy * Fy);              // step_pos :1850-1881 (old psi)
+            double acc = clampd(p.k_p_v * (vd - g.v), p.a_max[0], p.a_max[1]);
+            double v = clampd(g.v + p.t_s * acc, p.v_max_riding[0], p.v_max_riding[1]);
+            g.y += p.t_s * v * sin(g.psi);
+            g.x += p.t_s * v * cos(g.psi);
+            g.v = v;
+            invpend_step_yaw(d, g, xl, Fx, Fy);               // uses the new speed (:1902-1903)
+        } else {                                              // walking :1905-1916
+            g.v = p.v_max_walk;
+            g.theta = 0;
+            bike_control_move(d, g, Fx, Fy);
+            xl[0] = g.delta;
+            xl[1] = 0;
+            xl[2] = g.theta;
+            xl[3] = 0;
+            xl[4] = g.psi;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) d.lti[k * cap + a] = xl[k];
+    } else {                                                  // PlanarPoint: dynamics.py:996-1079
+        double vd = sqrt(Fx * Fx + Fy * Fy);                  // :1018
+        double acc = clampd(p.k_p_v * (vd - g.v), p.a_max[0], p.a_max[1]);
+        double v = clampd(g.v + p.t_s * acc, p.v_max_riding[0], p.v_max_riding[1]);
+        double psi_c = limit_angle(atan2(Fy, Fx));            // dynamics.py:112-121
+        double vbar = 0.5 * (v + g.v);                        // :1065
+        // implicit midpoint of psi' = -k (psi - psi_c), x' = v cos psi, y' = v sin psi in closed form
+        double hk = p.t_s * p.k_psi, pu = d.ppsi[a];
+        double pn = (pu * (1 - 0.5 * hk) + hk * psi_c) / (1 + 0.5 * hk);
+        double pm = 0.5 * (pu + pn);
+        g.x += p.t_s * vbar * cos(pm);
+        g.y += p.t_s * vbar * sin(pm);
+        d.ppsi[a] = pn;
+        g.psi = limit_angle(pn);                              // :959-964
+        g.v = v;
+    }
+    // ring-buffer bookkeeping — vehicle.py:1279-1282, 1407-1410, 1923-1926
+    g.ti = (g.ti + 1) % p.traj_len;
+    const int slot = g.ti & (d.hist_len - 1);
+    d.hx[(int64_t)slot * cap + a] = g.x;
+    d.hy[(int64_t)slot * cap + a] = g.y;
+    if (MODEL == CSF_INVPEND) {
+        bool good = (-p.delta_max_walk < g.delta) && (p.delta_max_walk > g.delta);
+        int run = d.dgood[a];
+        d.dgood[a] = good ? min(run + 1, 1 << 30) : 0;
+    }
+}
+
+// fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677
+__device__ __forceinline__ void write_record(const Dev &d, int64_t a, double x, double y, double psi, double v) {
+    d.rec[a] = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)cos(psi), (float)sin(psi));
+    if (d.p.model == CSF_BICYCLE) {                           // vehicle.py:1062-1064 (v <= 0: e := 0)
+        double e = 0.0;
+        if (v > 0.0) e = fmin(pow(v / d.p.v_max_riding[1], 0.1), 0.7);
+        d.rec2[a] = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
+    }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
+    const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= d.hi) return;
+    const int64_t cap = d.cap;
+    Agent g;
+    g.a = a;
+    g.x = d.s[a];
+    g.y = d.s[cap + a];
+    g.psi = d.s[2 * cap + a];
+    g.v = d.s[3 * cap + a];
+    g.delta = d.s[4 * cap + a];
+    g.theta = d.s[5 * cap + a];
+    g.vdes = d.vdes[a];
+    g.qb = d.qoff[a];
+    g.K = (int32_t)(d.qoff[a + 1] - g.qb);
+    g.ptr = d.ptr[a];
+    g.zn = d.znav[a] & 3;
+    g.zv0 = d.znp[a];
+    g.zd0 = d.znp[cap + a];
+    g.zd1 = d.znp[2 * cap + a];
+    g.ti = d.ti[a];
+    g.st = d.status[a];
+
+    double fdx, fdy;
+    if (phases & PH_DEST) {
+        dest_force<MODEL>(d, g, fdx, fdy);
+        d.F[2 * cap + a] = fdx;
+        d.F[3 * cap + a] = fdy;
+        d.ptr[a] = g.ptr;
+        d.znav[a] = (uint8_t)g.zn;
+        d.znp[a] = g.zv0;
+        d.znp[cap + a] = g.zd0;
+        d.znp[2 * cap + a] = g.zd1;
+    } else {
+        fdx = d.F[2 * cap + a];
+        fdy = d.F[3 * cap + a];
+    }
+    double Fx, Fy;
+    if (phases & PH_COMBINE) {
+        double rx = 0, ry = 0;
+        Fx = fdx;
+        Fy = fdy;
+        if (d.n > 1) {                                        // intersection.py:813, 825, 849-851
+            for (int c = 0; c < d.n_split; c++) {             // fixed order: reproducible
+                float2 pr = d.part[(int64_t)c * cap + a];
+                rx += (double)pr.x;
+                ry += (double)pr.y;
+            }
+            double rin = sqrt(rx * rx + ry * ry), lim = sqrt(fdx * fdx + fdy * fdy);
+            if (rin > lim) {                                  // utils.py:79-84
+                rx = rx * lim / rin;
+                ry = ry * lim / rin;
+            }
+            Fx = rx + fdx;                                    // :847-848
+            Fy = ry + fdy;
+        }
+        if (d.nv > 0) {                                       // :854-857
+            float2 fr = d.froad[a];
+            Fx += (double)fr.x;
+            Fy += (double)fr.y;
+        }
+        d.F[a] = Fx;                                          // :860-861
+        d.F[cap + a] = Fy;
+        d.F[4 * cap + a] = rx;
+        d.F[5 * cap + a] = ry;
+        if (!(isfinite(Fx) && isfinite(Fy))) g.st |= CSF_ST_NAN;
+    } else {
+        Fx = d.F[a];
+        Fy = d.F[cap + a];
+    }
+    if (phases & PH_INTEGRATE) {
+        integrate<MODEL>(d, g, Fx, Fy);
+        d.s[a] = g.x;
+        d.s[cap + a] = g.y;
+        d.s[2 * cap + a] = g.psi;
+        d.s[3 * cap + a] = g.v;
+        d.s[4 * cap + a] = g.delta;
+        d.s[5 * cap + a] = g.theta;
+        d.ti[a] = g.ti;
+        write_record(d, a, g.x, g.y, g.psi, g.v);
+        if (d.hist != nullptr) {
+            int64_t t1 = d.tick + 1;
+            if (t1 % d.hist_stride == 0) {
+                int64_t smp = (t1 / d.hist_stride - 1) % d.hist_cap;
+                double *o = d.hist + (smp * d.n + a) * d.ns;
+                o[0] = g.x;
+                o[1] = g.y;
+                o[2] = g.psi;
+                o[3] = g.v;
+                if (d.ns > 4) o[4] = g.delta;
+                if (d.ns > 5) o[5] = g.theta;
+            }
+        }
+    }
+    d.status[a] = g.st;
+}
+
+// (re)build the fp32 records, the short position ring and the model side-state from the fp64 state:
+// Vehicle.__init__ (vehicle.py:154-160, 1728-1736; dynamics.py:828) and update_road_user_positions (:660-677)
+__global__ void records_kernel(const Dev d) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= d.n_pad) return;
+    if (a >= d.n) {  // sentinel: far away, contributes exactly 0 (exp2 underflow), never NaN
+        d.rec[a] = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
+        if (d.p.model == CSF_BICYCLE) d.rec2[a] = make_float2(0.0f, 1.0f);
+        return;
+    }
+    write_record(d, a, d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);
+}
+
+void launch_agent(const Dev &d, int phases, hipStream_t st) {
+    if (d.hi <= d.lo) return;
+    dim3 g((unsigned)((d.hi - d.lo + 255) / 256)), b(256);
+    switch (d.p.model) {
+    case CSF_BICYCLE: hipLaunchKernelGGL(agent_kernel<CSF_BICYCLE>, g, b, 0, st, d, phases); break;
+    case CSF_TWOD: hipLaunchKernelGGL(agent_kernel<CSF_TWOD>, g, b, 0, st, d, phases); break;
+    case CSF_INVPEND: hipLaunchKernelGGL(agent_kernel<CSF_INVPEND>, g, b, 0, st, d, phases); break;
+    default: hipLaunchKernelGGL(agent_kernel<CSF_PLANARPOINT>, g, b, 0, st, d, phases); break;
+    }
+}
+
+void launch_records(const Dev &d, hipStream_t st) {
+    if (d.n_pad <= 0) return;
+    hipLaunchKernelGGL(records_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+}
+
+}  // namespace csf

@@ -1,0 +1,79 @@
+// csf_dev.h — device-side view of one engine: SoA agent state in HBM, shared by the pair kernel
+// (csf_pair.hip), the per-agent kernel (csf_agent.hip) and the host engine (csf_engine.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/csf.h"
+
+namespace csf {
+
+constexpr int WAVE = 64;
+constexpr int MAX_SPLIT = 64;  // max source chunks (partial sums per receiver)
+
+// fp32 constants of the pair kernel, derived on the host from csf_params.
+struct PairConsts {
+    float sg0, sg1, sg2, sg3, e0, e1;  // vehicle.py:1604-1612
+    float lf0;                         // log2(f_0); Bicycle field: log2(p_0 / p_decay) (vehicle.py:1101, 1132)
+    float kexp;                        // log2(e)
+    float ch, ch2;                     // cos(hfov/2), its square (intersection.py:733-736)
+    float ipd;                         // Bicycle field: 1 / p_decay (vehicle.py:1095-1099)
+    int32_t p2r;                       // intersection.py:739-741
+    int32_t f0_zero;                   // vehicle.py:1592-1593
+};
+
+// All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
+struct Dev {
+    csf_params p;
+    PairConsts pc;
+    int64_t n;         // agents (global population)
+    int64_t cap;       // SoA stride
+    int64_t lo, hi;    // receiver block integrated by this rank
+    int64_t n_pad;     // n rounded up to a multiple of 64 (sentinel source records behind n)
+    int32_t ns;        // states per agent
+    int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
+    int32_t back;      // int(1 / t_s) — vehicle.py:1487
+    int32_t n_split;   // source chunks of the pair kernel
+    double ox, oy;     // origin of the fp32 source records
+    int64_t tick;
+
+    double *s;         // [6][cap]  x, y, psi, v, delta, theta
+    double *vdes;      // [cap]
+    int64_t *qoff;     // [cap+1]
+    double *q;         // [3][qcap] x, y, stop
+    int64_t qcap;
+    int32_t *ptr;      // destpointer
+    uint8_t *znav;     // 0 cruise, 1 brake, 2 arrived; bit 7: not one-hot
+    double *znp;       // [3][cap] latched v0, d0, d1 (vehicle.py:428-430)
+    int32_t *ti;       // column of the reference's traj ring (vehicle.py:1279-1280)
+    double *hx, *hy;   // [hist_len][cap]
+    double *lti;       // [5][cap] InvPendulum LTI state (vehicle.py:1728)
+    uint8_t *zrid;     // 1 riding, 0 walking (vehicle.py:1732-1736)
+    int32_t *dgood;    // consecutive ring samples with |delta| < delta_max_walk (vehicle.py:1943-1947)
+    double *ppsi;      // PlanarPoint unwrapped yaw (dynamics.py:943-966)
+
+    float4 *rec;       // [n_pad] (x-ox, y-oy, cos psi, sin psi) fp32 source records
+    float2 *rec2;      // [n_pad] Bicycle field only: (e, 1/sqrt(1-e^2))
+    float2 *part;      // [MAX_SPLIT][cap] partial repulsive sums of the pair kernel
+    float2 *froad;     // [cap]
+    float4 *rv;        // [nv_pad] road vertices (x-ox, y-oy, -F0, -(sigma+1)/2)
+    int64_t nv, nv_pad;
+
+    double *F;         // [6][cap] Fx, Fy, Fdest_x, Fdest_y, Frep_x, Frep_y
+    uint32_t *status;
+
+    double *hist;      // opt-in history [hist_cap][n][ns]
+    int32_t hist_stride, hist_cap;
+};
+
+enum : int { PH_DEST = 1, PH_COMBINE = 2, PH_INTEGRATE = 4 };
+
+// launchers implemented in csf_pair.hip / csf_agent.hip
+void launch_pair(const Dev &d, hipStream_t st);
+void launch_road(const Dev &d, hipStream_t st);
+void launch_agent(const Dev &d, int phases, hipStream_t st);
+void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state
+void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
+                     int apply_fov, float2 *out, hipStream_t st);
+
+}  // namespace csf

@@ -1,0 +1,978 @@
+// csf_engine.hip — host side of libcsf_hip.so: the C ABI of include/csf.h.
+//
+// Owns the SoA population in HBM, the HIP streams, the per-tick launch sequence and (for world > 1) the
+// RCCL all-gather of the fp32 source records.  There is no CPU compute path in this library: every entry
+// point that produces numbers launches the kernels of csf_pair.hip / csf_agent.hip.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "csf_dev.h"
+
+using namespace csf;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// RCCL is resolved at run time so that single-GPU use does not depend on it.
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            err = std::string("cannot load librccl: ") + dlerror();
+            return false;
+        }
+#define SYM(field, name)                                      \
+    field = (decltype(field))dlsym(lib, name);                \
+    if (!field) {                                             \
+        err = std::string("librccl lacks symbol ") + name;    \
+        return false;                                         \
+    }
+        SYM(GetUniqueId, "ncclGetUniqueId")
+        SYM(CommInitRank, "ncclCommInitRank")
+        SYM(CommDestroy, "ncclCommDestroy")
+        SYM(AllGather, "ncclAllGather")
+        SYM(GroupStart, "ncclGroupStart")
+        SYM(GroupEnd, "ncclGroupEnd")
+        SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+        return true;
+    }
+} g_rccl;
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) e = hipMemset(p, 0, count * sizeof(T));
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct csf_engine {
+    Dev d{};
+    int device = 0;
+    int64_t cap = 0;
+    hipStream_t main = nullptr, comm = nullptr;
+    hipEvent_t ev_integ = nullptr, ev_gather = nullptr;
+    std::string err;
+
+    // host mirror (authoritative only while `host_ahead`; the device is authoritative after a tick)
+    std::vector<double> h_s, h_vdes, h_znp, h_hx, h_hy, h_lti, h_ppsi, h_F;
+    std::vector<int32_t> h_ptr, h_ti, h_dgood;
+    std::vector<uint8_t> h_znav, h_zrid;
+    std::vector<uint32_t> h_status;
+    std::vector<std::vector<double>> h_q;  // per agent: rows of (x, y, stop)
+    std::vector<double> h_road;            // per vertex (x, y, F0, sigma)
+    bool dirty = true;                     // host mirror changed since the last upload
+    bool device_ahead = false;             // ticks ran since the last download
+
+    DevBuf<double> s, vdes, q, znp, hx, hy, lti, ppsi, F, hist;
+    DevBuf<int64_t> qoff;
+    DevBuf<int32_t> ptr, ti, dgood;
+    DevBuf<uint8_t> znav, zrid;
+    DevBuf<uint32_t> status;
+    DevBuf<float4> rec, rv, kat4;
+    DevBuf<float2> rec2, part, froad, kat2;
+
+    // sharding
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;
+    bool gather_pending = false;
+
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev;  // triples: pair begin, pair end, agent end
+};
+
+namespace {
+
+int fail(csf_engine *e, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                           \
+    do {                                                                                          \
+        hipError_t _r = (call);                                                                   \
+        if (_r != hipSuccess)                                                                     \
+            return fail(e, CSF_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+#define NCCLCHK(e, call)                                                                          \
+    do {                                                                                          \
+        ncclResult_t _r = (call);                                                                 \
+        if (_r != ncclSuccess)                                                                    \
+            return fail(e, CSF_E_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r));        \
+    } while (0)
+
+const int NS_OF[4] = {5, 5, 6, 4};
+
+double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, vehicle.py:154-155)
+    const double PI = 3.141592653589793238462643383279502884;
+    th = std::floor(th / (2 * PI)) * (-2 * PI) + th;
+    if (th > PI) th -= 2 * PI;
+    else if (th < -PI) th += 2 * PI;
+    return th;
+}
+
+int check_params(csf_engine *e, const csf_params *p) {
+    if (!p) return fail(e, CSF_E_ARG, "params is NULL");
+    if (p->model < 0 || p->model > 3) return fail(e, CSF_E_ARG, "unknown model %d", p->model);
+    if (!(p->t_s > 0)) return fail(e, CSF_E_ARG, "t_s must be > 0");
+    if (p->traj_len < 2) return fail(e, CSF_E_ARG, "traj_len must be >= 2 (int(30/t_s) in the reference)");
+    if (p->priority_rule < 0 || p->priority_rule > 1) return fail(e, CSF_E_ARG, "unknown priority rule");
+    if (!(p->hfov >= 0)) return fail(e, CSF_E_ARG, "hfov must be >= 0");
+    return CSF_OK;
+}
+
+void derive_consts(csf_engine *e) {
+    const csf_params &p = e->d.p;
+    PairConsts &k = e->d.pc;
+    k.sg0 = (float)p.sigma_0;
+    k.sg1 = (float)p.sigma_1;
+    k.sg2 = (float)p.sigma_2;
+    k.sg3 = (float)p.sigma_3;
+    k.e0 = (float)p.e_0;
+    k.e1 = (float)p.e_1;
+    k.kexp = 1.4426950408889634f;
+    double half = 0.5 * std::min(p.hfov, 2 * 3.141592653589793);
+    k.ch = (float)std::cos(half);
+    if (p.hfov >= 2 * 3.141592653589793) k.ch = -2.0f;  // full circle: every bearing is inside
+    k.ch2 = k.ch * k.ch;
+    k.p2r = p.priority_rule == CSF_P2R;
+    if (p.model == CSF_BICYCLE) {
+        k.lf0 = (float)std::log2(p.p_0 / p.p_decay);
+        k.ipd = (float)(1.0 / p.p_decay);
+        k.f0_zero = 0;
+    } else {
+        k.lf0 = p.f_0 > 0 ? (float)std::log2(p.f_0) : -INFINITY;
+        k.ipd = 0.f;
+        k.f0_zero = p.f_0 == 0.0;
+    }
+    e->d.back = (int32_t)(1.0 / p.t_s);
+    int hl = 4;
+    while (hl < e->d.back + 2) hl *= 2;
+    e->d.hist_len = hl;
+    e->d.ns = NS_OF[p.model];
+}
+
+int alloc_all(csf_engine *e) {
+    const size_t cap = (size_t)e->cap;
+    const size_t hl = (size_t)e->d.hist_len;
+    HIPCHK(e, e->s.alloc(6 * cap));
+    HIPCHK(e, e->vdes.alloc(cap));
+    HIPCHK(e, e->qoff.alloc(cap + 1));
+    HIPCHK(e, e->ptr.alloc(cap));
+    HIPCHK(e, e->znav.alloc(cap));
+    HIPCHK(e, e->znp.alloc(3 * cap));
+    HIPCHK(e, e->ti.alloc(cap));
+    HIPCHK(e, e->hx.alloc(hl * cap));
+    HIPCHK(e, e->hy.alloc(hl * cap));
+    HIPCHK(e, e->lti.alloc(5 * cap));
+    HIPCHK(e, e->zrid.alloc(cap));
+    HIPCHK(e, e->dgood.alloc(cap));
+    HIPCHK(e, e->ppsi.alloc(cap));
+    HIPCHK(e, e->F.alloc(6 * cap));
+    HIPCHK(e, e->status.alloc(cap));
+    HIPCHK(e, e->part.alloc((size_t)MAX_SPLIT * cap));
+    HIPCHK(e, e->froad.alloc(cap));
+    // records: room for the per-rank padding of an 8-way shard
+    size_t nrec = (cap + 64 * 64 + 63) / 64 * 64;
+    HIPCHK(e, e->rec.alloc(nrec));
+    HIPCHK(e, e->rec2.alloc(nrec));
+    e->h_s.assign(6 * cap, 0.0);
+    e->h_vdes.assign(cap, 0.0);
+    e->h_znp.assign(3 * cap, 0.0);
+    e->h_hx.assign(hl * cap, 0.0);
+    e->h_hy.assign(hl * cap, 0.0);
+    e->h_lti.assign(5 * cap, 0.0);
+    e->h_ppsi.assign(cap, 0.0);
+    e->h_F.assign(6 * cap, 0.0);
+    e->h_ptr.assign(cap, 0);
+    e->h_ti.assign(cap, 0);
+    e->h_dgood.assign(cap, 0);
+    e->h_znav.assign(cap, 0);
+    e->h_zrid.assign(cap, 0);
+    e->h_status.assign(cap, 0);
+    e->h_q.assign(cap, {});
+    Dev &d = e->d;
+    d.cap = (int64_t)cap;
+    d.s = e->s.p;
+    d.vdes = e->vdes.p;
+    d.qoff = e->qoff.p;
+    d.ptr = e->ptr.p;
+    d.znav = e->znav.p;
+    d.znp = e->znp.p;
+    d.ti = e->ti.p;
+    d.hx = e->hx.p;
+    d.hy = e->hy.p;
+    d.lti = e->lti.p;
+    d.zrid = e->zrid.p;
+    d.dgood = e->dgood.p;
+    d.ppsi = e->ppsi.p;
+    d.F = e->F.p;
+    d.status = e->status.p;
+    d.part = e->part.p;
+    d.froad = e->froad.p;
+    d.rec = e->rec.p;
+    d.rec2 = e->rec2.p;
+    return CSF_OK;
+}
+
+void set_shard(csf_engine *e) {
+    Dev &d = e->d;
+    if (e->world <= 1) {
+        d.lo = 0;
+        d.hi = d.n;
+        d.n_pad = (d.n + 63) / 64 * 64;
+    } else {
+        int64_t shard = (d.n + e->world - 1) / e->world;
+        shard = (shard + 63) / 64 * 64;
+        d.lo = std::min<int64_t>(d.n, (int64_t)e->rank * shard);
+        d.hi = std::min<int64_t>(d.n, d.lo + shard);
+        d.n_pad = shard * e->world;
+    }
+    int64_t nloc = d.hi - d.lo;
+    int64_t blocks = (nloc + 15) / 16;
+    int64_t units = std::max<int64_t>(1, d.n_pad / 64);
+    int64_t split = blocks > 0 ? (1024 + blocks - 1) / blocks : 1;
+    split = std::max<int64_t>(1, std::min<int64_t>({split, (int64_t)MAX_SPLIT, units}));
+    d.n_split = (int32_t)split;
+}
+
+// device -> host mirror (needed before a structural change once ticks have run)
+int download_all(csf_engine *e) {
+    if (!e->device_ahead) return CSF_OK;
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    if (e->comm) HIPCHK(e, hipStreamSynchronize(e->comm));
+#define D2H(vec, buf) HIPCHK(e, hipMemcpy(vec.data(), buf.p, vec.size() * sizeof(vec[0]), hipMemcpyDeviceToHost))
+    D2H(e->h_s, e->s);
+    D2H(e->h_znp, e->znp);
+    D2H(e->h_hx, e->hx);
+    D2H(e->h_hy, e->hy);
+    D2H(e->h_lti, e->lti);
+    D2H(e->h_ppsi, e->ppsi);
+    D2H(e->h_F, e->F);
+    D2H(e->h_ptr, e->ptr);
+    D2H(e->h_ti, e->ti);
+    D2H(e->h_dgood, e->dgood);
+    D2H(e->h_znav, e->znav);
+    D2H(e->h_zrid, e->zrid);
+    D2H(e->h_status, e->status);
+#undef D2H
+    e->device_ahead = false;
+    return CSF_OK;
+}
+
+int upload_all(csf_engine *e) {
+    if (!e->dirty) return CSF_OK;
+    Dev &d = e->d;
+    const int64_t n = d.n;
+    // destination queues -> CSR
+    std::vector<int64_t> off((size_t)e->cap + 1, 0);
+    for (int64_t a = 0; a < n; a++) off[a + 1] = off[a] + (int64_t)e->h_q[a].size() / 3;
+    for (int64_t a = n; a < e->cap; a++) off[a + 1] = off[a];
+    int64_t rows = off[n];
+    if ((size_t)(3 * rows) > e->q.n) {
+        size_t want = (size_t)std::max<int64_t>(3 * rows * 2, 3 * 1024);
+        HIPCHK(e, e->q.alloc(want));
+    }
+    d.q = e->q.p;
+    d.qcap = (int64_t)(e->q.n / 3);
+    std::vector<double> flat(e->q.n, 0.0);
+    for (int64_t a = 0; a < n; a++) {
+        const std::vector<double> &qa = e->h_q[a];
+        for (size_t k = 0; k < qa.size() / 3; k++) {
+            flat[(size_t)(off[a] + k)] = qa[3 * k];
+            flat[(size_t)(d.qcap + off[a] + k)] = qa[3 * k + 1];
+            flat[(size_t)(2 * d.qcap + off[a] + k)] = qa[3 * k + 2];
+        }
+    }
+    if (!flat.empty()) HIPCHK(e, hipMemcpy(e->q.p, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->qoff.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+#define H2D(vec, buf) HIPCHK(e, hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
+    H2D(e->h_s, e->s);
+    H2D(e->h_vdes, e->vdes);
+    H2D(e->h_znp, e->znp);
+    H2D(e->h_hx, e->hx);
+    H2D(e->h_hy, e->hy);
+    H2D(e->h_lti, e->lti);
+    H2D(e->h_ppsi, e->ppsi);
+    H2D(e->h_F, e->F);
+    H2D(e->h_ptr, e->ptr);
+    H2D(e->h_ti, e->ti);
+    H2D(e->h_dgood, e->dgood);
+    H2D(e->h_znav, e->znav);
+    H2D(e->h_zrid, e->zrid);
+    H2D(e->h_status, e->status);
+#undef H2D
+    // origin of the fp32 records: centre of the bounding box of the population (and road)
+    if (n > 0) {
+        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        for (int64_t a = 0; a < n; a++) {
+            x0 = std::min(x0, e->h_s[a]);
+            x1 = std::max(x1, e->h_s[a]);
+            y0 = std::min(y0, e->h_s[e->cap + a]);
+            y1 = std::max(y1, e->h_s[e->cap + a]);
+        }
+        d.ox = 0.5 * (x0 + x1);
+        d.oy = 0.5 * (y0 + y1);
+        if (!std::isfinite(d.ox)) d.ox = 0;
+        if (!std::isfinite(d.oy)) d.oy = 0;
+    }
+    // road vertices (x - ox, y - oy, -F0, -(sigma+1)/2), padded with inert vertices
+    d.nv = (int64_t)e->h_road.size() / 4;
+    d.nv_pad = (d.nv + 63) / 64 * 64;
+    if (d.nv > 0) {
+        if ((size_t)d.nv_pad > e->rv.n) HIPCHK(e, e->rv.alloc((size_t)d.nv_pad));
+        std::vector<float4> rv((size_t)d.nv_pad, make_float4(1e15f, 1e15f, 0.f, -1.f));
+        for (int64_t k = 0; k < d.nv; k++)
+            rv[(size_t)k] = make_float4((float)(e->h_road[4 * k] - d.ox), (float)(e->h_road[4 * k + 1] - d.oy),
+                                        (float)(-e->h_road[4 * k + 2]), (float)(-0.5 * (e->h_road[4 * k + 3] + 1.0)));
+        HIPCHK(e, hipMemcpy(e->rv.p, rv.data(), rv.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    d.rv = e->rv.p;
+    set_shard(e);
+    if ((size_t)d.n_pad > e->rec.n) return fail(e, CSF_E_CAPACITY, "record buffer too small for this shard layout");
+    launch_records(d, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    e->gather_pending = false;
+    e->dirty = false;
+    return CSF_OK;
+}
+
+int prepare_mutation(csf_engine *e) {
+    int rc = download_all(e);
+    if (rc) return rc;
+    e->dirty = true;
+    return CSF_OK;
+}
+
+int all_gather_records(csf_engine *e) {
+    Dev &d = e->d;
+    size_t shard = (size_t)(d.n_pad / e->world);
+    HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
+    HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
+    const bool two = d.p.model == CSF_BICYCLE;
+    if (two) NCCLCHK(e, g_rccl.GroupStart());
+    NCCLCHK(e, g_rccl.AllGather(d.rec + (size_t)e->rank * shard, d.rec, shard * 4, ncclFloat32, e->nccl, e->comm));
+    if (two) {
+        NCCLCHK(e, g_rccl.AllGather(d.rec2 + (size_t)e->rank * shard, d.rec2, shard * 2, ncclFloat32, e->nccl, e->comm));
+        NCCLCHK(e, g_rccl.GroupEnd());
+    }
+    HIPCHK(e, hipEventRecord(e->ev_gather, e->comm));
+    e->gather_pending = true;
+    return CSF_OK;
+}
+
+int wait_gather(csf_engine *e) {
+    if (e->gather_pending) {
+        HIPCHK(e, hipStreamWaitEvent(e->main, e->ev_gather, 0));
+        e->gather_pending = false;
+    }
+    return CSF_OK;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI ======
+
+extern "C" {
+
+int32_t csf_abi_version(void) { return CSF_ABI_VERSION; }
+
+const char *csf_last_error(const csf_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t device) {
+    if (check_params(nullptr, params)) return nullptr;
+    if (n_capacity < 1) {
+        fail(nullptr, CSF_E_ARG, "n_capacity must be >= 1");
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t r = hipGetDeviceCount(&ndev);
+    if (r != hipSuccess || ndev <= 0) {
+        fail(nullptr, CSF_E_DEVICE, "no HIP device available (%s); this engine has no CPU fallback",
+             r != hipSuccess ? hipGetErrorString(r) : "device count 0");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(nullptr, CSF_E_DEVICE, "device %d out of range (%d visible)", device, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        fail(nullptr, CSF_E_DEVICE, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    csf_engine *e = new csf_engine();
+    e->device = device;
+    e->cap = n_capacity;
+    e->d.p = *params;
+    derive_consts(e);
+    auto bail = [&](const char *what) {
+        g_create_error = std::string(what) + ": " + e->err;
+        csf_destroy(e);
+        return (csf_engine *)nullptr;
+    };
+    if (hipStreamCreateWithFlags(&e->main, hipStreamNonBlocking) != hipSuccess) return bail("stream");
+    if (hipStreamCreateWithFlags(&e->comm, hipStreamNonBlocking) != hipSuccess) return bail("stream");
+    if (hipEventCreateWithFlags(&e->ev_integ, hipEventDisableTiming) != hipSuccess) return bail("event");
+    if (hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming) != hipSuccess) return bail("event");
+    if (alloc_all(e) != CSF_OK) return bail("allocation");
+    set_shard(e);
+    return e;
+}
+
+int csf_destroy(csf_engine *e) {
+    if (!e) return CSF_OK;
+    (void)hipSetDevice(e->device);
+    if (e->main) (void)hipStreamSynchronize(e->main);
+    if (e->comm) (void)hipStreamSynchronize(e->comm);
+    if (e->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(e->nccl);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);
+    if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
+    e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
+    e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qoff.release();
+    e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
+    e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release();
+    e->part.release(); e->froad.release(); e->kat2.release();
+    if (e->main) (void)hipStreamDestroy(e->main);
+    if (e->comm) (void)hipStreamDestroy(e->comm);
+    delete e;
+    return CSF_OK;
+}
+
+int64_t csf_num_agents(const csf_engine *e) { return e ? e->d.n : 0; }
+int32_t csf_num_states(const csf_engine *e) { return e ? e->d.ns : 0; }
+
+int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && (!s0 || !v_desired))) return fail(e, CSF_E_ARG, "csf_add_agents: bad arguments");
+    if (e->d.n + n > e->cap) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap);
+    if (e->world > 1 && e->nccl) return fail(e, CSF_E_STATE, "population is frozen once the shard communicator exists");
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = prepare_mutation(e);
+    if (rc) return rc;
+    const int ns = e->d.ns;
+    const int64_t cap = e->cap;
+    const csf_params &p = e->d.p;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t a = e->d.n + k;
+        const double *s = s0 + k * ns;
+        for (int c = 0; c < 6; c++) e->h_s[c * cap + a] = c < ns ? s[c] : 0.0;
+        e->h_s[2 * cap + a] = limit_angle_h(s[2]);               // vehicle.py:154-155
+        e->h_vdes[a] = v_desired[k];
+        e->h_q[a].assign({s[0], s[1], 0.0});                     // vehicle.py:183-185
+        e->h_ptr[a] = 0;
+        e->h_znav[a] = 0;                                        // vehicle.py:188
+        for (int c = 0; c < 3; c++) e->h_znp[c * cap + a] = 0.0;
+        e->h_ti[a] = 0;                                          // vehicle.py:146
+        e->h_hx[a] = s[0];                                       // traj[:, 0] = s  (vehicle.py:159-160)
+        e->h_hy[a] = s[1];
+        const double delta = ns > 4 ? s[4] : 0.0, theta = ns > 5 ? s[5] : 0.0;
+        e->h_lti[0 * cap + a] = delta;                           // vehicle.py:1728
+        e->h_lti[1 * cap + a] = 0.0;
+        e->h_lti[2 * cap + a] = theta;
+        e->h_lti[3 * cap + a] = 0.0;
+        e->h_lti[4 * cap + a] = e->h_s[2 * cap + a];
+        e->h_zrid[a] = s[3] < p.v_max_walk ? 0 : 1;              // vehicle.py:1732-1736
+        e->h_dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
+        e->h_ppsi[a] = e->h_s[2 * cap + a];                      // dynamics.py:828, 987-993
+        for (int c = 0; c < 6; c++) e->h_F[c * cap + a] = 0.0;
+        e->h_status[a] = 0;
+    }
+    e->d.n += n;
+    set_shard(e);
+    return CSF_OK;
+}
+
+int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && !idx)) return fail(e, CSF_E_ARG, "csf_remove_agents: bad arguments");
+    if (e->world > 1 && e->nccl) return fail(e, CSF_E_STATE, "population is frozen once the shard communicator exists");
+    HIPCHK(e, hipSetDevice(e->device));
+    std::vector<uint8_t> kill((size_t)e->d.n, 0);
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        kill[(size_t)idx[k]] = 1;
+    }
+    int rc = prepare_mutation(e);
+    if (rc) return rc;
+    const int64_t cap = e->cap, hl = e->d.hist_len;
+    int64_t w = 0;
+    for (int64_t a = 0; a < e->d.n; a++) {
+        if (kill[(size_t)a]) continue;
+        if (w != a) {
+            for (int c = 0; c < 6; c++) e->h_s[c * cap + w] = e->h_s[c * cap + a];
+            for (int c = 0; c < 6; c++) e->h_F[c * cap + w] = e->h_F[c * cap + a];
+            for (int c = 0; c < 3; c++) e->h_znp[c * cap + w] = e->h_znp[c * cap + a];
+            for (int c = 0; c < 5; c++) e->h_lti[c * cap + w] = e->h_lti[c * cap + a];
+            for (int64_t c = 0; c < hl; c++) {
+                e->h_hx[c * cap + w] = e->h_hx[c * cap + a];
+                e->h_hy[c * cap + w] = e->h_hy[c * cap + a];
+            }
+            e->h_vdes[w] = e->h_vdes[a];
+            e->h_ppsi[w] = e->h_ppsi[a];
+            e->h_ptr[w] = e->h_ptr[a];
+            e->h_ti[w] = e->h_ti[a];
+            e->h_dgood[w] = e->h_dgood[a];
+            e->h_znav[w] = e->h_znav[a];
+            e->h_zrid[w] = e->h_zrid[a];
+            e->h_status[w] = e->h_status[a];
+            e->h_q[w] = std::move(e->h_q[a]);
+        }
+        w++;
+    }
+    e->d.n = w;
+    set_shard(e);
+    return CSF_OK;
+}
+
+int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int64_t *offsets,
+                       const double *xyz_stop, int32_t reset) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && (!agent || !offsets || !xyz_stop))) return fail(e, CSF_E_ARG, "csf_set_dest_queue: bad arguments");
+    for (int64_t k = 0; k < n; k++) {
+        if (agent[k] < 0 || agent[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", agent[k]);
+        if (offsets[k + 1] < offsets[k]) return fail(e, CSF_E_ARG, "offsets must be non-decreasing");
+        if (reset && offsets[k + 1] == offsets[k]) return fail(e, CSF_E_ARG, "reset with an empty queue");
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = prepare_mutation(e);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n; k++) {
+        std::vector<double> &qa = e->h_q[(size_t)agent[k]];
+        if (reset) {                                             // vehicle.py:642-645
+            qa.clear();
+            e->h_ptr[(size_t)agent[k]] = 0;
+        }
+        qa.insert(qa.end(), xyz_stop + 3 * offsets[k], xyz_stop + 3 * offsets[k + 1]);  // :646-647
+    }
+    return CSF_OK;
+}
+
+int csf_set_road_vertices(csf_engine *e, int32_t n_edges, const int64_t *offsets, const double *xy,
+                          const double *F0, const double *sigma) {
+    if (!e) return CSF_E_ARG;
+    if (n_edges < 0 || (n_edges > 0 && (!offsets || !xy || !F0 || !sigma)))
+        return fail(e, CSF_E_ARG, "csf_set_road_vertices: bad arguments");
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = prepare_mutation(e);
+    if (rc) return rc;
+    e->h_road.clear();
+    for (int32_t k = 0; k < n_edges; k++)
+        for (int64_t v = offsets[k]; v < offsets[k + 1]; v++) {
+            e->h_road.push_back(xy[2 * v]);
+            e->h_road.push_back(xy[2 * v + 1]);
+            e->h_road.push_back(F0[k]);
+            e->h_road.push_back(sigma[k]);
+        }
+    return CSF_OK;
+}
+
+int csf_set_params(csf_engine *e, const csf_params *params) {
+    if (!e) return CSF_E_ARG;
+    int rc = check_params(e, params);
+    if (rc) return rc;
+    if (params->model != e->d.p.model) return fail(e, CSF_E_ARG, "the model of an engine cannot change");
+    if (params->t_s != e->d.p.t_s || params->traj_len != e->d.p.traj_len)
+        return fail(e, CSF_E_ARG, "t_s is immutable (parameters.py:516-528)");
+    e->d.p = *params;
+    derive_consts(e);
+    return CSF_OK;
+}
+
+int csf_set_priority_rule(csf_engine *e, int32_t rule) {
+    if (!e) return CSF_E_ARG;
+    if (rule < 0 || rule > 1) return fail(e, CSF_E_ARG, "unknown priority rule %d", rule);
+    e->d.p.priority_rule = rule;
+    derive_consts(e);
+    return CSF_OK;
+}
+
+int csf_set_v_desired(csf_engine *e, int64_t n, const int32_t *idx, const double *v_desired) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && (!idx || !v_desired))) return fail(e, CSF_E_ARG, "csf_set_v_desired: bad arguments");
+    for (int64_t k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+    HIPCHK(e, hipSetDevice(e->device));
+    for (int64_t k = 0; k < n; k++) e->h_vdes[(size_t)idx[k]] = v_desired[k];
+    if (!e->dirty) {  // device copy is current: patch it in place
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        HIPCHK(e, hipMemcpy(e->vdes.p, e->h_vdes.data(), (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return CSF_OK;
+}
+
+int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && (!idx || !s))) return fail(e, CSF_E_ARG, "csf_push_state: bad arguments");
+    for (int64_t k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = prepare_mutation(e);
+    if (rc) return rc;
+    const int ns = e->d.ns;
+    const int64_t cap = e->cap;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t a = idx[k];
+        for (int c = 0; c < ns; c++) e->h_s[c * cap + a] = s[k * ns + c];
+        // keep the model side-state consistent with the pushed vehicle.s
+        e->h_ppsi[a] = e->h_s[2 * cap + a];
+        const int slot = e->h_ti[a] & (e->d.hist_len - 1);
+        e->h_hx[(size_t)slot * cap + a] = e->h_s[a];
+        e->h_hy[(size_t)slot * cap + a] = e->h_s[cap + a];
+    }
+    return CSF_OK;
+}
+
+static int enqueue_tick(csf_engine *e) {
+    Dev &d = e->d;
+    const bool sharded = e->world > 1;
+    hipEvent_t *pe = nullptr;
+    if (e->profile) {
+        size_t base = e->ev.size();
+        e->ev.resize(base + 3);
+        for (int k = 0; k < 3; k++) HIPCHK(e, hipEventCreate(&e->ev[base + k]));
+        pe = &e->ev[base];
+    }
+    if (sharded) {
+        launch_agent(d, PH_DEST, e->main);  // needs only the agent's own state: overlaps the all-gather
+        int rc = wait_gather(e);
+        if (rc) return rc;
+    }
+    if (pe) HIPCHK(e, hipEventRecord(pe[0], e->main));
+    if (d.n > 1) launch_pair(d, e->main);
+    if (pe) HIPCHK(e, hipEventRecord(pe[1], e->main));
+    launch_road(d, e->main);
+    launch_agent(d, sharded ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main);
+    if (pe) HIPCHK(e, hipEventRecord(pe[2], e->main));
+    HIPCHK(e, hipGetLastError());
+    d.tick++;
+    if (sharded) return all_gather_records(e);
+    return CSF_OK;
+}
+
+int csf_step(csf_engine *e, int64_t n_ticks) {
+    if (!e) return CSF_E_ARG;
+    if (n_ticks < 0) return fail(e, CSF_E_ARG, "n_ticks must be >= 0");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (e->world > 1 && !e->nccl) return fail(e, CSF_E_STATE, "csf_comm_init must run before csf_step when world > 1");
+    int rc = upload_all(e);
+    if (rc) return rc;
+    if (e->d.n == 0) {  // intersection.py:888: nothing to do, time still advances
+        e->d.tick += n_ticks;
+        return CSF_OK;
+    }
+    for (int64_t t = 0; t < n_ticks; t++) {
+        rc = enqueue_tick(e);
+        if (rc) return rc;
+    }
+    if (n_ticks > 0) e->device_ahead = true;
+    return CSF_OK;
+}
+
+int csf_sync(csf_engine *e) {
+    if (!e) return CSF_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    HIPCHK(e, hipStreamSynchronize(e->comm));
+    return CSF_OK;
+}
+
+int csf_calc_forces(csf_engine *e) {
+    if (!e) return CSF_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);
+    if (rc) return rc;
+    if (e->d.n == 0) return CSF_OK;
+    rc = wait_gather(e);
+    if (rc) return rc;
+    if (e->d.n > 1) launch_pair(e->d, e->main);
+    launch_road(e->d, e->main);
+    launch_agent(e->d, PH_DEST | PH_COMBINE, e->main);
+    HIPCHK(e, hipGetLastError());
+    e->device_ahead = true;
+    return CSF_OK;
+}
+
+int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy) {
+    if (!e) return CSF_E_ARG;
+    if (!Fx || !Fy) return fail(e, CSF_E_ARG, "csf_apply_forces: NULL force array");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (e->world > 1) return fail(e, CSF_E_STATE, "csf_apply_forces is a single-device entry point");
+    int rc = upload_all(e);
+    if (rc) return rc;
+    if (e->d.n == 0) return CSF_OK;
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    HIPCHK(e, hipMemcpy(e->F.p, Fx, (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->F.p + e->cap, Fy, (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
+    launch_agent(e->d, PH_INTEGRATE, e->main);
+    HIPCHK(e, hipGetLastError());
+    e->d.tick++;
+    e->device_ahead = true;
+    return CSF_OK;
+}
+
+int csf_dest_force(csf_engine *e, double *Fx, double *Fy) {
+    if (!e) return CSF_E_ARG;
+    if (!Fx || !Fy) return fail(e, CSF_E_ARG, "csf_dest_force: NULL output");
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);
+    if (rc) return rc;
+    if (e->d.n == 0) return CSF_OK;
+    launch_agent(e->d, PH_DEST, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    e->device_ahead = true;
+    HIPCHK(e, hipMemcpy(Fx, e->F.p + 2 * e->cap, (size_t)e->d.n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(Fy, e->F.p + 3 * e->cap, (size_t)e->d.n * sizeof(double), hipMemcpyDeviceToHost));
+    return CSF_OK;
+}
+
+int csf_get_state(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, int64_t *tick) {
+    if (!e) return CSF_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);  // a never-stepped engine still answers from a consistent device copy
+    if (rc) return rc;
+    rc = csf_sync(e);
+    if (rc) return rc;
+    const int64_t n = e->d.n, cap = e->cap;
+    const int ns = e->d.ns;
+    if (tick) *tick = e->d.tick;
+    if (n == 0) return CSF_OK;
+    if (s_out) {
+        std::vector<double> tmp((size_t)n);
+        for (int c = 0; c < ns; c++) {
+            HIPCHK(e, hipMemcpy(tmp.data(), e->s.p + c * cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+            for (int64_t a = 0; a < n; a++) s_out[a * ns + c] = tmp[(size_t)a];
+        }
+    }
+    if (dest_ptr) HIPCHK(e, hipMemcpy(dest_ptr, e->ptr.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (znav) {
+        std::vector<uint8_t> z((size_t)n);
+        HIPCHK(e, hipMemcpy(z.data(), e->znav.p, (size_t)n, hipMemcpyDeviceToHost));
+        for (int64_t a = 0; a < n; a++) {
+            znav[3 * a + 0] = (z[(size_t)a] & 3) == 0;
+            znav[3 * a + 1] = (z[(size_t)a] & 3) == 1;
+            znav[3 * a + 2] = (z[(size_t)a] & 3) == 2;
+        }
+    }
+    return CSF_OK;
+}
+
+static int get_F(csf_engine *e, int comp, double *out) {
+    if (!out) return CSF_OK;
+    HIPCHK(e, hipMemcpy(out, e->F.p + (size_t)comp * e->cap, (size_t)e->d.n * sizeof(double), hipMemcpyDeviceToHost));
+    return CSF_OK;
+}
+
+int csf_get_forces(csf_engine *e, double *Fx, double *Fy) {
+    if (!e) return CSF_E_ARG;
+    int rc = csf_sync(e);
+    if (rc) return rc;
+    if (e->dirty && !e->device_ahead) {
+        rc = upload_all(e);
+        if (rc) return rc;
+    }
+    if (e->d.n == 0) return CSF_OK;
+    if ((rc = get_F(e, 0, Fx))) return rc;
+    return get_F(e, 1, Fy);
+}
+
+int csf_get_force_parts(csf_engine *e, double *Fdest_x, double *Fdest_y, double *Frep_x, double *Frep_y) {
+    if (!e) return CSF_E_ARG;
+    int rc = csf_sync(e);
+    if (rc) return rc;
+    if (e->d.n == 0) return CSF_OK;
+    if ((rc = get_F(e, 2, Fdest_x))) return rc;
+    if ((rc = get_F(e, 3, Fdest_y))) return rc;
+    if ((rc = get_F(e, 4, Frep_x))) return rc;
+    return get_F(e, 5, Frep_y);
+}
+
+int csf_status(csf_engine *e, uint32_t *per_agent_flags) {
+    if (!e) return CSF_E_ARG;
+    if (!per_agent_flags) return fail(e, CSF_E_ARG, "csf_status: NULL output");
+    int rc = upload_all(e);
+    if (rc) return rc;
+    rc = csf_sync(e);
+    if (rc) return rc;
+    if (e->d.n == 0) return CSF_OK;
+    HIPCHK(e, hipMemcpy(per_agent_flags, e->status.p, (size_t)e->d.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CSF_OK;
+}
+
+int csf_enable_history(csf_engine *e, int32_t stride, int32_t capacity) {
+    if (!e) return CSF_E_ARG;
+    if (stride < 1 || capacity < 1) return fail(e, CSF_E_ARG, "stride and capacity must be >= 1");
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = csf_sync(e);
+    if (rc) return rc;
+    HIPCHK(e, e->hist.alloc((size_t)capacity * (size_t)e->cap * (size_t)e->d.ns));
+    e->d.hist = e->hist.p;
+    e->d.hist_stride = stride;
+    e->d.hist_cap = capacity;
+    return CSF_OK;
+}
+
+int csf_get_history(csf_engine *e, int64_t first_sample, int64_t n_samples, double *out) {
+    if (!e) return CSF_E_ARG;
+    if (!e->d.hist) return fail(e, CSF_E_STATE, "history is not enabled");
+    if (!out || first_sample < 0 || n_samples < 0) return fail(e, CSF_E_ARG, "csf_get_history: bad arguments");
+    int rc = csf_sync(e);
+    if (rc) return rc;
+    const int64_t have = e->d.tick / e->d.hist_stride;
+    if (first_sample + n_samples > have || have - first_sample > e->d.hist_cap)
+        return fail(e, CSF_E_ARG, "samples [%lld, %lld) are not in the ring (have %lld, capacity %d)",
+                    (long long)first_sample, (long long)(first_sample + n_samples), (long long)have, e->d.hist_cap);
+    const size_t row = (size_t)e->d.n * (size_t)e->d.ns;
+    for (int64_t k = 0; k < n_samples; k++) {
+        int64_t slot = (first_sample + k) % e->d.hist_cap;
+        HIPCHK(e, hipMemcpy(out + (size_t)k * row, e->hist.p + (size_t)slot * row, row * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return CSF_OK;
+}
+
+int csf_pair_force(csf_engine *e, const double *src, int64_t m, const double *x, const double *y,
+                   const double *psi, int32_t apply_fov, double *Fx, double *Fy) {
+    if (!e) return CSF_E_ARG;
+    if (m < 0 || !src || (m > 0 && (!x || !y || !psi || !Fx || !Fy))) return fail(e, CSF_E_ARG, "csf_pair_force: bad arguments");
+    if (m == 0) return CSF_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    const csf_params &p = e->d.p;
+    std::vector<float4> hs((size_t)m), hr((size_t)m);
+    std::vector<float2> h2((size_t)m), ho((size_t)m);
+    double ev = 0.0;  // vehicle.py:1062-1064
+    if (src[3] > 0.0) ev = std::min(std::pow(src[3] / p.v_max_riding[1], 0.1), 0.7);
+    for (int64_t k = 0; k < m; k++) {
+        hs[(size_t)k] = make_float4(0.f, 0.f, (float)std::cos(src[2]), (float)std::sin(src[2]));
+        hr[(size_t)k] = make_float4((float)(x[k] - src[0]), (float)(y[k] - src[1]), (float)std::cos(psi[k]), (float)std::sin(psi[k]));
+        h2[(size_t)k] = make_float2((float)ev, (float)(1.0 / std::sqrt(1.0 - ev * ev)));
+    }
+    if (e->kat4.n < (size_t)(2 * m)) HIPCHK(e, e->kat4.alloc((size_t)(2 * m)));
+    if (e->kat2.n < (size_t)(2 * m)) HIPCHK(e, e->kat2.alloc((size_t)(2 * m)));
+    HIPCHK(e, hipMemcpy(e->kat4.p, hs.data(), (size_t)m * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->kat4.p + m, hr.data(), (size_t)m * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->kat2.p, h2.data(), (size_t)m * sizeof(float2), hipMemcpyHostToDevice));
+    launch_pair_kat(e->d, e->kat4.p, e->kat2.p, e->kat4.p + m, m, apply_fov, e->kat2.p + m, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    HIPCHK(e, hipMemcpy(ho.data(), e->kat2.p + m, (size_t)m * sizeof(float2), hipMemcpyDeviceToHost));
+    for (int64_t k = 0; k < m; k++) {
+        Fx[k] = ho[(size_t)k].x;
+        Fy[k] = ho[(size_t)k].y;
+    }
+    return CSF_OK;
+}
+
+int csf_comm_unique_id(uint8_t id_out[CSF_UNIQUE_ID_BYTES]) {
+    if (!id_out) return CSF_E_ARG;
+    if (!g_rccl.load()) return fail(nullptr, CSF_E_COMM, "%s", g_rccl.err.c_str());
+    static_assert(sizeof(ncclUniqueId) == CSF_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, CSF_E_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+    memcpy(id_out, &id, sizeof id);
+    return CSF_OK;
+}
+
+int csf_comm_init(csf_engine *e, const uint8_t id[CSF_UNIQUE_ID_BYTES], int32_t rank, int32_t world) {
+    if (!e) return CSF_E_ARG;
+    if (world < 1 || rank < 0 || rank >= world) return fail(e, CSF_E_ARG, "bad rank %d / world %d", rank, world);
+    if (world > 64) return fail(e, CSF_E_ARG, "world > 64 is not supported");
+    if (e->nccl) return fail(e, CSF_E_STATE, "communicator already initialised");
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = download_all(e);
+    if (rc) return rc;
+    e->rank = rank;
+    e->world = world;
+    e->dirty = true;
+    set_shard(e);
+    if (world == 1 && !id) return CSF_OK;
+    if (!id) return fail(e, CSF_E_ARG, "unique id is NULL");
+    if (!g_rccl.load()) return fail(e, CSF_E_COMM, "%s", g_rccl.err.c_str());
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCLCHK(e, g_rccl.CommInitRank(&e->nccl, world, uid, rank));
+    return CSF_OK;
+}
+
+int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi) {
+    if (!e) return CSF_E_ARG;
+    if (lo) *lo = e->d.lo;
+    if (hi) *hi = e->d.hi;
+    return CSF_OK;
+}
+
+int csf_profile_enable(csf_engine *e, int32_t on) {
+    if (!e) return CSF_E_ARG;
+    e->profile = on != 0;
+    return CSF_OK;
+}
+
+int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *launches) {
+    if (!e) return CSF_E_ARG;
+    int rc = csf_sync(e);
+    if (rc) return rc;
+    double pm = 0, am = 0;
+    int64_t cnt = 0;
+    for (size_t k = 0; k + 2 < e->ev.size(); k += 3) {
+        float a = 0, b = 0;
+        HIPCHK(e, hipEventElapsedTime(&a, e->ev[k], e->ev[k + 1]));
+        HIPCHK(e, hipEventElapsedTime(&b, e->ev[k + 1], e->ev[k + 2]));
+        pm += a;
+        am += b;
+        cnt++;
+    }
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    e->ev.clear();
+    if (pair_ms) *pair_ms = pm;
+    if (agent_ms) *agent_ms = am;
+    if (launches) *launches = cnt;
+    return CSF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+"""Array-level host API of the stepping engine: a thin, typed wrapper over the C ABI (include/csf.h).
+
+`Engine` is what `intersection.SocialForceIntersection` drives; benchmarks and parity tests use it
+directly with NumPy arrays.  Every number it returns was computed by the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import BICYCLE, INVPEND, N_STATES, PLANARPOINT, TWOD, EngineError, Params  # noqa: F401
+
+MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT}
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One population of one vehicle class on one MI355X (csf_engine)."""
+
+    def __init__(self, params, capacity, device=0):
+        self._lib = _ffi.load()
+        self._h = None
+        if not isinstance(params, Params):
+            raise TypeError("params must be a cyclistsocialforce_amd._ffi.Params")
+        self.params = params
+        self.model = int(params.model)
+        self.ns = N_STATES[self.model]
+        h = self._lib.csf_create(C.byref(params), int(capacity), int(device))
+        if not h:
+            raise EngineError(self._lib.csf_last_error(None).decode())
+        self._h = C.c_void_p(h)
+        self.capacity = int(capacity)
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise EngineError(f"[{rc}] " + self._lib.csf_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.csf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n(self):
+        return int(self._lib.csf_num_agents(self._h))
+
+    # -- population -------------------------------------------------------------------------
+    def add_agents(self, s0, v_desired):
+        s0 = np.asarray(s0, dtype=np.float64)
+        if s0.ndim != 2 or s0.shape[1] < self.ns:
+            raise ValueError(f"s0 must be [n, >={self.ns}]")
+        s0 = _f64(s0[:, : self.ns])
+        vd = _f64(np.broadcast_to(np.asarray(v_desired, dtype=np.float64), (s0.shape[0],)))
+        self._ck(self._lib.csf_add_agents(self._h, s0.shape[0], _ptr(s0), _ptr(vd)))
+
+    def remove_agents(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self._ck(self._lib.csf_remove_agents(self._h, idx.size, _ptr(idx)))
+
+    def set_dest_queue(self, agents, offsets, xyz_stop, reset=False):
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        xyz = _f64(xyz_stop).reshape(-1, 3)
+        if offsets.shape != (agents.size + 1,) or offsets[-1] != xyz.shape[0]:
+            raise ValueError("offsets must be [n+1] and end at the number of rows")
+        self._ck(self._lib.csf_set_dest_queue(self._h, agents.size, _ptr(agents), _ptr(offsets), _ptr(xyz), int(reset)))
+
+    def set_road(self, offsets, verts, F0, sigma):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        verts = _f64(verts).reshape(-1, 2)
+        F0 = _f64(F0)
+        sigma = _f64(sigma)
+        self._ck(self._lib.csf_set_road_vertices(self._h, offsets.size - 1, _ptr(offsets), _ptr(verts), _ptr(F0), _ptr(sigma)))
+
+    def set_params(self, params):
+        self._ck(self._lib.csf_set_params(self._h, C.byref(params)))
+        self.params = params
+
+    def set_v_desired(self, idx, v):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        v = _f64(np.broadcast_to(np.asarray(v, dtype=np.float64), idx.shape))
+        self._ck(self._lib.csf_set_v_desired(self._h, idx.size, _ptr(idx), _ptr(v)))
+
+    def set_priority_rule(self, rule):
+        self._ck(self._lib.csf_set_priority_rule(self._h, int(rule)))
+
+    def push_state(self, idx, s):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        s = _f64(s).reshape(idx.size, self.ns)
+        self._ck(self._lib.csf_push_state(self._h, idx.size, _ptr(idx), _ptr(s)))
+
+    # -- hot path ---------------------------------------------------------------------------
+    def step(self, n_ticks=1, sync=False):
+        self._ck(self._lib.csf_step(self._h, int(n_ticks)))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._ck(self._lib.csf_sync(self._h))
+
+    def calc_forces(self):
+        self._ck(self._lib.csf_calc_forces(self._h))
+        return self.forces()
+
+    def apply_forces(self, Fx, Fy):
+        Fx = _f64(Fx)
+        Fy = _f64(Fy)
+        if Fx.size != self.n or Fy.size != self.n:
+            raise ValueError("Fx, Fy must have one entry per agent")
+        self._ck(self._lib.csf_apply_forces(self._h, _ptr(Fx), _ptr(Fy)))
+
+    def dest_force(self):
+        fx = np.zeros(self.n)
+        fy = np.zeros(self.n)
+        self._ck(self._lib.csf_dest_force(self._h, _ptr(fx), _ptr(fy)))
+        return fx, fy
+
+    # -- read-back --------------------------------------------------------------------------
+    def state(self, with_nav=False):
+        n = self.n
+        s = np.zeros((n, self.ns))
+        if not with_nav:
+            self._ck(self._lib.csf_get_state(self._h, _ptr(s), None, None, None))
+            return s
+        ptr = np.zeros(n, dtype=np.int32)
+        zn = np.zeros((n, 3), dtype=np.uint8)
+        tick = C.c_int64(0)
+        self._ck(self._lib.csf_get_state(self._h, _ptr(s), _ptr(ptr), _ptr(zn), C.byref(tick)))
+        return s, ptr, zn.astype(bool), tick.value
+
+    @property
+    def tick(self):
+        t = C.c_int64(0)
+        self._ck(self._lib.csf_get_state(self._h, None, None, None, C.byref(t)))
+        return t.value
+
+    def forces(self):
+        fx = np.zeros(self.n)
+        fy = np.zeros(self.n)
+        self._ck(self._lib.csf_get_forces(self._h, _ptr(fx), _ptr(fy)))
+        return fx, fy
+
+    def force_parts(self):
+        a = [np.zeros(self.n) for _ in range(4)]
+        self._ck(self._lib.csf_get_force_parts(self._h, *[_ptr(x) for x in a]))
+        return a
+
+    def status(self):
+        st = np.zeros(self.n, dtype=np.uint32)
+        self._ck(self._lib.csf_status(self._h, _ptr(st)))
+        return st
+
+    def enable_history(self, stride=1, capacity=3000):
+        self._ck(self._lib.csf_enable_history(self._h, int(stride), int(capacity)))
+
+    def history(self, first, count):
+        out = np.zeros((count, self.n, self.ns))
+        self._ck(self._lib.csf_get_history(self._h, int(first), int(count), _ptr(out)))
+        return out
+
+    def pair_force(self, src, x, y, psi, apply_fov=False):
+        src = _f64(src).reshape(4)
+        x = _f64(x); y = _f64(y); psi = _f64(psi)
+        fx = np.zeros(x.size)
+        fy = np.zeros(x.size)
+        self._ck(self._lib.csf_pair_force(self._h, _ptr(src), x.size, _ptr(x), _ptr(y), _ptr(psi), int(apply_fov), _ptr(fx), _ptr(fy)))
+        return fx, fy
+
+    # -- sharding ---------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = _ffi.load()
+        buf = (C.c_uint8 * _ffi.UNIQUE_ID_BYTES)()
+        rc = lib.csf_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(f"[{rc}] " + lib.csf_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        if unique_id is None:
+            self._ck(self._lib.csf_comm_init(self._h, None, int(rank), int(world)))
+            return
+        buf = (C.c_uint8 * _ffi.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._ck(self._lib.csf_comm_init(self._h, buf, int(rank), int(world)))
+
+    def shard_range(self):
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        self._ck(self._lib.csf_shard_range(self._h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    # -- measurement ------------------------------------------------------------------------
+    def profile(self, on=True):
+        self._ck(self._lib.csf_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
+        self._ck(self._lib.csf_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value

@@ -1,0 +1,180 @@
+/*
+ * csf.h — C ABI of the MI355X cyclist social-force stepping engine (libcsf_hip.so).
+ *
+ * The reference (chris-konrad/cyclistsocialforce) is pure Python and has no FFI of its own; the
+ * drop-in seam is `SocialForceIntersection.step()` (intersection.py:866-896), i.e. one population
+ * tick.  Each entry point below names the reference code it replaces.  The Python host
+ * (cyclistsocialforce_amd/) binds these with ctypes; INTEGRATION.md shows the stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host arrays are borrowed for the duration of a call;
+ *     outputs are written into caller-allocated buffers;
+ *   - every function returns 0 on success or a negative csf_status_code; the message is available
+ *     from csf_last_error(engine) (or csf_last_error(NULL) when creation itself failed);
+ *   - an engine is bound to one HIP device and one host thread at a time (not re-entrant);
+ *   - there is NO CPU fallback: without a usable gfx950 device csf_create fails with CSF_E_DEVICE.
+ */
+#ifndef CSF_H
+#define CSF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSF_ABI_VERSION 1
+
+/* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
+ * :1991 (PlanarPointBicycle) */
+enum csf_model { CSF_BICYCLE = 0, CSF_TWOD = 1, CSF_INVPEND = 2, CSF_PLANARPOINT = 3 };
+
+/* priority rule — intersection.py:263, 739-741 */
+enum csf_priority_rule { CSF_UNREGULATED = 0, CSF_P2R = 1 };
+
+enum csf_status_code {
+    CSF_OK = 0,
+    CSF_E_ARG = -1,      /* bad argument (null pointer, size, index out of range) */
+    CSF_E_DEVICE = -2,   /* no usable HIP device / HIP runtime error */
+    CSF_E_CAPACITY = -3, /* more agents than the engine was created for */
+    CSF_E_STATE = -4,    /* call not valid in the current engine state */
+    CSF_E_COMM = -5      /* RCCL error */
+};
+
+/* per-agent status bits reported by csf_status() (reference: exceptions / prints) */
+#define CSF_ST_SPLINE 1u   /* vehicle.py:1495-1507: splprep would raise on duplicate points */
+#define CSF_ST_NAN 2u      /* a force became non-finite (vehicle.py:1180-1185 "Isnan!") */
+#define CSF_ST_NAVSTATE 4u /* vehicle.py:416-425: navigation state not one-hot */
+
+/* POD mirror of the reference's parameter objects (parameters.py).  One set per engine = per vehicle
+ * class; the only per-agent parameter is v_desired_default (csf_add_agents).  Field order is ABI. */
+typedef struct csf_params {
+    /* VehicleParameters — parameters.py:430-508 */
+    double t_s, d_arrived_inter, d_arrived_stop, v_max_stop, v_max_harddecel, hfov;
+    double f_0, e_0, e_1, sigma_0, sigma_1, sigma_2, sigma_3;
+    /* BicycleParameters — parameters.py:780-800 */
+    double v_max_riding[2], p_decay, p_0, l, l_2, delta_max, a_max[2], a_desired_default[2];
+    double k_p_v, k_p_delta, g;
+    /* InvPendulumBicycleParameters — parameters.py:1429-1472 */
+    double h, m, i_bike_longlong, i_steer_vertvert, c_steer, v_max_walk, delta_max_walk;
+    /* PlanarPointBicycleParameters — parameters.py:1180-1201 (gain = -Re(pole), dynamics.py:933-940) */
+    double k_psi;
+    int32_t model;         /* enum csf_model */
+    int32_t priority_rule; /* enum csf_priority_rule */
+    int32_t traj_len;      /* columns of the reference's traj ring buffer, int(30 / t_s) — vehicle.py:159 */
+    int32_t reserved;
+} csf_params;
+
+typedef struct csf_engine csf_engine;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+
+/* SocialForceIntersection.__init__ (intersection.py:259-330): an empty population of one vehicle
+ * class on HIP device `device`.  `n_capacity` bounds the number of agents.  Returns NULL on failure. */
+csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t device);
+int csf_destroy(csf_engine *e);
+const char *csf_last_error(const csf_engine *e);
+int32_t csf_abi_version(void);
+
+/* ---- population ------------------------------------------------------------------------------ */
+
+/* Vehicle.__init__ (vehicle.py:64-204) for n agents at once: s0 is [n, n_states] row-major
+ * (n_states = 5, 5, 6, 4 by model), v_desired is [n].  Every new agent gets the single-row
+ * destination queue (x0, y0, 0) of vehicle.py:183-185.  add_road_user: intersection.py:458-539. */
+int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired);
+
+/* remove_road_user / remove_road_users_by_id (intersection.py:576-634): indices into the current
+ * population, any order; the remaining agents keep their relative order. */
+int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
+
+/* Vehicle.setDestinations (vehicle.py:606-647) for n agents: CSR (offsets[n+1], xyz_stop[sum,3]);
+ * reset = 0 appends to the agent's queue, reset = 1 replaces it and rewinds the pointer. */
+int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int64_t *offsets,
+                       const double *xyz_stop, int32_t reset);
+
+/* RoadEdge objects (intersection.py:214-242) flattened: CSR over vertices, one (F0, sigma) per edge. */
+int csf_set_road_vertices(csf_engine *e, int32_t n_edges, const int64_t *offsets, const double *xy,
+                          const double *F0, const double *sigma);
+
+int csf_set_params(csf_engine *e, const csf_params *params);           /* parameter mutation between ticks */
+int csf_set_v_desired(csf_engine *e, int64_t n, const int32_t *idx, const double *v_desired);
+int csf_set_priority_rule(csf_engine *e, int32_t rule);                /* intersection.py:324 */
+
+/* host-side mutation of vehicle.s between ticks (calibration.py:455-460): s is [n, n_states] */
+int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s);
+
+int64_t csf_num_agents(const csf_engine *e);
+int32_t csf_num_states(const csf_engine *e);
+
+/* ---- the hot call ---------------------------------------------------------------------------- */
+
+/* n_ticks x SocialForceIntersection.step() (intersection.py:866-896): FOV mask + all-pairs repulsive
+ * field + column sum + clamp (:690-845), destination force (vehicle.py:1416-1558), road edges
+ * (:853-857), controller + kinematics (vehicle.py:1218-1272, 1810-1950; dynamics.py:996-1079) and the
+ * position snapshot (:660-677).  Asynchronous: returns once the work is enqueued; csf_sync waits. */
+int csf_step(csf_engine *e, int64_t n_ticks);
+int csf_sync(csf_engine *e);
+
+/* calc_forces() alone (intersection.py:747-864): forces of the next tick from the current snapshot.
+ * Like the reference it advances the destination queue / navigation state of every agent. */
+int csf_calc_forces(csf_engine *e);
+/* vehicle.step(Fx, Fy) for every agent with caller-supplied forces (calibration.py:438-460 replay,
+ * intersection.py:891-894).  Fx, Fy are [n]. */
+int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy);
+/* calcDestinationForce() of every agent (vehicle.py:1189-1194, 1416-1558); mutates queue pointer and
+ * navigation state exactly like the reference does. */
+int csf_dest_force(csf_engine *e, double *Fx, double *Fy);
+
+/* ---- read-back (all synchronise first) -------------------------------------------------------- */
+
+/* s_out [n, n_states]; dest_ptr [n] (destpointer), znav [n,3] one-hot, tick = ticks since creation.
+ * Any output pointer may be NULL. */
+int csf_get_state(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, int64_t *tick);
+/* total force of the last evaluated tick (vehicle.force, intersection.py:860-861) */
+int csf_get_forces(csf_engine *e, double *Fx, double *Fy);
+/* parts of it: destination force and clamped repulsive sum (before road edges) */
+int csf_get_force_parts(csf_engine *e, double *Fdest_x, double *Fdest_y, double *Frep_x, double *Frep_y);
+int csf_status(csf_engine *e, uint32_t *per_agent_flags);
+
+/* opt-in history (vehicle.traj, vehicle.py:159, 1407-1410): record every `stride`-th tick into a
+ * device ring of `capacity` samples; csf_get_history copies samples [first, first+n) (sample k = state
+ * after tick (k+1)*stride) of all agents into out [n_samples, n_agents, n_states]. */
+int csf_enable_history(csf_engine *e, int32_t stride, int32_t capacity);
+int csf_get_history(csf_engine *e, int64_t first_sample, int64_t n_samples, double *out);
+
+/* ---- single-function entry points for known-answer tests -------------------------------------- */
+
+/* calcRepulsiveForce of one source at m receivers through the device code of the pair kernel
+ * (vehicle.py:1560-1648 for TWOD/INVPEND/PLANARPOINT engines, :1054-1147 for BICYCLE engines).
+ * src = (x, y, psi, v); receivers x, y, psi [m]; apply_fov != 0 also applies the mask of
+ * intersection.py:690-745 (masked pairs return 0). */
+int csf_pair_force(csf_engine *e, const double *src, int64_t m, const double *x, const double *y,
+                   const double *psi, int32_t apply_fov, double *Fx, double *Fy);
+
+/* ---- sharding over the GPUs of one node ------------------------------------- */
+
+/* The population is replicated on the host side of every rank; rank r integrates the contiguous
+ * receiver block [r*N/world, (r+1)*N/world) and all-gathers the fp32 source records (x, y, cos psi,
+ * sin psi [, e, k]) of the other blocks with one RCCL all-gather per tick on a second HIP stream.
+ * Call csf_comm_unique_id on rank 0, distribute the 128 bytes out of band (torch.distributed), then
+ * csf_comm_init on every rank before the first csf_step.  world == 1 needs none of this. */
+#define CSF_UNIQUE_ID_BYTES 128
+int csf_comm_unique_id(uint8_t id_out[CSF_UNIQUE_ID_BYTES]);
+int csf_comm_init(csf_engine *e, const uint8_t id[CSF_UNIQUE_ID_BYTES], int32_t rank, int32_t world);
+/* the receiver block of this rank: [lo, hi) */
+int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+
+/* HIP-event time of the pair kernel, measured on the stream it is launched on: enable, run csf_step,
+ * then read the accumulated milliseconds and launch count (reset on read).  Costs two event records
+ * per tick while enabled. */
+int csf_profile_enable(csf_engine *e, int32_t on);
+int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSF_H */

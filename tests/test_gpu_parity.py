@@ -1,0 +1,327 @@
+"""Parity of the HIP path (through the C ABI, libcsf_hip.so) against the golden vectors of the literal
+reference and against the CPU oracle on identical seeded inputs.  All tests need a real MI355X.
+
+Tolerances (stated per BASELINE.json north_star: "trajectories within 1e-4 rel of the CPU reference"):
+  * O(N) per-agent work runs in fp64 on the GPU: 2e-7 against the reference (its own FITPACK / lm noise);
+  * the all-pairs sum runs in fp32: single pair forces 2e-5 of f_0, trajectories 1e-4 relative to the
+    extent of the scene.
+"""
+import numpy as np
+import pytest
+
+from oracle import csf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3}
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from cyclistsocialforce_amd import engine, parameters
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.Engine = engine.Engine
+    ns.pod = parameters.default_pod
+    return ns
+
+
+def make_engine(amd, model, s0, vdes, off, dq, rule=0, capacity=None, **over):
+    p = amd.pod(model, priority_rule=rule, **over)
+    s0 = np.asarray(s0, dtype=float)
+    n = s0.shape[0]
+    e = amd.Engine(p, capacity or max(n, 1))
+    e.add_agents(s0, vdes)
+    # golden queues already hold the (x0, y0, 0) start row the constructor creates: replace
+    e.set_dest_queue(np.arange(n), off, dq, reset=True)
+    return e
+
+
+def test_pair_field_twod_golden(amd, golden):
+    """vehicle.py:1560-1648 through the pair kernel's device function."""
+    g = golden("pair_fields")
+    e = amd.Engine(amd.pod("twod"), 4)
+    fx = np.zeros(g["x"].size); fy = np.zeros(g["x"].size)
+    for k in range(g["x"].size):
+        a, b = e.pair_force(np.r_[g["src"][k], 5.0], g["x"][k:k + 1], g["y"][k:k + 1], g["psi"][k:k + 1])
+        fx[k], fy[k] = a[0], b[0]
+    f0 = 7.0
+    np.testing.assert_allclose(fx, g["twod_fx"], rtol=2e-4, atol=2e-5 * f0)
+    np.testing.assert_allclose(fy, g["twod_fy"], rtol=2e-4, atol=2e-5 * f0)
+
+
+def test_pair_field_bicycle_golden(amd, golden):
+    """vehicle.py:1054-1147."""
+    g = golden("pair_fields")
+    e = amd.Engine(amd.pod("bicycle"), 4)
+    fx = np.zeros(g["x"].size); fy = np.zeros(g["x"].size)
+    for k in range(g["x"].size):
+        a, b = e.pair_force(np.r_[g["src"][k], g["src_v"][k]], g["x"][k:k + 1], g["y"][k:k + 1], g["psi"][k:k + 1])
+        fx[k], fy[k] = a[0], b[0]
+    np.testing.assert_allclose(fx, g["bicycle_fx"], rtol=2e-4, atol=2e-5 * 6.0)
+    np.testing.assert_allclose(fy, g["bicycle_fy"], rtol=2e-4, atol=2e-5 * 6.0)
+
+
+def test_pair_field_far_and_coincident_are_zero(amd):
+    """SURVEY finding 4: far pairs are exactly 0 (never NaN); coincident agents contribute 0."""
+    e = amd.Engine(amd.pod("twod"), 4)
+    fx, fy = e.pair_force([0, 0, 0, 5], [-3000.0, 0.0, 1e6], [8000.0, 0.0, 1e6], [0.0, 0.3, 1.0])
+    assert np.all(fx == 0.0) and np.all(fy == 0.0)
+
+
+@pytest.mark.parametrize("tag", ["n3", "n16", "n32", "n16_p2r"])
+def test_fov_mask_golden(amd, golden, tag):
+    """intersection.py:690-745: the kernel's dot-product test reproduces get_untracked_foes."""
+    g = golden("masks_totals")
+    rule = int(g[f"{tag}_p2r"])
+    e = amd.Engine(amd.pod("twod", priority_rule=rule), 4)
+    s0 = g[f"{tag}_s0"]
+    U = g[f"{tag}_untracked0"]
+    n = s0.shape[0]
+    for i in range(n):
+        fx, fy = e.pair_force(np.r_[s0[i, :3], 5.0], s0[:, 0], s0[:, 1], s0[:, 2], apply_fov=True)
+        fx0, fy0 = e.pair_force(np.r_[s0[i, :3], 5.0], s0[:, 0], s0[:, 1], s0[:, 2], apply_fov=False)
+        zero = (fx == 0) & (fy == 0)
+        live = (np.hypot(fx0, fy0) > 0)          # pairs whose unmasked force is representable
+        np.testing.assert_array_equal(zero[live], U[i][live], err_msg=f"source {i}")
+        assert zero[i]
+
+
+@pytest.mark.parametrize("tag", ["n2", "n3", "n16", "n32", "n16_p2r"])
+def test_calc_forces_golden(amd, golden, tag):
+    """intersection.py:747-864 after one warm-up tick (spline branch of the destination force)."""
+    g = golden("masks_totals")
+    rule = int(g[f"{tag}_p2r"])
+    e = make_engine(amd, "twod", g[f"{tag}_s0"], g[f"{tag}_vdes"], g[f"{tag}_off"], g[f"{tag}_dq"], rule)
+    e.step(1)
+    np.testing.assert_allclose(e.state(), g[f"{tag}_s1"], rtol=1e-5, atol=1e-5)
+    fx, fy = e.calc_forces()
+    np.testing.assert_allclose(fx, g[f"{tag}_Fx1"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(fy, g[f"{tag}_Fy1"], rtol=2e-4, atol=2e-4)
+
+
+def test_control_move_golden(amd, golden):
+    """vehicle.py:1218-1272 through csf_apply_forces (one engine per case class, batched)."""
+    g = golden("control_move")
+    for is_bike, model in ((False, "twod"), (True, "bicycle")):
+        sel = np.where(g["is_bicycle"] == is_bike)[0]
+        s = g["s"][sel]
+        n = len(sel)
+        e = amd.Engine(amd.pod(model), n)
+        e.add_agents(s, 5.0)
+        rows, off = [], [0]
+        for k in sel:
+            d = g["dest"][k]
+            rows.append([d[0], d[1], 0.0])
+            if d[2] == 0:                     # not the last destination: a second row keeps isLastDest False
+                rows.append([d[0], d[1], 0.0])
+            off.append(len(rows))
+        e.set_dest_queue(np.arange(n), off, np.array(rows), reset=True)
+        e.apply_forces(g["F"][sel, 0], g["F"][sel, 1])
+        np.testing.assert_allclose(e.state(), g["s_next"][sel], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["demo_a", "turn", "stop_last", "stop_mid", "pp_turn"])
+def test_dest_force_runs_golden(amd, golden, tag):
+    """vehicle.py:354-457, 545-594, 1416-1558: single agent in closed loop on its destination force."""
+    g = golden("dest_force_runs")
+    model = str(g[f"{tag}_model"])
+    S = g[f"{tag}_s"]
+    dq = g[f"{tag}_dq"]
+    e = make_engine(amd, model, S[:1], float(g[f"{tag}_vdes"]), [0, dq.shape[0]], dq)
+    T = g[f"{tag}_Fdest"].shape[0]
+    tol = 2e-7
+    for t in range(T):
+        fx, fy = e.dest_force()
+        s, ptr, zn, _ = e.state(with_nav=True)
+        np.testing.assert_allclose([fx[0], fy[0]], g[f"{tag}_Fdest"][t], rtol=tol, atol=tol, err_msg=f"tick {t}")
+        assert ptr[0] == g[f"{tag}_ptr"][t], f"tick {t}"
+        np.testing.assert_array_equal(zn[0], g[f"{tag}_znav"][t], err_msg=f"tick {t}")
+        e.apply_forces(fx, fy)
+        np.testing.assert_allclose(e.state()[0], S[t + 1], rtol=tol, atol=tol, err_msg=f"tick {t}")
+    assert e.status()[0] == 0
+
+
+def test_planarpoint_steps_golden(amd, golden):
+    """dynamics.py:996-1079 (closed-form implicit midpoint)."""
+    g = golden("planarpoint_steps")
+    s0 = g["s01"][:, :4]
+    e = amd.Engine(amd.pod("planarpoint"), s0.shape[0])
+    e.add_agents(s0, 5.0)
+    e.apply_forces(g["F01"][:, 0], g["F01"][:, 1])
+    np.testing.assert_allclose(e.state(), g["s01"][:, 4:], rtol=1e-7, atol=1e-8)
+    e.apply_forces(g["F01"][:, 2], g["F01"][:, 3])
+    np.testing.assert_allclose(e.state(), g["s2"], rtol=1e-7, atol=1e-8)
+
+
+def test_road_edges_golden(amd, golden):
+    """intersection.py:118-242 on the curve-scenario geometry: total - dest - repulsive = road term."""
+    g = golden("road_edges")
+    n = g["x"].size
+    s0 = np.c_[g["x"], g["y"], np.zeros(n), np.full(n, 4.0)]
+    e = amd.Engine(amd.pod("planarpoint", f_0=0.0), n)   # f_0 = 0 switches the agent-agent field off
+    e.add_agents(s0, 5.0)
+    e.set_road(g["off"], g["verts"], g["F0"], g["sigma"])
+    fx, fy = e.calc_forces()
+    fdx, fdy, frx, fry = e.force_parts()
+    assert np.all(frx == 0) and np.all(fry == 0)
+    scale = np.maximum(np.hypot(g["Fx"], g["Fy"]), 1e-3)
+    assert np.max(np.abs(fx - fdx - g["Fx"]) / scale) < 5e-5
+    assert np.max(np.abs(fy - fdy - g["Fy"]) / scale) < 5e-5
+
+
+TRAJ = [
+    ("demo_twod", "twod", 0), ("demo_bicycle", "bicycle", 0), ("demo_planarpoint", "planarpoint", 0),
+    ("demo_invpend", "invpend", 0), ("dense_twod", "twod", 0), ("dense_bicycle", "bicycle", 0),
+    ("dense_planarpoint", "planarpoint", 0), ("dense_invpend", "invpend", 0), ("p2r_twod", "twod", 1),
+    ("road_pp", "planarpoint", 0), ("lap_twod", "twod", 0),
+]
+
+
+@pytest.mark.parametrize("prefix,model,rule", TRAJ)
+def test_population_trajectories_golden(amd, golden, prefix, model, rule):
+    """intersection.py:866-896 end to end against the literal reference (1e-4 of the scene extent)."""
+    g = golden("trajectories")
+    e = make_engine(amd, model, g[f"{prefix}_s0"], g[f"{prefix}_vdes"], g[f"{prefix}_off"], g[f"{prefix}_dq"], rule)
+    if f"{prefix}_verts" in g.files:
+        e.set_road(g[f"{prefix}_roff"], g[f"{prefix}_verts"], g[f"{prefix}_F0"], g[f"{prefix}_sigma"])
+    S = g[f"{prefix}_S"]
+    every = {"lap_twod": 50}.get(prefix, 10)
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    worst = 0.0
+    for k in range(1, S.shape[0]):
+        e.step(every)
+        got = e.state()
+        worst = max(worst, np.abs(got[:, :2] - S[k][:, :2]).max() / extent)
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"{prefix} sample {k}")
+        np.testing.assert_allclose(got[:, 3], S[k][:, 3], rtol=0, atol=2e-3, err_msg=f"{prefix} speed sample {k}")
+    assert (e.status() == 0).all()
+    print(f"{prefix}: worst position deviation / extent = {worst:.3e}")
+
+
+def synthetic_population(n, box, seed=0):
+    """SURVEY.md §8(d) synthetic inputs."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, box, n); y = rng.uniform(0, box, n)
+    psi = rng.uniform(-np.pi, np.pi, n); v = rng.uniform(3, 6, n)
+    d = np.array([50.0, 99.0, 100.0])
+    dq = np.zeros((n, 4, 3))
+    dq[:, 0, 0] = x; dq[:, 0, 1] = y
+    dq[:, 1:, 0] = x[:, None] + d[None, :] * np.cos(psi)[:, None]
+    dq[:, 1:, 1] = y[:, None] + d[None, :] * np.sin(psi)[:, None]
+    off = np.arange(n + 1) * 4
+    return x, y, psi, v, off, dq.reshape(-1, 3)
+
+
+@pytest.mark.parametrize("model,n,box,ticks", [("twod", 1024, 200.0, 200), ("invpend", 512, 120.0, 100),
+                                                ("bicycle", 512, 120.0, 100), ("planarpoint", 512, 120.0, 100)])
+def test_random_population_vs_oracle(amd, model, n, box, ticks):
+    """BASELINE config 2 shape (random placement in an open square) against the CPU oracle."""
+    x, y, psi, v, off, dq = synthetic_population(n, box)
+    ns = orc.N_STATES[MODELS[model]]
+    s0 = np.zeros((n, ns)); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
+    e = make_engine(amd, model, s0, 5.0, off, dq)
+    pop = orc.Population(orc.default_params(model), s0, 5.0, off, dq)
+    e.step(ticks); pop.step(ticks)
+    got, ref = e.state(), pop.state()
+    rel = np.abs(got[:, :2] - ref[:, :2]).max() / box
+    print(f"{model} N={n}: max |dpos| / box after {ticks} ticks = {rel:.3e}")
+    assert rel < 1e-4
+    assert np.abs(got[:, 3] - ref[:, 3]).max() < 5e-3
+    fx, fy = e.forces(); ox, oy = pop.forces()
+    assert np.abs(np.c_[fx - ox, fy - oy]).max() < 5e-3
+    assert (e.status() == 0).all()
+
+
+def test_full_size_properties_16k(amd):
+    """N = 16384 (BASELINE metric size): properties that need no oracle run.
+    (a) bit-reproducible; (b) invariant under a permutation of the agents; (c) superposition of source
+    sets before the clamp; (d) a strided sample of receivers against the oracle's single-receiver sum."""
+    n, box = 16384, 200.0
+    x, y, psi, v, off, dq = synthetic_population(n, box)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    big = 1e6                                     # |F_dest| = v_desired on tick 0: clamp never active
+    e1 = make_engine(amd, "twod", s0, big, off, dq)
+    e1.calc_forces()
+    _, _, rx1, ry1 = e1.force_parts()
+    e2 = make_engine(amd, "twod", s0, big, off, dq)
+    e2.calc_forces()
+    _, _, rx2, ry2 = e2.force_parts()
+    assert np.array_equal(rx1, rx2) and np.array_equal(ry1, ry2)                      # (a)
+    perm = np.random.default_rng(1).permutation(n)
+    dq4 = dq.reshape(n, 4, 3)
+    e3 = make_engine(amd, "twod", s0[perm], big, off, dq4[perm].reshape(-1, 3))
+    e3.calc_forces()
+    _, _, rx3, ry3 = e3.force_parts()
+    scale = np.hypot(rx1, ry1).max()
+    assert np.abs(rx3 - rx1[perm]).max() < 2e-5 * scale                               # (b)
+    assert np.abs(ry3 - ry1[perm]).max() < 2e-5 * scale
+    # (c) receivers 0..63 feel sources A = [64, n/2) and B = [n/2, n) additively
+    half = n // 2
+    def sub(lo, hi):
+        idx = np.r_[np.arange(64), np.arange(lo, hi)]
+        ee = make_engine(amd, "twod", s0[idx], big, np.arange(idx.size + 1) * 4, dq4[idx].reshape(-1, 3))
+        ee.calc_forces()
+        return [a[:64] for a in ee.force_parts()[2:]]
+    ax, ay = sub(64, half); bx, by = sub(half, n); cx, cy = sub(64, n)
+    assert np.abs(ax + bx - cx).max() < 2e-5 * scale and np.abs(ay + by - cy).max() < 2e-5 * scale
+    # (d) sample of receivers against the oracle's pair function
+    p = orc.default_params("twod")
+    for j in range(0, n, 1024):
+        U = np.array([orc.lib().csfo_untracked(p.hfov, 0, i, j, x[i], y[i], x[j], y[j], psi[j]) for i in range(n)], dtype=bool)
+        src = np.where(~U)[0]
+        fx = fy = 0.0
+        for i in src:
+            a, b = orc.pair_twod(p, (x[i], y[i], psi[i]), x[j:j + 1], y[j:j + 1], psi[j:j + 1])
+            fx += a[0]; fy += b[0]
+        assert abs(fx - rx1[j]) < 1e-4 * max(1.0, np.hypot(fx, fy)), j
+        assert abs(fy - ry1[j]) < 1e-4 * max(1.0, np.hypot(fx, fy)), j
+
+
+def test_edge_cases(amd):
+    """Empty population, single agent (intersection.py:849-851), ragged queues, add/remove mid-run."""
+    p = amd.pod("twod")
+    e = amd.Engine(p, 8)
+    e.step(3)                                           # n == 0: intersection.py:888
+    assert e.n == 0 and e.tick == 3
+    e.add_agents(np.array([[0.0, 0, 0, 5, 0]]), 5.0)
+    e.set_dest_queue([0], [0, 2], [[50.0, 0, 0], [100.0, 0, 0]])
+    e.step(10)
+    s = e.state()
+    assert s.shape == (1, 5) and s[0, 0] > 0.3 and abs(s[0, 1]) < 1e-9
+    # ragged queues + removal keeps order
+    e.add_agents(np.array([[0.0, 10, 0, 5, 0], [0.0, 20, 0, 5, 0], [0.0, 30, 0, 5, 0]]), [4.0, 5.0, 6.0])
+    e.set_dest_queue([1, 3], [0, 1, 4], [[60.0, 10, 0], [20.0, 30, 0], [40.0, 31, 0], [60.0, 30, 1]])
+    e.step(5)
+    before = e.state()
+    e.remove_agents([2])
+    after = e.state()
+    np.testing.assert_array_equal(after, before[[0, 1, 3]])
+    e.step(5)
+    assert e.n == 3 and np.isfinite(e.state()).all()
+    with pytest.raises(Exception):
+        e.add_agents(np.zeros((9, 5)), 5.0)             # capacity
+    with pytest.raises(Exception):
+        e.remove_agents([7])
+
+
+def test_history_and_push_state(amd):
+    p = amd.pod("twod")
+    e = amd.Engine(p, 4)
+    e.add_agents(np.array([[0.0, 0, 0, 5, 0], [0.0, 50, 0, 4, 0]]), 5.0)
+    e.set_dest_queue([0, 1], [0, 1, 2], [[100.0, 0, 0], [100.0, 50, 0]])
+    e.enable_history(stride=2, capacity=16)
+    states = []
+    for _ in range(10):
+        e.step(1)
+        states.append(e.state())
+    h = e.history(0, 5)
+    for k in range(5):
+        np.testing.assert_array_equal(h[k], states[2 * k + 1])
+    s = e.state()
+    s[0, 0] += 1.0
+    e.push_state([0], s[0:1])
+    np.testing.assert_array_equal(e.state()[0], s[0])
