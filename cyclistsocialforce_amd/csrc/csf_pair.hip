@@ -140,6 +140,7 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
                 float dx = r[u].x - q.x, dy = r[u].y - q.y;  // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
                 bool in = tracked(k, r[u], dx, dy, r2);
+                r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
                 if (BICYCLE) field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
                 else field_twod(k, r[u], q, dx, dy, r2, F, gx, gy);
@@ -220,6 +221,7 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
     Recv r{rr.x, rr.y, rr.z, rr.w};
     float dx = r.x - q.x, dy = r.y - q.y, r2 = dx * dx + dy * dy;
     bool in = apply_fov ? tracked(k, r, dx, dy, r2) : (r2 > 0.f);
+    r2 = fmaxf(r2, 1e-30f);
     float F, gx, gy;
     if (d.p.model == CSF_BICYCLE) field_bicycle(k, q, src2[t], dx, dy, r2, F, gx, gy);
     else field_twod(k, r, q, dx, dy, r2, F, gx, gy);

@@ -49,8 +49,13 @@ def test_pair_field_twod_golden(amd, golden):
         a, b = e.pair_force(np.r_[g["src"][k], 5.0], g["x"][k:k + 1], g["y"][k:k + 1], g["psi"][k:k + 1])
         fx[k], fy[k] = a[0], b[0]
     f0 = 7.0
-    np.testing.assert_allclose(fx, g["twod_fx"], rtol=2e-4, atol=2e-5 * f0)
-    np.testing.assert_allclose(fy, g["twod_fy"], rtol=2e-4, atol=2e-5 * f0)
+    # the field's tangential part jumps at phi = 0 (np.sign(phi), vehicle.py:1625): receivers placed within
+    # 1e-6 rad of straight ahead are decided by rounding in ANY precision, the reference's fp64 included
+    bearing = np.arctan2(g["y"] - g["src"][:, 1], g["x"] - g["src"][:, 0]) - g["src"][:, 2]
+    ok = np.abs(np.sin(bearing)) > 1e-6
+    assert ok.sum() >= g["x"].size - 8
+    np.testing.assert_allclose(fx[ok], g["twod_fx"][ok], rtol=2e-4, atol=2e-5 * f0)
+    np.testing.assert_allclose(fy[ok], g["twod_fy"][ok], rtol=2e-4, atol=2e-5 * f0)
 
 
 def test_pair_field_bicycle_golden(amd, golden):
@@ -259,15 +264,17 @@ def test_full_size_properties_16k(amd):
     scale = np.hypot(rx1, ry1).max()
     assert np.abs(rx3 - rx1[perm]).max() < 2e-5 * scale                               # (b)
     assert np.abs(ry3 - ry1[perm]).max() < 2e-5 * scale
-    # (c) receivers 0..63 feel sources A = [64, n/2) and B = [n/2, n) additively
+    # (c) receivers 0..63 feel the source sets A = [64, n/2) and B = [n/2, n) additively; every sub-engine also
+    #     contains the 64 receivers themselves (set D), so  F(D+A) + F(D+B) - F(D) = F(D+A+B)
     half = n // 2
     def sub(lo, hi):
         idx = np.r_[np.arange(64), np.arange(lo, hi)]
         ee = make_engine(amd, "twod", s0[idx], big, np.arange(idx.size + 1) * 4, dq4[idx].reshape(-1, 3))
         ee.calc_forces()
         return [a[:64] for a in ee.force_parts()[2:]]
-    ax, ay = sub(64, half); bx, by = sub(half, n); cx, cy = sub(64, n)
-    assert np.abs(ax + bx - cx).max() < 2e-5 * scale and np.abs(ay + by - cy).max() < 2e-5 * scale
+    ax, ay = sub(64, half); bx, by = sub(half, n); cx, cy = sub(64, n); dx_, dy_ = sub(64, 64)
+    assert np.abs(ax + bx - dx_ - cx).max() < 2e-5 * scale and np.abs(ay + by - dy_ - cy).max() < 2e-5 * scale
+    assert np.abs(cx - rx1[:64]).max() < 2e-5 * scale and np.abs(cy - ry1[:64]).max() < 2e-5 * scale
     # (d) sample of receivers against the oracle's pair function
     p = orc.default_params("twod")
     for j in range(0, n, 1024):
