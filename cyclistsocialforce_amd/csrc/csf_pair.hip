@@ -35,12 +35,15 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 // The receiver ignores the source when the bearing of the source, relative to the receiver's heading,
 // is outside +-hfov/2 (hfov of the SOURCE's class, :733-735; one class per engine), when it is to the
 // left under priority-to-the-right, or when it is the receiver itself / coincident (rho = 0).
+// WIDE: hfov/2 > pi/2 (cos < 0); P2R: priority to the right.  Both are launch-time template flags so that
+// the inner loop carries no uniform branches.
+template <bool WIDE, bool P2R>
 __device__ __forceinline__ bool tracked(const PairConsts &k, const Recv &r, float dx, float dy, float r2) {
     float t = -(dx * r.c + dy * r.s);  // rho * cos(relative bearing)
     float t2 = t * t, lim = k.ch2 * r2;
-    bool in = (k.ch >= 0.0f) ? (t >= 0.0f && t2 >= lim) : (t >= 0.0f || t2 <= lim);
-    if (k.p2r) in = in && !((r.s * dx - r.c * dy) > 0.0f);  // rho * sin(relative bearing) > 0
-    return in && r2 > 0.0f;
+    bool in = WIDE ? ((t >= 0.0f) | (t2 <= lim)) : ((t >= 0.0f) & (t2 >= lim));
+    if (P2R) in = in & !((r.s * dx - r.c * dy) > 0.0f);  // rho * sin(relative bearing) > 0
+    return in & (r2 > 0.0f);
 }
 
 // vehicle.py:1560-1648: force of source (record q) on receiver r, returned as magnitude F and an
@@ -61,8 +64,9 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
     float big = a * rs, small = 0.5f * fabsf(sphi) * rs;
     float sg = __builtin_amdgcn_fmed3f(sphi * 1e38f, -1.0f, 1.0f);  // np.sign(phi), 0 at phi = 0 :1625
     bool pos = cphi >= 0.0f;
-    float h1 = pos ? small : big;                     // sqrt((1 - cos phi)/2)       :1624
-    float h2s = pos ? big * sg : 0.5f * sphi * rs;    // sqrt((1 + cos phi)/2) * sign(phi)
+    float bs = big * sg, al = 0.5f * sphi * rs;
+    float h1 = (pos ? small : big);  // sqrt((1 - cos phi)/2)  :1624
+    float h2s = pos ? bs : al;                        // sqrt((1 + cos phi)/2) * sign(phi)
     float sigma = sga - sgb * h1;                     // :1624
     float dsig = -0.5f * sgb * h2s;                   // :1625
     float ec = e * cphi;
@@ -94,11 +98,10 @@ __device__ __forceinline__ void field_bicycle(const PairConsts &k, const float4 
     F = P;
 }
 
-template <bool BICYCLE>
+template <bool BICYCLE, bool WIDE, bool P2R>
 __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
     __shared__ float4 tile[TILE];
     __shared__ float2 tile2[BICYCLE ? TILE : 1];
-    const PairConsts k = d.pc;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
@@ -116,13 +119,17 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
     for (int u = 0; u < RPW; u++) {
         int64_t j = j0 + u < d.hi ? j0 + u : d.hi - 1;  // clamp: duplicates are not stored
         float4 q = d.rec[j];
-        r[u].x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.x)));
-        r[u].y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.y)));
-        r[u].c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.z)));
-        r[u].s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.w)));
+        r[u].x = q.x;
+        r[u].y = q.y;
+        r[u].c = q.z;
+        r[u].s = q.w;
+        asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].c), "+v"(r[u].s));
         ax[u] = 0.0f;
         ay[u] = 0.0f;
     }
+    PairConsts k = d.pc;
+    asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0),
+                 "+v"(k.kexp), "+v"(k.ch2));
 
     for (int64_t base = ibeg; base < iend; base += TILE) {
         int cnt = (int)((iend - base) < TILE ? (iend - base) : TILE);  // multiple of 64
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
             for (int u = 0; u < RPW; u++) {
                 float dx = r[u].x - q.x, dy = r[u].y - q.y;  // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
-                bool in = tracked(k, r[u], dx, dy, r2);
+                bool in = tracked<WIDE, P2R>(k, r[u], dx, dy, r2);
                 r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
                 if (BICYCLE) field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
@@ -220,7 +227,11 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
     float4 q = src[t], rr = recv[t];
     Recv r{rr.x, rr.y, rr.z, rr.w};
     float dx = r.x - q.x, dy = r.y - q.y, r2 = dx * dx + dy * dy;
-    bool in = apply_fov ? tracked(k, r, dx, dy, r2) : (r2 > 0.f);
+    bool in = r2 > 0.f;
+    if (apply_fov) {
+        if (k.ch >= 0.f) in = k.p2r ? tracked<false, true>(k, r, dx, dy, r2) : tracked<false, false>(k, r, dx, dy, r2);
+        else in = k.p2r ? tracked<true, true>(k, r, dx, dy, r2) : tracked<true, false>(k, r, dx, dy, r2);
+    }
     r2 = fmaxf(r2, 1e-30f);
     float F, gx, gy;
     if (d.p.model == CSF_BICYCLE) field_bicycle(k, q, src2[t], dx, dy, r2, F, gx, gy);
@@ -236,11 +247,23 @@ static dim3 recv_grid(const Dev &d, int split) {
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
 
+template <bool BICYCLE>
+static void launch_pair_t(const Dev &d, dim3 g, hipStream_t st) {
+    const bool wide = d.pc.ch < 0.f, p2r = d.pc.p2r != 0;
+    if (wide) {
+        if (p2r) hipLaunchKernelGGL((pair_kernel<BICYCLE, true, true>), g, dim3(BLOCK), 0, st, d);
+        else hipLaunchKernelGGL((pair_kernel<BICYCLE, true, false>), g, dim3(BLOCK), 0, st, d);
+    } else {
+        if (p2r) hipLaunchKernelGGL((pair_kernel<BICYCLE, false, true>), g, dim3(BLOCK), 0, st, d);
+        else hipLaunchKernelGGL((pair_kernel<BICYCLE, false, false>), g, dim3(BLOCK), 0, st, d);
+    }
+}
+
 void launch_pair(const Dev &d, hipStream_t st) {
     if (d.hi <= d.lo) return;
     dim3 g = recv_grid(d, d.n_split);
-    if (d.p.model == CSF_BICYCLE) hipLaunchKernelGGL(pair_kernel<true>, g, dim3(BLOCK), 0, st, d);
-    else hipLaunchKernelGGL(pair_kernel<false>, g, dim3(BLOCK), 0, st, d);
+    if (d.p.model == CSF_BICYCLE) launch_pair_t<true>(d, g, st);
+    else launch_pair_t<false>(d, g, st);
 }
 
 void launch_road(const Dev &d, hipStream_t st) {
