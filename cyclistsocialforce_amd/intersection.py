@@ -1,0 +1,401 @@
+"""`SocialForceIntersection` and the road-element classes with the interface of
+`cyclistsocialforce.intersection` (SocialForceIntersection :253-916, RoadEdge :214, RoadSegment :72,
+Straight/CurvedRoadSegment :118/:149, RoadSegmentCollection :32), driving the HIP engine.
+
+One `step()` is exactly one `csf_step(engine, 1)`: FOV mask, all-pairs repulsive field, clamp, destination
+force, road-edge force, controller + kinematics for every vehicle, snapshot refresh — all on the GPU.
+The Python objects are a mirror: user mutations of `vehicle.s`, `vehicle.params.v_desired_default`, the
+destination queues or the population are pushed to the device before the next tick, and `vehicle.s`,
+`traj`, `destpointer`, `znav`, `force`, `F` are refreshed after it.  `step_n(k)` runs k ticks without any
+per-tick Python work.
+
+Out of scope: SUMO co-simulation (`activate_sumo_cosimulation=True` raises), matplotlib
+animation (`animate=True` raises), and populations mixing vehicle classes in one intersection.
+"""
+import numpy as np
+
+from . import _ffi
+from .engine import Engine
+from .parameters import RoadElementParameters
+from .vehicle import Vehicle
+
+PRIORITY_RULES = {"unregulated": _ffi.UNREGULATED, "p2r": _ffi.P2R}
+
+
+# ----------------------------------------------------------------------------- road elements
+
+class RoadEdge:
+    """intersection.py:214-250: a polyline whose vertices repel road users with -F_0 r^-sigma."""
+
+    def __init__(self, vertices, params=None):
+        self.vertices = np.asarray(vertices, dtype=float)
+        self.params = params if params is not None else RoadElementParameters()
+
+    def edges(self):
+        return [self]
+
+
+class RoadSegment:
+    """intersection.py:72-115: two edges at +-width/2 around a centre line starting at x0 = (x, y, heading).
+    As in the reference the segment's own `params` are defaults; the edges carry the ones passed in."""
+
+    def __init__(self, x0, width, ds=0.1, params=None):
+        self.params = RoadElementParameters()
+        self.x0 = x0
+        self.x1 = x0
+        self.width = width
+        self.edge_list = []
+        self.ds = ds
+
+    def edges(self):
+        return list(self.edge_list)
+
+    @staticmethod
+    def _place(local_xy, origin, heading):
+        c, s = np.cos(heading), np.sin(heading)
+        rot = np.array([[c, -s], [s, c]])
+        return (rot @ np.asarray(local_xy, dtype=float).T).T + np.asarray(origin[:2], dtype=float)
+
+
+class StraightRoadSegment(RoadSegment):
+    """intersection.py:118-146: vertices every `ds` along a straight of `length`."""
+
+    def __init__(self, x0, width, length, ds=0.1, params=None):
+        RoadSegment.__init__(self, x0, width, ds, params)
+        params = params if params is not None else RoadElementParameters()
+        self.length = length
+        along = np.arange(0, length + self.ds, self.ds)                # :126
+        for side in (-0.5, 0.5):                                       # right edge first (:127-140)
+            local = np.c_[along, np.full_like(along, side * width)]
+            self.edge_list.append(RoadEdge(self._place(local, x0, x0[2]), params=params))
+        self.x1 = np.zeros_like(np.asarray(x0, dtype=float))           # :142-146
+        self.x1[:2] = np.asarray(x0[:2], dtype=float) + length * np.array([np.cos(x0[2]), np.sin(x0[2])])
+        self.x1[2] = x0[2]
+
+
+class CurvedRoadSegment(RoadSegment):
+    """intersection.py:149-211: circular arc of `radius` through `angle`, turning "left" or "right"."""
+
+    def __init__(self, x0, width, radius, angle, direction, ds=0.1, params=None):
+        RoadSegment.__init__(self, x0, width, ds, params)
+        params = params if params is not None else RoadElementParameters()
+        assert direction in ("left", "right"), f'direction has to be "left" or "right, instead it was {direction}'
+        self.length = radius * angle
+        self.radius, self.angle, self.direction = radius, angle, direction
+        turn = 1 if direction == "left" else -1                        # :166
+        beta = x0[2] - np.pi / 2                                       # :173
+        for sign in (+1, -1):                                          # right edge first (:176-207)
+            r_edge = radius + sign * turn * width / 2
+            grid = np.linspace(0, angle, int(r_edge * angle / self.ds))
+            local = np.c_[turn * (r_edge * np.cos(grid) - radius), r_edge * np.sin(grid)]
+            self.edge_list.append(RoadEdge(self._place(local, x0, beta), params=params))
+        end_local = np.array([[turn * (radius * np.cos(angle) - radius), radius * np.sin(angle)]])
+        self.x1 = np.zeros(3)                                          # :209-211
+        self.x1[:2] = self._place(end_local, x0, beta)[0]
+        self.x1[2] = x0[2] + turn * angle
+
+
+class RoadSegmentCollection:
+    """intersection.py:32-69"""
+
+    def __init__(self, segs):
+        self.segs = segs
+
+    def edges(self):
+        return [e for seg in self.segs for e in seg.edges()]
+
+    def get_destinations_from_segments(self):
+        return [seg.x1[0] for seg in self.segs], [seg.x1[1] for seg in self.segs]
+
+    def __getitem__(self, i):
+        if not isinstance(i, int):
+            raise ValueError("Subscription index must be integer!")
+        if i > len(self.segs):
+            raise IndexError(f"RoadSegmentCollection has {len(self.segs)} segments, but i={i} was requested")
+        return self.segs[i]
+
+
+def flatten_road_elements(elements):
+    """(offsets[n_edges+1], vertices[sum,2], F0[n_edges], sigma[n_edges]) of a road_elements list."""
+    edges = [e for el in elements for e in el.edges()]
+    off = np.zeros(len(edges) + 1, dtype=np.int64)
+    for k, e in enumerate(edges):
+        off[k + 1] = off[k] + e.vertices.shape[0]
+    verts = np.vstack([e.vertices for e in edges]) if edges else np.zeros((0, 2))
+    return off, verts, np.array([e.params.F_0 for e in edges]), np.array([e.params.sigma for e in edges])
+
+
+# ----------------------------------------------------------------------------- the population tick
+
+class SocialForceIntersection:
+    """Open space / intersection managing one population of road users (intersection.py:253-916)."""
+
+    def __init__(self, vehicleList, id="", priority_rule="unregulated", animate=False, axes=None,
+                 activate_sumo_cosimulation=False, net=None, road_elements=[], bicycle_drawing_kwargs={},
+                 capacity=None, device=0, track_params=True):
+        if activate_sumo_cosimulation:
+            raise NotImplementedError("SUMO co-simulation is outside the scope of the MI355X engine")
+        if animate:
+            raise NotImplementedError("matplotlib animation is outside the scope of the MI355X engine; "
+                                      "attach drawing objects to the vehicles instead")
+        if priority_rule not in PRIORITY_RULES:
+            raise ValueError(f"priority_rule must be one of {tuple(PRIORITY_RULES)}")
+        assert isinstance(id, str), "Intersection ID has to be a string."
+        self.bicycle_drawing_kwargs = bicycle_drawing_kwargs
+        self.is_first_step = True
+        self.activate_sumo_cosimulation = False
+        self.id = id
+        self.priority_rule = priority_rule
+        self.animate = False
+        self.ax = axes
+        self.road_elements = road_elements
+        self.hist_n_vecs = []
+        self.vehicles = []
+        self.n_bikes = 0
+        self.vehicleX = np.zeros((0, 1))
+        self.vehicleY = np.zeros((0, 1))
+        self.vehicleTheta = np.zeros((0, 1))
+        self._device = device
+        self._capacity = capacity
+        self._track_params = track_params
+        self._engine = None
+        self._S = None            # host mirror [capacity, n_states]; vehicle.s are row views
+        self._shadow = None       # device's view of the mirror after the last pull / push
+        self._vd = None
+        self._rule_on_device = None
+        self._pod_bytes = None
+        self._road_sig = None
+        self._pending = []        # vehicles waiting to be added to the engine
+        for v in vehicleList:
+            self._attach(v)
+
+    # ------------------------------------------------------------------ population management
+    def _attach(self, v):
+        if not isinstance(v, Vehicle):
+            raise TypeError("road users must be cyclistsocialforce_amd.vehicle.Vehicle objects")
+        if v._owner is not None and v._owner is not self:
+            raise RuntimeError(f"vehicle {v.id} already belongs to another intersection")
+        if self.vehicles and type(v).MODEL != type(self.vehicles[0]).MODEL:
+            raise NotImplementedError("one intersection holds one vehicle class (one engine per rider model)")
+        if v._solo is not None:
+            v._solo.close()
+            v._solo = None
+        v._owner = self
+        v._index = len(self.vehicles)
+        v._queue_synced = -1
+        self.vehicles.append(v)
+        self._pending.append(v)
+        self.n_bikes = len(self.vehicles)
+        self.vehicleX = np.vstack((self.vehicleX, [[v.s[0]]]))         # intersection.py:531-538
+        self.vehicleY = np.vstack((self.vehicleY, [[v.s[1]]]))
+        self.vehicleTheta = np.vstack((self.vehicleTheta, [[v.s[2]]]))
+
+    def add_road_user(self, user):
+        """intersection.py:458-539 (without the SUMO route handling)."""
+        self._attach(user)
+
+    def get_road_user_ids(self):
+        return [v.id for v in self.vehicles]
+
+    def has_road_user(self, userId):
+        assert isinstance(userId, str), "User ID has to be a string."
+        return userId in self.get_road_user_ids()
+
+    def remove_road_user(self, i_remove):
+        """intersection.py:618-634"""
+        self._remove([int(i_remove)])
+
+    def remove_road_users_by_id(self, ruids):
+        """intersection.py:576-616"""
+        idx = [k for k, v in enumerate(self.vehicles) if v.id in ruids]
+        if idx:
+            self._remove(idx)
+
+    def _remove(self, idx):
+        idx = sorted(set(idx))
+        for k in idx:
+            if not 0 <= k < len(self.vehicles):
+                raise IndexError(f"no road user {k}")
+        if self._engine is not None:
+            self._flush_pending()
+            self._engine.remove_agents(idx)
+        gone = set(idx)
+        keep = [k for k in range(len(self.vehicles)) if k not in gone]
+        for k in idx:
+            v = self.vehicles[k]
+            v.s = v.s.copy()
+            v._owner, v._index = None, -1
+            if v in self._pending:
+                self._pending.remove(v)
+        self.vehicles = [self.vehicles[k] for k in keep]
+        if self._S is not None:
+            self._S[: len(keep)] = self._S[keep]
+            self._shadow[: len(keep)] = self._shadow[keep]
+            self._vd[: len(keep)] = self._vd[keep]
+        for new, v in enumerate(self.vehicles):
+            v._index = new
+            if self._S is not None and v not in self._pending:
+                v.s = self._S[new]
+        self.n_bikes = len(self.vehicles)
+        self.vehicleX = np.delete(self.vehicleX, idx, 0)
+        self.vehicleY = np.delete(self.vehicleY, idx, 0)
+        self.vehicleTheta = np.delete(self.vehicleTheta, idx, 0)
+
+    def addEdge(self, roadEdge):
+        self.road_elements.append(roadEdge)
+
+    # ------------------------------------------------------------------ host <-> device mirror
+    def _engine_ready(self):
+        if not self.vehicles:
+            raise RuntimeError("the intersection is empty")
+        v0 = self.vehicles[0]
+        if self._engine is None:
+            cap = self._capacity or max(256, 4 * len(self.vehicles))
+            self._engine = Engine(v0._pod(PRIORITY_RULES[self.priority_rule]), cap, device=self._device)
+            self._capacity = cap
+            ns = type(v0).N_STATES
+            self._S = np.zeros((cap, ns))
+            self._shadow = np.zeros((cap, ns))
+            self._vd = np.zeros(cap)
+            self._rule_on_device = self.priority_rule
+            self._pod_bytes = bytes(v0._pod(PRIORITY_RULES[self.priority_rule]))
+        self._flush_pending()
+        return self._engine
+
+    def _flush_pending(self):
+        if not self._pending:
+            return
+        e = self._engine
+        if len(self.vehicles) > self._capacity:
+            raise RuntimeError(f"intersection capacity {self._capacity} exceeded; pass capacity= at construction")
+        new = self._pending
+        self._pending = []
+        s0 = np.array([v.s for v in new], dtype=float)
+        vd = np.array([float(v.params.v_desired_default) for v in new])
+        first = new[0]._index
+        e.add_agents(s0, vd)
+        for k, v in enumerate(new):
+            self._S[first + k] = v.s
+            v.s = self._S[first + k]
+            self._shadow[first + k] = v.s
+            self._vd[first + k] = vd[k]
+            v._queue_synced = -1
+
+    def _mark_queue_dirty(self, v):
+        if getattr(v, "_queue_reset", False):
+            v._queue_synced = -1
+
+    def _push_mutations(self):
+        """Everything the user may have changed on the Python side since the last tick."""
+        e = self._engine_ready()
+        n = len(self.vehicles)
+        # destination queues: appended rows go up with reset=0, replaced queues with reset=1
+        for mode in (1, 0):
+            agents, rows, off = [], [], [0]
+            for v in self.vehicles:
+                q = v.destqueue
+                if mode == 1 and v._queue_synced < 0:
+                    agents.append(v._index); rows.append(q); off.append(off[-1] + q.shape[0])
+                    v._queue_synced = q.shape[0]
+                elif mode == 0 and 0 <= v._queue_synced < q.shape[0]:
+                    agents.append(v._index); rows.append(q[v._queue_synced:]); off.append(off[-1] + q.shape[0] - v._queue_synced)
+                    v._queue_synced = q.shape[0]
+                v._queue_dirty = False
+            if agents:
+                e.set_dest_queue(agents, off, np.vstack(rows), reset=bool(mode))
+        # vehicle.s edited in place (calibration.py:455-460)
+        changed = np.where(np.any(self._S[:n] != self._shadow[:n], axis=1))[0]
+        if changed.size:
+            e.push_state(changed, self._S[changed])
+            self._shadow[changed] = self._S[changed]
+        if self._track_params:
+            # params.v_desired_default is the per-agent parameter (demoCSFstandalone.py:104-113)
+            vd = np.array([float(v.params.v_desired_default) for v in self.vehicles])
+            ch = np.where(vd != self._vd[:n])[0]
+            if ch.size:
+                e.set_v_desired(ch, vd[ch])
+                self._vd[ch] = vd[ch]
+            pod = self.vehicles[0]._pod(PRIORITY_RULES[self.priority_rule])
+            if bytes(pod) != self._pod_bytes:
+                e.set_params(pod)
+                self._pod_bytes = bytes(pod)
+        if self.priority_rule != self._rule_on_device:
+            if self.priority_rule not in PRIORITY_RULES:
+                raise ValueError(f"priority_rule must be one of {tuple(PRIORITY_RULES)}")
+            e.set_priority_rule(PRIORITY_RULES[self.priority_rule])
+            self._rule_on_device = self.priority_rule
+        sig = tuple(id(el) for el in self.road_elements)
+        if sig != self._road_sig:
+            off, verts, F0, sg = flatten_road_elements(self.road_elements)
+            e.set_road(off, verts, F0, sg)
+            self._road_sig = sig
+        return e
+
+    def _pull(self, forces=True, advance=1):
+        e = self._engine
+        n = len(self.vehicles)
+        s, ptr, zn, _ = e.state(with_nav=True)
+        self._S[:n] = s
+        self._shadow[:n] = s
+        fx, fy = e.forces() if forces else (None, None)
+        for k, v in enumerate(self.vehicles):
+            v.destpointer = int(ptr[k])
+            v.znav[:] = zn[k]
+            v.dest = v.destqueue[v.destpointer, :]
+            if forces:
+                v.force = (fx[k], fy[k])                               # intersection.py:860-862
+        if advance:
+            for k, v in enumerate(self.vehicles):
+                if forces:
+                    v.F.append(float(np.hypot(fx[k], fy[k])))
+                v.i = (v.i + advance - 1) % v.traj.shape[1]
+                v._advance_history(fx[k] if forces else 0.0, fy[k] if forces else 0.0)
+        self.update_road_user_positions()
+        return fx, fy
+
+    def update_road_user_positions(self):
+        """intersection.py:660-677"""
+        n = len(self.vehicles)
+        if n and self._S is not None and not self._pending:
+            self.vehicleX[:, 0] = self._S[:n, 0]
+            self.vehicleY[:, 0] = self._S[:n, 1]
+            self.vehicleTheta[:, 0] = self._S[:n, 2]
+        else:
+            for k, v in enumerate(self.vehicles):
+                self.vehicleX[k, 0], self.vehicleY[k, 0], self.vehicleTheta[k, 0] = v.s[0], v.s[1], v.s[2]
+
+    # ------------------------------------------------------------------ reference API
+    def calc_forces(self):
+        """intersection.py:747-864: total force on every road user from the current snapshot."""
+        e = self._push_mutations()
+        fx, fy = e.calc_forces()
+        self._pull(forces=True, advance=0)
+        for k, v in enumerate(self.vehicles):
+            v.F.append(float(np.hypot(fx[k], fy[k])))
+        return fx, fy
+
+    def step(self):
+        """intersection.py:866-896: one simulation tick of the whole population."""
+        self.is_first_step = False
+        if self.n_bikes > 0:
+            e = self._push_mutations()
+            e.step(1)
+            self._pull(forces=True, advance=1)
+        self.hist_n_vecs.append(self.n_bikes)
+
+    def step_n(self, n_ticks, pull=True):
+        """n_ticks ticks with no per-tick host work (the benchmark path).  `traj` receives only the final
+        state; enable the engine's device-side history for dense trajectories."""
+        if self.n_bikes > 0 and n_ticks > 0:
+            e = self._push_mutations()
+            e.step(int(n_ticks))
+            if pull:
+                self._pull(forces=True, advance=int(n_ticks))
+        self.hist_n_vecs.extend([self.n_bikes] * int(n_ticks))
+
+    def set_animated(self, animated):
+        """intersection.py:899-915 (no-op: animation is out of scope)."""
+
+    @property
+    def engine(self):
+        return self._engine_ready()

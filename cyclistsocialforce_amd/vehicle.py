@@ -1,0 +1,253 @@
+"""Vehicle classes with the constructors, attributes and methods of `cyclistsocialforce.vehicle`
+(Vehicle :49, Bicycle :990, TwoDBicycle :1292, InvPendulumBicycle :1651, PlanarPointBicycle :1991),
+executed by the HIP engine.
+
+A vehicle owns NumPy state (`s`, `traj`, `trajF`, `destqueue`, ...) exactly like the reference object.
+The numbers are produced on the GPU:
+
+* inside a `SocialForceIntersection` the vehicle is one row of the population engine and `s` is refreshed
+  from the device after every tick;
+* stepped on its own (`calcDestinationForce`, `calcRepulsiveForce`, `step(Fx, Fy)` — the seam-1 hooks of
+  SURVEY.md §8(b), used by calibration replay, calibration.py:438-460) it drives a private one-agent engine.
+
+There is no NumPy fallback: without libcsf_hip.so / a GPU these methods raise `EngineError`.
+"""
+import numpy as np
+
+from . import _ffi
+from .engine import Engine
+from .parameters import (BicycleParameters, InvPendulumBicycleParameters, PlanarPointBicycleParameters,
+                         VehicleParameters)
+from .utils import limitAngle
+
+
+class Vehicle:
+    """Parent class — vehicle.py:49-917.  Abstract here: a concrete class selects the rider model."""
+
+    PARAMS_TYPE = VehicleParameters
+    MODEL = None
+    N_STATES = 4
+    STATE_NAMES = ["x[m]", "y[m]", "psi[rad]", "v[m/s]"]
+
+    def __init__(self, s0, id="unknown", route=(), saveForces=False, params=None):
+        if self.MODEL is None:
+            raise NotImplementedError("instantiate Bicycle, TwoDBicycle, InvPendulumBicycle or PlanarPointBicycle")
+        if params is None:                                             # vehicle.py:139-143
+            self.params = self.PARAMS_TYPE()
+        else:
+            if not isinstance(params, self.PARAMS_TYPE):
+                raise TypeError(f"Params must be a '{self.PARAMS_TYPE.__name__}' object. "
+                                f"Instead it was '{type(params).__name__}'.")
+            self.params = params
+        self.i = 0                                                     # vehicle.py:146
+        if len(s0) < self.N_STATES:                                    # vehicle.py:149-152
+            raise ValueError(f"The initial state s0 has to be size {self.N_STATES} with states "
+                             f"{self.STATE_NAMES}. Instead it was {s0}.")
+        if len(s0) > self.N_STATES:
+            s0 = s0[:self.N_STATES]
+        self.s = np.array(s0, dtype=float)                             # vehicle.py:154-156
+        self.s[2] = limitAngle(s0[2])
+        self.s_names = list(self.STATE_NAMES)
+        self.traj = np.zeros((len(s0), int(30 / self.params.t_s)))     # vehicle.py:159-160
+        self.traj[:, 0] = self.s
+        self.saveForces = saveForces
+        if self.saveForces:
+            self.trajF = np.zeros((2, int(30 / self.params.t_s)))
+        assert isinstance(id, str), "User ID has to be a string."      # vehicle.py:167-168
+        self.id = id
+        assert isinstance(route, tuple), "Route has to be a tuple"     # vehicle.py:171-177
+        assert all(isinstance(r, str) for r in route), "Edge IDs in route list have to be str"
+        self.follow_route = bool(route)
+        self.route = route
+        self.drawing = None
+        self.dest = np.array([s0[0], s0[1], 0.0])                      # vehicle.py:183-185
+        self.destqueue = np.c_[self.dest[0], self.dest[1], self.dest[2]]
+        self.destpointer = 0
+        self.znav = np.array([True, False, False])                     # vehicle.py:188
+        self.F = []
+        self.force = (0.0, 0.0)
+        self.uncontrolled = False
+        # engine binding
+        self._owner = None        # SocialForceIntersection that holds this vehicle, or None
+        self._index = -1
+        self._solo = None         # private one-agent engine
+        self._queue_dirty = True
+        self._s_shadow = self.s.copy()
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _pod(self, priority_rule=0):
+        return self.params.to_pod(self.MODEL, priority_rule)
+
+    def _solo_engine(self):
+        """The vehicle's own one-agent engine, kept in step with the Python-side attributes."""
+        if self._owner is not None:
+            raise RuntimeError("this vehicle belongs to a SocialForceIntersection; step the intersection")
+        if self._solo is None:
+            self._solo = Engine(self._pod(), 1)
+            self._solo.add_agents(self.s[None, :], float(self.params.v_desired_default))
+            self._queue_dirty = True
+            self._s_shadow = self.s.copy()
+            self._vd_shadow = float(self.params.v_desired_default)
+        e = self._solo
+        if self._queue_dirty:
+            e.set_dest_queue([0], [0, self.destqueue.shape[0]], self.destqueue, reset=True)
+            self._queue_dirty = False
+        if not np.array_equal(self.s, self._s_shadow):
+            e.push_state([0], self.s[None, :])
+            self._s_shadow = self.s.copy()
+        if float(self.params.v_desired_default) != self._vd_shadow:
+            e.set_v_desired([0], float(self.params.v_desired_default))
+            self._vd_shadow = float(self.params.v_desired_default)
+        return e
+
+    def _pull(self, s_row, ptr, znav_row):
+        """Adopt the engine's view after a device tick (also advances the traj ring like vehicle.step)."""
+        self.s[:] = s_row
+        self._s_shadow[:] = s_row
+        self.destpointer = int(ptr)
+        self.znav[:] = znav_row
+        self.dest = self.destqueue[self.destpointer, :]
+
+    def _advance_history(self, Fx, Fy):
+        self.i = (self.i + 1) % self.traj.shape[1]                     # vehicle.py:1279-1282 (see DESIGN D5)
+        self.traj[:, self.i] = self.s
+        if self.saveForces:
+            self.trajF[0, self.i] = Fx
+            self.trajF[1, self.i] = Fy
+        self.update_drawing(Fres=(Fx, Fy))
+
+    # ------------------------------------------------------------------ reference API
+    def calcRepulsiveForce(self, x, y, psi):
+        """vehicle.py:250-279 / 1560-1648: force this vehicle exerts on road users at (x, y, psi)."""
+        if getattr(self.params, "f_0", 1.0) == 0.0 and self.MODEL != _ffi.BICYCLE:
+            return 0.0, 0.0                                            # vehicle.py:1592-1593
+        x = np.atleast_1d(np.asarray(x, dtype=float)).ravel()
+        y = np.atleast_1d(np.asarray(y, dtype=float)).ravel()
+        psi = np.atleast_1d(np.asarray(psi, dtype=float)).ravel() if psi is not None else np.zeros_like(x)
+        eng = self._owner._engine_ready() if self._owner is not None else self._solo_engine()
+        return eng.pair_force(np.r_[self.s[:3], self.s[3]], x, y, psi)
+
+    def calcDestinationForce(self):
+        """vehicle.py:281-299, 1189-1194, 1416-1558 (advances the destination queue / nav state)."""
+        e = self._solo_engine()
+        fx, fy = e.dest_force()
+        s, ptr, zn, _ = e.state(with_nav=True)
+        self.destpointer = int(ptr[0])
+        self.znav[:] = zn[0]
+        self.dest = self.destqueue[self.destpointer, :]
+        return float(fx[0]), float(fy[0])
+
+    def step(self, F1=0, F2=0):
+        """vehicle.py:301-328, 1274-1289, 1386-1414, 1883-1930: one control + kinematics step."""
+        e = self._solo_engine()
+        e.apply_forces([float(F1)], [float(F2)])
+        s, ptr, zn, _ = e.state(with_nav=True)
+        self._pull(s[0], ptr[0], zn[0])
+        self._advance_history(float(F1), float(F2))
+
+    def updateDestination(self):
+        raise NotImplementedError("the queue is advanced inside calcDestinationForce() on the device")
+
+    def getDestinationDistance(self):
+        """vehicle.py:596-604"""
+        dest = self.destqueue[self.destpointer, :]
+        return np.sqrt(np.power(dest[0] - self.s[0], 2) + np.power(dest[1] - self.s[1], 2))
+
+    def isLastDest(self):
+        """vehicle.py:537-543"""
+        if self.destqueue is None:
+            return True
+        return self.destpointer + 1 >= np.shape(self.destqueue)[0]
+
+    def setDestinations(self, x, y, stop=None, reset=False):
+        """vehicle.py:606-647"""
+        x = np.array([x], dtype=float).flatten()
+        y = np.array([y], dtype=float).flatten()
+        stop = np.zeros_like(x) if stop is None else np.array([stop], dtype=float).flatten()
+        if reset or self.destqueue is None:
+            self.destqueue = np.c_[x, y, stop]
+            self.destpointer = 0
+            self.dest = [x[0], y[0], stop[0]]
+        else:
+            self.destqueue = np.vstack((self.destqueue, np.c_[x, y, stop]))
+        self._queue_dirty = True
+        self._queue_reset = bool(reset)
+        if self._owner is not None:
+            self._owner._mark_queue_dirty(self)
+
+    def setSplineDestinations(self, x, y, npoints, stop=False, reset=False):
+        """vehicle.py:649-693 (host-side convenience; uses scipy like the reference)."""
+        from scipy import interpolate
+
+        assert len(x) >= 3, "Provide at least 3 points to calculate a cubic trajectory prototype"
+        x = np.insert(np.array(x, dtype=float), 0, self.s[0])
+        y = np.insert(np.array(y, dtype=float), 0, self.s[1])
+        tck, _ = interpolate.splprep((x, y), s=0.0)
+        x_i, y_i = interpolate.splev(np.linspace(0, 1, npoints), tck)
+        if stop:
+            flags = np.zeros_like(x_i)
+            flags[-1] = 1.0
+            self.setDestinations(x_i, y_i, stop=flags, reset=reset)
+        else:
+            self.setDestinations(x_i, y_i, reset=reset)
+
+    def add_drawing(self, ax, drawing=None, **kwargs):
+        """vehicle.py:695-720: only caller-supplied drawings (matplotlib artists are out of scope)."""
+        if drawing is None:
+            raise NotImplementedError("pass a drawing object with update(vehicle, Fdest=, Frep=, Fres=)")
+        self.drawing = drawing
+
+    def update_drawing(self, Fdest=None, Frep=None, Fres=None):
+        """vehicle.py:722-732"""
+        if self.drawing is not None:
+            self.drawing.update(self, Fdest=Fdest, Frep=Frep, Fres=Fres)
+
+
+class Bicycle(Vehicle):
+    """vehicle.py:990-1289 — 2D kinematic bicycle, elliptic repulsive field, straight-line destination force."""
+
+    PARAMS_TYPE = BicycleParameters
+    MODEL = _ffi.BICYCLE
+    N_STATES = 5
+    STATE_NAMES = ["x[m]", "y[m]", "psi[rad]", "v[m/s]", "delta[rad]"]
+
+    def __init__(self, s0, **kwargs):
+        Vehicle.__init__(self, s0, **kwargs)
+        self.destspline = None
+
+
+class TwoDBicycle(Bicycle):
+    """vehicle.py:1292-1648 — "2D model": spline path planner + the new repulsive field.
+
+    The reference constructor is broken at HEAD (vehicle.py:1359, SURVEY finding 2); the documented
+    signature is honoured here."""
+
+    PARAMS_TYPE = InvPendulumBicycleParameters
+    MODEL = _ffi.TWOD
+
+    def __init__(self, s0, id="unknown", route=(), saveForces=False, params=None):
+        Bicycle.__init__(self, s0, id=id, route=route, saveForces=saveForces, params=params)
+
+
+class InvPendulumBicycle(TwoDBicycle):
+    """vehicle.py:1651-1950 — inverted-pendulum roll/steer/yaw loop."""
+
+    MODEL = _ffi.INVPEND
+    N_STATES = 6
+    STATE_NAMES = ["x[m]", "y[m]", "psi[rad]", "v[m/s]", "delta[rad]", "theta[rad]"]
+
+    def __init__(self, s0, **kwargs):
+        TwoDBicycle.__init__(self, s0, **kwargs)
+
+
+InvertedPendulumBicycle = InvPendulumBicycle  # README.md:14 name
+
+
+class PlanarPointBicycle(Vehicle):
+    """vehicle.py:1991-2028 — mass-less particle with first-order yaw tracking (dynamics.py:802-1079)."""
+
+    PARAMS_TYPE = PlanarPointBicycleParameters
+    MODEL = _ffi.PLANARPOINT
+
+    def __init__(self, s0, **kwargs):
+        Vehicle.__init__(self, s0, **kwargs)

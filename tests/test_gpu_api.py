@@ -1,0 +1,141 @@
+"""The reference's own loop, unchanged in shape, on the engine (needs a MI355X): vehicle constructors ->
+SocialForceIntersection -> Scenario.run, checked against the golden trajectories of the literal reference
+(demo/demoCSFstandalone.py:101-146 geometry; scenarios/curve-scenario.py road)."""
+import numpy as np
+import pytest
+
+from cyclistsocialforce_amd.intersection import (CurvedRoadSegment, RoadSegmentCollection,
+                                                 SocialForceIntersection, StraightRoadSegment)
+from cyclistsocialforce_amd.parameters import RoadElementParameters
+from cyclistsocialforce_amd.scenario import Scenario
+from cyclistsocialforce_amd.vehicle import (Bicycle, InvPendulumBicycle, PlanarPointBicycle, TwoDBicycle)
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = {"twod": TwoDBicycle, "bicycle": Bicycle, "planarpoint": PlanarPointBicycle, "invpend": InvPendulumBicycle}
+
+
+def demo_bikes(cls):
+    """demoCSFstandalone.py:101-118"""
+    a = cls((-23 + 17, 0, 0, 5, 0, 0, 0, 0), id="a", saveForces=True)
+    a.params.v_desired_default = 4.5
+    b = cls((0 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), id="b", saveForces=True)
+    b.params.v_desired_default = 5.0
+    c = cls((-2 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), id="c", saveForces=True)
+    c.params.v_desired_default = 5.0
+    a.setDestinations((35, 64, 65), (0, 0, 0))
+    b.setDestinations((15, 15, 15), (20, 49, 50))
+    c.setDestinations((13, 13, 13), (20, 49, 50))
+    return a, b, c
+
+
+@pytest.mark.parametrize("model", ["twod", "bicycle", "planarpoint", "invpend"])
+def test_standalone_demo_through_scenario(golden, model):
+    g = golden("trajectories")
+    bikes = demo_bikes(CLASSES[model])
+    ins = SocialForceIntersection(bikes)
+
+    class Demo(Scenario):                        # demoCSFstandalone.py:94-141
+        def __init__(self):
+            self.intersection = ins
+            Scenario.__init__(self, self._step_func, t_r=0, verbose=False)
+
+        def _step_func(self):
+            self.intersection.step()
+
+    scn = Demo()
+    scn.run(7)                                   # demoCSFstandalone.py:144-146
+    S = g[f"demo_{model}_S"]
+    F = g[f"demo_{model}_F"]
+    for k, v in enumerate(bikes):
+        assert v.i == 700
+        np.testing.assert_allclose(v.s, S[-1][k], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(v.traj[:2, 10:701:10].T, S[1:, k, :2], rtol=0, atol=2e-4)   # vehicle.traj history
+        np.testing.assert_allclose(v.trajF[:, 700], F[-1][k], rtol=0, atol=2e-3)               # saveForces
+        np.testing.assert_allclose(v.force, F[-1][k], rtol=0, atol=2e-3)
+        assert len(v.F) == 700
+    assert ins.hist_n_vecs == [3] * 700
+    np.testing.assert_allclose(ins.vehicleX[:, 0], S[-1][:, 0], atol=2e-4)
+    if model == "twod":                          # SURVEY.md §8(c) known answers
+        np.testing.assert_allclose(bikes[0].s[:2], [21.366756374020543, -0.52069184088739151], atol=2e-4)
+
+
+def test_planarpoint_on_curve_road(golden):
+    """scenarios/curve-scenario.py:63-81 road built with the road classes; agents + static-obstacle forces."""
+    g = golden("trajectories")
+    rp = RoadElementParameters(sigma=2.0, F_0=0.15)
+    s1 = StraightRoadSegment(np.array((0, -20, np.pi / 2)), 5, 25, params=rp, ds=0.1)
+    s2 = CurvedRoadSegment(s1.x1, 5, 10, np.pi / 2, "right", params=rp, ds=0.1)
+    s3 = CurvedRoadSegment(s2.x1, 5, 10, np.pi / 2, "left", params=rp, ds=0.1)
+    s4 = StraightRoadSegment(s3.x1, 5, 20, params=rp, ds=0.1)
+    segs = RoadSegmentCollection((s1, s2, s3, s4))
+    vs = []
+    for k, (x, y) in enumerate(((0.5, -19.0), (-0.8, -16.0), (1.0, -12.0))):
+        v = PlanarPointBicycle((x, y, np.pi / 2, 4.0), id=str(k))
+        v.setDestinations(*segs.get_destinations_from_segments())
+        vs.append(v)
+    ins = SocialForceIntersection(vs, road_elements=[segs])
+    S = g["road_pp_S"]
+    for k in range(1, S.shape[0]):
+        ins.step_n(10)
+        got = np.array([v.s for v in vs])
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=2e-4, err_msg=f"sample {k}")
+
+
+def test_mutation_between_ticks_and_population_changes(golden):
+    """User edits of vehicle.s / v_desired_default / destinations and add/remove are honoured by the next tick:
+    checked against a fresh intersection built directly in the edited configuration."""
+    def build(n):
+        rng = np.random.default_rng(5)
+        vs = []
+        for k in range(n):
+            x, y, psi = rng.uniform(0, 20), rng.uniform(0, 20), rng.uniform(-np.pi, np.pi)
+            v = TwoDBicycle((x, y, psi, 4.0, 0.0), id=f"v{k}")
+            v.setDestinations(x + np.array([30, 60]) * np.cos(psi), y + np.array([30, 60]) * np.sin(psi))
+            vs.append(v)
+        return vs
+
+    vs = build(6)
+    ins = SocialForceIntersection(vs[:5])
+    ins.step()
+    ins.step()
+    # edit: teleport 0, slow down 1, new route for 2, remove 3, add the 6th vehicle
+    vs[0].s[0] += 2.0
+    vs[1].params.v_desired_default = 3.0
+    vs[2].setDestinations((50.0,), (50.0,), reset=True)
+    ins.remove_road_users_by_id(["v3"])
+    ins.add_road_user(vs[5])
+    for _ in range(20):
+        ins.step()
+    assert [v.id for v in ins.vehicles] == ["v0", "v1", "v2", "v4", "v5"]
+    assert vs[1].s[3] < 3.6 and vs[0].s[3] > 3.6          # the new desired speed took effect
+    assert vs[2].destqueue.shape == (1, 3) and vs[2].isLastDest()
+    assert np.isfinite([v.s for v in ins.vehicles]).all() and vs[3]._owner is None
+    assert vs[5].i == 20 and vs[0].i == 22
+    # a standalone vehicle steps through its private engine (seam 1 of SURVEY.md §8(b))
+    lone = vs[3]
+    fx, fy = lone.calcDestinationForce()
+    before = lone.s.copy()
+    lone.step(fx, fy)
+    assert not np.array_equal(before, lone.s) and np.isfinite(lone.s).all()
+
+
+def test_vehicle_hooks_against_golden(golden):
+    """calcRepulsiveForce / calcDestinationForce / step on single vehicles (vehicle.py:250-328)."""
+    g = golden("pair_fields")
+    v = TwoDBicycle((0, 0, 0, 5, 0))
+    fx, fy = v.calcRepulsiveForce(np.array([5.0, -3.0, 2.0, 0.5]), np.array([0.5, 4.0, -7.0, 0.0]),
+                                  np.array([0.0, 1.0, -2.5, np.pi]))
+    np.testing.assert_allclose(fx, g["twod_fx"][:4], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(fy, g["twod_fy"][:4], rtol=2e-4, atol=1e-4)
+    r = golden("dest_force_runs")
+    S = r["demo_a_s"]
+    a = TwoDBicycle(tuple(S[0]), id="a")
+    a.params.v_desired_default = 4.5
+    a.setDestinations((35, 64, 65), (0, 0, 0))
+    for t in range(60):
+        fx, fy = a.calcDestinationForce()
+        np.testing.assert_allclose([fx, fy], r["demo_a_Fdest"][t], rtol=2e-7, atol=2e-7)
+        a.step(fx, fy)
+        np.testing.assert_allclose(a.s, S[t + 1], rtol=2e-7, atol=2e-7)
+    assert a.i == 60 and a.destpointer == r["demo_a_ptr"][59]

@@ -1,0 +1,189 @@
+"""CPU-only tests of the host side: parameter objects, vehicle constructors, road geometry, helpers, the
+scenario driver, the sharding arithmetic, and that libcsf_hip.so loads and exports every symbol that
+include/csf.h declares (no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cyclistsocialforce_amd import _ffi, parallel, parameters, utils
+from cyclistsocialforce_amd.engine import Engine, EngineError
+from cyclistsocialforce_amd.intersection import (CurvedRoadSegment, RoadSegmentCollection,
+                                                 SocialForceIntersection, StraightRoadSegment,
+                                                 flatten_road_elements)
+from cyclistsocialforce_amd.scenario import Scenario
+from cyclistsocialforce_amd.vehicle import (Bicycle, InvertedPendulumBicycle, InvPendulumBicycle,
+                                            PlanarPointBicycle, TwoDBicycle, Vehicle)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "csf.h")).read()
+    declared = set(re.findall(r"\b(csf_[a-z_0-9]+)\s*\(", header))
+    declared -= {"csf_engine", "csf_params"}
+    assert declared == set(_ffi.SYMBOLS), declared ^ set(_ffi.SYMBOLS)
+    lib = _ffi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.csf_abi_version() == 1
+    assert ctypes.sizeof(_ffi.Params) == 296
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(EngineError, match="no CPU fallback"):
+        Engine(parameters.default_pod("twod"), 8)
+
+
+def test_params_struct_matches_oracle_layout():
+    """The test harness fills csf_params and the oracle's csfo_params from one table: layouts must agree."""
+    from oracle import csf_oracle as orc
+
+    assert ctypes.sizeof(orc.Params) == ctypes.sizeof(_ffi.Params)
+    assert [f[0] for f in orc.Params._fields_] == [f[0] for f in _ffi.Params._fields_]
+    for m in range(4):
+        assert bytes(parameters.default_pod(m)) == bytes(orc.default_params(m)), m
+
+
+def test_parameter_validation_follows_the_reference():
+    p = parameters.InvPendulumBicycleParameters()
+    assert p.l == 1.0 and p.l_1 == 0.5 and p.v_max_riding == [-1.0, 7.0] and p.hfov == np.pi * 2 / 3
+    with pytest.raises(AttributeError):       # parameters.py:516-519
+        p.t_s = 0.02
+    with pytest.raises(TypeError):            # floats must be float
+        p.v_desired_default = 5
+    with pytest.raises(ValueError):
+        p.v_desired_default = -1.0
+    p.v_desired_default = 4.5                 # demoCSFstandalone.py:104
+    with pytest.raises(ValueError):           # parameters.py:637-641: e_0 in ]e_1, 1]
+        p.e_0 = 0.5
+    p.f_0 = 3                                 # parameters.py:623: f_0 is cast
+    assert p.f_0 == 3.0
+    with pytest.raises(TypeError):
+        parameters.BicycleParameters(a_max=(-1, 1))
+    b = parameters.BicycleParameters()
+    assert b.a_max == [-10.0, 10.0] and b.v_max_stop == 0.6 and b.l_2 == 0.5
+    assert parameters.VehicleParameters().hfov == 2 * np.pi
+    pp = parameters.PlanarPointBicycleParameters()
+    assert pp.to_pod(_ffi.PLANARPOINT).k_psi == 2.0
+    assert parameters.PlanarPointBicycleParameters(poles=[-3 + 0j]).to_pod(3).k_psi == 3.0
+    r = parameters.RoadElementParameters(sigma=2.0, F_0=0.15)
+    with pytest.raises(AttributeError):
+        r.F_0 = 0.2
+    pod = p.to_pod(_ffi.TWOD, 1)
+    assert pod.traj_len == 3000 and pod.priority_rule == 1 and pod.a_max[0] == -3.0 and pod.m == 87.0
+
+
+def test_vehicle_constructors_follow_the_reference():
+    v = TwoDBicycle((-6, 0, 0, 5, 0, 0, 0, 0), id="a", saveForces=True)   # demo passes 8-tuples
+    assert v.s.shape == (5,) and v.traj.shape == (5, 3000) and v.trajF.shape == (2, 3000)
+    assert isinstance(v.params, parameters.InvPendulumBicycleParameters)
+    assert TwoDBicycle.N_STATES == 5 and InvPendulumBicycle.N_STATES == 6 and PlanarPointBicycle.N_STATES == 4
+    assert InvertedPendulumBicycle is InvPendulumBicycle
+    assert InvPendulumBicycle((0, 0, 0, 5, 0, 0)).STATE_NAMES[-1] == "theta[rad]"
+    with pytest.raises(ValueError):
+        Bicycle((0, 0, 0, 5))                                             # vehicle.py:149-150
+    with pytest.raises(AssertionError):
+        Bicycle((0, 0, 0, 5, 0), id=3)
+    with pytest.raises(AssertionError):
+        Bicycle((0, 0, 0, 5, 0), route=["e1"])
+    with pytest.raises(TypeError):
+        Bicycle((0, 0, 0, 5, 0), params=parameters.VehicleParameters())   # vehicle.py:245-247
+    with pytest.raises(NotImplementedError):
+        Vehicle((0, 0, 0, 5))
+    w = PlanarPointBicycle((1, 2, 7.0, 4))
+    assert abs(w.s[2] - (7.0 - 2 * np.pi)) < 1e-15                        # limitAngle at construction
+    np.testing.assert_array_equal(w.destqueue, [[1, 2, 0]])               # vehicle.py:183-185
+    w.setDestinations((5, 9), (0, 1))
+    assert w.destqueue.shape == (3, 3) and w.destpointer == 0             # appended (vehicle.py:646-647)
+    w.setDestinations((7,), (7,), stop=(1,), reset=True)
+    np.testing.assert_array_equal(w.destqueue, [[7, 7, 1]])
+    assert w.isLastDest() and abs(w.getDestinationDistance() - np.hypot(6, 5)) < 1e-12
+
+
+def test_intersection_host_bookkeeping():
+    a, b = TwoDBicycle((0, 0, 0, 5, 0), id="a"), TwoDBicycle((1, 2, 0.5, 4, 0), id="b")
+    ins = SocialForceIntersection((a, b))
+    assert ins.n_bikes == 2 and ins.vehicleX.shape == (2, 1) and ins.vehicleTheta[1, 0] == 0.5
+    assert ins.get_road_user_ids() == ["a", "b"] and ins.has_road_user("b")
+    c = TwoDBicycle((3, 3, 0, 5, 0), id="c")
+    ins.add_road_user(c)
+    assert ins.n_bikes == 3
+    ins.remove_road_users_by_id(["a"])
+    assert ins.get_road_user_ids() == ["b", "c"] and ins.vehicleX[0, 0] == 1.0 and a._owner is None
+    ins.remove_road_user(1)
+    assert ins.get_road_user_ids() == ["b"]
+    with pytest.raises(NotImplementedError):
+        SocialForceIntersection((), activate_sumo_cosimulation=True)
+    with pytest.raises(NotImplementedError):
+        SocialForceIntersection((b2 := Bicycle((0, 0, 0, 5, 0)), PlanarPointBicycle((0, 0, 0, 5))))
+    with pytest.raises(ValueError):
+        SocialForceIntersection((), priority_rule="left")
+    empty = SocialForceIntersection(())
+    empty.step()                                                          # intersection.py:888, 896
+    assert empty.hist_n_vecs == [0]
+
+
+def test_road_geometry_matches_reference_vertices(golden):
+    """StraightRoadSegment / CurvedRoadSegment (intersection.py:118-211) on scenarios/curve-scenario.py:63-81."""
+    g = golden("road_edges")
+    rp = parameters.RoadElementParameters(sigma=2.0, F_0=0.15)
+    x0 = np.array((0, -20, np.pi / 2))
+    s1 = StraightRoadSegment(x0, 5, 25, params=rp, ds=0.1)
+    s2 = CurvedRoadSegment(s1.x1, 5, 10, np.pi / 2, "right", params=rp, ds=0.1)
+    s3 = CurvedRoadSegment(s2.x1, 5, 10, np.pi / 2, "left", params=rp, ds=0.1)
+    s4 = StraightRoadSegment(s3.x1, 5, 20, params=rp, ds=0.1)
+    segs = RoadSegmentCollection((s1, s2, s3, s4))
+    off, verts, F0, sg = flatten_road_elements([segs])
+    np.testing.assert_array_equal(off, g["off"])
+    np.testing.assert_allclose(verts, g["verts"], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(F0, g["F0"])
+    np.testing.assert_array_equal(sg, g["sigma"])
+    np.testing.assert_allclose(np.array([s.x1 for s in segs.segs]), g["x1"], atol=1e-12)
+    assert s1.params.F_0 == 0.05                                          # segment params reset (intersection.py:74)
+    xs, ys = segs.get_destinations_from_segments()
+    assert len(xs) == 4 and segs[1] is s2
+
+
+def test_utils_against_golden(golden):
+    g = golden("utils")
+    np.testing.assert_allclose([utils.limitAngle(float(t)) for t in g["a"]], g["limitAngle"], atol=1e-15)
+    np.testing.assert_allclose(utils.limitAngle(g["a"].copy()), g["limitAngle"], atol=1e-15)
+    np.testing.assert_allclose(utils.angleDifference(g["a1"], g["a2"]), g["angleDifference"], atol=1e-15)
+    lx, ly = utils.limitMagnitude(g["x"].copy(), g["y"].copy(), g["r"].copy())
+    np.testing.assert_allclose(lx, g["lx"], rtol=1e-15)
+    np.testing.assert_allclose(ly, g["ly"], rtol=1e-15)
+    rho, phi = utils.cart2polar(np.array([1.0, 0.0, -1.0]), np.array([0.0, -2.0, 1e-30]))
+    np.testing.assert_allclose(rho, [1, 2, 1]); np.testing.assert_allclose(phi, [0, -np.pi / 2, np.pi])
+    assert utils.thresh(5.0, (-1.0, 2.0)) == 2.0
+
+
+def test_scenario_driver():
+    calls = []
+    scn = Scenario(lambda: calls.append(1), t_s=0.01, t_r=0, verbose=False)
+    scn.run(0.25)
+    assert len(calls) == 25 and scn.i == 25 and abs(scn.t - 0.25) < 1e-12 and len(scn.hist_run_time) == 25
+    scn.reset()
+    assert scn.i == 0 and scn.t == 0
+    with pytest.raises(NotImplementedError):
+        Scenario(lambda: None, animate=True)
+
+
+def test_shard_bounds_cover_the_population():
+    for n in (1, 3, 63, 64, 65, 1000, 16384, 262144, 1048576):
+        for world in (1, 2, 4, 8):
+            blocks = [parallel.shard_bounds(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            for (lo, hi), (lo2, _) in zip(blocks, blocks[1:]):
+                assert hi == lo2 and lo <= hi
+            if world > 1:
+                size = parallel.shard_size(n, world)
+                assert size % 64 == 0 and size * world >= n
+                assert all(hi - lo <= size for lo, hi in blocks)
+    assert parallel.shard_bounds(16384, 8, 3) == (6144, 8192)
