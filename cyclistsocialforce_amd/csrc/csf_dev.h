@@ -16,7 +16,7 @@ struct PairConsts {
     float sg0, sg1, sg2, sg3, e0, e1;  // vehicle.py:1604-1612
     float lf0;                         // log2(f_0); Bicycle field: log2(p_0 / p_decay) (vehicle.py:1101, 1132)
     float kexp;                        // log2(e)
-    float ch, ch2;                     // cos(hfov/2), its square (intersection.py:733-736)
+    float chs;                         // -cos^2(hfov/2) for hfov <= pi, +cos^2 beyond (intersection.py:733-736)
     float ipd;                         // Bicycle field: 1 / p_decay (vehicle.py:1095-1099)
     int32_t p2r;                       // intersection.py:739-741
     int32_t f0_zero;                   // vehicle.py:1592-1593
@@ -34,6 +34,7 @@ struct Dev {
     int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
     int32_t back;      // int(1 / t_s) — vehicle.py:1487
     int32_t n_split;   // source chunks of the pair kernel
+    int32_t pair_variant;  // 0: cull-first kernel (default), 1: evaluate-then-mask kernel (CSF_PAIR_VARIANT=1)
     double ox, oy;     // origin of the fp32 source records
     int64_t tick;
 

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -175,10 +176,10 @@ void derive_consts(csf_engine *e) {
     k.e0 = (float)p.e_0;
     k.e1 = (float)p.e_1;
     k.kexp = 1.4426950408889634f;
-    double half = 0.5 * std::min(p.hfov, 2 * 3.141592653589793);
-    k.ch = (float)std::cos(half);
-    if (p.hfov >= 2 * 3.141592653589793) k.ch = -2.0f;  // full circle: every bearing is inside
-    k.ch2 = k.ch * k.ch;
+    const double PI_ = 3.141592653589793;
+    double ch = std::cos(0.5 * std::min(p.hfov, 2 * PI_));
+    k.chs = (float)(p.hfov <= PI_ ? -ch * ch : ch * ch);
+    if (p.hfov >= 2 * PI_) k.chs = 4.0f;  // full circle: every bearing is inside (t|t| + 4 rho^2 > 0)
     k.p2r = p.priority_rule == CSF_P2R;
     if (p.model == CSF_BICYCLE) {
         k.lf0 = (float)std::log2(p.p_0 / p.p_decay);
@@ -189,6 +190,8 @@ void derive_consts(csf_engine *e) {
         k.ipd = 0.f;
         k.f0_zero = p.f_0 == 0.0;
     }
+    const char *variant = getenv("CSF_PAIR_VARIANT");
+    e->d.pair_variant = variant ? atoi(variant) : 0;
     e->d.back = (int32_t)(1.0 / p.t_s);
     int hl = 4;
     while (hl < e->d.back + 2) hl *= 2;

@@ -6,20 +6,35 @@
 // (intersection.py:226-242) for the static-obstacle term.
 //
 // Mapping (CDNA4, 64-wide waves): SOURCES sit in the lanes, RECEIVERS are wave-uniform.  One wave owns
-// RPW receivers whose record and every receiver-only term live in scalar registers; the workgroup streams
-// the fp32 source records (x, y, cos psi, sin psi) through an LDS tile that all of its waves share; each
-// lane accumulates its sources' contribution and one butterfly of wavefront shuffles per receiver forms
-// the column sum.  Nothing is gathered, no atomics: the result is bit-reproducible.
-// The math is trig-free: every angle of the reference enters only through sin/cos, which are dot and
-// cross products of unit vectors here.
+// RPW receivers; the workgroup streams the fp32 source records (x, y, cos psi, sin psi) through an LDS tile
+// that all of its waves share; each lane accumulates its sources' contribution and one butterfly of
+// wavefront shuffles per receiver forms the column sum.  No atomics: the result is bit-reproducible.
+//
+// The kernel is VALU-issue bound (tools/valu_ubench.hip: ~3-4.5 cycles per wave64 fp32 instruction, ~8.3 per
+// transcendental, v_pk_* at ~4.7 for two results), so the work is organised to issue as little as possible:
+//   1. CULL FIRST.  The field-of-view test costs ~12 instructions, the field itself ~70.  With the
+//      reference's default 120 degree field of view two thirds of all pairs are masked.  Every lane tests its
+//      source, the wave ballots, and the lanes that pass append their tile index to a per-receiver queue in
+//      LDS (prefix = v_mbcnt of the ballot).  The field is evaluated only on full batches popped from the
+//      queue, so all 64 lanes do useful work there.
+//   2. TWO PAIRS PER LANE in the field evaluation, written on float2 so that hipcc emits v_pk_fma_f32 /
+//      v_pk_mul_f32 / v_pk_add_f32.
+//   3. Wave-uniform operands are kept in VGPRs (an SGPR operand makes a VALU instruction slower here).
+// The math is trig-free: every angle of the reference enters only through sin/cos, which are dot and cross
+// products of unit vectors here.
 #include "csf_dev.h"
 
 namespace csf {
 
 constexpr int RPW = 4;               // receivers per wave
 constexpr int WPB = 4;               // waves per workgroup
-constexpr int TILE = 1024;           // source records per LDS tile (16 KiB)
 constexpr int BLOCK = WPB * WAVE;
+constexpr int TILE = 1024;           // simple kernels: source records per LDS tile (16 KiB)
+constexpr int TILE2 = 2048;          // culling kernel: 32 KiB tile
+constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
+constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct Recv {
     float x, y, c, s;
@@ -30,20 +45,21 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ v2f rsq2(v2f x) { return v2f{fast_rsq(x.x), fast_rsq(x.y)}; }
+__device__ __forceinline__ v2f fabs2(v2f x) { return v2f{fabsf(x.x), fabsf(x.y)}; }
 
 // intersection.py:690-745 for receiver r and source (dx, dy) = receiver - source.
-// The receiver ignores the source when the bearing of the source, relative to the receiver's heading,
-// is outside +-hfov/2 (hfov of the SOURCE's class, :733-735; one class per engine), when it is to the
-// left under priority-to-the-right, or when it is the receiver itself / coincident (rho = 0).
-// WIDE: hfov/2 > pi/2 (cos < 0); P2R: priority to the right.  Both are launch-time template flags so that
-// the inner loop carries no uniform branches.
-template <bool WIDE, bool P2R>
-__device__ __forceinline__ bool tracked(const PairConsts &k, const Recv &r, float dx, float dy, float r2) {
-    float t = -(dx * r.c + dy * r.s);  // rho * cos(relative bearing)
-    float t2 = t * t, lim = k.ch2 * r2;
-    bool in = WIDE ? ((t >= 0.0f) | (t2 <= lim)) : ((t >= 0.0f) & (t2 >= lim));
-    if (P2R) in = in & !((r.s * dx - r.c * dy) > 0.0f);  // rho * sin(relative bearing) > 0
-    return in & (r2 > 0.0f);
+// The receiver ignores the source when the bearing of the source, relative to the receiver's heading, is
+// outside +-hfov/2 (hfov of the SOURCE's class, :733-735; one class per engine), when it is to the left under
+// priority-to-the-right, or when it is the receiver itself / coincident (rho = 0).
+// With t = rho cos(bearing) the test |bearing| <= hfov/2 is  t|t| - cos^2(hfov/2) rho^2 >= 0  for hfov <= pi and
+// t|t| + cos^2(hfov/2) rho^2 >= 0  beyond; chs carries the sign.  The comparison is strict so that rho = 0 fails.
+template <bool P2R>
+__device__ __forceinline__ bool tracked(float chs, const Recv &r, float dx, float dy, float r2) {
+    float t = -(dx * r.c + dy * r.s);
+    bool in = (t * fabsf(t) + chs * r2) > 0.0f;
+    if (P2R) in = in & !((r.s * dx - r.c * dy) > 0.0f);  // rho * sin(bearing) > 0: the source is to the left
+    return in;
 }
 
 // vehicle.py:1560-1648: force of source (record q) on receiver r, returned as magnitude F and an
@@ -65,7 +81,7 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
     float sg = __builtin_amdgcn_fmed3f(sphi * 1e38f, -1.0f, 1.0f);  // np.sign(phi), 0 at phi = 0 :1625
     bool pos = cphi >= 0.0f;
     float bs = big * sg, al = 0.5f * sphi * rs;
-    float h1 = (pos ? small : big);  // sqrt((1 - cos phi)/2)  :1624
+    float h1 = pos ? small : big;                     // sqrt((1 - cos phi)/2)       :1624
     float h2s = pos ? bs : al;                        // sqrt((1 + cos phi)/2) * sign(phi)
     float sigma = sga - sgb * h1;                     // :1624
     float dsig = -0.5f * sgb * h2s;                   // :1625
@@ -84,7 +100,47 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
     F = P * ig;                                       // :1644-1646: |F| = P
 }
 
-// vehicle.py:1054-1147: older elliptic field of base Bicycle; q2 = (e, 1/sqrt(1-e^2)) of the source.
+// The same field for TWO sources per lane (components .x / .y), float2 arithmetic -> v_pk_* instructions.
+// valid0 / valid1 mask the lanes of a partial batch.  Adds the two contributions to (ax, ay).
+__device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r, const float4 q0, const float4 q1,
+                                              bool valid0, bool valid1, float &ax, float &ay) {
+    const v2f qx{q0.x, q1.x}, qy{q0.y, q1.y}, qc{q0.z, q1.z}, qs{q0.w, q1.w};
+    v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
+    v2f r2 = dx * dx + dy * dy;
+    r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};  // lanes of a partial batch may alias the receiver
+    v2f inv = rsq2(r2), rho = r2 * inv;
+    v2f srel = qs * r.c - qc * r.s;
+    v2f s2 = srel * srel;
+    v2f sga = k.sg0 + k.sg1 * s2, sgb = k.sg2 + k.sg3 * s2, e = k.e0 - k.e1 * s2;
+    v2f cphi = (dx * qc + dy * qs) * inv, sphi = (dy * qc - dx * qs) * inv;
+    v2f a = 0.5f + 0.5f * fabs2(cphi);
+    v2f rs = rsq2(a);
+    v2f big = a * rs, hrs = 0.5f * rs;
+    v2f al = sphi * hrs;
+    v2f sg{__builtin_amdgcn_fmed3f(sphi.x * 1e38f, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(sphi.y * 1e38f, -1.0f, 1.0f)};
+    v2f small = al * sg, bs = big * sg;                // |sphi| hrs and sign(phi) big
+    const bool p0 = cphi.x >= 0.0f, p1 = cphi.y >= 0.0f;
+    v2f h1{p0 ? small.x : big.x, p1 ? small.y : big.y};
+    v2f h2s{p0 ? bs.x : al.x, p1 ? bs.y : al.y};
+    v2f sigma = sga - sgb * h1;
+    v2f hd = 0.5f * sgb * h2s;                        // = -dsig
+    v2f ec = e * cphi;
+    v2f q2 = 1.0f - ec * ec;
+    v2f qq{fast_sqrt(q2.x), fast_sqrt(q2.y)};
+    v2f isg{fast_rcp(sigma.x), fast_rcp(sigma.y)};
+    v2f grho = q2 * sigma;
+    v2f gphi = (e * ec) * (sphi * sigma) + q2 * hd;
+    v2f gx = grho * dx - gphi * dy, gy = grho * dy + gphi * dx;
+    v2f ig = rsq2(gx * gx + gy * gy);
+    v2f ex = k.lf0 - k.kexp * (rho * qq * isg);
+    v2f F = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * ig;
+    F = v2f{valid0 ? F.x : 0.0f, valid1 ? F.y : 0.0f};
+    v2f cx = F * gx, cy = F * gy;
+    ax += cx.x + cx.y;
+    ay += cy.x + cy.y;
+}
+
+// vehicle.py:1054-1147: older elliptic field of base Bicycle; q2v = (e, 1/sqrt(1-e^2)) of the source.
 __device__ __forceinline__ void field_bicycle(const PairConsts &k, const float4 q, const float2 q2v, float dx,
                                               float dy, float r2, float &F, float &gx, float &gy) {
     float inv = fast_rsq(r2), rho = r2 * inv;
@@ -98,38 +154,123 @@ __device__ __forceinline__ void field_bicycle(const PairConsts &k, const float4 
     F = P;
 }
 
-template <bool BICYCLE, bool WIDE, bool P2R>
+__device__ __forceinline__ void load_receivers(const Dev &d, int64_t j0, Recv (&r)[RPW]) {
+#pragma unroll
+    for (int u = 0; u < RPW; u++) {
+        int64_t j = j0 + u < d.hi ? j0 + u : d.hi - 1;  // clamp: results of the duplicates are not stored
+        float4 q = d.rec[j];
+        r[u].x = q.x;
+        r[u].y = q.y;
+        r[u].c = q.z;
+        r[u].s = q.w;
+        asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].c), "+v"(r[u].s));  // stay in VGPRs
+    }
+}
+
+// column sum (intersection.py:841-843): butterfly over the 64 lanes of the wave, lane 0 stores the partial
+__device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane, const float (&ax)[RPW],
+                                             const float (&ay)[RPW]) {
+#pragma unroll
+    for (int u = 0; u < RPW; u++) {
+        float sx = ax[u], sy = ay[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sx += __shfl_xor(sx, o, WAVE);
+            sy += __shfl_xor(sy, o, WAVE);
+        }
+        if (lane == 0 && j0 + u < d.hi) d.part[(int64_t)blockIdx.y * d.cap + j0 + u] = make_float2(sx, sy);
+    }
+}
+
+__device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend) {
+    const int64_t units = d.n_pad / WAVE;  // blockIdx.y selects a chunk of sources, in units of 64 records
+    const int64_t per = (units + d.n_split - 1) / d.n_split;
+    ibeg = (int64_t)blockIdx.y * per * WAVE;
+    iend = ibeg + per * WAVE;
+    if (iend > d.n_pad) iend = d.n_pad;
+}
+
+// ---- culling kernel (TwoD field): test -> ballot -> LDS queue -> packed field on full batches ------------
+template <bool P2R>
+__global__ __launch_bounds__(BLOCK) void pair_cull_kernel(const Dev d) {
+    __shared__ float4 tile[TILE2];
+    __shared__ unsigned short queue[WPB][RPW][QCAP];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
+    int64_t ibeg, iend;
+    source_chunk(d, ibeg, iend);
+
+    Recv r[RPW];
+    load_receivers(d, j0, r);
+    float ax[RPW], ay[RPW];
+    int qhead[RPW], qlen[RPW];  // wave-uniform ring state of the four queues
+#pragma unroll
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f, qhead[u] = qlen[u] = 0;
+    PairConsts k = d.pc;
+    asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0),
+                 "+v"(k.kexp), "+v"(k.chs));
+
+    // pop up to CHUNK queued sources of receiver u and evaluate the field, two per lane
+    auto pop = [&](int u) {
+        const int n = qlen[u] < CHUNK ? qlen[u] : CHUNK;
+        const int i0 = queue[wave][u][(qhead[u] + lane) & (QCAP - 1)];
+        const int i1 = queue[wave][u][(qhead[u] + WAVE + lane) & (QCAP - 1)];
+        const bool v0 = lane < n, v1 = lane + WAVE < n;
+        field_twod_x2(k, r[u], tile[v0 ? i0 : 0], tile[v1 ? i1 : 0], v0, v1, ax[u], ay[u]);
+        qhead[u] = __builtin_amdgcn_readfirstlane((qhead[u] + n) & (QCAP - 1));
+        qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] - n);
+    };
+
+    for (int64_t base = ibeg; base < iend; base += TILE2) {
+        const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += BLOCK) tile[t] = d.rec[base + t];
+        __syncthreads();
+        for (int t = lane; t < cnt; t += WAVE) {
+            const float4 q = tile[t];
+#pragma unroll
+            for (int u = 0; u < RPW; u++) {
+                const float dx = r[u].x - q.x, dy = r[u].y - q.y;
+                const bool in = tracked<P2R>(k.chs, r[u], dx, dy, dx * dx + dy * dy);
+                const unsigned long long m = __ballot(in);
+                if (in) {
+                    const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    queue[wave][u][(qhead[u] + qlen[u] + pre) & (QCAP - 1)] = (unsigned short)t;
+                }
+                qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] + __builtin_popcountll(m));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (qlen[u] >= CHUNK) pop(u);
+            }
+        }
+        // the queues hold indices into this tile: drain them before it is replaced
+#pragma unroll
+        for (int u = 0; u < RPW; u++)
+            while (qlen[u] > 0) pop(u);
+    }
+    reduce_store(d, j0, lane, ax, ay);
+}
+
+// ---- simple kernel: every pair evaluated, masked afterwards (Bicycle field; also the TwoD field on request) --
+template <bool BICYCLE, bool P2R>
 __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
     __shared__ float4 tile[TILE];
     __shared__ float2 tile2[BICYCLE ? TILE : 1];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
-
-    // source chunk of this workgroup (blockIdx.y), in units of 64 records
-    const int64_t units = d.n_pad / WAVE;
-    const int64_t per = (units + d.n_split - 1) / d.n_split;
-    const int64_t ibeg = (int64_t)blockIdx.y * per * WAVE;
-    int64_t iend = ibeg + per * WAVE;
-    if (iend > d.n_pad) iend = d.n_pad;
+    int64_t ibeg, iend;
+    source_chunk(d, ibeg, iend);
 
     Recv r[RPW];
+    load_receivers(d, j0, r);
     float ax[RPW], ay[RPW];
 #pragma unroll
-    for (int u = 0; u < RPW; u++) {
-        int64_t j = j0 + u < d.hi ? j0 + u : d.hi - 1;  // clamp: duplicates are not stored
-        float4 q = d.rec[j];
-        r[u].x = q.x;
-        r[u].y = q.y;
-        r[u].c = q.z;
-        r[u].s = q.w;
-        asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].c), "+v"(r[u].s));
-        ax[u] = 0.0f;
-        ay[u] = 0.0f;
-    }
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f;
     PairConsts k = d.pc;
     asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0),
-                 "+v"(k.kexp), "+v"(k.ch2));
+                 "+v"(k.kexp), "+v"(k.chs));
 
     for (int64_t base = ibeg; base < iend; base += TILE) {
         int cnt = (int)((iend - base) < TILE ? (iend - base) : TILE);  // multiple of 64
@@ -146,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
             for (int u = 0; u < RPW; u++) {
                 float dx = r[u].x - q.x, dy = r[u].y - q.y;  // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
-                bool in = tracked<WIDE, P2R>(k, r[u], dx, dy, r2);
+                bool in = tracked<P2R>(k.chs, r[u], dx, dy, r2);
                 r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
                 if (BICYCLE) field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
@@ -157,18 +298,7 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
             }
         }
     }
-
-    // column sum (intersection.py:841-843): butterfly over the 64 lanes of the wave
-#pragma unroll
-    for (int u = 0; u < RPW; u++) {
-        float sx = ax[u], sy = ay[u];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            sx += __shfl_xor(sx, o, WAVE);
-            sy += __shfl_xor(sy, o, WAVE);
-        }
-        if (lane == 0 && j0 + u < d.hi) d.part[(int64_t)blockIdx.y * d.cap + j0 + u] = make_float2(sx, sy);
-    }
+    reduce_store(d, j0, lane, ax, ay);
 }
 
 // intersection.py:226-242: F = sum_k -F0 r_k^-sigma (v_k - p)/r_k over the polyline vertices.
@@ -178,16 +308,11 @@ __global__ __launch_bounds__(BLOCK) void road_kernel(const Dev d) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
-    float rx[RPW], ry[RPW], ax[RPW], ay[RPW];
+    Recv r[RPW];
+    load_receivers(d, j0, r);
+    float ax[RPW], ay[RPW];
 #pragma unroll
-    for (int u = 0; u < RPW; u++) {
-        int64_t j = j0 + u < d.hi ? j0 + u : d.hi - 1;
-        float4 q = d.rec[j];
-        rx[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.x)));
-        ry[u] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, q.y)));
-        ax[u] = 0.f;
-        ay[u] = 0.f;
-    }
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.f;
     for (int64_t base = 0; base < d.nv_pad; base += TILE) {
         int cnt = (int)((d.nv_pad - base) < TILE ? (d.nv_pad - base) : TILE);
         __syncthreads();
@@ -197,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) void road_kernel(const Dev d) {
             float4 v = tile[t];  // (x, y, -F0, -(sigma+1)/2); padding has F0 = 0
 #pragma unroll
             for (int u = 0; u < RPW; u++) {
-                float ex = v.x - rx[u], ey = v.y - ry[u];        // :235-236 (numerators)
+                float ex = v.x - r[u].x, ey = v.y - r[u].y;      // :235-236 (numerators)
                 float r2 = ex * ex + ey * ey;                    // :231-234
                 float m = v.z * fast_exp2(v.w * fast_log2(r2));  // -F0 r^-(sigma+1)    :238
                 m = r2 > 0.f ? m : 0.f;
@@ -219,6 +344,7 @@ __global__ __launch_bounds__(BLOCK) void road_kernel(const Dev d) {
 }
 
 // Known-answer entry: m independent (source, receiver) pairs through the same device functions.
+// Even slots go through the scalar field, odd slots through lane .y of the packed one (both are product code).
 __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *src2, const float4 *recv,
                                 int64_t m, int apply_fov, float2 *out) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,17 +354,24 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
     Recv r{rr.x, rr.y, rr.z, rr.w};
     float dx = r.x - q.x, dy = r.y - q.y, r2 = dx * dx + dy * dy;
     bool in = r2 > 0.f;
-    if (apply_fov) {
-        if (k.ch >= 0.f) in = k.p2r ? tracked<false, true>(k, r, dx, dy, r2) : tracked<false, false>(k, r, dx, dy, r2);
-        else in = k.p2r ? tracked<true, true>(k, r, dx, dy, r2) : tracked<true, false>(k, r, dx, dy, r2);
-    }
+    if (apply_fov) in = k.p2r ? tracked<true>(k.chs, r, dx, dy, r2) : tracked<false>(k.chs, r, dx, dy, r2);
     r2 = fmaxf(r2, 1e-30f);
-    float F, gx, gy;
-    if (d.p.model == CSF_BICYCLE) field_bicycle(k, q, src2[t], dx, dy, r2, F, gx, gy);
-    else field_twod(k, r, q, dx, dy, r2, F, gx, gy);
-    if (d.p.model != CSF_BICYCLE && k.f0_zero) F = 0.f;
-    F = in ? F : 0.f;
-    out[t] = make_float2(F * gx, F * gy);
+    float fx = 0.f, fy = 0.f;
+    if (d.p.model == CSF_BICYCLE) {
+        float F, gx, gy;
+        field_bicycle(k, q, src2[t], dx, dy, r2, F, gx, gy);
+        fx = F * gx;
+        fy = F * gy;
+    } else if (t & 1) {
+        field_twod_x2(k, r, make_float4(r.x, r.y, 1.f, 0.f), q, false, true, fx, fy);
+    } else {
+        float F, gx, gy;
+        field_twod(k, r, q, dx, dy, r2, F, gx, gy);
+        fx = F * gx;
+        fy = F * gy;
+    }
+    if (!in) fx = fy = 0.f;
+    out[t] = make_float2(fx, fy);
 }
 
 static dim3 recv_grid(const Dev &d, int split) {
@@ -247,23 +380,20 @@ static dim3 recv_grid(const Dev &d, int split) {
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
 
-template <bool BICYCLE>
-static void launch_pair_t(const Dev &d, dim3 g, hipStream_t st) {
-    const bool wide = d.pc.ch < 0.f, p2r = d.pc.p2r != 0;
-    if (wide) {
-        if (p2r) hipLaunchKernelGGL((pair_kernel<BICYCLE, true, true>), g, dim3(BLOCK), 0, st, d);
-        else hipLaunchKernelGGL((pair_kernel<BICYCLE, true, false>), g, dim3(BLOCK), 0, st, d);
-    } else {
-        if (p2r) hipLaunchKernelGGL((pair_kernel<BICYCLE, false, true>), g, dim3(BLOCK), 0, st, d);
-        else hipLaunchKernelGGL((pair_kernel<BICYCLE, false, false>), g, dim3(BLOCK), 0, st, d);
-    }
-}
-
 void launch_pair(const Dev &d, hipStream_t st) {
     if (d.hi <= d.lo) return;
-    dim3 g = recv_grid(d, d.n_split);
-    if (d.p.model == CSF_BICYCLE) launch_pair_t<true>(d, g, st);
-    else launch_pair_t<false>(d, g, st);
+    const dim3 g = recv_grid(d, d.n_split), b(BLOCK);
+    const bool p2r = d.pc.p2r != 0;
+    if (d.p.model == CSF_BICYCLE) {
+        if (p2r) hipLaunchKernelGGL((pair_kernel<true, true>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_kernel<true, false>), g, b, 0, st, d);
+    } else if (d.pair_variant == 1) {
+        if (p2r) hipLaunchKernelGGL((pair_kernel<false, true>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_kernel<false, false>), g, b, 0, st, d);
+    } else {
+        if (p2r) hipLaunchKernelGGL(pair_cull_kernel<true>, g, b, 0, st, d);
+        else hipLaunchKernelGGL(pair_cull_kernel<false>, g, b, 0, st, d);
+    }
 }
 
 void launch_road(const Dev &d, hipStream_t st) {
