@@ -1,0 +1,95 @@
+// csf_bin.hip — spatial binning of the source records for the cull-first pair kernel.
+//
+// The pair kernel streams the sources in batches of 64 (one per lane).  When consecutive records are spatial
+// neighbours, a whole batch can be classified against a receiver's field-of-view cone from its bounding
+// circle alone (csf_pair.hip): entirely outside -> skipped, entirely inside -> queued without per-lane tests.
+// This file provides the order and the circles:
+//   * every REBIN ticks: Morton key of each record's cell (0.5 m) -> stable radix sort (hipCUB) -> perm[];
+//   * every tick: bounding circle of each batch of 64 records in perm order (positions move every tick, the
+//     order only drifts, so correctness never depends on how fresh perm is).
+// Nothing here changes results: the per-pair test of intersection.py:690-745 stays exact; the sort is stable
+// and deterministic, so runs are bit-reproducible.
+#include <hipcub/hipcub.hpp>
+
+#include "csf_dev.h"
+
+namespace csf {
+
+__device__ __forceinline__ uint32_t spread16(uint32_t v) {  // 16 bits -> even bit positions
+    v &= 0xFFFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__global__ void keys_kernel(const Dev d, uint32_t *keys, int32_t *vals) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= d.n_pad) return;
+    const float4 q = d.rec[a];
+    uint32_t key = 0xFFFFFFFFu;  // sentinels (padding, shard holes) sort to the end
+    if (fabsf(q.x) < 1e9f && fabsf(q.y) < 1e9f) {
+        const float cell = 2.0f;  // cells of 0.5 m, +-16 km around the origin of the records
+        int xi = (int)floorf(q.x * cell) + 32768, yi = (int)floorf(q.y * cell) + 32768;
+        xi = xi < 0 ? 0 : (xi > 65535 ? 65535 : xi);
+        yi = yi < 0 ? 0 : (yi > 65535 ? 65535 : yi);
+        key = spread16((uint32_t)xi) | (spread16((uint32_t)yi) << 1);
+        if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
+    }
+    keys[a] = key;
+    vals[a] = (int32_t)a;
+}
+
+__global__ void identity_perm_kernel(const Dev d) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < d.n_pad) d.perm[a] = (int32_t)a;
+}
+
+// one wave per batch of 64 records in perm order: centre and radius of the bounding box's circumcircle
+__global__ __launch_bounds__(256) void bounds_kernel(const Dev d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b * 64 >= d.n_pad) return;
+    const float4 q = d.rec[d.perm[b * 64 + lane]];
+    float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
+        y0 = fminf(y0, __shfl_xor(y0, o, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    }
+    if (lane == 0) {
+        const float w = x1 - x0, h = y1 - y0;
+        const float rad = 0.5f * sqrtf(w * w + h * h) * 1.0001f + 1e-4f;  // rounded up: the circle must contain
+        d.bnd[b] = make_float4(0.5f * (x0 + x1), 0.5f * (y0 + y1), rad, 0.0f);
+    }
+}
+
+size_t bin_temp_bytes(int64_t n_pad) {
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                       (const int32_t *)nullptr, (int32_t *)nullptr, (int)n_pad);
+    return bytes;
+}
+
+int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,
+                 hipStream_t st) {
+    if (d.n_pad <= 0) return 0;
+    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d, keys, vals);
+    return (int)hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, vals, d.perm, (int)d.n_pad, 0, 32, st);
+}
+
+void launch_identity_perm(const Dev &d, hipStream_t st) {
+    if (d.n_pad <= 0) return;
+    hipLaunchKernelGGL(identity_perm_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+}
+
+void launch_bounds(const Dev &d, hipStream_t st) {
+    if (d.n_pad <= 0) return;
+    const int64_t batches = d.n_pad / 64;
+    hipLaunchKernelGGL(bounds_kernel, dim3((unsigned)((batches + 3) / 4)), dim3(256), 0, st, d);
+}
+
+}  // namespace csf

@@ -17,6 +17,7 @@ struct PairConsts {
     float lf0;                         // log2(f_0); Bicycle field: log2(p_0 / p_decay) (vehicle.py:1101, 1132)
     float kexp;                        // log2(e)
     float chs;                         // -cos^2(hfov/2) for hfov <= pi, +cos^2 beyond (intersection.py:733-736)
+    float ch;                          // cos(hfov/2) (batch classification, hfov <= pi only)
     float ipd;                         // Bicycle field: 1 / p_decay (vehicle.py:1095-1099)
     int32_t p2r;                       // intersection.py:739-741
     int32_t f0_zero;                   // vehicle.py:1592-1593
@@ -34,7 +35,8 @@ struct Dev {
     int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
     int32_t back;      // int(1 / t_s) — vehicle.py:1487
     int32_t n_split;   // source chunks of the pair kernel
-    int32_t pair_variant;  // 0: cull-first kernel (default), 1: evaluate-then-mask kernel (CSF_PAIR_VARIANT=1)
+    int32_t pair_variant;  // 0: cull-first kernel on binned records (default), 1: evaluate-then-mask, 2: cull-first, unbinned
+    int32_t classify;      // batches carry bounding circles and the FOV is narrow enough to classify them
     double ox, oy;     // origin of the fp32 source records
     int64_t tick;
 
@@ -55,6 +57,8 @@ struct Dev {
 
     float4 *rec;       // [n_pad] (x-ox, y-oy, cos psi, sin psi) fp32 source records
     float2 *rec2;      // [n_pad] Bicycle field only: (e, 1/sqrt(1-e^2))
+    int32_t *perm;     // [n_pad] spatially binned order of the source records (position -> record index)
+    float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
     float2 *part;      // [MAX_SPLIT][cap] partial repulsive sums of the pair kernel
     float2 *froad;     // [cap]
     float4 *rv;        // [nv_pad] road vertices (x-ox, y-oy, -F0, -(sigma+1)/2)
@@ -74,6 +78,12 @@ void launch_pair(const Dev &d, hipStream_t st);
 void launch_road(const Dev &d, hipStream_t st);
 void launch_agent(const Dev &d, int phases, hipStream_t st);
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state
+// csf_bin.hip: spatial binning of the source records (Morton order) and per-batch bounding circles
+size_t bin_temp_bytes(int64_t n_pad);
+int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,
+                 hipStream_t st);
+void launch_identity_perm(const Dev &d, hipStream_t st);
+void launch_bounds(const Dev &d, hipStream_t st);
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
                      int apply_fov, float2 *out, hipStream_t st);
 

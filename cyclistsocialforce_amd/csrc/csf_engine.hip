@@ -106,7 +106,11 @@ struct csf_engine {
     DevBuf<int32_t> ptr, ti, dgood;
     DevBuf<uint8_t> znav, zrid;
     DevBuf<uint32_t> status;
-    DevBuf<float4> rec, rv, kat4;
+    DevBuf<float4> rec, rv, kat4, bnd;
+    DevBuf<int32_t> perm, sort_vals;
+    DevBuf<uint32_t> sort_keys, sort_keys_out;
+    DevBuf<uint8_t> sort_tmp;
+    int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, part, froad, kat2;
 
     // sharding
@@ -180,6 +184,7 @@ void derive_consts(csf_engine *e) {
     double ch = std::cos(0.5 * std::min(p.hfov, 2 * PI_));
     k.chs = (float)(p.hfov <= PI_ ? -ch * ch : ch * ch);
     if (p.hfov >= 2 * PI_) k.chs = 4.0f;  // full circle: every bearing is inside (t|t| + 4 rho^2 > 0)
+    k.ch = (float)ch;
     k.p2r = p.priority_rule == CSF_P2R;
     if (p.model == CSF_BICYCLE) {
         k.lf0 = (float)std::log2(p.p_0 / p.p_decay);
@@ -223,6 +228,12 @@ int alloc_all(csf_engine *e) {
     size_t nrec = (cap + 64 * 64 + 63) / 64 * 64;
     HIPCHK(e, e->rec.alloc(nrec));
     HIPCHK(e, e->rec2.alloc(nrec));
+    HIPCHK(e, e->perm.alloc(nrec));
+    HIPCHK(e, e->bnd.alloc(nrec / 64));
+    HIPCHK(e, e->sort_vals.alloc(nrec));
+    HIPCHK(e, e->sort_keys.alloc(nrec));
+    HIPCHK(e, e->sort_keys_out.alloc(nrec));
+    HIPCHK(e, e->sort_tmp.alloc(bin_temp_bytes((int64_t)nrec) + 256));
     e->h_s.assign(6 * cap, 0.0);
     e->h_vdes.assign(cap, 0.0);
     e->h_znp.assign(3 * cap, 0.0);
@@ -259,6 +270,8 @@ int alloc_all(csf_engine *e) {
     d.froad = e->froad.p;
     d.rec = e->rec.p;
     d.rec2 = e->rec2.p;
+    d.perm = e->perm.p;
+    d.bnd = e->bnd.p;
     return CSF_OK;
 }
 
@@ -278,9 +291,30 @@ void set_shard(csf_engine *e) {
     int64_t nloc = d.hi - d.lo;
     int64_t blocks = (nloc + 15) / 16;
     int64_t units = std::max<int64_t>(1, d.n_pad / 64);
-    int64_t split = blocks > 0 ? (1024 + blocks - 1) / blocks : 1;
+    // Many more workgroups than the chip holds at once: receivers see very different numbers of sources (field
+    // of view, position in the scene), so the hardware's dynamic workgroup dispatch is the load balancer.
+    int64_t split = blocks > 0 ? (16384 + blocks - 1) / blocks : 1;
     split = std::max<int64_t>(1, std::min<int64_t>({split, (int64_t)MAX_SPLIT, units}));
+    if (const char *ov = getenv("CSF_NSPLIT")) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoi(ov), (int64_t)MAX_SPLIT, units}));
     d.n_split = (int32_t)split;
+}
+
+constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long
+constexpr int64_t BIN_MIN_AGENTS = 1024;
+
+// (re)build the spatially binned order of the records; decides whether batches are classified this tick
+int rebin(csf_engine *e) {
+    Dev &d = e->d;
+    const bool binned = d.pair_variant == 0 && d.p.model != CSF_BICYCLE && d.n >= BIN_MIN_AGENTS;
+    d.classify = binned && d.p.hfov <= 3.141592653589793;
+    if (binned) {
+        int rc = launch_rebin(d, e->sort_keys.p, e->sort_keys_out.p, e->sort_vals.p, e->sort_tmp.p, e->sort_tmp.n, e->main);
+        if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the record bins failed (%d)", rc);
+    } else {
+        launch_identity_perm(d, e->main);
+    }
+    e->ticks_since_rebin = 0;
+    return CSF_OK;
 }
 
 // device -> host mirror (needed before a structural change once ticks have run)
@@ -378,6 +412,8 @@ int upload_all(csf_engine *e) {
     set_shard(e);
     if ((size_t)d.n_pad > e->rec.n) return fail(e, CSF_E_CAPACITY, "record buffer too small for this shard layout");
     launch_records(d, e->main);
+    int rrc = rebin(e);
+    if (rrc) return rrc;
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
     e->gather_pending = false;
@@ -480,7 +516,8 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qoff.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release();
-    e->part.release(); e->froad.release(); e->kat2.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->perm.release();
+    e->sort_vals.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);
     delete e;
@@ -686,6 +723,14 @@ static int enqueue_tick(csf_engine *e) {
         int rc = wait_gather(e);
         if (rc) return rc;
     }
+    if (d.classify || e->ticks_since_rebin >= REBIN_TICKS) {
+        if (e->ticks_since_rebin >= REBIN_TICKS) {
+            int rc = rebin(e);
+            if (rc) return rc;
+        }
+        if (d.classify) launch_bounds(d, e->main);
+    }
+    e->ticks_since_rebin++;
     if (pe) HIPCHK(e, hipEventRecord(pe[0], e->main));
     if (d.n > 1) launch_pair(d, e->main);
     if (pe) HIPCHK(e, hipEventRecord(pe[1], e->main));
@@ -733,6 +778,7 @@ int csf_calc_forces(csf_engine *e) {
     if (e->d.n == 0) return CSF_OK;
     rc = wait_gather(e);
     if (rc) return rc;
+    if (e->d.classify) launch_bounds(e->d, e->main);
     if (e->d.n > 1) launch_pair(e->d, e->main);
     launch_road(e->d, e->main);
     launch_agent(e->d, PH_DEST | PH_COMBINE, e->main);

@@ -30,7 +30,13 @@ constexpr int RPW = 4;               // receivers per wave
 constexpr int WPB = 4;               // waves per workgroup
 constexpr int BLOCK = WPB * WAVE;
 constexpr int TILE = 1024;           // simple kernels: source records per LDS tile (16 KiB)
-constexpr int TILE2 = 2048;          // culling kernel: 32 KiB tile
+#ifndef CSF_TILE2
+#define CSF_TILE2 1024
+#endif
+#ifndef CSF_CULL_WAVES
+#define CSF_CULL_WAVES 5
+#endif
+constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 5 waves/SIMD measured best (tools/sweep_cull.sh)
 constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
 constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
 
@@ -190,10 +196,18 @@ __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_
     if (iend > d.n_pad) iend = d.n_pad;
 }
 
-// ---- culling kernel (TwoD field): test -> ballot -> LDS queue -> packed field on full batches ------------
-template <bool P2R>
-__global__ __launch_bounds__(BLOCK) void pair_cull_kernel(const Dev d) {
+// ---- culling kernel (TwoD field): classify batches -> test -> ballot -> LDS queue -> packed field ---------
+// CLASSIFY: the records are streamed in spatially binned order (csf_bin.hip) and every batch of 64 carries a
+// bounding circle.  Per receiver and tile, lane b classifies batch b against the field-of-view cone:
+//   outside (smallest bearing in the circle > hfov/2)  -> skipped without touching its records,
+//   inside  (largest bearing in the circle  < hfov/2)  -> all 64 lanes queued without per-lane tests,
+//   else                                               -> exact per-lane test (intersection.py:690-745).
+// Both shortcuts keep a 1e-4 margin in the cosine and need the receiver outside the circle, so the exact test
+// decides every borderline source: results are identical with and without CLASSIFY.
+template <bool P2R, bool CLASSIFY>
+__global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     __shared__ float4 tile[TILE2];
+    __shared__ float4 tbnd[TILE2 / WAVE];
     __shared__ unsigned short queue[WPB][RPW][QCAP];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -224,21 +238,49 @@ __global__ __launch_bounds__(BLOCK) void pair_cull_kernel(const Dev d) {
 
     for (int64_t base = ibeg; base < iend; base += TILE2) {
         const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
+        const int nb = cnt >> 6;
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += BLOCK) tile[t] = d.rec[base + t];
+        for (int t = threadIdx.x; t < cnt; t += BLOCK) tile[t] = d.rec[d.perm[base + t]];
+        if (CLASSIFY && (int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
         __syncthreads();
-        for (int t = lane; t < cnt; t += WAVE) {
-            const float4 q = tile[t];
 #pragma unroll
-            for (int u = 0; u < RPW; u++) {
-                const float dx = r[u].x - q.x, dy = r[u].y - q.y;
-                const bool in = tracked<P2R>(k.chs, r[u], dx, dy, dx * dx + dy * dy);
-                const unsigned long long m = __ballot(in);
-                if (in) {
-                    const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    queue[wave][u][(qhead[u] + qlen[u] + pre) & (QCAP - 1)] = (unsigned short)t;
+        for (int u = 0; u < RPW; u++) {
+            unsigned cand = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u), inside = 0u;
+            if (CLASSIFY) {
+                const float4 bb = tbnd[lane & 31];
+                const float ex = bb.x - r[u].x, ey = bb.y - r[u].y;      // receiver -> centre of the batch
+                const float D2 = ex * ex + ey * ey;
+                const float invD = fast_rsq(fmaxf(D2, 1e-30f));
+                const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
+                const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
+                const float cb = (ex * r[u].c + ey * r[u].s) * invD;      // cos / |sin| of the centre's bearing
+                const float sb = fabsf(r[u].c * ey - r[u].s * ex) * invD;
+                const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
+                // outside: the heading misses the circle (|beta| > alpha) and cos(|beta| - alpha) < cos(hfov/2)
+                const bool out = apart & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f);
+                const bool in = !P2R & apart & ((cb * ca - sb * sa) > k.ch + 1e-4f);  // cos(|beta| + alpha) > cos(hfov/2)
+                const bool valid = lane < nb;
+                cand = (unsigned)__ballot(valid & !out);
+                inside = (unsigned)__ballot(valid & in);
+            }
+            while (cand) {
+                const int b = __builtin_ctz(cand);
+                cand &= cand - 1u;
+                const int t = (b << 6) + lane;
+                if ((inside >> b) & 1u) {
+                    queue[wave][u][(qhead[u] + qlen[u] + lane) & (QCAP - 1)] = (unsigned short)t;
+                    qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] + WAVE);
+                } else {
+                    const float4 q = tile[t];
+                    const float dx = r[u].x - q.x, dy = r[u].y - q.y;
+                    const bool in = tracked<P2R>(k.chs, r[u], dx, dy, dx * dx + dy * dy);
+                    const unsigned long long m = __ballot(in);
+                    if (in) {
+                        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        queue[wave][u][(qhead[u] + qlen[u] + pre) & (QCAP - 1)] = (unsigned short)t;
+                    }
+                    qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] + __builtin_popcountll(m));
                 }
-                qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] + __builtin_popcountll(m));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (qlen[u] >= CHUNK) pop(u);
@@ -390,9 +432,12 @@ void launch_pair(const Dev &d, hipStream_t st) {
     } else if (d.pair_variant == 1) {
         if (p2r) hipLaunchKernelGGL((pair_kernel<false, true>), g, b, 0, st, d);
         else hipLaunchKernelGGL((pair_kernel<false, false>), g, b, 0, st, d);
+    } else if (d.classify) {
+        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, true>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_cull_kernel<false, true>), g, b, 0, st, d);
     } else {
-        if (p2r) hipLaunchKernelGGL(pair_cull_kernel<true>, g, b, 0, st, d);
-        else hipLaunchKernelGGL(pair_cull_kernel<false>, g, b, 0, st, d);
+        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, false>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_cull_kernel<false, false>), g, b, 0, st, d);
     }
 }
 
