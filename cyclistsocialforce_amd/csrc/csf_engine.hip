@@ -431,7 +431,6 @@ int prepare_mutation(csf_engine *e) {
 int all_gather_records(csf_engine *e) {
     Dev &d = e->d;
     size_t shard = (size_t)(d.n_pad / e->world);
-    HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
     HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
     const bool two = d.p.model == CSF_BICYCLE;
     if (two) NCCLCHK(e, g_rccl.GroupStart());
@@ -708,6 +707,12 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
     return CSF_OK;
 }
 
+// One tick, all on the main stream (dependent launches in one stream cost ~2 us; a cross-stream event wait was
+// measured at ~11 us here, more than running the destination-force phase beside the pair kernel saves):
+//   main:  [agent(DEST) - wait(ev_gather)] - bounds - pair - road - agent(DEST|COMBINE|INTEGRATE) - record(ev_integ)
+//   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)                      (world > 1 only)
+// When sharded, the destination-force phase (it needs only the agent's own state) is issued before the wait
+// on the gather so that it overlaps the collective.
 static int enqueue_tick(csf_engine *e) {
     Dev &d = e->d;
     const bool sharded = e->world > 1;
@@ -719,7 +724,7 @@ static int enqueue_tick(csf_engine *e) {
         pe = &e->ev[base];
     }
     if (sharded) {
-        launch_agent(d, PH_DEST, e->main);  // needs only the agent's own state: overlaps the all-gather
+        launch_agent(d, PH_DEST, e->main);
         int rc = wait_gather(e);
         if (rc) return rc;
     }
@@ -739,7 +744,10 @@ static int enqueue_tick(csf_engine *e) {
     if (pe) HIPCHK(e, hipEventRecord(pe[2], e->main));
     HIPCHK(e, hipGetLastError());
     d.tick++;
-    if (sharded) return all_gather_records(e);
+    if (sharded) {
+        HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
+        return all_gather_records(e);
+    }
     return CSF_OK;
 }
 

@@ -22,6 +22,8 @@
 //   3. Wave-uniform operands are kept in VGPRs (an SGPR operand makes a VALU instruction slower here).
 // The math is trig-free: every angle of the reference enters only through sin/cos, which are dot and cross
 // products of unit vectors here.
+#include <type_traits>
+
 #include "csf_dev.h"
 
 namespace csf {
@@ -107,24 +109,26 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
 }
 
 // The same field for TWO sources per lane (components .x / .y), float2 arithmetic -> v_pk_* instructions.
-// valid0 / valid1 mask the lanes of a partial batch.  Adds the two contributions to (ax, ay).
-__device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r, const float4 q0, const float4 q1,
-                                              bool valid0, bool valid1, float &ax, float &ay) {
-    const v2f qx{q0.x, q1.x}, qy{q0.y, q1.y}, qc{q0.z, q1.z}, qs{q0.w, q1.w};
+// FULL: both sources of every lane are real, tracked pairs (rho > 0); otherwise valid0 / valid1 mask the lanes
+// of a partial batch, whose dummy record may coincide with the receiver.  Accumulates into packed (ax, ay).
+template <bool FULL>
+__device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r, const v2f qx, const v2f qy,
+                                              const v2f qc, const v2f qs, bool valid0, bool valid1, v2f &ax,
+                                              v2f &ay) {
     v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
     v2f r2 = dx * dx + dy * dy;
-    r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};  // lanes of a partial batch may alias the receiver
+    if (!FULL) r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};
     v2f inv = rsq2(r2), rho = r2 * inv;
-    v2f srel = qs * r.c - qc * r.s;
+    v2f srel = qs * r.c - qc * r.s;                   // sin(psi0 - psi)            :1595
     v2f s2 = srel * srel;
-    v2f sga = k.sg0 + k.sg1 * s2, sgb = k.sg2 + k.sg3 * s2, e = k.e0 - k.e1 * s2;
-    v2f cphi = (dx * qc + dy * qs) * inv, sphi = (dy * qc - dx * qs) * inv;
+    v2f sga = k.sg0 + k.sg1 * s2, sgb = k.sg2 + k.sg3 * s2, e = k.e0 - k.e1 * s2;   // :1604-1612
+    v2f cphi = (dx * qc + dy * qs) * inv, sphi = (dy * qc - dx * qs) * inv;           // :1618-1621
     v2f a = 0.5f + 0.5f * fabs2(cphi);
     v2f rs = rsq2(a);
     v2f big = a * rs, hrs = 0.5f * rs;
     v2f al = sphi * hrs;
     v2f sg{__builtin_amdgcn_fmed3f(sphi.x * 1e38f, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(sphi.y * 1e38f, -1.0f, 1.0f)};
-    v2f small = al * sg, bs = big * sg;                // |sphi| hrs and sign(phi) big
+    v2f small = al * sg, bs = big * sg;                // |sphi| hrs and sign(phi) big          :1624-1625
     const bool p0 = cphi.x >= 0.0f, p1 = cphi.y >= 0.0f;
     v2f h1{p0 ? small.x : big.x, p1 ? small.y : big.y};
     v2f h2s{p0 ? bs.x : al.x, p1 ? bs.y : al.y};
@@ -134,16 +138,15 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
     v2f q2 = 1.0f - ec * ec;
     v2f qq{fast_sqrt(q2.x), fast_sqrt(q2.y)};
     v2f isg{fast_rcp(sigma.x), fast_rcp(sigma.y)};
-    v2f grho = q2 * sigma;
+    v2f grho = q2 * sigma;                            // :1631-1642, common factor P/(sigma^2 q) removed
     v2f gphi = (e * ec) * (sphi * sigma) + q2 * hd;
     v2f gx = grho * dx - gphi * dy, gy = grho * dy + gphi * dx;
     v2f ig = rsq2(gx * gx + gy * gy);
-    v2f ex = k.lf0 - k.kexp * (rho * qq * isg);
-    v2f F = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * ig;
-    F = v2f{valid0 ? F.x : 0.0f, valid1 ? F.y : 0.0f};
-    v2f cx = F * gx, cy = F * gy;
-    ax += cx.x + cx.y;
-    ay += cy.x + cy.y;
+    v2f ex = k.lf0 - k.kexp * (rho * qq * isg);       // :1628
+    v2f F = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * ig;   // :1644-1646
+    if (!FULL) F = v2f{valid0 ? F.x : 0.0f, valid1 ? F.y : 0.0f};
+    ax += F * gx;
+    ay += F * gy;
 }
 
 // vehicle.py:1054-1147: older elliptic field of base Bicycle; q2v = (e, 1/sqrt(1-e^2)) of the source.
@@ -173,18 +176,36 @@ __device__ __forceinline__ void load_receivers(const Dev &d, int64_t j0, Recv (&
     }
 }
 
-// column sum (intersection.py:841-843): butterfly over the 64 lanes of the wave, lane 0 stores the partial
+// column sum (intersection.py:841-843) of the 2 x RPW per-lane accumulators of a wave.  The eight values are
+// reduced together: each of the first three butterfly steps hands half of the values to the partner lane, the
+// last three steps finish the one value a lane is left with.  10 shuffles instead of 48; fixed order.
 __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane, const float (&ax)[RPW],
                                              const float (&ay)[RPW]) {
+    static_assert(RPW == 4, "the reduction below is written for eight values");
+    float v[8] = {ax[0], ay[0], ax[1], ay[1], ax[2], ay[2], ax[3], ay[3]};
+    float w[4];
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
 #pragma unroll
-    for (int u = 0; u < RPW; u++) {
-        float sx = ax[u], sy = ay[u];
+    for (int i = 0; i < 4; i++) {
+        const float send = h5 ? v[i] : v[i + 4], keep = h5 ? v[i + 4] : v[i];
+        w[i] = keep + __shfl_xor(send, 32, WAVE);
+    }
+    float y[2];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            sx += __shfl_xor(sx, o, WAVE);
-            sy += __shfl_xor(sy, o, WAVE);
-        }
-        if (lane == 0 && j0 + u < d.hi) d.part[(int64_t)blockIdx.y * d.cap + j0 + u] = make_float2(sx, sy);
+    for (int i = 0; i < 2; i++) {
+        const float send = h4 ? w[i] : w[i + 2], keep = h4 ? w[i + 2] : w[i];
+        y[i] = keep + __shfl_xor(send, 16, WAVE);
+    }
+    float z = (h3 ? y[1] : y[0]) + __shfl_xor(h3 ? y[0] : y[1], 8, WAVE);
+    z += __shfl_xor(z, 4, WAVE);
+    z += __shfl_xor(z, 2, WAVE);
+    z += __shfl_xor(z, 1, WAVE);
+    // lane 8*k holds value index 4*bit5 + 2*bit4 + bit3
+    const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    const int u = idx >> 1;
+    if ((lane & 7) == 0 && j0 + u < d.hi) {
+        float *dst = (float *)&d.part[(int64_t)blockIdx.y * d.cap + j0 + u];
+        dst[idx & 1] = z;
     }
 }
 
@@ -206,8 +227,8 @@ __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_
 // decides every borderline source: results are identical with and without CLASSIFY.
 template <bool P2R, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
-    __shared__ float4 tile[TILE2];
-    __shared__ float4 tbnd[TILE2 / WAVE];
+    __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
+    __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
     __shared__ unsigned short queue[WPB][RPW][QCAP];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -217,21 +238,24 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
 
     Recv r[RPW];
     load_receivers(d, j0, r);
-    float ax[RPW], ay[RPW];
+    v2f ax[RPW], ay[RPW];
     int qhead[RPW], qlen[RPW];  // wave-uniform ring state of the four queues
 #pragma unroll
-    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f, qhead[u] = qlen[u] = 0;
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = v2f{0.0f, 0.0f}, qhead[u] = qlen[u] = 0;
     PairConsts k = d.pc;
     asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0),
                  "+v"(k.kexp), "+v"(k.chs));
 
-    // pop up to CHUNK queued sources of receiver u and evaluate the field, two per lane
-    auto pop = [&](int u) {
-        const int n = qlen[u] < CHUNK ? qlen[u] : CHUNK;
-        const int i0 = queue[wave][u][(qhead[u] + lane) & (QCAP - 1)];
-        const int i1 = queue[wave][u][(qhead[u] + WAVE + lane) & (QCAP - 1)];
+    // pop CHUNK (or, when draining, whatever is left) queued sources of receiver u; the field takes two per lane
+    auto pop = [&](int u, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const int n = FULL ? CHUNK : (qlen[u] < CHUNK ? qlen[u] : CHUNK);
+        int i0 = queue[wave][u][(qhead[u] + lane) & (QCAP - 1)];
+        int i1 = queue[wave][u][(qhead[u] + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
-        field_twod_x2(k, r[u], tile[v0 ? i0 : 0], tile[v1 ? i1 : 0], v0, v1, ax[u], ay[u]);
+        if (!FULL) i0 = v0 ? i0 : 0, i1 = v1 ? i1 : 0;
+        field_twod_x2<FULL>(k, r[u], v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
+                            v2f{ts[i0], ts[i1]}, v0, v1, ax[u], ay[u]);
         qhead[u] = __builtin_amdgcn_readfirstlane((qhead[u] + n) & (QCAP - 1));
         qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] - n);
     };
@@ -240,7 +264,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
         const int nb = cnt >> 6;
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += BLOCK) tile[t] = d.rec[d.perm[base + t]];
+        for (int t = threadIdx.x; t < cnt; t += BLOCK) {
+            const float4 q = d.rec[d.perm[base + t]];
+            tx[t] = q.x;
+            ty[t] = q.y;
+            tc[t] = q.z;
+            ts[t] = q.w;
+        }
         if (CLASSIFY && (int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
         __syncthreads();
 #pragma unroll
@@ -271,8 +301,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     queue[wave][u][(qhead[u] + qlen[u] + lane) & (QCAP - 1)] = (unsigned short)t;
                     qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] + WAVE);
                 } else {
-                    const float4 q = tile[t];
-                    const float dx = r[u].x - q.x, dy = r[u].y - q.y;
+                    const float dx = r[u].x - tx[t], dy = r[u].y - ty[t];
                     const bool in = tracked<P2R>(k.chs, r[u], dx, dy, dx * dx + dy * dy);
                     const unsigned long long m = __ballot(in);
                     if (in) {
@@ -283,15 +312,20 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (qlen[u] >= CHUNK) pop(u);
+                if (qlen[u] >= CHUNK) pop(u, std::true_type{});
             }
         }
         // the queues hold indices into this tile: drain them before it is replaced
 #pragma unroll
-        for (int u = 0; u < RPW; u++)
-            while (qlen[u] > 0) pop(u);
+        for (int u = 0; u < RPW; u++) {
+            while (qlen[u] >= CHUNK) pop(u, std::true_type{});
+            if (qlen[u] > 0) pop(u, std::false_type{});
+        }
     }
-    reduce_store(d, j0, lane, ax, ay);
+    float sx[RPW], sy[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; u++) sx[u] = ax[u].x + ax[u].y, sy[u] = ay[u].x + ay[u].y;
+    reduce_store(d, j0, lane, sx, sy);
 }
 
 // ---- simple kernel: every pair evaluated, masked afterwards (Bicycle field; also the TwoD field on request) --
@@ -405,7 +439,11 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
         fx = F * gx;
         fy = F * gy;
     } else if (t & 1) {
-        field_twod_x2(k, r, make_float4(r.x, r.y, 1.f, 0.f), q, false, true, fx, fy);
+        v2f px{0.f, 0.f}, py{0.f, 0.f};
+        if (t & 2) field_twod_x2<true>(k, r, v2f{q.x, q.x}, v2f{q.y, q.y}, v2f{q.z, q.z}, v2f{q.w, q.w}, true, true, px, py);
+        else field_twod_x2<false>(k, r, v2f{r.x, q.x}, v2f{r.y, q.y}, v2f{1.f, q.z}, v2f{0.f, q.w}, false, true, px, py);
+        fx = (t & 2) ? 0.5f * (px.x + px.y) : px.x + px.y;
+        fy = (t & 2) ? 0.5f * (py.x + py.y) : py.x + py.y;
     } else {
         float F, gx, gy;
         field_twod(k, r, q, dx, dy, r2, F, gx, gy);
