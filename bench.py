@@ -79,7 +79,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    rehearse = os.environ.get("CSF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal of the multi-rank code path
+    if world > 1 or rehearse:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -100,6 +101,9 @@ def main():
     eng.set_dest_queue(np.arange(n), off, dq, reset=True)
     if world > 1:
         shard_engine(eng, dist, rank, world)
+    elif rehearse:
+        from cyclistsocialforce_amd.parallel import broadcast_unique_id
+        eng.comm_init(broadcast_unique_id(dist, rank, Engine.comm_unique_id), rank, world)
 
     def fence():
         eng.sync()

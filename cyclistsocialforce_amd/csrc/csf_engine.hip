@@ -715,7 +715,7 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
 // on the gather so that it overlaps the collective.
 static int enqueue_tick(csf_engine *e) {
     Dev &d = e->d;
-    const bool sharded = e->world > 1;
+    const bool sharded = e->world > 1 || e->nccl != nullptr;  // a 1-rank communicator rehearses the sharded path
     hipEvent_t *pe = nullptr;
     if (e->profile) {
         size_t base = e->ev.size();

@@ -110,11 +110,11 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
 
 // The same field for TWO sources per lane (components .x / .y), float2 arithmetic -> v_pk_* instructions.
 // FULL: both sources of every lane are real, tracked pairs (rho > 0); otherwise valid0 / valid1 mask the lanes
-// of a partial batch, whose dummy record may coincide with the receiver.  Accumulates into packed (ax, ay).
+// of a partial batch, whose dummy record may coincide with the receiver.  Accumulates into (ax, ay).
 template <bool FULL>
 __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r, const v2f qx, const v2f qy,
-                                              const v2f qc, const v2f qs, bool valid0, bool valid1, v2f &ax,
-                                              v2f &ay) {
+                                              const v2f qc, const v2f qs, bool valid0, bool valid1, float &ax,
+                                              float &ay) {
     v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
     v2f r2 = dx * dx + dy * dy;
     if (!FULL) r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};
@@ -145,8 +145,9 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
     v2f ex = k.lf0 - k.kexp * (rho * qq * isg);       // :1628
     v2f F = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * ig;   // :1644-1646
     if (!FULL) F = v2f{valid0 ? F.x : 0.0f, valid1 ? F.y : 0.0f};
-    ax += F * gx;
-    ay += F * gy;
+    const v2f cx = F * gx, cy = F * gy;
+    ax += cx.x + cx.y;
+    ay += cy.x + cy.y;
 }
 
 // vehicle.py:1054-1147: older elliptic field of base Bicycle; q2v = (e, 1/sqrt(1-e^2)) of the source.
@@ -238,10 +239,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
 
     Recv r[RPW];
     load_receivers(d, j0, r);
-    v2f ax[RPW], ay[RPW];
+    float ax[RPW], ay[RPW];
     int qhead[RPW], qlen[RPW];  // wave-uniform ring state of the four queues
 #pragma unroll
-    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = v2f{0.0f, 0.0f}, qhead[u] = qlen[u] = 0;
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f, qhead[u] = qlen[u] = 0;
     PairConsts k = d.pc;
     asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0),
                  "+v"(k.kexp), "+v"(k.chs));
@@ -322,10 +323,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             if (qlen[u] > 0) pop(u, std::false_type{});
         }
     }
-    float sx[RPW], sy[RPW];
-#pragma unroll
-    for (int u = 0; u < RPW; u++) sx[u] = ax[u].x + ax[u].y, sy[u] = ay[u].x + ay[u].y;
-    reduce_store(d, j0, lane, sx, sy);
+    reduce_store(d, j0, lane, ax, ay);
 }
 
 // ---- simple kernel: every pair evaluated, masked afterwards (Bicycle field; also the TwoD field on request) --
@@ -439,11 +437,11 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
         fx = F * gx;
         fy = F * gy;
     } else if (t & 1) {
-        v2f px{0.f, 0.f}, py{0.f, 0.f};
+        float px = 0.f, py = 0.f;
         if (t & 2) field_twod_x2<true>(k, r, v2f{q.x, q.x}, v2f{q.y, q.y}, v2f{q.z, q.z}, v2f{q.w, q.w}, true, true, px, py);
         else field_twod_x2<false>(k, r, v2f{r.x, q.x}, v2f{r.y, q.y}, v2f{1.f, q.z}, v2f{0.f, q.w}, false, true, px, py);
-        fx = (t & 2) ? 0.5f * (px.x + px.y) : px.x + px.y;
-        fy = (t & 2) ? 0.5f * (py.x + py.y) : py.x + py.y;
+        fx = (t & 2) ? 0.5f * px : px;
+        fy = (t & 2) ? 0.5f * py : py;
     } else {
         float F, gx, gy;
         field_twod(k, r, q, dx, dy, r2, F, gx, gy);

@@ -332,3 +332,20 @@ def test_history_and_push_state(amd):
     s[0, 0] += 1.0
     e.push_state([0], s[0:1])
     np.testing.assert_array_equal(e.state()[0], s[0])
+
+
+def test_single_rank_communicator_path(amd):
+    """world = 1 with a real RCCL communicator: the sharded tick (split agent phases, all-gather on the comm
+    stream, event choreography) must reproduce the unsharded engine bit for bit."""
+    n, box = 1500, 120.0
+    x, y, psi, v, off, dq = synthetic_population(n, box, seed=4)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    ref = make_engine(amd, "twod", s0, 5.0, off, dq)
+    ref.step(40)
+    e = make_engine(amd, "twod", s0, 5.0, off, dq)
+    uid = amd.Engine.comm_unique_id()
+    assert len(uid) == 128
+    e.comm_init(uid, 0, 1)
+    assert e.shard_range() == (0, n)
+    e.step(40)
+    np.testing.assert_array_equal(e.state(), ref.state())
