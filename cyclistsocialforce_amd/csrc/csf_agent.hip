@@ -118,98 +118,141 @@ __device__ void direct_approach(const Dev &d, Agent &g, double &fx, double &fy) 
     }
 }
 
-// ---- cubic B-spline through m in {4,5,6} points (scipy splprep(s=0) + splev, vehicle.py:1496-1510) ----
-// Chord-length parameter u, clamped knots with interior knots u[2..m-3].  The end conditions make the first
-// and last coefficient equal the end points, so only an (m-2)x(m-2) totally positive system remains; it is
-// eliminated without pivoting.  Evaluation returns position, first and second derivative at one parameter.
+// ---- cubic B-spline through M in {4,5,6} points (scipy splprep(s=0) + splev, vehicle.py:1496-1510) ----
+// Chord-length parameter u, clamped knots with interior knots u[2..M-3] (FITPACK's rule for s = 0).  The end
+// conditions make the first and last coefficient equal the end points, so only an (M-2)x(M-2) totally positive
+// system remains; it is eliminated without pivoting.  Everything is templated on M and unrolled so that knots
+// and coefficients live in registers: a span is chosen with selects, never with an indexed load (indexed
+// per-lane arrays go to scratch memory, which made this kernel latency-bound).
+template <int M>
 struct Spline {
-    double t[10];
-    double cx[6], cy[6];
-    int n;
+    double t[M + 4];
+    double cx[M], cy[M];
 };
 
-__device__ __forceinline__ int span_of(const Spline &s, double u) {
-    int l = 3;
-    while (l < s.n - 1 && u >= s.t[l + 1]) l++;
-    return l;
+// the six knots t[l-2..l+3] and four coefficients c[l-3..l] of the span l = 3 + si that contains u
+struct Window {
+    double k[6];
+    double x[4], y[4];
+};
+
+template <int M>
+__device__ __forceinline__ void window_at(const Spline<M> &s, double u, Window &w) {
+    int si = 0;  // interior knots <= u; u = 1 falls into the last span (fpbspl / splev convention)
+#pragma unroll
+    for (int j = 0; j < M - 4; j++) si += (u >= s.t[4 + j]) ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        double v = s.t[1 + q];
+#pragma unroll
+        for (int c = 1; c <= M - 4; c++) v = (si == c) ? s.t[1 + q + c] : v;
+        w.k[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double vx = s.cx[q], vy = s.cy[q];
+#pragma unroll
+        for (int c = 1; c <= M - 4; c++) {
+            vx = (si == c) ? s.cx[q + c] : vx;
+            vy = (si == c) ? s.cy[q + c] : vy;
+        }
+        w.x[q] = vx;
+        w.y[q] = vy;
+    }
 }
 
-// non-zero cubic basis values N[0..3] at u in span l, plus the quadratic (N2[0..2]) and linear (N1[0..1]) ones
-__device__ __forceinline__ void basis(const Spline &s, int l, double u, double N3[4], double N2[3], double N1[2]) {
-    double a1 = u - s.t[l], b1 = s.t[l + 1] - u;
-    double w = 1.0 / (s.t[l + 1] - s.t[l]);
+// non-zero cubic basis values N3[0..3] at u for the window's span (Cox - de Boor), plus the quadratic and
+// linear ones that the derivatives use.  k[2] = t[l], k[3] = t[l+1].
+__device__ __forceinline__ void basis(const double (&k)[6], double u, double N3[4], double N2[3], double N1[2]) {
+    const double a1 = u - k[2], b1 = k[3] - u;
+    const double w = 1.0 / (k[3] - k[2]);
     N1[0] = b1 * w;
     N1[1] = a1 * w;
-    double a2 = u - s.t[l - 1], b2 = s.t[l + 2] - u;
-    double w0 = N1[0] / (s.t[l + 1] - s.t[l - 1]), w1 = N1[1] / (s.t[l + 2] - s.t[l]);
+    const double a2 = u - k[1], b2 = k[4] - u;
+    const double w0 = N1[0] / (k[3] - k[1]), w1 = N1[1] / (k[4] - k[2]);
     N2[0] = b1 * w0;
     N2[1] = a2 * w0 + b2 * w1;
     N2[2] = a1 * w1;
-    double a3 = u - s.t[l - 2], b3 = s.t[l + 3] - u;
-    double v0 = N2[0] / (s.t[l + 1] - s.t[l - 2]), v1 = N2[1] / (s.t[l + 2] - s.t[l - 1]),
-           v2 = N2[2] / (s.t[l + 3] - s.t[l]);
+    const double a3 = u - k[0], b3 = k[5] - u;
+    const double v0 = N2[0] / (k[3] - k[0]), v1 = N2[1] / (k[4] - k[1]), v2 = N2[2] / (k[5] - k[2]);
     N3[0] = b1 * v0;
     N3[1] = a3 * v0 + b2 * v1;
     N3[2] = a2 * v1 + b3 * v2;
     N3[3] = a1 * v2;
 }
 
-__device__ bool spline_fit(Spline &s, int m, const double *px, const double *py) {
-    double u[6];
+template <int M>
+__device__ __forceinline__ bool spline_fit(Spline<M> &s, const double (&px)[M], const double (&py)[M]) {
+    double u[M];
     u[0] = 0;
-    for (int r = 1; r < m; r++) {
-        double ex = px[r] - px[r - 1], ey = py[r] - py[r - 1];
-        double dd = sqrt(ex * ex + ey * ey);
-        if (!(dd > 0.0)) return false;  // splprep raises ValueError here
+    bool ok = true;
+#pragma unroll
+    for (int r = 1; r < M; r++) {
+        const double ex = px[r] - px[r - 1], ey = py[r] - py[r - 1];
+        const double dd = sqrt(ex * ex + ey * ey);
+        ok = ok && (dd > 0.0);  // splprep raises ValueError on duplicate consecutive points
         u[r] = u[r - 1] + dd;
     }
-    double tot = u[m - 1];
-    for (int r = 1; r < m - 1; r++) u[r] /= tot;
-    u[m - 1] = 1.0;
-    s.n = m;
+    if (!ok) return false;
+    const double tot = u[M - 1];
+#pragma unroll
+    for (int r = 1; r < M - 1; r++) u[r] /= tot;
+    u[M - 1] = 1.0;
+#pragma unroll
     for (int j = 0; j < 4; j++) {
         s.t[j] = 0.0;
-        s.t[m + j] = 1.0;
+        s.t[M + j] = 1.0;
     }
-    for (int j = 0; j < m - 4; j++) s.t[4 + j] = u[2 + j];
-    // interior unknowns c_1 .. c_{m-2}
-    const int q = m - 2;
-    double A[4][4], bx[4], by[4];
-    for (int r = 0; r < q; r++) {
-        for (int c = 0; c < q; c++) A[r][c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < M - 4; j++) s.t[4 + j] = u[2 + j];
+    // collocation rows of the interior points u_1 .. u_{M-2}; the span of u_r is known statically:
+    // u_1 is in the first span, u_r (2 <= r <= M-3) is the interior knot t[r+2], u_{M-2} is in the last span
+    constexpr int Q = M - 2;
+    double A[Q][Q], bx[Q], by[Q];
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+#pragma unroll
+        for (int c = 0; c < Q; c++) A[r][c] = 0.0;
+        const int si = (r == 0) ? 0 : ((r < M - 4) ? r : M - 4);  // row r is point r+1
+        double k[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) k[q] = s.t[1 + si + q];
         double N3[4], N2[3], N1[2];
-        double ur = u[r + 1];
-        int l = span_of(s, ur);
-        basis(s, l, ur, N3, N2, N1);
+        basis(k, u[r + 1], N3, N2, N1);
         double rx = px[r + 1], ry = py[r + 1];
+#pragma unroll
         for (int j = 0; j < 4; j++) {
-            int c = l - 3 + j;  // coefficient index
+            const int c = si + j;  // coefficient index
             if (c == 0) {
                 rx -= N3[j] * px[0];
                 ry -= N3[j] * py[0];
-            } else if (c == m - 1) {
-                rx -= N3[j] * px[m - 1];
-                ry -= N3[j] * py[m - 1];
-            } else A[r][c - 1] = N3[j];
+            } else if (c == M - 1) {
+                rx -= N3[j] * px[M - 1];
+                ry -= N3[j] * py[M - 1];
+            } else {
+                A[r][c - 1] = N3[j];
+            }
         }
         bx[r] = rx;
         by[r] = ry;
     }
-    for (int c = 0; c < q; c++) {
-        double piv = A[c][c];
-        if (piv == 0.0) return false;
-        for (int r = c + 1; r < q; r++) {
-            double f = A[r][c] / piv;
-            if (f != 0.0) {
-                for (int j = c; j < q; j++) A[r][j] -= f * A[c][j];
-                bx[r] -= f * bx[c];
-                by[r] -= f * by[c];
-            }
+#pragma unroll
+    for (int c = 0; c < Q; c++) {
+        const double ip = 1.0 / A[c][c];
+#pragma unroll
+        for (int r = c + 1; r < Q; r++) {
+            const double f = A[r][c] * ip;
+#pragma unroll
+            for (int j = c; j < Q; j++) A[r][j] -= f * A[c][j];
+            bx[r] -= f * bx[c];
+            by[r] -= f * by[c];
         }
     }
-    for (int r = q - 1; r >= 0; r--) {
+#pragma unroll
+    for (int r = Q - 1; r >= 0; r--) {
         double sx = bx[r], sy = by[r];
-        for (int j = r + 1; j < q; j++) {
+#pragma unroll
+        for (int j = r + 1; j < Q; j++) {
             sx -= A[r][j] * bx[j];
             sy -= A[r][j] * by[j];
         }
@@ -218,52 +261,104 @@ __device__ bool spline_fit(Spline &s, int m, const double *px, const double *py)
     }
     s.cx[0] = px[0];
     s.cy[0] = py[0];
-    for (int r = 0; r < q; r++) {
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
         s.cx[r + 1] = bx[r];
         s.cy[r + 1] = by[r];
     }
-    s.cx[m - 1] = px[m - 1];
-    s.cy[m - 1] = py[m - 1];
+    s.cx[M - 1] = px[M - 1];
+    s.cy[M - 1] = py[M - 1];
     return true;
 }
 
-__device__ void spline_pos(const Spline &s, double u, double &X, double &Y) {
+template <int M>
+__device__ __forceinline__ void spline_pos(const Spline<M> &s, double u, double &X, double &Y) {
+    Window w;
+    window_at(s, u, w);
     double N3[4], N2[3], N1[2];
-    int l = span_of(s, u);
-    basis(s, l, u, N3, N2, N1);
-    X = 0;
-    Y = 0;
-    for (int j = 0; j < 4; j++) {
-        X += N3[j] * s.cx[l - 3 + j];
-        Y += N3[j] * s.cy[l - 3 + j];
-    }
+    basis(w.k, u, N3, N2, N1);
+    X = N3[0] * w.x[0] + N3[1] * w.x[1] + N3[2] * w.x[2] + N3[3] * w.x[3];
+    Y = N3[0] * w.y[0] + N3[1] * w.y[1] + N3[2] * w.y[2] + N3[3] * w.y[3];
 }
 
-__device__ void spline_der(const Spline &s, double u, double &dX, double &dY, double &ddX, double &ddY) {
+// position, first and second derivative at u (splev with der = 0, 1, 2)
+template <int M>
+__device__ __forceinline__ void spline_all(const Spline<M> &s, double u, double &X, double &Y, double &dX,
+                                           double &dY, double &ddX, double &ddY) {
+    Window w;
+    window_at(s, u, w);
     double N3[4], N2[3], N1[2];
-    int l = span_of(s, u);
-    basis(s, l, u, N3, N2, N1);
+    basis(w.k, u, N3, N2, N1);
+    X = N3[0] * w.x[0] + N3[1] * w.x[1] + N3[2] * w.x[2] + N3[3] * w.x[3];
+    Y = N3[0] * w.y[0] + N3[1] * w.y[1] + N3[2] * w.y[2] + N3[3] * w.y[3];
     double ex[3], ey[3];
-    for (int k = 0; k < 3; k++) {
-        double w = 3.0 / (s.t[l + k + 1] - s.t[l + k - 2]);
-        ex[k] = w * (s.cx[l - 2 + k] - s.cx[l - 3 + k]);
-        ey[k] = w * (s.cy[l - 2 + k] - s.cy[l - 3 + k]);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {  // c'_j = 3 (c_{j+1} - c_j) / (t_{j+4} - t_{j+1})
+        const double f = 3.0 / (w.k[q + 3] - w.k[q]);
+        ex[q] = f * (w.x[q + 1] - w.x[q]);
+        ey[q] = f * (w.y[q + 1] - w.y[q]);
     }
     dX = N2[0] * ex[0] + N2[1] * ex[1] + N2[2] * ex[2];
     dY = N2[0] * ey[0] + N2[1] * ey[1] + N2[2] * ey[2];
     double gx[2], gy[2];
-    for (int k = 0; k < 2; k++) {
-        double w = 2.0 / (s.t[l + k + 1] - s.t[l + k - 1]);
-        gx[k] = w * (ex[k + 1] - ex[k]);
-        gy[k] = w * (ey[k + 1] - ey[k]);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const double f = 2.0 / (w.k[q + 3] - w.k[q + 1]);
+        gx[q] = f * (ex[q + 1] - ex[q]);
+        gy[q] = f * (ey[q + 1] - ey[q]);
     }
     ddX = N1[0] * gx[0] + N1[1] * gx[1];
     ddY = N1[0] * gy[0] + N1[1] * gy[1];
 }
 
+// vehicle.py:1494-1558 once the M control points are known
+template <int M>
+__device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const double (&px)[M], const double (&py)[M], bool last,
+                             double vd, double &fx, double &fy) {
+    const int nS = 20, ipred = 3, ipredlast = 5;              // :1446-1448
+    Spline<M> s;
+    if (!spline_fit(s, px, py)) {                             // :1495-1507 raises in the reference
+        g.st |= CSF_ST_SPLINE;
+        fx = 0;
+        fy = 0;
+        return;
+    }
+    int i = 1;                                                // :1516-1522
+    if (last) {
+        double best = INFINITY;
+        for (int k = 0; k < nS; k++) {
+            double X, Y;
+            spline_pos(s, k == nS - 1 ? 1.0 : (double)k / (nS - 1), X, Y);
+            const double dd = (X - g.x) * (X - g.x) + (Y - g.y) * (Y - g.y);
+            if (dd < best) {
+                best = dd;
+                i = k;
+            }
+        }
+    }
+    const int iprev = i + (qstop(d, g, g.ptr) ? ipredlast : ipred);  // :1523-1526
+    if (iprev < nS) {                                         // :1529-1553
+        const double ui = i == nS - 1 ? 1.0 : (double)i / (nS - 1);
+        const double up = iprev == nS - 1 ? 1.0 : (double)iprev / (nS - 1);
+        double X0, Y0, X1, Y1, dX, dY, ddX, ddY;
+        spline_all(s, ui, X0, Y0, dX, dY, ddX, ddY);
+        spline_pos(s, up, X1, Y1);
+        const double sp = sqrt(dX * dX + dY * dY);
+        const double R = sp * sp * sp / fabs(dX * ddY - dY * ddX);  // :1532-1537
+        const double thetacomf = 10 * (2 * PI / 360);         // :1541
+        double v = fmax(2.5, sqrt(thetacomf * d.p.g * R));    // :1542-1544
+        v = fmin(v, vd);                                      // :1545
+        const double ex = X1 - X0, ey = Y1 - Y0;
+        const double tmp = v / sqrt(ex * ex + ey * ey);       // :1548-1553
+        fx = tmp * ex;
+        fy = tmp * ey;
+    } else {
+        direct_approach(d, g, fx, fy);                        // :1555-1556 (second queue + nav update)
+    }
+}
+
 // vehicle.py:1416-1558
 __device__ void twod_dest(const Dev &d, Agent &g, double &fx, double &fy) {
-    const int nSplV = 4, nS = 20, ipred = 3, ipredlast = 5;   // :1444-1448
     update_destination(d, g);                                 // :1451
     double ddest, vd = update_nav(d, g, ddest);               // :1452
     if (g.ti == 0) {                                          // :1455-1458
@@ -277,71 +372,29 @@ __device__ void twod_dest(const Dev &d, Agent &g, double &fx, double &fy) {
         return;
     }
     const int hm = d.hist_len - 1;
-    double px[6], py[6];
-    int m;
-    bool last = g.ptr + 1 >= g.K;                             // :537-543
-    if (!last) {                                              // :1465-1479
-        px[0] = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
-        py[0] = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
-        px[1] = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a];
-        py[1] = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
-        int hi = min(g.ptr + nSplV, g.K);
-        m = 2;
-        for (int k = g.ptr; k < hi; k++, m++) {
-            px[m] = qx(d, g, k);
-            py[m] = qy(d, g, k);
+    const double h1x = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a], h1y = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
+    const double h0x = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a], h0y = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
+    const bool last = g.ptr + 1 >= g.K;                       // :537-543
+    if (!last) {                                              // :1465-1479: two trajectory points + up to 4 destinations
+        const int cnt = min(g.ptr + 4, g.K) - g.ptr;          // >= 2
+        if (cnt == 2) {
+            const double px[4] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1)};
+            const double py[4] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1)};
+            spline_force<4>(d, g, px, py, false, vd, fx, fy);
+        } else if (cnt == 3) {
+            const double px[5] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1), qx(d, g, g.ptr + 2)};
+            const double py[5] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1), qy(d, g, g.ptr + 2)};
+            spline_force<5>(d, g, px, py, false, vd, fx, fy);
+        } else {
+            const double px[6] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1), qx(d, g, g.ptr + 2), qx(d, g, g.ptr + 3)};
+            const double py[6] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1), qy(d, g, g.ptr + 2), qy(d, g, g.ptr + 3)};
+            spline_force<6>(d, g, px, py, false, vd, fx, fy);
         }
-    } else {                                                  // :1486-1492
-        int back = max(0, g.ti - d.back);
-        px[0] = d.hx[(int64_t)(back & hm) * d.cap + g.a];
-        py[0] = d.hy[(int64_t)(back & hm) * d.cap + g.a];
-        px[1] = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
-        py[1] = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
-        px[2] = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a];
-        py[2] = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
-        px[3] = qx(d, g, g.ptr);
-        py[3] = qy(d, g, g.ptr);
-        m = 4;
-    }
-    Spline s;
-    if (!spline_fit(s, m, px, py)) {                          // :1495-1507 raises in the reference
-        g.st |= CSF_ST_SPLINE;
-        fx = 0;
-        fy = 0;
-        return;
-    }
-    int i = 1;                                                // :1516-1522
-    if (last) {
-        double best = INFINITY;
-        for (int k = 0; k < nS; k++) {
-            double X, Y;
-            spline_pos(s, k == nS - 1 ? 1.0 : (double)k / (nS - 1), X, Y);
-            double dd = (X - g.x) * (X - g.x) + (Y - g.y) * (Y - g.y);
-            if (dd < best) {
-                best = dd;
-                i = k;
-            }
-        }
-    }
-    int iprev = i + (qstop(d, g, g.ptr) ? ipredlast : ipred); // :1523-1526
-    if (iprev < nS) {                                         // :1529-1553
-        double ui = i == nS - 1 ? 1.0 : (double)i / (nS - 1);
-        double up = iprev == nS - 1 ? 1.0 : (double)iprev / (nS - 1);
-        double X0, Y0, X1, Y1, dX, dY, ddX, ddY;
-        spline_pos(s, ui, X0, Y0);
-        spline_pos(s, up, X1, Y1);
-        spline_der(s, ui, dX, dY, ddX, ddY);
-        double sp = sqrt(dX * dX + dY * dY);
-        double R = sp * sp * sp / fabs(dX * ddY - dY * ddX);  // :1532-1537
-        const double thetacomf = 10 * (2 * PI / 360);         // :1541
-        double v = fmax(2.5, sqrt(thetacomf * d.p.g * R));    // :1542-1544
-        v = fmin(v, vd);                                      // :1545
-        double ex = X1 - X0, ey = Y1 - Y0;
-        double tmp = v / sqrt(ex * ex + ey * ey);             // :1548-1553
-        fx = tmp * ex;
-        fy = tmp * ey;
-    } else {
-        direct_approach(d, g, fx, fy);                        // :1555-1556 (second queue + nav update)
+    } else {                                                  // :1486-1492: last leg, three trajectory points
+        const int back = max(0, g.ti - d.back);
+        const double px[4] = {d.hx[(int64_t)(back & hm) * d.cap + g.a], h1x, h0x, qx(d, g, g.ptr)};
+        const double py[4] = {d.hy[(int64_t)(back & hm) * d.cap + g.a], h1y, h0y, qy(d, g, g.ptr)};
+        spline_force<4>(d, g, px, py, true, vd, fx, fy);
     }
 }
 
