@@ -294,6 +294,21 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 cand = (unsigned)__ballot(valid & !out);
                 inside = (unsigned)__ballot(valid & in);
             }
+            // batches that are entirely inside the field of view need neither the test nor the queue: two at a
+            // time they go straight into the packed field evaluation (one batch per half of the register pairs)
+            {
+                unsigned ins = inside;
+                while (__builtin_popcount(ins) >= 2) {
+                    const int b1 = __builtin_ctz(ins);
+                    ins &= ins - 1u;
+                    const int b2 = __builtin_ctz(ins);
+                    ins &= ins - 1u;
+                    const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
+                    field_twod_x2<true>(k, r[u], v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
+                                        v2f{ts[i0], ts[i1]}, true, true, ax[u], ay[u]);
+                }
+                cand = (cand & ~inside) | ins;  // an odd one out takes the queue together with the partial batches
+            }
             while (cand) {
                 const int b = __builtin_ctz(cand);
                 cand &= cand - 1u;
