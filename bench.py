@@ -41,6 +41,19 @@ def synthetic_population(n, box, seed=0):
     return s0, np.arange(n + 1) * 4, dq.reshape(-1, 3)
 
 
+def measured_traffic():
+    """HBM bytes per launch of the pair kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE are collected in their own runs, tools/pmc_passes.sh; bench.py cannot run under rocprofv3 itself)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pair_kernel_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        rec = json.load(fh)
+    return rec.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(n, box, ticks):
     """The oracle (CPU port of the reference algorithm) on this box's host cores, bounded sample."""
     from oracle import csf_oracle as orc
@@ -137,6 +150,7 @@ def main():
         pair_s = pair_ms * 1e-3 / max(launches, 1)
         alg_bytes = 16.0 * n * n_loc + 8.0 * n_loc          # source records consumed + partial sums written
         pairs = float(n) * n_loc
+        traffic, traffic_src = measured_traffic() if (world == 1 and n == 16384 and args.model == "twod") else (None, None)
         out = {
             "metric": "agent-steps/sec at N=16k TwoDBicycle", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -149,7 +163,8 @@ def main():
             "healthy": healthy,
             "roofline": {
                 "bound": "hbm", "kernel": "pair_kernel", "achieved": alg_bytes / pair_s / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg_bytes / pair_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": alg_bytes / pair_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
                 "launch_us": pair_s * 1e6, "agent_kernel_us": agent_ms * 1e3 / max(launches, 1),
                 "note": "algorithmic bytes = 16 B x N sources per receiver (SURVEY.md 8(d)); served from LDS/L2, "
                         "so the kernel is VALU-bound: see valu",
