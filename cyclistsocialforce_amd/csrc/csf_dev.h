@@ -78,7 +78,7 @@ void launch_pair(const Dev &d, hipStream_t st);
 void launch_road(const Dev &d, hipStream_t st);
 void launch_agent(const Dev &d, int phases, hipStream_t st);
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state
-// csf_bin.hip: spatial binning of the source records (Morton order) and per-batch bounding circles
+// csf_bin.hip: spatial binning of the source records (Hilbert order) and per-batch bounding circles
 size_t bin_temp_bytes(int64_t n_pad);
 int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,
                  hipStream_t st);
