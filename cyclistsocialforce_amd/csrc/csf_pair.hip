@@ -274,26 +274,37 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         }
         if (CLASSIFY && (int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
         __syncthreads();
+        // classification of the tile's (at most 16) batches for all four receivers in one pass:
+        // lanes 16u .. 16u+15 hold receiver u, lane & 15 selects the batch
+        static_assert(TILE2 / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
+        unsigned long long cand_all = ~0ull, inside_all = 0ull;
+        if (CLASSIFY) {
+            const int grp = lane >> 4;
+            const float rx = grp == 0 ? r[0].x : (grp == 1 ? r[1].x : (grp == 2 ? r[2].x : r[3].x));
+            const float ry = grp == 0 ? r[0].y : (grp == 1 ? r[1].y : (grp == 2 ? r[2].y : r[3].y));
+            const float rc = grp == 0 ? r[0].c : (grp == 1 ? r[1].c : (grp == 2 ? r[2].c : r[3].c));
+            const float rs = grp == 0 ? r[0].s : (grp == 1 ? r[1].s : (grp == 2 ? r[2].s : r[3].s));
+            const float4 bb = tbnd[lane & 15];
+            const float ex = bb.x - rx, ey = bb.y - ry;               // receiver -> centre of the batch
+            const float D2 = ex * ex + ey * ey;
+            const float invD = fast_rsq(fmaxf(D2, 1e-30f));
+            const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
+            const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
+            const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
+            const float sb = fabsf(rc * ey - rs * ex) * invD;
+            const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
+            // outside: the heading misses the circle (|beta| > alpha) and cos(|beta| - alpha) < cos(hfov/2)
+            const bool out = apart & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f);
+            const bool in = !P2R & apart & ((cb * ca - sb * sa) > k.ch + 1e-4f);  // cos(|beta| + alpha) > cos(hfov/2)
+            const bool valid = (lane & 15) < nb;
+            cand_all = __ballot(valid & !out);
+            inside_all = __ballot(valid & in);
+        }
 #pragma unroll
         for (int u = 0; u < RPW; u++) {
-            unsigned cand = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u), inside = 0u;
-            if (CLASSIFY) {
-                const float4 bb = tbnd[lane & 31];
-                const float ex = bb.x - r[u].x, ey = bb.y - r[u].y;      // receiver -> centre of the batch
-                const float D2 = ex * ex + ey * ey;
-                const float invD = fast_rsq(fmaxf(D2, 1e-30f));
-                const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
-                const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
-                const float cb = (ex * r[u].c + ey * r[u].s) * invD;      // cos / |sin| of the centre's bearing
-                const float sb = fabsf(r[u].c * ey - r[u].s * ex) * invD;
-                const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
-                // outside: the heading misses the circle (|beta| > alpha) and cos(|beta| - alpha) < cos(hfov/2)
-                const bool out = apart & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f);
-                const bool in = !P2R & apart & ((cb * ca - sb * sa) > k.ch + 1e-4f);  // cos(|beta| + alpha) > cos(hfov/2)
-                const bool valid = lane < nb;
-                cand = (unsigned)__ballot(valid & !out);
-                inside = (unsigned)__ballot(valid & in);
-            }
+            const unsigned live = nb >= 16 ? 0xFFFFu : ((1u << nb) - 1u);
+            unsigned cand = (unsigned)(cand_all >> (16 * u)) & live;
+            const unsigned inside = (unsigned)(inside_all >> (16 * u)) & live;
             // batches that are entirely inside the field of view need neither the test nor the queue: two at a
             // time they go straight into the packed field evaluation (one batch per half of the register pairs)
             {

@@ -349,3 +349,23 @@ def test_single_rank_communicator_path(amd):
     assert e.shard_range() == (0, n)
     e.step(40)
     np.testing.assert_array_equal(e.state(), ref.state())
+
+
+@pytest.mark.parametrize("hfov,rule", [(0.6, 0), (np.pi * 2 / 3, 1), (np.pi, 0), (4.0, 0), (4.0, 1), (2 * np.pi, 0)])
+def test_field_of_view_variants_vs_oracle(amd, hfov, rule):
+    """Narrow, half-plane, wide and full-circle fields of view, with and without priority-to-the-right
+    (intersection.py:733-741), on a binned population (N >= 1024: batch classification where it applies)."""
+    n, box = 1600, 90.0
+    x, y, psi, v, off, dq = synthetic_population(n, box, seed=11)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    e = make_engine(amd, "twod", s0, 1e6, off, dq, rule=rule, hfov=float(hfov))
+    e.calc_forces()
+    _, _, rx, ry = e.force_parts()
+    p = orc.default_params("twod", priority_rule=rule, hfov=float(hfov))
+    pop = orc.Population(p, s0, 1e6, off, dq)
+    pop.calc_forces_range(0, n)
+    _, _, ox, oy = pop.force_parts()
+    scale = max(np.hypot(ox, oy).max(), 1.0)
+    err = np.abs(np.c_[rx - ox, ry - oy]).max() / scale
+    print(f"hfov={hfov:.3f} rule={rule}: max |dF_rep| / max|F_rep| = {err:.2e}")
+    assert err < 5e-5
