@@ -666,8 +666,15 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         Fx = fdx;
         Fy = fdy;
         if (d.n > 1) {                                        // intersection.py:813, 825, 849-851
-            for (int c = 0; c < d.n_split; c++) {             // fixed order: reproducible
-                float2 pr = d.part[(int64_t)c * cap + a];
+            int c = 0;                                        // fixed order: reproducible
+            for (; c + 4 <= d.n_split; c += 4) {              // four independent loads in flight
+                const float2 p0 = d.part[(int64_t)c * cap + a], p1 = d.part[(int64_t)(c + 1) * cap + a];
+                const float2 p2 = d.part[(int64_t)(c + 2) * cap + a], p3 = d.part[(int64_t)(c + 3) * cap + a];
+                rx = (((rx + (double)p0.x) + (double)p1.x) + (double)p2.x) + (double)p3.x;
+                ry = (((ry + (double)p0.y) + (double)p1.y) + (double)p2.y) + (double)p3.y;
+            }
+            for (; c < d.n_split; c++) {
+                const float2 pr = d.part[(int64_t)c * cap + a];
                 rx += (double)pr.x;
                 ry += (double)pr.y;
             }

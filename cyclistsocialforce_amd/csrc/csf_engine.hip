@@ -288,12 +288,27 @@ void set_shard(csf_engine *e) {
         d.hi = std::min<int64_t>(d.n, d.lo + shard);
         d.n_pad = shard * e->world;
     }
+    if (const char *fake = getenv("CSF_FAKE_SHARD")) {  // timing aid: "r/w" computes only rank r's receiver block of w
+        int fr = 0, fw = 1;                               // (no communicator, other blocks' records go stale)
+        if (sscanf(fake, "%d/%d", &fr, &fw) == 2 && fw > 1 && fr >= 0 && fr < fw) {
+            int64_t shard = ((d.n + fw - 1) / fw + 63) / 64 * 64;
+            d.lo = std::min<int64_t>(d.n, (int64_t)fr * shard);
+            d.hi = std::min<int64_t>(d.n, d.lo + shard);
+        }
+    }
     int64_t nloc = d.hi - d.lo;
     int64_t blocks = (nloc + 15) / 16;
     int64_t units = std::max<int64_t>(1, d.n_pad / 64);
     // Many more workgroups than the chip holds at once: receivers see very different numbers of sources (field
-    // of view, position in the scene), so the hardware's dynamic workgroup dispatch is the load balancer.
-    int64_t split = blocks > 0 ? (16384 + blocks - 1) / blocks : 1;
+    // of view, position in the scene), so the hardware's dynamic workgroup dispatch is the load balancer.  Chunks
+    // of one LDS tile (1024 sources) measured best for 1-, 2-, 4- and 8-way shards of N = 16 384.
+    int64_t split;
+    if (d.n_pad >= 16384) {
+        split = blocks > 0 ? (16384 + blocks - 1) / blocks : 1;
+        split = std::min<int64_t>(split, d.n_pad / 1024);
+    } else {
+        split = blocks > 0 ? (1024 + blocks - 1) / blocks : 1;
+    }
     split = std::max<int64_t>(1, std::min<int64_t>({split, (int64_t)MAX_SPLIT, units}));
     if (const char *ov = getenv("CSF_NSPLIT")) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoi(ov), (int64_t)MAX_SPLIT, units}));
     d.n_split = (int32_t)split;
