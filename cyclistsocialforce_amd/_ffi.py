@@ -20,7 +20,7 @@ SYMBOLS = (
     "csf_create", "csf_destroy", "csf_last_error", "csf_abi_version", "csf_add_agents", "csf_remove_agents",
     "csf_set_dest_queue", "csf_set_road_vertices", "csf_set_params", "csf_set_v_desired",
     "csf_set_priority_rule", "csf_push_state", "csf_num_agents", "csf_num_states", "csf_step", "csf_sync",
-    "csf_calc_forces", "csf_apply_forces", "csf_dest_force", "csf_get_state", "csf_get_forces",
+    "csf_calc_forces", "csf_apply_forces", "csf_replay_forces", "csf_dest_force", "csf_get_state", "csf_get_forces",
     "csf_get_force_parts", "csf_status", "csf_enable_history", "csf_get_history", "csf_pair_force",
     "csf_comm_unique_id", "csf_comm_init", "csf_shard_range", "csf_profile_enable", "csf_profile_read",
 )
@@ -90,6 +90,7 @@ def load():
     L.csf_sync.argtypes = [vp]
     L.csf_calc_forces.argtypes = [vp]
     L.csf_apply_forces.argtypes = [vp, dp, dp]
+    L.csf_replay_forces.argtypes = [vp, i64, dp, dp, vp, i32, i32, dp]
     L.csf_dest_force.argtypes = [vp, dp, dp]
     L.csf_get_state.argtypes = [vp, dp, vp, vp, C.POINTER(i64)]
     L.csf_get_forces.argtypes = [vp, dp, dp]
@@ -103,10 +104,6 @@ def load():
     L.csf_shard_range.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.csf_profile_enable.argtypes = [vp, i32]
     L.csf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
-    for name in SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int:  # default: status code
-            fn.restype = C.c_int
     if L.csf_abi_version() != 1:
         raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 1")
     _lib = L

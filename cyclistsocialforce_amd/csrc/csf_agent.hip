@@ -701,7 +701,11 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         Fy = d.F[cap + a];
     }
     if (phases & PH_INTEGRATE) {
-        integrate<MODEL>(d, g, Fx, Fy);
+        const bool frozen = d.replay_len != nullptr && d.replay_tick >= d.replay_len[a];  // replay sequence ended
+        if (!frozen) {
+            if (phases & PH_FIXSPEED) g.v = sqrt(Fx * Fx + Fy * Fy);   // calibration.py:454-458
+            integrate<MODEL>(d, g, Fx, Fy);
+        }
         d.s[a] = g.x;
         d.s[cap + a] = g.y;
         d.s[2 * cap + a] = g.psi;

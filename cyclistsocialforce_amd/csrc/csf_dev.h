@@ -67,11 +67,13 @@ struct Dev {
     double *F;         // [6][cap] Fx, Fy, Fdest_x, Fdest_y, Frep_x, Frep_y
     uint32_t *status;
 
+    const int32_t *replay_len;  // csf_replay_forces: per-agent number of ticks (NULL = all), and the tick within
+    int64_t replay_tick;        // the replay
     double *hist;      // opt-in history [hist_cap][n][ns]
     int32_t hist_stride, hist_cap;
 };
 
-enum : int { PH_DEST = 1, PH_COMBINE = 2, PH_INTEGRATE = 4 };
+enum : int { PH_DEST = 1, PH_COMBINE = 2, PH_INTEGRATE = 4, PH_FIXSPEED = 8 };
 
 // launchers implemented in csf_pair.hip / csf_agent.hip
 void launch_pair(const Dev &d, hipStream_t st);

@@ -640,9 +640,11 @@ int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int
         std::vector<double> &qa = e->h_q[(size_t)agent[k]];
         if (reset) {                                             // vehicle.py:642-645
             qa.clear();
-            e->h_ptr[(size_t)agent[k]] = 0;
+            if (reset == 1) e->h_ptr[(size_t)agent[k]] = 0;      // reset == 2: rows edited in place, pointer kept
         }
         qa.insert(qa.end(), xyz_stop + 3 * offsets[k], xyz_stop + 3 * offsets[k + 1]);  // :646-647
+        const int32_t rows = (int32_t)(qa.size() / 3);
+        if (e->h_ptr[(size_t)agent[k]] >= rows) e->h_ptr[(size_t)agent[k]] = rows - 1;
     }
     return CSF_OK;
 }
@@ -825,6 +827,59 @@ int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy) {
     HIPCHK(e, hipGetLastError());
     e->d.tick++;
     e->device_ahead = true;
+    return CSF_OK;
+}
+
+int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const double *Fy, const int32_t *lengths,
+                      int32_t fix_speed, int32_t stride, double *states_out) {
+    if (!e) return CSF_E_ARG;
+    if (n_ticks < 0 || stride < 1 || (n_ticks > 0 && (!Fx || !Fy))) return fail(e, CSF_E_ARG, "csf_replay_forces: bad arguments");
+    if (e->world > 1) return fail(e, CSF_E_STATE, "csf_replay_forces is a single-device entry point");
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);
+    if (rc) return rc;
+    const int64_t n = e->d.n, cap = e->cap;
+    if (n == 0 || n_ticks == 0) return CSF_OK;
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    const int64_t chunk = std::min<int64_t>(n_ticks, 256);
+    DevBuf<double> fbuf, hbuf;
+    DevBuf<int32_t> lbuf;
+    HIPCHK(e, fbuf.alloc((size_t)chunk * 2 * (size_t)cap));
+    const int64_t n_samples = n_ticks / stride;
+    if (states_out && n_samples > 0) HIPCHK(e, hbuf.alloc((size_t)n_samples * (size_t)n * (size_t)e->d.ns));
+    if (lengths) {
+        HIPCHK(e, lbuf.alloc((size_t)n));
+        HIPCHK(e, hipMemcpy(lbuf.p, lengths, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    Dev dd = e->d;                       // a view of the engine with replay forces and a private history ring
+    dd.replay_len = lengths ? lbuf.p : nullptr;
+    dd.hist = (states_out && n_samples > 0) ? hbuf.p : nullptr;
+    dd.hist_stride = stride;
+    dd.hist_cap = (int32_t)std::max<int64_t>(n_samples, 1);
+    std::vector<double> host((size_t)chunk * 2 * (size_t)cap, 0.0);
+    for (int64_t t0 = 0; t0 < n_ticks; t0 += chunk) {
+        const int64_t cnt = std::min<int64_t>(chunk, n_ticks - t0);
+        for (int64_t t = 0; t < cnt; t++) {
+            memcpy(&host[(size_t)(t * 2) * cap], Fx + (t0 + t) * n, (size_t)n * sizeof(double));
+            memcpy(&host[(size_t)(t * 2 + 1) * cap], Fy + (t0 + t) * n, (size_t)n * sizeof(double));
+        }
+        HIPCHK(e, hipMemcpy(fbuf.p, host.data(), (size_t)cnt * 2 * cap * sizeof(double), hipMemcpyHostToDevice));
+        for (int64_t t = 0; t < cnt; t++) {
+            dd.F = fbuf.p + (size_t)(t * 2) * cap;   // PH_INTEGRATE alone reads only Fx = F[0][.], Fy = F[1][.]
+            dd.replay_tick = t0 + t;
+            dd.tick = t0 + t;                        // history sample index counts from the start of the replay
+            launch_agent(dd, PH_INTEGRATE | (fix_speed ? PH_FIXSPEED : 0), e->main);
+        }
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->main));
+    }
+    e->d.tick += n_ticks;
+    e->device_ahead = true;
+    if (dd.hist)
+        HIPCHK(e, hipMemcpy(states_out, hbuf.p, (size_t)n_samples * n * e->d.ns * sizeof(double), hipMemcpyDeviceToHost));
+    fbuf.release();
+    hbuf.release();
+    lbuf.release();
     return CSF_OK;
 }
 

@@ -80,7 +80,7 @@ class Engine:
         xyz = _f64(xyz_stop).reshape(-1, 3)
         if offsets.shape != (agents.size + 1,) or offsets[-1] != xyz.shape[0]:
             raise ValueError("offsets must be [n+1] and end at the number of rows")
-        self._ck(self._lib.csf_set_dest_queue(self._h, agents.size, _ptr(agents), _ptr(offsets), _ptr(xyz), int(reset)))
+        self._ck(self._lib.csf_set_dest_queue(self._h, agents.size, _ptr(agents), _ptr(offsets), _ptr(xyz), int(reset)))  # reset: 0 append, 1 replace, 2 replace + keep pointer
 
     def set_road(self, offsets, verts, F0, sigma):
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -125,6 +125,21 @@ class Engine:
         if Fx.size != self.n or Fy.size != self.n:
             raise ValueError("Fx, Fy must have one entry per agent")
         self._ck(self._lib.csf_apply_forces(self._h, _ptr(Fx), _ptr(Fy)))
+
+    def replay_forces(self, Fx, Fy, lengths=None, fix_speed=False, stride=1, return_states=True):
+        """Calibration replay (calibration.py:438-460): Fx, Fy are [T, n]; returns states [T // stride, n, n_states]."""
+        Fx = _f64(Fx)
+        Fy = _f64(Fy)
+        if Fx.ndim != 2 or Fx.shape != Fy.shape or Fx.shape[1] != self.n:
+            raise ValueError("Fx, Fy must be [n_ticks, n_agents]")
+        T = Fx.shape[0]
+        out = np.zeros((T // stride, self.n, self.ns)) if return_states else None
+        ln = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.int32)
+        if ln is not None and ln.shape != (self.n,):
+            raise ValueError("lengths must have one entry per agent")
+        self._ck(self._lib.csf_replay_forces(self._h, T, _ptr(Fx), _ptr(Fy), None if ln is None else _ptr(ln),
+                                             int(bool(fix_speed)), int(stride), None if out is None else _ptr(out)))
+        return out
 
     def dest_force(self):
         fx = np.zeros(self.n)

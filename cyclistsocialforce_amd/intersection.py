@@ -290,19 +290,23 @@ class SocialForceIntersection:
         e = self._engine_ready()
         n = len(self.vehicles)
         # destination queues: appended rows go up with reset=0, replaced queues with reset=1
-        for mode in (1, 0):
+        for mode in (1, 2, 0):
             agents, rows, off = [], [], [0]
             for v in self.vehicles:
                 q = v.destqueue
-                if mode == 1 and v._queue_synced < 0:
+                if mode == 1 and v._queue_synced == -1:                  # new or reset queue: pointer rewinds
                     agents.append(v._index); rows.append(q); off.append(off[-1] + q.shape[0])
                     v._queue_synced = q.shape[0]
-                elif mode == 0 and 0 <= v._queue_synced < q.shape[0]:
+                elif mode == 2 and v._queue_synced == -2:                # rows edited in place: pointer kept
+                    agents.append(v._index); rows.append(q); off.append(off[-1] + q.shape[0])
+                    v._queue_synced = q.shape[0]
+                elif mode == 0 and 0 <= v._queue_synced < q.shape[0]:    # appended rows
                     agents.append(v._index); rows.append(q[v._queue_synced:]); off.append(off[-1] + q.shape[0] - v._queue_synced)
                     v._queue_synced = q.shape[0]
-                v._queue_dirty = False
             if agents:
-                e.set_dest_queue(agents, off, np.vstack(rows), reset=bool(mode))
+                e.set_dest_queue(agents, off, np.vstack(rows), reset=mode)
+        for v in self.vehicles:
+            v._queue_dirty = False
         # vehicle.s edited in place (calibration.py:455-460)
         changed = np.where(np.any(self._S[:n] != self._shadow[:n], axis=1))[0]
         if changed.size:

@@ -71,6 +71,7 @@ class Vehicle:
         self._owner = None        # SocialForceIntersection that holds this vehicle, or None
         self._index = -1
         self._solo = None         # private one-agent engine
+        self._solo_synced = False
         self._queue_dirty = True
         self._s_shadow = self.s.copy()
 
@@ -90,8 +91,11 @@ class Vehicle:
             self._vd_shadow = float(self.params.v_desired_default)
         e = self._solo
         if self._queue_dirty:
-            e.set_dest_queue([0], [0, self.destqueue.shape[0]], self.destqueue, reset=True)
+            keep = getattr(self, "_queue_keep_ptr", False) and self._solo_synced
+            e.set_dest_queue([0], [0, self.destqueue.shape[0]], self.destqueue, reset=2 if keep else 1)
             self._queue_dirty = False
+            self._queue_keep_ptr = False
+            self._solo_synced = True
         if not np.array_equal(self.s, self._s_shadow):
             e.push_state([0], self.s[None, :])
             self._s_shadow = self.s.copy()
@@ -174,6 +178,31 @@ class Vehicle:
         self._queue_reset = bool(reset)
         if self._owner is not None:
             self._owner._mark_queue_dirty(self)
+
+    def stop(self, stoptype=0, stopdest=None):
+        """vehicle.py:459-503, stoptype 0: stop at the next destination in the queue (sets its stop flag; the
+        reference does this through `self.dest`, a view of the queue row).  Types 1 and 2 reference attributes
+        that no parameter class defines (`params.AMAX`, vehicle.py:486) and are not mirrored."""
+        if stoptype != 0:
+            raise NotImplementedError("only stoptype 0 (stop at the next destination) is mirrored")
+        self.destqueue[self.destpointer, 2] = 1.0
+        self.dest = self.destqueue[self.destpointer, :]
+        self._queue_edit()
+
+    def go(self, gotype=0):
+        """vehicle.py:505-535, gotype 0: keep the current destination but do not stop there."""
+        if gotype != 0:
+            raise NotImplementedError("only gotype 0 (clear the stop flag of the current destination) is mirrored")
+        self.destqueue[self.destpointer, 2] = 0.0
+        self.dest = self.destqueue[self.destpointer, :]
+        self._queue_edit()
+
+    def _queue_edit(self):
+        """Rows were edited in place: the engine's copy is replaced, the destination pointer kept."""
+        self._queue_dirty = True
+        self._queue_keep_ptr = True
+        if self._owner is not None:
+            self._queue_synced = -2
 
     def setSplineDestinations(self, x, y, npoints, stop=False, reset=False):
         """vehicle.py:649-693 (host-side convenience; uses scipy like the reference)."""

@@ -90,7 +90,9 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
 int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
 
 /* Vehicle.setDestinations (vehicle.py:606-647) for n agents: CSR (offsets[n+1], xyz_stop[sum,3]);
- * reset = 0 appends to the agent's queue, reset = 1 replaces it and rewinds the pointer. */
+ * reset = 0 appends to the agent's queue, reset = 1 replaces it and rewinds the pointer, reset = 2 replaces
+ * it and keeps the pointer (rows edited in place: Vehicle.stop / Vehicle.go set the stop flag of the current
+ * destination, vehicle.py:459-535). */
 int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int64_t *offsets,
                        const double *xyz_stop, int32_t reset);
 
@@ -123,6 +125,13 @@ int csf_calc_forces(csf_engine *e);
 /* vehicle.step(Fx, Fy) for every agent with caller-supplied forces (calibration.py:438-460 replay,
  * intersection.py:891-894).  Fx, Fy are [n]. */
 int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy);
+/* Calibration replay (calibration.py:438-460): n_ticks x vehicle.step(Fx[t][a], Fy[t][a]) for every agent with
+ * recorded forces, in one call.  Fx, Fy are [n_ticks, n] row-major.  lengths is [n] or NULL: agent a is stepped
+ * for its first lengths[a] ticks only (sequences of different length).  fix_speed != 0 sets v = |F| before every
+ * step (calibration.py:454-458).  states_out is NULL or [n_ticks / stride, n, n_states]: the state after ticks
+ * stride, 2*stride, ...  (vehicle.traj).  Single-device entry point. */
+int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const double *Fy, const int32_t *lengths,
+                      int32_t fix_speed, int32_t stride, double *states_out);
 /* calcDestinationForce() of every agent (vehicle.py:1189-1194, 1416-1558); mutates queue pointer and
  * navigation state exactly like the reference does. */
 int csf_dest_force(csf_engine *e, double *Fx, double *Fy);
