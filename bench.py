@@ -127,13 +127,13 @@ def main():
 
     eng.step(args.warmup)
     fence()
-    eng.profile(True)
+    eng.profile(8)   # HIP events around the pair kernel on every 8th tick of the timed region
     t0 = time.perf_counter()
     eng.step(args.steps)
     fence()
     dt = time.perf_counter() - t0
     pair_ms, agent_ms, launches = eng.profile_read()
-    eng.profile(False)
+    eng.profile(0)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -5,8 +5,10 @@
 // circle alone (csf_pair.hip): entirely outside -> skipped, entirely inside -> queued without per-lane tests.
 // This file provides the order and the circles:
 //   * every REBIN ticks: Hilbert index of each record's cell (0.5 m) -> stable radix sort (hipCUB) -> perm[];
-//   * every tick: bounding circle of each batch of 64 records in perm order (positions move every tick, the
-//     order only drifts, so correctness never depends on how fresh perm is).
+//   * bounding circle of each batch of 64 records in perm order: right after a re-sort by bounds_kernel, otherwise
+//     by the pair kernel itself, which emits the circles of the NEXT tick from this tick's records grown by the
+//     largest possible displacement of one tick (positions move every tick, the order only drifts, so
+//     correctness never depends on how fresh perm is).
 // Nothing here changes results: the per-pair test of intersection.py:690-745 stays exact; the sort is stable
 // and deterministic, so runs are bit-reproducible.
 #include <hipcub/hipcub.hpp>
@@ -58,25 +60,10 @@ __global__ void identity_perm_kernel(const Dev d) {
     if (a < d.n_pad) d.perm[a] = (int32_t)a;
 }
 
-// one wave per batch of 64 records in perm order: centre and radius of the bounding box's circumcircle
 __global__ __launch_bounds__(256) void bounds_kernel(const Dev d) {
-    const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b * 64 >= d.n_pad) return;
-    const float4 q = d.rec[d.perm[b * 64 + lane]];
-    float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        x0 = fminf(x0, __shfl_xor(x0, o, 64));
-        x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
-        y0 = fminf(y0, __shfl_xor(y0, o, 64));
-        y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
-    }
-    if (lane == 0) {
-        const float w = x1 - x0, h = y1 - y0;
-        const float rad = 0.5f * sqrtf(w * w + h * h) * 1.0001f + 1e-4f;  // rounded up: the circle must contain
-        d.bnd[b] = make_float4(0.5f * (x0 + x1), 0.5f * (y0 + y1), rad, 0.0f);
-    }
+    batch_circle(d, b, threadIdx.x & 63, 0.0f, d.bnd);
 }
 
 size_t bin_temp_bytes(int64_t n_pad) {

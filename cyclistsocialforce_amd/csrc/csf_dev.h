@@ -59,6 +59,8 @@ struct Dev {
     float2 *rec2;      // [n_pad] Bicycle field only: (e, 1/sqrt(1-e^2))
     int32_t *perm;     // [n_pad] spatially binned order of the source records (position -> record index)
     float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
+    float4 *bnd_next;  // written by the pair kernel for the next tick (from this tick's records + bnd_margin)
+    float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
     float2 *part;      // [MAX_SPLIT][cap] partial repulsive sums of the pair kernel
     float2 *froad;     // [cap]
     float4 *rv;        // [nv_pad] road vertices (x-ox, y-oy, -F0, -(sigma+1)/2)
@@ -86,7 +88,28 @@ int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals
                  hipStream_t st);
 void launch_identity_perm(const Dev &d, hipStream_t st);
 void launch_bounds(const Dev &d, hipStream_t st);
+
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
                      int apply_fov, float2 *out, hipStream_t st);
+
+// bounding circle of batch b (64 records in perm order), computed by one wave: centre and radius of the bounding
+// box's circumcircle, grown by `margin`
+__device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, float margin, float4 *out) {
+    const float4 q = d.rec[d.perm[b * 64 + lane]];
+    float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
+        y0 = fminf(y0, __shfl_xor(y0, o, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    }
+    if (lane == 0) {
+        const float w = x1 - x0, h = y1 - y0;
+        const float rad = 0.5f * sqrtf(w * w + h * h) * 1.0001f + 1e-4f + margin;  // rounded up: must contain
+        out[b] = make_float4(0.5f * (x0 + x1), 0.5f * (y0 + y1), rad, 0.0f);
+    }
+}
+
 
 }  // namespace csf

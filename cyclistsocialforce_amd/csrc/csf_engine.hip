@@ -106,7 +106,8 @@ struct csf_engine {
     DevBuf<int32_t> ptr, ti, dgood;
     DevBuf<uint8_t> znav, zrid;
     DevBuf<uint32_t> status;
-    DevBuf<float4> rec, rv, kat4, bnd;
+    DevBuf<float4> rec, rv, kat4, bnd, bnd2;
+    bool bounds_fresh = false;   // d.bnd describes the current records (else: recompute before the pair kernel)
     DevBuf<int32_t> perm, sort_vals;
     DevBuf<uint32_t> sort_keys, sort_keys_out;
     DevBuf<uint8_t> sort_tmp;
@@ -119,7 +120,7 @@ struct csf_engine {
     bool gather_pending = false;
 
     // profiling
-    bool profile = false;
+    int profile = 0;             // 0 off, k > 0: HIP events around the pair kernel on every k-th tick
     std::vector<hipEvent_t> ev;  // triples: pair begin, pair end, agent end
 };
 
@@ -197,6 +198,10 @@ void derive_consts(csf_engine *e) {
     }
     const char *variant = getenv("CSF_PAIR_VARIANT");
     e->d.pair_variant = variant ? atoi(variant) : 0;
+    {   // no rider model moves faster than its speed clamp (vehicle.py:1258, 1876, 1905; dynamics.py:1025)
+        double vmax = std::max({std::fabs(p.v_max_riding[0]), std::fabs(p.v_max_riding[1]), std::fabs(p.v_max_walk)});
+        e->d.bnd_margin = (float)(p.t_s * vmax * 1.01 + 1e-4);
+    }
     e->d.back = (int32_t)(1.0 / p.t_s);
     int hl = 4;
     while (hl < e->d.back + 2) hl *= 2;
@@ -230,6 +235,7 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->rec2.alloc(nrec));
     HIPCHK(e, e->perm.alloc(nrec));
     HIPCHK(e, e->bnd.alloc(nrec / 64));
+    HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->sort_vals.alloc(nrec));
     HIPCHK(e, e->sort_keys.alloc(nrec));
     HIPCHK(e, e->sort_keys_out.alloc(nrec));
@@ -272,6 +278,7 @@ int alloc_all(csf_engine *e) {
     d.rec2 = e->rec2.p;
     d.perm = e->perm.p;
     d.bnd = e->bnd.p;
+    d.bnd_next = e->bnd2.p;
     return CSF_OK;
 }
 
@@ -329,7 +336,30 @@ int rebin(csf_engine *e) {
         launch_identity_perm(d, e->main);
     }
     e->ticks_since_rebin = 0;
+    e->bounds_fresh = false;
     return CSF_OK;
+}
+
+// bounding circles for the pair launch that follows; afterwards the circles emitted by that launch become current
+int bounds_before_pair(csf_engine *e) {
+    Dev &d = e->d;
+    if (e->ticks_since_rebin >= REBIN_TICKS) {
+        int rc = rebin(e);
+        if (rc) return rc;
+    }
+    if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
+    e->ticks_since_rebin++;
+    return CSF_OK;
+}
+
+void bounds_after_pair(csf_engine *e, bool records_will_move_one_tick) {
+    Dev &d = e->d;
+    if (!d.classify || d.n <= 1) {
+        e->bounds_fresh = false;
+        return;
+    }
+    std::swap(d.bnd, d.bnd_next);                   // the launch wrote the next tick's circles
+    e->bounds_fresh = records_will_move_one_tick;   // valid only if exactly one integrate follows
 }
 
 // device -> host mirror (needed before a structural change once ticks have run)
@@ -530,7 +560,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qoff.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->perm.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release();
     e->sort_vals.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);
@@ -734,7 +764,7 @@ static int enqueue_tick(csf_engine *e) {
     Dev &d = e->d;
     const bool sharded = e->world > 1 || e->nccl != nullptr;  // a 1-rank communicator rehearses the sharded path
     hipEvent_t *pe = nullptr;
-    if (e->profile) {
+    if (e->profile > 0 && e->d.tick % e->profile == 0) {
         size_t base = e->ev.size();
         e->ev.resize(base + 3);
         for (int k = 0; k < 3; k++) HIPCHK(e, hipEventCreate(&e->ev[base + k]));
@@ -745,16 +775,13 @@ static int enqueue_tick(csf_engine *e) {
         int rc = wait_gather(e);
         if (rc) return rc;
     }
-    if (d.classify || e->ticks_since_rebin >= REBIN_TICKS) {
-        if (e->ticks_since_rebin >= REBIN_TICKS) {
-            int rc = rebin(e);
-            if (rc) return rc;
-        }
-        if (d.classify) launch_bounds(d, e->main);
+    {
+        int rc = bounds_before_pair(e);
+        if (rc) return rc;
     }
-    e->ticks_since_rebin++;
     if (pe) HIPCHK(e, hipEventRecord(pe[0], e->main));
     if (d.n > 1) launch_pair(d, e->main);
+    bounds_after_pair(e, true);
     if (pe) HIPCHK(e, hipEventRecord(pe[1], e->main));
     launch_road(d, e->main);
     launch_agent(d, sharded ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main);
@@ -803,8 +830,10 @@ int csf_calc_forces(csf_engine *e) {
     if (e->d.n == 0) return CSF_OK;
     rc = wait_gather(e);
     if (rc) return rc;
-    if (e->d.classify) launch_bounds(e->d, e->main);
+    rc = bounds_before_pair(e);
+    if (rc) return rc;
     if (e->d.n > 1) launch_pair(e->d, e->main);
+    bounds_after_pair(e, false);                     // the records do not move: recompute next time
     launch_road(e->d, e->main);
     launch_agent(e->d, PH_DEST | PH_COMBINE, e->main);
     HIPCHK(e, hipGetLastError());
@@ -825,6 +854,7 @@ int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy) {
     HIPCHK(e, hipMemcpy(e->F.p + e->cap, Fy, (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
     launch_agent(e->d, PH_INTEGRATE, e->main);
     HIPCHK(e, hipGetLastError());
+    e->bounds_fresh = false;
     e->d.tick++;
     e->device_ahead = true;
     return CSF_OK;
@@ -875,6 +905,7 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
     }
     e->d.tick += n_ticks;
     e->device_ahead = true;
+    e->bounds_fresh = false;
     if (dd.hist)
         HIPCHK(e, hipMemcpy(states_out, hbuf.p, (size_t)n_samples * n * e->d.ns * sizeof(double), hipMemcpyDeviceToHost));
     fbuf.release();
@@ -1076,7 +1107,7 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi) {
 
 int csf_profile_enable(csf_engine *e, int32_t on) {
     if (!e) return CSF_E_ARG;
-    e->profile = on != 0;
+    e->profile = on > 0 ? on : 0;
     return CSF_OK;
 }
 

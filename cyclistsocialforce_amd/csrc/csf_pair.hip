@@ -237,6 +237,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
 
+    // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
+    // batch): a separate launch per tick would cost more in launch gaps than in work
+    if (CLASSIFY && d.bnd_next != nullptr && blockIdx.y == 0) {
+        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_pad; b += (int64_t)gridDim.x * WPB)
+            batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
+    }
+
     Recv r[RPW];
     load_receivers(d, j0, r);
     float ax[RPW], ay[RPW];

@@ -221,8 +221,9 @@ class Engine:
         return lo.value, hi.value
 
     # -- measurement ------------------------------------------------------------------------
-    def profile(self, on=True):
-        self._ck(self._lib.csf_profile_enable(self._h, int(bool(on))))
+    def profile(self, every=1):
+        """HIP events around the pair kernel on every `every`-th tick (0 / False: off)."""
+        self._ck(self._lib.csf_profile_enable(self._h, int(every)))
 
     def profile_read(self):
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)

@@ -177,9 +177,10 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 
-/* HIP-event time of the pair kernel, measured on the stream it is launched on: enable, run csf_step,
- * then read the accumulated milliseconds and launch count (reset on read).  Costs two event records
- * per tick while enabled. */
+/* HIP-event time of the pair kernel, measured on the stream it is launched on: enable with on = k > 0 to
+ * bracket the kernel on every k-th tick (an event record costs a few microseconds of launch gap, so the timed
+ * region of bench.py samples every 8th tick), run csf_step, then read the accumulated milliseconds and the
+ * number of sampled launches (reset on read). */
 int csf_profile_enable(csf_engine *e, int32_t on);
 int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *launches);
 
