@@ -614,7 +614,9 @@ __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
 
 // fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677
 __device__ __forceinline__ void write_record(const Dev &d, int64_t a, double x, double y, double psi, double v) {
-    d.rec[a] = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)cos(psi), (float)sin(psi));
+    const float4 q = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)cos(psi), (float)sin(psi));
+    d.rec[a] = q;
+    if (d.recs_valid) d.recs[d.pos[a]] = q;                   // the copy in binned order (csf_bin.hip)
     if (d.p.model == CSF_BICYCLE) {                           // vehicle.py:1062-1064 (v <= 0: e := 0)
         double e = 0.0;
         if (v > 0.0) e = fmin(pow(v / d.p.v_max_riding[1], 0.1), 0.7);

@@ -60,6 +60,14 @@ __global__ void identity_perm_kernel(const Dev d) {
     if (a < d.n_pad) d.perm[a] = (int32_t)a;
 }
 
+__global__ void sorted_copy_kernel(const Dev d) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.n_pad) return;
+    const int32_t a = d.perm[p];
+    d.pos[a] = (int32_t)p;
+    d.recs[p] = d.rec[a];
+}
+
 __global__ __launch_bounds__(256) void bounds_kernel(const Dev d) {
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b * 64 >= d.n_pad) return;
@@ -83,6 +91,11 @@ int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals
 void launch_identity_perm(const Dev &d, hipStream_t st) {
     if (d.n_pad <= 0) return;
     hipLaunchKernelGGL(identity_perm_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+}
+
+void launch_sorted_copy(const Dev &d, hipStream_t st) {
+    if (d.n_pad <= 0) return;
+    hipLaunchKernelGGL(sorted_copy_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
 }
 
 void launch_bounds(const Dev &d, hipStream_t st) {

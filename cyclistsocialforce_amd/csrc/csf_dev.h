@@ -58,6 +58,10 @@ struct Dev {
     float4 *rec;       // [n_pad] (x-ox, y-oy, cos psi, sin psi) fp32 source records
     float2 *rec2;      // [n_pad] Bicycle field only: (e, 1/sqrt(1-e^2))
     int32_t *perm;     // [n_pad] spatially binned order of the source records (position -> record index)
+    int32_t *pos;      // [n_pad] inverse of perm (record index -> position)
+    float4 *recs;      // [n_pad] the records in binned order (single device: written by the agent kernel beside
+                       // rec, so that the pair kernel's tile fill is one coalesced load instead of perm -> rec)
+    int32_t recs_valid;
     float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
     float4 *bnd_next;  // written by the pair kernel for the next tick (from this tick's records + bnd_margin)
     float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
@@ -87,6 +91,7 @@ size_t bin_temp_bytes(int64_t n_pad);
 int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,
                  hipStream_t st);
 void launch_identity_perm(const Dev &d, hipStream_t st);
+void launch_sorted_copy(const Dev &d, hipStream_t st);  // pos[] and recs[] from perm[] and rec[]
 void launch_bounds(const Dev &d, hipStream_t st);
 
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,

@@ -106,7 +106,8 @@ struct csf_engine {
     DevBuf<int32_t> ptr, ti, dgood;
     DevBuf<uint8_t> znav, zrid;
     DevBuf<uint32_t> status;
-    DevBuf<float4> rec, rv, kat4, bnd, bnd2;
+    DevBuf<float4> rec, recs, rv, kat4, bnd, bnd2;
+    DevBuf<int32_t> pos;
     bool bounds_fresh = false;   // d.bnd describes the current records (else: recompute before the pair kernel)
     DevBuf<int32_t> perm, sort_vals;
     DevBuf<uint32_t> sort_keys, sort_keys_out;
@@ -234,6 +235,8 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->rec.alloc(nrec));
     HIPCHK(e, e->rec2.alloc(nrec));
     HIPCHK(e, e->perm.alloc(nrec));
+    HIPCHK(e, e->pos.alloc(nrec));
+    HIPCHK(e, e->recs.alloc(nrec));
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->sort_vals.alloc(nrec));
@@ -277,6 +280,8 @@ int alloc_all(csf_engine *e) {
     d.rec = e->rec.p;
     d.rec2 = e->rec2.p;
     d.perm = e->perm.p;
+    d.pos = e->pos.p;
+    d.recs = e->recs.p;
     d.bnd = e->bnd.p;
     d.bnd_next = e->bnd2.p;
     return CSF_OK;
@@ -335,6 +340,9 @@ int rebin(csf_engine *e) {
     } else {
         launch_identity_perm(d, e->main);
     }
+    // the binned copy of the records is maintained by the agent kernel only where every record is local
+    d.recs_valid = binned && e->world <= 1 && e->nccl == nullptr;
+    if (d.recs_valid) launch_sorted_copy(d, e->main);
     e->ticks_since_rebin = 0;
     e->bounds_fresh = false;
     return CSF_OK;
@@ -560,7 +568,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qoff.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
     e->sort_vals.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);

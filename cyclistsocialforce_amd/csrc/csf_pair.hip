@@ -54,7 +54,7 @@ __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sq
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ v2f rsq2(v2f x) { return v2f{fast_rsq(x.x), fast_rsq(x.y)}; }
-__device__ __forceinline__ v2f fabs2(v2f x) { return v2f{fabsf(x.x), fabsf(x.y)}; }
+__device__ __forceinline__ v2f fabs2(v2f x) { return __builtin_elementwise_max(x, -x); }  // one v_pk_max_f32
 
 // intersection.py:690-745 for receiver r and source (dx, dy) = receiver - source.
 // The receiver ignores the source when the bearing of the source, relative to the receiver's heading, is
@@ -95,8 +95,6 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
     float dsig = -0.5f * sgb * h2s;                   // :1625
     float ec = e * cphi;
     float q2 = 1.0f - ec * ec;
-    float qq = fast_sqrt(q2);
-    float isg = fast_rcp(sigma);
     // :1631-1642 with the positive factor P / (sigma^2 q) taken out of both polar components and the
     // rotation by phi1 written with rho*cos(phi1) = dx, rho*sin(phi1) = dy
     float grho = q2 * sigma;
@@ -104,7 +102,8 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
     gx = grho * dx - gphi * dy;
     gy = grho * dy + gphi * dx;
     float ig = fast_rsq(gx * gx + gy * gy);
-    float P = fast_exp2(k.lf0 - k.kexp * (rho * qq * isg));  // f_0 exp(-rho q / sigma)      :1628
+    float qos = q2 * fast_rsq(grho * sigma);          // q / sigma = q^2 / sqrt(q^2 sigma^2): one rsq, no sqrt + rcp
+    float P = fast_exp2(k.lf0 - k.kexp * (rho * qos));  // f_0 exp(-rho q / sigma)            :1628
     F = P * ig;                                       // :1644-1646: |F| = P
 }
 
@@ -116,6 +115,11 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
                                               const v2f qc, const v2f qs, bool valid0, bool valid1, float &ax,
                                               float &ay) {
     v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
+#ifdef CSF_SKIP_FIELD   // timing-only build (tools/): everything but the field arithmetic
+    ax += dx.x + dx.y + qc.x + qs.y;
+    ay += dy.x + dy.y + qc.y + qs.x;
+    return;
+#endif
     v2f r2 = dx * dx + dy * dy;
     if (!FULL) r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};
     v2f inv = rsq2(r2), rho = r2 * inv;
@@ -127,7 +131,8 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
     v2f rs = rsq2(a);
     v2f big = a * rs, hrs = 0.5f * rs;
     v2f al = sphi * hrs;
-    v2f sg{__builtin_amdgcn_fmed3f(sphi.x * 1e38f, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(sphi.y * 1e38f, -1.0f, 1.0f)};
+    const v2f blown = sphi * 1e38f;                   // one packed multiply, then clamp to -1, 0, +1
+    v2f sg{__builtin_amdgcn_fmed3f(blown.x, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(blown.y, -1.0f, 1.0f)};
     v2f small = al * sg, bs = big * sg;                // |sphi| hrs and sign(phi) big          :1624-1625
     const bool p0 = cphi.x >= 0.0f, p1 = cphi.y >= 0.0f;
     v2f h1{p0 ? small.x : big.x, p1 ? small.y : big.y};
@@ -136,13 +141,12 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
     v2f hd = 0.5f * sgb * h2s;                        // = -dsig
     v2f ec = e * cphi;
     v2f q2 = 1.0f - ec * ec;
-    v2f qq{fast_sqrt(q2.x), fast_sqrt(q2.y)};
-    v2f isg{fast_rcp(sigma.x), fast_rcp(sigma.y)};
     v2f grho = q2 * sigma;                            // :1631-1642, common factor P/(sigma^2 q) removed
     v2f gphi = (e * ec) * (sphi * sigma) + q2 * hd;
     v2f gx = grho * dx - gphi * dy, gy = grho * dy + gphi * dx;
     v2f ig = rsq2(gx * gx + gy * gy);
-    v2f ex = k.lf0 - k.kexp * (rho * qq * isg);       // :1628
+    v2f qos = q2 * rsq2(grho * sigma);                // q / sigma = q^2 / sqrt(q^2 sigma^2): one rsq, no sqrt + rcp
+    v2f ex = k.lf0 - k.kexp * (rho * qos);            // :1628
     v2f F = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * ig;   // :1644-1646
     if (!FULL) F = v2f{valid0 ? F.x : 0.0f, valid1 ? F.y : 0.0f};
     const v2f cx = F * gx, cy = F * gy;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         const int nb = cnt >> 6;
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
-            const float4 q = d.rec[d.perm[base + t]];
+            const float4 q = d.recs_valid ? d.recs[base + t] : d.rec[d.perm[base + t]];
             tx[t] = q.x;
             ty[t] = q.y;
             tc[t] = q.z;
