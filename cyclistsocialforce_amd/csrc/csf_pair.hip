@@ -235,6 +235,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
     __shared__ unsigned short queue[WPB][RPW][QCAP];
+    __shared__ float4 rrec[WPB * RPW];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
@@ -248,8 +249,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
 
-    Recv r[RPW];
-    load_receivers(d, j0, r);
+    Recv r[RPW];                // filled below, together with the first tile
     float ax[RPW], ay[RPW];
     int qhead[RPW], qlen[RPW];  // wave-uniform ring state of the four queues
 #pragma unroll
@@ -272,10 +272,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] - n);
     };
 
-    for (int64_t base = ibeg; base < iend; base += TILE2) {
-        const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
-        const int nb = cnt >> 6;
-        __syncthreads();
+    auto fill_tile = [&](int64_t base, int cnt) {
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
             const float4 q = d.recs_valid ? d.recs[base + t] : d.rec[d.perm[base + t]];
             tx[t] = q.x;
@@ -283,8 +280,35 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             tc[t] = q.z;
             ts[t] = q.w;
         }
-        if (CLASSIFY && (int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
-        __syncthreads();
+        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
+    };
+    // first tile and the workgroup's 16 receiver records travel together: one global round trip, not two
+    if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
+    fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
+    if (threadIdx.x < WPB * RPW) {
+        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
+        rrec[threadIdx.x] = d.rec[j < d.hi ? j : d.hi - 1];  // clamp: results of the duplicates are not stored
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RPW; u++) {
+        const float4 q = rrec[wave * RPW + u];
+        r[u].x = q.x, r[u].y = q.y, r[u].c = q.z, r[u].s = q.w;
+        asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].c), "+v"(r[u].s));  // stay in VGPRs
+    }
+
+    for (int64_t base = ibeg; base < iend; base += TILE2) {
+        const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
+        const int nb = cnt >> 6;
+#ifdef CSF_SKIP_LOOP    // timing-only build (tools/): start-up, tile fill and reduction alone
+        ax[0] += tx[lane] + r[0].x;
+        continue;
+#endif
+        if (base != ibeg) {
+            __syncthreads();
+            fill_tile(base, cnt);
+            __syncthreads();
+        }
         // classification of the tile's (at most 16) batches for all four receivers in one pass:
         // lanes 16u .. 16u+15 hold receiver u, lane & 15 selects the batch
         static_assert(TILE2 / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
