@@ -157,7 +157,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{n} {args.model} agents, uniform random in {box:g} m x {box:g} m, "
-                                   f"all-pairs exact (no cutoff), t_s=0.01", "agents": n, "model": args.model,
+                                   f"all-pairs exact (no cutoff), t_s=0.01", "agents": n, "rider_model": args.model,
                        "parallelism": f"index-sharded x{world}, RCCL all-gather of fp32 records per tick"
                        if world > 1 else "single GPU"},
             "healthy": healthy,
