@@ -234,7 +234,7 @@ template <bool P2R, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
-    __shared__ unsigned short queue[WPB][RPW][QCAP];
+    __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave: drained after each receiver
     __shared__ float4 rrec[WPB * RPW];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -249,11 +249,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
 
-    Recv r[RPW];                // filled below, together with the first tile
-    float ax[RPW], ay[RPW];
-    int qhead[RPW], qlen[RPW];  // wave-uniform ring state of the four queues
+    float ax[RPW], ay[RPW];     // the receivers themselves stay in LDS (rrec); one at a time is held in registers
+    int qhead = 0, qlen = 0;    // wave-uniform ring state of the queue
+    Recv ru{0.f, 0.f, 1.f, 0.f};  // the receiver being worked on (wave-uniform, kept in VGPRs)
 #pragma unroll
-    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f, qhead[u] = qlen[u] = 0;
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f;
     PairConsts k = d.pc;
     asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0),
                  "+v"(k.kexp), "+v"(k.chs));
@@ -261,15 +261,15 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // pop CHUNK (or, when draining, whatever is left) queued sources of receiver u; the field takes two per lane
     auto pop = [&](int u, auto full) {
         constexpr bool FULL = decltype(full)::value;
-        const int n = FULL ? CHUNK : (qlen[u] < CHUNK ? qlen[u] : CHUNK);
-        int i0 = queue[wave][u][(qhead[u] + lane) & (QCAP - 1)];
-        int i1 = queue[wave][u][(qhead[u] + WAVE + lane) & (QCAP - 1)];
+        const int n = FULL ? CHUNK : (qlen < CHUNK ? qlen : CHUNK);
+        int i0 = queue[wave][(qhead + lane) & (QCAP - 1)];
+        int i1 = queue[wave][(qhead + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
         if (!FULL) i0 = v0 ? i0 : 0, i1 = v1 ? i1 : 0;
-        field_twod_x2<FULL>(k, r[u], v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
+        field_twod_x2<FULL>(k, ru, v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
                             v2f{ts[i0], ts[i1]}, v0, v1, ax[u], ay[u]);
-        qhead[u] = __builtin_amdgcn_readfirstlane((qhead[u] + n) & (QCAP - 1));
-        qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] - n);
+        qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
+        qlen = __builtin_amdgcn_readfirstlane(qlen - n);
     };
 
     auto fill_tile = [&](int64_t base, int cnt) {
@@ -290,18 +290,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         rrec[threadIdx.x] = d.rec[j < d.hi ? j : d.hi - 1];  // clamp: results of the duplicates are not stored
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < RPW; u++) {
-        const float4 q = rrec[wave * RPW + u];
-        r[u].x = q.x, r[u].y = q.y, r[u].c = q.z, r[u].s = q.w;
-        asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].c), "+v"(r[u].s));  // stay in VGPRs
-    }
-
     for (int64_t base = ibeg; base < iend; base += TILE2) {
         const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
         const int nb = cnt >> 6;
 #ifdef CSF_SKIP_LOOP    // timing-only build (tools/): start-up, tile fill and reduction alone
-        ax[0] += tx[lane] + r[0].x;
+        ax[0] += tx[lane] + rrec[wave * RPW].x;
         continue;
 #endif
         if (base != ibeg) {
@@ -315,10 +308,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         unsigned long long cand_all = ~0ull, inside_all = 0ull;
         if (CLASSIFY) {
             const int grp = lane >> 4;
-            const float rx = grp == 0 ? r[0].x : (grp == 1 ? r[1].x : (grp == 2 ? r[2].x : r[3].x));
-            const float ry = grp == 0 ? r[0].y : (grp == 1 ? r[1].y : (grp == 2 ? r[2].y : r[3].y));
-            const float rc = grp == 0 ? r[0].c : (grp == 1 ? r[1].c : (grp == 2 ? r[2].c : r[3].c));
-            const float rs = grp == 0 ? r[0].s : (grp == 1 ? r[1].s : (grp == 2 ? r[2].s : r[3].s));
+            const float4 rl = rrec[wave * RPW + grp];
+            const float rx = rl.x, ry = rl.y, rc = rl.z, rs = rl.w;
             const float4 bb = tbnd[lane & 15];
             const float ex = bb.x - rx, ey = bb.y - ry;               // receiver -> centre of the batch
             const float D2 = ex * ex + ey * ey;
@@ -337,6 +328,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         }
 #pragma unroll
         for (int u = 0; u < RPW; u++) {
+            {
+                const float4 q = rrec[wave * RPW + u];
+                ru.x = q.x, ru.y = q.y, ru.c = q.z, ru.s = q.w;
+                asm volatile("" : "+v"(ru.x), "+v"(ru.y), "+v"(ru.c), "+v"(ru.s));  // stay in VGPRs, not SGPRs
+            }
             const unsigned live = nb >= 16 ? 0xFFFFu : ((1u << nb) - 1u);
             unsigned cand = (unsigned)(cand_all >> (16 * u)) & live;
             const unsigned inside = (unsigned)(inside_all >> (16 * u)) & live;
@@ -350,7 +346,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     const int b2 = __builtin_ctz(ins);
                     ins &= ins - 1u;
                     const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
-                    field_twod_x2<true>(k, r[u], v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
+                    field_twod_x2<true>(k, ru, v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
                                         v2f{ts[i0], ts[i1]}, true, true, ax[u], ay[u]);
                 }
                 cand = (cand & ~inside) | ins;  // an odd one out takes the queue together with the partial batches
@@ -360,28 +356,25 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 cand &= cand - 1u;
                 const int t = (b << 6) + lane;
                 if ((inside >> b) & 1u) {
-                    queue[wave][u][(qhead[u] + qlen[u] + lane) & (QCAP - 1)] = (unsigned short)t;
-                    qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] + WAVE);
+                    queue[wave][(qhead + qlen + lane) & (QCAP - 1)] = (unsigned short)t;
+                    qlen = __builtin_amdgcn_readfirstlane(qlen + WAVE);
                 } else {
-                    const float dx = r[u].x - tx[t], dy = r[u].y - ty[t];
-                    const bool in = tracked<P2R>(k.chs, r[u], dx, dy, dx * dx + dy * dy);
+                    const float dx = ru.x - tx[t], dy = ru.y - ty[t];
+                    const bool in = tracked<P2R>(k.chs, ru, dx, dy, dx * dx + dy * dy);
                     const unsigned long long m = __ballot(in);
                     if (in) {
                         const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        queue[wave][u][(qhead[u] + qlen[u] + pre) & (QCAP - 1)] = (unsigned short)t;
+                        queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)t;
                     }
-                    qlen[u] = __builtin_amdgcn_readfirstlane(qlen[u] + __builtin_popcountll(m));
+                    qlen = __builtin_amdgcn_readfirstlane(qlen + __builtin_popcountll(m));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (qlen[u] >= CHUNK) pop(u, std::true_type{});
+                if (qlen >= CHUNK) pop(u, std::true_type{});
             }
-        }
-        // the queues hold indices into this tile: drain them before it is replaced
-#pragma unroll
-        for (int u = 0; u < RPW; u++) {
-            while (qlen[u] >= CHUNK) pop(u, std::true_type{});
-            if (qlen[u] > 0) pop(u, std::false_type{});
+            // the queue holds indices into this tile for this receiver: drain it before either changes
+            while (qlen >= CHUNK) pop(u, std::true_type{});
+            if (qlen > 0) pop(u, std::false_type{});
         }
     }
     reduce_store(d, j0, lane, ax, ay);
