@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcsf_hip.so")
+# CSF_LIB selects another build of the same library (kernel A/B measurements, tools/ab.sh)
+LIB_PATH = os.environ.get("CSF_LIB") or os.path.join(HERE, "libcsf_hip.so")
 
 BICYCLE, TWOD, INVPEND, PLANARPOINT = 0, 1, 2, 3
 UNREGULATED, P2R = 0, 1

@@ -77,6 +77,7 @@ struct Dev {
     int64_t replay_tick;        // the replay
     double *hist;      // opt-in history [hist_cap][n][ns]
     int32_t hist_stride, hist_cap;
+    uint64_t *trace;   // CSF_TRACE_BLOCKS: (start, end, hw id) of every pair-kernel workgroup of the last tick, else NULL
 };
 
 enum : int { PH_DEST = 1, PH_COMBINE = 2, PH_INTEGRATE = 4, PH_FIXSPEED = 8 };

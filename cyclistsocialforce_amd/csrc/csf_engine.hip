@@ -114,6 +114,8 @@ struct csf_engine {
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, part, froad, kat2;
+    DevBuf<uint64_t> trace;   // CSF_TRACE_BLOCKS (measurement aid)
+    size_t trace_words = 0;
 
     // sharding
     int rank = 0, world = 1;
@@ -284,6 +286,13 @@ int alloc_all(csf_engine *e) {
     d.recs = e->recs.p;
     d.bnd = e->bnd.p;
     d.bnd_next = e->bnd2.p;
+    d.trace = nullptr;
+    if (getenv("CSF_TRACE_BLOCKS")) {  // 3 words per wave: the grid is at most (cap/16) x MAX_SPLIT workgroups of 4 waves
+        e->trace_words = 3 * 4 * ((size_t)cap / 16 + 1) * MAX_SPLIT;
+        HIPCHK(e, e->trace.alloc(e->trace_words));
+        HIPCHK(e, hipMemset(e->trace.p, 0, e->trace_words * sizeof(uint64_t)));
+        d.trace = e->trace.p;
+    }
     return CSF_OK;
 }
 
@@ -560,6 +569,16 @@ int csf_destroy(csf_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->main) (void)hipStreamSynchronize(e->main);
     if (e->comm) (void)hipStreamSynchronize(e->comm);
+    if (e->trace.p) {  // CSF_TRACE_BLOCKS=<file>: workgroup timeline of the last pair-kernel launch
+        std::vector<uint64_t> h(e->trace_words);
+        if (hipMemcpy(h.data(), e->trace.p, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(getenv("CSF_TRACE_BLOCKS"), "wb")) {
+                fwrite(h.data(), sizeof(uint64_t), h.size(), f);
+                fclose(f);
+            }
+        }
+        e->trace.release();
+    }
     if (e->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(e->nccl);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);

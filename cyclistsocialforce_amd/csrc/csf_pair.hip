@@ -241,6 +241,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
+    const uint64_t t_start = d.trace ? wall_clock64() : 0;
 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
@@ -378,6 +379,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         }
     }
     reduce_store(d, j0, lane, ax, ay);
+    if (d.trace && lane == 0) {   // tools/block_trace.py: when did every wave run, and where
+        uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave);
+        o[0] = t_start;
+        o[1] = wall_clock64();
+        o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))                 // HW_REG_HW_ID
+               | ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+    }
 }
 
 // ---- simple kernel: every pair evaluated, masked afterwards (Bicycle field; also the TwoD field on request) --

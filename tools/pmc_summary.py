@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Average the rocprofv3 --pmc counters of one kernel over its launches.
+
+usage: pmc_summary.py DIR [kernel-substring]      (DIR as written by tools/pmc_passes.sh / pmc_ab.sh)
+Prints one JSON object {counter: mean per launch}; the first launches (warm-up of bench.py) are included.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def summarise(root, needle="pair_cull_kernel"):
+    acc, cnt = defaultdict(float), defaultdict(int)
+    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if needle in row["Kernel_Name"]:
+                    acc[row["Counter_Name"]] += float(row["Counter_Value"])
+                    cnt[row["Counter_Name"]] += 1
+    return {k: acc[k] / cnt[k] for k in sorted(acc)}, (max(cnt.values()) if cnt else 0)
+
+
+if __name__ == "__main__":
+    out, n = summarise(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "pair_cull_kernel")
+    print(json.dumps({"launches_averaged": n, "counters": out}, indent=1))
