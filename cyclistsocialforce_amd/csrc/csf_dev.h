@@ -21,6 +21,8 @@ struct PairConsts {
     float ipd;                         // Bicycle field: 1 / p_decay (vehicle.py:1095-1099)
     int32_t p2r;                       // intersection.py:739-741
     int32_t f0_zero;                   // vehicle.py:1592-1593
+    int32_t fov_classify;              // hfov <= pi: whole batches can be classified against the field-of-view cone
+    float rfar;                        // sources farther than this add less than far_eps * f_0 / n in magnitude (inf: off)
 };
 
 // All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
@@ -36,7 +38,7 @@ struct Dev {
     int32_t back;      // int(1 / t_s) — vehicle.py:1487
     int32_t n_split;   // source chunks of the pair kernel
     int32_t pair_variant;  // 0: cull-first kernel on binned records (default), 1: evaluate-then-mask, 2: cull-first, unbinned
-    int32_t classify;      // batches carry bounding circles and the FOV is narrow enough to classify them
+    int32_t classify;      // the records are binned and every batch of 64 carries a bounding circle
     double ox, oy;     // origin of the fp32 source records
     int64_t tick;
 

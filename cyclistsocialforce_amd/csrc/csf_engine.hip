@@ -114,6 +114,7 @@ struct csf_engine {
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, part, froad, kat2;
+    double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
     DevBuf<uint64_t> trace;   // CSF_TRACE_BLOCKS (measurement aid)
     size_t trace_words = 0;
 
@@ -174,6 +175,40 @@ int check_params(csf_engine *e, const csf_params *p) {
     return CSF_OK;
 }
 
+// Far-field radius of the TwoD field (vehicle.py:1560-1648).  |F| = f_0 exp(-rho q / sigma) with
+// q = sqrt(1 - e^2 cos^2 phi), sigma = sga - sgb |sin(phi/2)|, all functions of s2 = sin^2(psi0 - psi) in [0, 1] and of
+// phi: kappa = min q / sigma bounds the decay from below, so every source beyond
+//     R = ln(n / far_eps) / kappa
+// adds less than far_eps f_0 / n, and all of them together less than far_eps f_0, to a receiver's column sum.
+// far_eps defaults to 2^-24 (half an fp32 ulp of f_0; CSF_FAR_EPS overrides, 0 switches the cull off): what is
+// left out is below the rounding of the fp32 sum it would have been added to.  Batches of binned records
+// whose bounding circle lies entirely beyond R are skipped by the pair kernel.
+double far_kappa(const csf_params &p) {
+    if (p.model == CSF_BICYCLE) return 0.0;
+    double kappa = INFINITY;
+    for (int i = 0; i <= 256; i++) {
+        const double s2 = i / 256.0;
+        const double e = p.e_0 - p.e_1 * s2, sga = p.sigma_0 + p.sigma_1 * s2, sgb = p.sigma_2 + p.sigma_3 * s2;
+        for (int j = 0; j <= 512; j++) {
+            const double phi = 3.141592653589793 * j / 512.0;
+            const double q2 = 1.0 - e * e * std::cos(phi) * std::cos(phi), sigma = sga - sgb * std::sin(0.5 * phi);
+            if (!(sigma > 0) || !(q2 > 0)) return 0.0;   // degenerate parameters: no usable bound
+            kappa = std::min(kappa, std::sqrt(q2) / sigma);
+        }
+    }
+    return std::isfinite(kappa) ? 0.98 * kappa : 0.0;  // the grid is fine but finite
+}
+
+double far_radius(double kappa, int64_t n, double far_eps) {
+    if (!(far_eps > 0) || !(kappa > 0) || n < 1) return INFINITY;
+    return std::log((double)n / far_eps) / kappa;
+}
+
+void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
+    const char *fe = getenv("CSF_FAR_EPS");
+    e->d.pc.rfar = (float)far_radius(e->far_kappa, e->d.n, fe ? atof(fe) : 5.9604644775390625e-8);
+}
+
 void derive_consts(csf_engine *e) {
     const csf_params &p = e->d.p;
     PairConsts &k = e->d.pc;
@@ -199,6 +234,9 @@ void derive_consts(csf_engine *e) {
         k.ipd = 0.f;
         k.f0_zero = p.f_0 == 0.0;
     }
+    k.fov_classify = p.hfov <= PI_;
+    e->far_kappa = far_kappa(p);
+    update_far_radius(e);
     const char *variant = getenv("CSF_PAIR_VARIANT");
     e->d.pair_variant = variant ? atoi(variant) : 0;
     {   // no rider model moves faster than its speed clamp (vehicle.py:1258, 1876, 1905; dynamics.py:1025)
@@ -342,7 +380,8 @@ constexpr int64_t BIN_MIN_AGENTS = 1024;
 int rebin(csf_engine *e) {
     Dev &d = e->d;
     const bool binned = d.pair_variant == 0 && d.p.model != CSF_BICYCLE && d.n >= BIN_MIN_AGENTS;
-    d.classify = binned && d.p.hfov <= 3.141592653589793;
+    d.classify = binned;
+    update_far_radius(e);
     if (binned) {
         int rc = launch_rebin(d, e->sort_keys.p, e->sort_keys_out.p, e->sort_vals.p, e->sort_tmp.p, e->sort_tmp.n, e->main);
         if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the record bins failed (%d)", rc);
@@ -1129,6 +1168,13 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi) {
     if (!e) return CSF_E_ARG;
     if (lo) *lo = e->d.lo;
     if (hi) *hi = e->d.hi;
+    return CSF_OK;
+}
+
+int csf_far_radius(const csf_engine *e, double *radius_m) {
+    if (!e || !radius_m) return CSF_E_ARG;
+    const bool binned = e->d.pair_variant == 0 && e->d.p.model != CSF_BICYCLE && e->d.n >= BIN_MIN_AGENTS;
+    *radius_m = binned ? (double)e->d.pc.rfar : (double)INFINITY;  // no bounding circles, no cull
     return CSF_OK;
 }
 

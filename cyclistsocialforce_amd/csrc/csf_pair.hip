@@ -222,14 +222,24 @@ __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_
     if (iend > d.n_pad) iend = d.n_pad;
 }
 
+// One LDS load per value: hipcc would otherwise merge the loads of (x, y) and (c, s) of ONE record into
+// ds_read2st64_b32, whose register pair then has to be taken apart with v_mov to form the packed operands
+// {x[i0], x[i1]} ... of the field (7 moves per evaluation).
+typedef const volatile __attribute__((address_space(3))) float *lds_vfp;   // volatile: not merged; LDS: ds_read_b32
+__device__ __forceinline__ v2f lds_pair(const float *a, int i0, int i1) {
+    return v2f{*(lds_vfp)(a + i0), *(lds_vfp)(a + i1)};
+}
+
 // ---- culling kernel (TwoD field): classify batches -> test -> ballot -> LDS queue -> packed field ---------
 // CLASSIFY: the records are streamed in spatially binned order (csf_bin.hip) and every batch of 64 carries a
-// bounding circle.  Per receiver and tile, lane b classifies batch b against the field-of-view cone:
+// bounding circle.  Per receiver and tile, lane b classifies batch b against the field-of-view cone (hfov <= pi):
 //   outside (smallest bearing in the circle > hfov/2)  -> skipped without touching its records,
 //   inside  (largest bearing in the circle  < hfov/2)  -> all 64 lanes queued without per-lane tests,
 //   else                                               -> exact per-lane test (intersection.py:690-745).
 // Both shortcuts keep a 1e-4 margin in the cosine and need the receiver outside the circle, so the exact test
-// decides every borderline source: results are identical with and without CLASSIFY.
+// decides every borderline source: these two leave the results identical with and without CLASSIFY.
+// A batch is also skipped when all of it lies beyond the far-field radius k.rfar (csf_engine.hip: far_radius),
+// where the contributions are below the resolution of the fp32 column sum.
 template <bool P2R, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
@@ -267,8 +277,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         int i1 = queue[wave][(qhead + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
         if (!FULL) i0 = v0 ? i0 : 0, i1 = v1 ? i1 : 0;
-        field_twod_x2<FULL>(k, ru, v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
-                            v2f{ts[i0], ts[i1]}, v0, v1, ax[u], ay[u]);
+        field_twod_x2<FULL>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
+                            lds_pair(ts, i0, i1), v0, v1, ax[u], ay[u]);
         qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
         qlen = __builtin_amdgcn_readfirstlane(qlen - n);
     };
@@ -320,9 +330,14 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
             const float sb = fabsf(rc * ey - rs * ex) * invD;
             const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
+            const bool fov = apart & (k.fov_classify != 0);
             // outside: the heading misses the circle (|beta| > alpha) and cos(|beta| - alpha) < cos(hfov/2)
-            const bool out = apart & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f);
-            const bool in = !P2R & apart & ((cb * ca - sb * sa) > k.ch + 1e-4f);  // cos(|beta| + alpha) > cos(hfov/2)
+            // far: every source of the batch is beyond the radius at which the field has decayed below the
+            // resolution of the fp32 column sum (csf_engine.hip: far_radius)
+            const float reach = k.rfar + bb.z;
+            const bool far = D2 > reach * reach;
+            const bool out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
+            const bool in = !P2R & fov & !far & ((cb * ca - sb * sa) > k.ch + 1e-4f);  // cos(|beta| + alpha) > cos(hfov/2)
             const bool valid = (lane & 15) < nb;
             cand_all = __ballot(valid & !out);
             inside_all = __ballot(valid & in);
@@ -347,8 +362,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     const int b2 = __builtin_ctz(ins);
                     ins &= ins - 1u;
                     const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
-                    field_twod_x2<true>(k, ru, v2f{tx[i0], tx[i1]}, v2f{ty[i0], ty[i1]}, v2f{tc[i0], tc[i1]},
-                                        v2f{ts[i0], ts[i1]}, true, true, ax[u], ay[u]);
+                    field_twod_x2<true>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
+                                        lds_pair(ts, i0, i1), true, true, ax[u], ay[u]);
                 }
                 cand = (cand & ~inside) | ins;  // an odd one out takes the queue together with the partial batches
             }

@@ -220,6 +220,12 @@ class Engine:
         self._ck(self._lib.csf_shard_range(self._h, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
+    def far_radius(self):
+        """Radius (m) beyond which batches of sources are skipped (inf: every pair is evaluated); include/csf.h."""
+        r = C.c_double(0)
+        self._ck(self._lib.csf_far_radius(self._h, C.byref(r)))
+        return r.value
+
     # -- measurement ------------------------------------------------------------------------
     def profile(self, every=1):
         """HIP events around the pair kernel on every `every`-th tick (0 / False: off)."""

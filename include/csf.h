@@ -184,6 +184,14 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi);
 int csf_profile_enable(csf_engine *e, int32_t on);
 int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *launches);
 
+/* Far-field radius of the pair kernel (metres; +inf when the cull is off).  The repulsive field of
+ * vehicle.py:1560-1648 decays at least like f_0 exp(-kappa rho); sources beyond
+ * R = ln(n / eps) / kappa together add less than eps * f_0 (eps = 2^-24 unless the environment variable
+ * CSF_FAR_EPS says otherwise; CSF_FAR_EPS=0 evaluates every pair) to a receiver's force, which is below
+ * the resolution of the fp32 column sum; batches of binned source records entirely beyond R are skipped.
+ * The reference has no such cut-off: this is the engine's only approximation besides fp32. */
+int csf_far_radius(const csf_engine *e, double *radius_m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -369,3 +369,36 @@ def test_field_of_view_variants_vs_oracle(amd, hfov, rule):
     err = np.abs(np.c_[rx - ox, ry - oy]).max() / scale
     print(f"hfov={hfov:.3f} rule={rule}: max |dF_rep| / max|F_rep| = {err:.2e}")
     assert err < 5e-5
+
+
+def test_far_field_cull_bound(amd, monkeypatch):
+    """Batches beyond the far-field radius are skipped (include/csf.h: csf_far_radius).  What is left out of a
+    receiver's column sum must stay below eps * f_0; with eps = 0 every pair is evaluated."""
+    n, box = 4096, 500.0
+    x, y, psi, v, off, dq = synthetic_population(n, box)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    f0 = amd.pod("twod").f_0
+
+    def rep(eps):
+        if eps is None:
+            monkeypatch.delenv("CSF_FAR_EPS", raising=False)
+        else:
+            monkeypatch.setenv("CSF_FAR_EPS", repr(eps))
+        e = make_engine(amd, "twod", s0, 1e6, off, dq)       # |F_dest| = 1e6: the clamp never acts
+        e.calc_forces()
+        r = e.far_radius()
+        _, _, rx, ry = e.force_parts()
+        return r, rx, ry
+
+    r0, x0, y0 = rep(0.0)
+    assert np.isinf(r0)
+    r1, x1, y1 = rep(None)                                    # default: eps = 2^-24
+    assert 100.0 < r1 < box                                   # the cull is active in this scene
+    scale = np.hypot(x0, y0).max()
+    bound = 2.0 ** -24 * f0 + 8 * np.finfo(np.float32).eps * scale
+    assert np.abs(x1 - x0).max() <= bound and np.abs(y1 - y0).max() <= bound
+    r2, x2, y2 = rep(1e-3)                                    # a coarse eps: visibly different, still bounded
+    assert r2 < r1
+    d2 = np.hypot(x2 - x0, y2 - y0).max()
+    print(f"far radius {r1:.1f} m (eps 2^-24), {r2:.1f} m (eps 1e-3); max omitted {np.hypot(x1 - x0, y1 - y0).max():.2e} / {d2:.2e}")
+    assert d2 <= 1e-3 * f0 + 8 * np.finfo(np.float32).eps * scale
