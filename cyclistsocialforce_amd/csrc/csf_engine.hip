@@ -529,19 +529,32 @@ int prepare_mutation(csf_engine *e) {
     return CSF_OK;
 }
 
+// CSF_COMM_STREAM=second puts the all-gather on a second HIP stream, so that the destination-force phase of the
+// next tick (launched before the wait) overlaps it.  Measured with a 1-rank communicator the two cross-stream
+// event waits per tick and the extra launch cost 26 us against 8 us in stream order, more than the ~6 us of
+// destination-force work they can hide, so the default keeps the collective in stream order on the main stream.
+bool comm_second_stream() {
+    static const bool second = getenv("CSF_COMM_STREAM") && std::string(getenv("CSF_COMM_STREAM")) == "second";
+    return second;
+}
+
 int all_gather_records(csf_engine *e) {
     Dev &d = e->d;
     size_t shard = (size_t)(d.n_pad / e->world);
-    HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
+    const bool second = comm_second_stream();
+    hipStream_t cs = second ? e->comm : e->main;
+    if (second) HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
     const bool two = d.p.model == CSF_BICYCLE;
     if (two) NCCLCHK(e, g_rccl.GroupStart());
-    NCCLCHK(e, g_rccl.AllGather(d.rec + (size_t)e->rank * shard, d.rec, shard * 4, ncclFloat32, e->nccl, e->comm));
+    NCCLCHK(e, g_rccl.AllGather(d.rec + (size_t)e->rank * shard, d.rec, shard * 4, ncclFloat32, e->nccl, cs));
     if (two) {
-        NCCLCHK(e, g_rccl.AllGather(d.rec2 + (size_t)e->rank * shard, d.rec2, shard * 2, ncclFloat32, e->nccl, e->comm));
+        NCCLCHK(e, g_rccl.AllGather(d.rec2 + (size_t)e->rank * shard, d.rec2, shard * 2, ncclFloat32, e->nccl, cs));
         NCCLCHK(e, g_rccl.GroupEnd());
     }
-    HIPCHK(e, hipEventRecord(e->ev_gather, e->comm));
-    e->gather_pending = true;
+    if (second) {
+        HIPCHK(e, hipEventRecord(e->ev_gather, e->comm));
+        e->gather_pending = true;
+    }
     return CSF_OK;
 }
 
@@ -822,10 +835,11 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
 
 // One tick, all on the main stream (dependent launches in one stream cost ~2 us; a cross-stream event wait was
 // measured at ~11 us here, more than running the destination-force phase beside the pair kernel saves):
-//   main:  [agent(DEST) - wait(ev_gather)] - bounds - pair - road - agent(DEST|COMBINE|INTEGRATE) - record(ev_integ)
-//   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)                      (world > 1 only)
-// When sharded, the destination-force phase (it needs only the agent's own state) is issued before the wait
-// on the gather so that it overlaps the collective.
+//   main:  bounds - pair - road - agent(DEST|COMBINE|INTEGRATE) - [all-gather(records)]       (world > 1: RCCL)
+// CSF_COMM_STREAM=second moves the collective to a second stream and issues the destination-force phase of the
+// next tick (it needs only the agent's own state) before the wait on it:
+//   main:  agent(DEST) - wait(ev_gather) - bounds - pair - road - agent(COMBINE|INTEGRATE) - record(ev_integ)
+//   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)
 static int enqueue_tick(csf_engine *e) {
     Dev &d = e->d;
     const bool sharded = e->world > 1 || e->nccl != nullptr;  // a 1-rank communicator rehearses the sharded path
@@ -836,7 +850,8 @@ static int enqueue_tick(csf_engine *e) {
         for (int k = 0; k < 3; k++) HIPCHK(e, hipEventCreate(&e->ev[base + k]));
         pe = &e->ev[base];
     }
-    if (sharded) {
+    const bool overlap = sharded && comm_second_stream();
+    if (overlap) {
         launch_agent(d, PH_DEST, e->main);
         int rc = wait_gather(e);
         if (rc) return rc;
@@ -850,12 +865,12 @@ static int enqueue_tick(csf_engine *e) {
     bounds_after_pair(e, true);
     if (pe) HIPCHK(e, hipEventRecord(pe[1], e->main));
     launch_road(d, e->main);
-    launch_agent(d, sharded ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main);
+    launch_agent(d, overlap ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main);
     if (pe) HIPCHK(e, hipEventRecord(pe[2], e->main));
     HIPCHK(e, hipGetLastError());
     d.tick++;
     if (sharded) {
-        HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
+        if (overlap) HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
         return all_gather_records(e);
     }
     return CSF_OK;
