@@ -36,9 +36,9 @@ constexpr int TILE = 1024;           // simple kernels: source records per LDS t
 #define CSF_TILE2 1024
 #endif
 #ifndef CSF_CULL_WAVES
-#define CSF_CULL_WAVES 5
+#define CSF_CULL_WAVES 7
 #endif
-constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 5 waves/SIMD measured best (tools/sweep_cull.sh)
+constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 7 waves/SIMD (72 VGPRs, 12 B spilled) measured best (tools/sweep_cull.sh)
 constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
 constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
 
