@@ -14,7 +14,7 @@ animation (`animate=True` raises), and populations mixing vehicle classes in one
 """
 import numpy as np
 
-from . import _ffi
+from . import _ffi, parameters
 from .engine import Engine
 from .parameters import RoadElementParameters
 from .vehicle import Vehicle
@@ -166,6 +166,20 @@ class SocialForceIntersection:
         self._pod_bytes = None
         self._road_sig = None
         self._pending = []        # vehicles waiting to be added to the engine
+        # bulk mirror of the per-vehicle attributes the device produces (Vehicle properties read these): one
+        # read-back per tick refreshes every vehicle, with no Python loop over the population
+        self._ptr = None          # destpointer [capacity]
+        self._zn = None           # znav [capacity, 3]; vehicle.znav are row views
+        self._fx = self._fy = None
+        self._have_force = False
+        self._ti = None           # vehicle.i [capacity]
+        self._traj = None         # vehicle.traj [rows, n_states, traj_len]; vehicle.traj are views
+        self._dirty_queues = {}   # vehicle -> None (rows appended) | -1 (queue replaced) | -2 (rows edited in place)
+        self._drawn = []          # vehicles with a drawing / saveForces (the only per-tick Python loop)
+        self._drawn_stale = True
+        self._flog = []           # |F| of every evaluated tick since the last fold (vehicle.F)
+        self._flog_base = 0
+        self._params_seen = -1
         for v in vehicleList:
             self._attach(v)
 
@@ -182,7 +196,10 @@ class SocialForceIntersection:
             v._solo = None
         v._owner = self
         v._index = len(self.vehicles)
+        v._live = False
         v._queue_synced = -1
+        v._f_seen = self._flog_base + len(self._flog)
+        self._dirty_queues[v] = -1
         self.vehicles.append(v)
         self._pending.append(v)
         self.n_bikes = len(self.vehicles)
@@ -219,27 +236,47 @@ class SocialForceIntersection:
         if self._engine is not None:
             self._flush_pending()
             self._engine.remove_agents(idx)
+        self._fold_all_force_logs()                  # indices are about to change
         gone = set(idx)
         keep = [k for k in range(len(self.vehicles)) if k not in gone]
         for k in idx:
             v = self.vehicles[k]
-            v.s = v.s.copy()
-            v._owner, v._index = None, -1
+            self._detach(v)
             if v in self._pending:
                 self._pending.remove(v)
+            self._dirty_queues.pop(v, None)
         self.vehicles = [self.vehicles[k] for k in keep]
+        m = len(keep)
         if self._S is not None:
-            self._S[: len(keep)] = self._S[keep]
-            self._shadow[: len(keep)] = self._shadow[keep]
-            self._vd[: len(keep)] = self._vd[keep]
+            for a in (self._S, self._shadow, self._vd, self._ptr, self._zn, self._fx, self._fy, self._ti):
+                a[:m] = a[keep]
+        if self._traj is not None and m:
+            self._traj[:m] = self._traj[keep]
         for new, v in enumerate(self.vehicles):
             v._index = new
-            if self._S is not None and v not in self._pending:
-                v.s = self._S[new]
+            if v._live:
+                self._bind(v)
+        self._drawn_stale = True
         self.n_bikes = len(self.vehicles)
         self.vehicleX = np.delete(self.vehicleX, idx, 0)
         self.vehicleY = np.delete(self.vehicleY, idx, 0)
         self.vehicleTheta = np.delete(self.vehicleTheta, idx, 0)
+
+    def _bind(self, v):
+        """vehicle attributes that are views of the bulk mirror"""
+        k = v._index
+        v.s = self._S[k]
+        v.znav = self._zn[k]
+        v.traj = self._traj[k]
+
+    def _detach(self, v):
+        """the vehicle leaves with private copies of everything it saw through the mirror"""
+        if v._live:
+            st = dict(i=v.i, destpointer=v.destpointer, force=v.force)
+            v.s, v.znav, v.traj = v.s.copy(), v.znav.copy(), v.traj.copy()
+            v._live = False
+            v.i, v.destpointer, v.force = st["i"], st["destpointer"], st["force"]
+        v._owner, v._index = None, -1
 
     def addEdge(self, roadEdge):
         self.road_elements.append(roadEdge)
@@ -257,6 +294,11 @@ class SocialForceIntersection:
             self._S = np.zeros((cap, ns))
             self._shadow = np.zeros((cap, ns))
             self._vd = np.zeros(cap)
+            self._ptr = np.zeros(cap, dtype=np.int64)
+            self._zn = np.zeros((cap, 3), dtype=bool)
+            self._fx = np.zeros(cap)
+            self._fy = np.zeros(cap)
+            self._ti = np.zeros(cap, dtype=np.int64)
             self._rule_on_device = self.priority_rule
             self._pod_bytes = bytes(v0._pod(PRIORITY_RULES[self.priority_rule]))
         self._flush_pending()
@@ -274,55 +316,89 @@ class SocialForceIntersection:
         vd = np.array([float(v.params.v_desired_default) for v in new])
         first = new[0]._index
         e.add_agents(s0, vd)
+        # vehicle.traj rows of the bulk history (grown geometrically; every vehicle of an engine shares t_s)
+        shape = new[0].traj.shape
+        n = len(self.vehicles)
+        if self._traj is None or self._traj.shape[0] < n:
+            grown = np.zeros((max(n, 2 * (0 if self._traj is None else self._traj.shape[0])),) + shape)
+            if self._traj is not None:
+                grown[: self._traj.shape[0]] = self._traj
+            self._traj = grown
+            for v in self.vehicles:
+                if v._live:
+                    v.traj = self._traj[v._index]
         for k, v in enumerate(new):
-            self._S[first + k] = v.s
-            v.s = self._S[first + k]
-            self._shadow[first + k] = v.s
-            self._vd[first + k] = vd[k]
-            v._queue_synced = -1
+            if v.traj.shape != self._traj.shape[1:]:
+                raise NotImplementedError("all road users of one intersection share t_s (one engine per vehicle class)")
+            r = first + k
+            self._S[r] = v.s
+            self._shadow[r] = v.s
+            self._vd[r] = vd[k]
+            self._zn[r] = v.znav
+            self._traj[r] = v.traj
+            st = (v.i, v.destpointer, v.force)
+            v._live = True
+            v.i, v.destpointer, v.force = st
+            self._bind(v)
+            self._dirty_queues[v] = -1
+        self._drawn_stale = True
 
-    def _mark_queue_dirty(self, v):
-        if getattr(v, "_queue_reset", False):
-            v._queue_synced = -1
+    def _mark_queue_dirty(self, v, how=None):
+        """how: None rows appended, -1 queue replaced (pointer rewinds), -2 rows edited in place (pointer kept)"""
+        prev = self._dirty_queues.get(v, 0)          # 0: clean
+        if how == -1 or prev == -1:
+            self._dirty_queues[v] = -1
+        elif how == -2 or prev == -2:
+            self._dirty_queues[v] = -2
+        else:
+            self._dirty_queues[v] = None
 
     def _push_mutations(self):
         """Everything the user may have changed on the Python side since the last tick."""
         e = self._engine_ready()
         n = len(self.vehicles)
-        # destination queues: appended rows go up with reset=0, replaced queues with reset=1
-        for mode in (1, 2, 0):
-            agents, rows, off = [], [], [0]
-            for v in self.vehicles:
+        # destination queues (only vehicles whose setDestinations / stop / go ran since the last push):
+        # replaced queues go up with reset=1, rows edited in place with reset=2, appended rows with reset=0
+        if self._dirty_queues:
+            groups = {1: ([], [], [0]), 2: ([], [], [0]), 0: ([], [], [0])}
+            for v, how in self._dirty_queues.items():
                 q = v.destqueue
-                if mode == 1 and v._queue_synced == -1:                  # new or reset queue: pointer rewinds
-                    agents.append(v._index); rows.append(q); off.append(off[-1] + q.shape[0])
-                    v._queue_synced = q.shape[0]
-                elif mode == 2 and v._queue_synced == -2:                # rows edited in place: pointer kept
-                    agents.append(v._index); rows.append(q); off.append(off[-1] + q.shape[0])
-                    v._queue_synced = q.shape[0]
-                elif mode == 0 and 0 <= v._queue_synced < q.shape[0]:    # appended rows
-                    agents.append(v._index); rows.append(q[v._queue_synced:]); off.append(off[-1] + q.shape[0] - v._queue_synced)
-                    v._queue_synced = q.shape[0]
-            if agents:
-                e.set_dest_queue(agents, off, np.vstack(rows), reset=mode)
-        for v in self.vehicles:
-            v._queue_dirty = False
+                if how == -1 or v._queue_synced < 0:
+                    mode, rows = 1, q
+                elif how == -2:
+                    mode, rows = 2, q
+                elif v._queue_synced < q.shape[0]:
+                    mode, rows = 0, q[v._queue_synced:]
+                else:
+                    continue
+                agents, blocks, off = groups[mode]
+                agents.append(v._index); blocks.append(rows); off.append(off[-1] + rows.shape[0])
+                v._queue_synced = q.shape[0]
+                v._queue_dirty = False
+            self._dirty_queues = {}
+            for mode in (1, 2, 0):
+                agents, blocks, off = groups[mode]
+                if agents:
+                    e.set_dest_queue(agents, off, np.vstack(blocks), reset=mode)
         # vehicle.s edited in place (calibration.py:455-460)
         changed = np.where(np.any(self._S[:n] != self._shadow[:n], axis=1))[0]
         if changed.size:
             e.push_state(changed, self._S[changed])
             self._shadow[changed] = self._S[changed]
         if self._track_params:
-            # params.v_desired_default is the per-agent parameter (demoCSFstandalone.py:104-113)
-            vd = np.array([float(v.params.v_desired_default) for v in self.vehicles])
-            ch = np.where(vd != self._vd[:n])[0]
-            if ch.size:
-                e.set_v_desired(ch, vd[ch])
-                self._vd[ch] = vd[ch]
-            pod = self.vehicles[0]._pod(PRIORITY_RULES[self.priority_rule])
-            if bytes(pod) != self._pod_bytes:
-                e.set_params(pod)
-                self._pod_bytes = bytes(pod)
+            # params.v_desired_default is the per-agent parameter (demoCSFstandalone.py:104-113); the population is
+            # rescanned only after some parameter object was assigned to
+            if parameters.mutation_count() != self._params_seen:
+                self._params_seen = parameters.mutation_count()
+                vd = np.array([float(v.params.v_desired_default) for v in self.vehicles])
+                ch = np.where(vd != self._vd[:n])[0]
+                if ch.size:
+                    e.set_v_desired(ch, vd[ch])
+                    self._vd[ch] = vd[ch]
+                pod = self.vehicles[0]._pod(PRIORITY_RULES[self.priority_rule])
+                if bytes(pod) != self._pod_bytes:
+                    e.set_params(pod)
+                    self._pod_bytes = bytes(pod)
         if self.priority_rule != self._rule_on_device:
             if self.priority_rule not in PRIORITY_RULES:
                 raise ValueError(f"priority_rule must be one of {tuple(PRIORITY_RULES)}")
@@ -336,26 +412,59 @@ class SocialForceIntersection:
         return e
 
     def _pull(self, forces=True, advance=1):
+        """One read-back of the device's view into the bulk mirror (vehicle.s, znav, traj are views of it)."""
         e = self._engine
         n = len(self.vehicles)
         s, ptr, zn, _ = e.state(with_nav=True)
         self._S[:n] = s
         self._shadow[:n] = s
+        self._ptr[:n] = ptr
+        self._zn[:n] = zn
         fx, fy = e.forces() if forces else (None, None)
-        for k, v in enumerate(self.vehicles):
-            v.destpointer = int(ptr[k])
-            v.znav[:] = zn[k]
-            v.dest = v.destqueue[v.destpointer, :]
-            if forces:
-                v.force = (fx[k], fy[k])                               # intersection.py:860-862
+        if forces:
+            self._fx[:n] = fx                                         # intersection.py:860-862
+            self._fy[:n] = fy
+            self._have_force = True
         if advance:
-            for k, v in enumerate(self.vehicles):
-                if forces:
-                    v.F.append(float(np.hypot(fx[k], fy[k])))
-                v.i = (v.i + advance - 1) % v.traj.shape[1]
-                v._advance_history(fx[k] if forces else 0.0, fy[k] if forces else 0.0)
+            if forces:
+                self._log_forces(fx, fy)
+            T = self._traj.shape[2]
+            self._ti[:n] = (self._ti[:n] + advance) % T               # vehicle.py:1279-1282 (see DESIGN D5)
+            self._traj[np.arange(n), :, self._ti[:n]] = self._S[:n]
+            if self._drawn_stale:
+                self._drawn = [v for v in self.vehicles if v.drawing is not None or v.saveForces]
+                self._drawn_stale = False
+            for v in self._drawn:
+                k = v._index
+                Fx, Fy = (fx[k], fy[k]) if forces else (0.0, 0.0)
+                if v.saveForces:
+                    v.trajF[0, self._ti[k]] = Fx
+                    v.trajF[1, self._ti[k]] = Fy
+                v.update_drawing(Fres=(Fx, Fy))
         self.update_road_user_positions()
         return fx, fy
+
+    # vehicle.F: the per-tick magnitudes are logged as arrays and folded into a vehicle's list when it is read
+    def _log_forces(self, fx, fy):
+        self._flog.append(np.hypot(fx, fy))
+        if len(self._flog) >= 4096:
+            self._fold_all_force_logs()
+
+    def _fold_force_log(self, v):
+        start = v._f_seen - self._flog_base
+        if start < len(self._flog):
+            k = v._index
+            v._F.extend(float(a[k]) for a in self._flog[start:])
+            v._f_seen = self._flog_base + len(self._flog)
+
+    def _fold_all_force_logs(self):
+        if self._flog:
+            for v in self.vehicles:
+                self._fold_force_log(v)
+        self._flog_base += len(self._flog)
+        self._flog = []
+        for v in self.vehicles:
+            v._f_seen = self._flog_base
 
     def update_road_user_positions(self):
         """intersection.py:660-677"""
@@ -374,8 +483,7 @@ class SocialForceIntersection:
         e = self._push_mutations()
         fx, fy = e.calc_forces()
         self._pull(forces=True, advance=0)
-        for k, v in enumerate(self.vehicles):
-            v.F.append(float(np.hypot(fx[k], fy[k])))
+        self._log_forces(fx, fy)
         return fx, fy
 
     def step(self):

@@ -12,6 +12,15 @@ import numpy as np
 from . import _ffi
 
 
+_MUTATIONS = [0]
+
+
+def mutation_count():
+    """Number of assignments to any parameter attribute so far (the intersection rescans its population for changed
+    per-agent parameters only when this moved)."""
+    return _MUTATIONS[0]
+
+
 class _Field:
     """Descriptor restating one reference property: (type check, range check, optional immutability)."""
 
@@ -74,6 +83,10 @@ class VehicleParameters:
     """parameters.py:421-750 — tactical parameters and the repulsive force field."""
 
     LIMIT_PREC = 1e-4
+
+    def __setattr__(self, name, value):   # every assignment (validated fields and plain attributes) is counted
+        object.__setattr__(self, name, value)
+        _MUTATIONS[0] += 1
 
     t_s = _Field(check=_ge0)
     d_arrived_inter = _Field(check=_ge0, immutable=False)

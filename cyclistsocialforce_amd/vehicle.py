@@ -39,6 +39,9 @@ class Vehicle:
                 raise TypeError(f"Params must be a '{self.PARAMS_TYPE.__name__}' object. "
                                 f"Instead it was '{type(params).__name__}'.")
             self.params = params
+        self._owner = None        # SocialForceIntersection that holds this vehicle, or None
+        self._index = -1
+        self._live = False        # True once the intersection's engine holds this vehicle (bulk mirror active)
         self.i = 0                                                     # vehicle.py:146
         if len(s0) < self.N_STATES:                                    # vehicle.py:149-152
             raise ValueError(f"The initial state s0 has to be size {self.N_STATES} with states "
@@ -60,20 +63,84 @@ class Vehicle:
         self.follow_route = bool(route)
         self.route = route
         self.drawing = None
-        self.dest = np.array([s0[0], s0[1], 0.0])                      # vehicle.py:183-185
-        self.destqueue = np.c_[self.dest[0], self.dest[1], self.dest[2]]
+        self.destqueue = np.c_[float(s0[0]), float(s0[1]), 0.0]       # vehicle.py:183-185: (x0, y0, no stop)
         self.destpointer = 0
         self.znav = np.array([True, False, False])                     # vehicle.py:188
         self.F = []
         self.force = (0.0, 0.0)
         self.uncontrolled = False
         # engine binding
-        self._owner = None        # SocialForceIntersection that holds this vehicle, or None
-        self._index = -1
         self._solo = None         # private one-agent engine
         self._solo_synced = False
         self._queue_dirty = True
         self._s_shadow = self.s.copy()
+
+    # ------------------------------------------------------------------ mirrored scalars
+    # Inside a SocialForceIntersection these live in the intersection's bulk arrays (one device read-back per tick
+    # refreshes every vehicle at once); on its own the vehicle keeps them itself.
+    @property
+    def i(self):
+        """column of `traj` written last (vehicle.py:146, 1279-1282)"""
+        return int(self._owner._ti[self._index]) if self._live else self._i
+
+    @i.setter
+    def i(self, value):
+        self._i = int(value)
+        if self._live:
+            self._owner._ti[self._index] = int(value)
+
+    @property
+    def destpointer(self):
+        return int(self._owner._ptr[self._index]) if self._live else self._destpointer
+
+    @destpointer.setter
+    def destpointer(self, value):
+        self._destpointer = int(value)
+        if self._live:
+            self._owner._ptr[self._index] = int(value)
+
+    @property
+    def dest(self):
+        """current destination (x, y, stop): the row of the queue the pointer is on (vehicle.py:183-185, 545-594)"""
+        return self.destqueue[self.destpointer, :]
+
+    @dest.setter
+    def dest(self, value):  # the reference rebinds `dest` to the queue row; here it always is that row
+        pass
+
+    @property
+    def force(self):
+        """total force of the last evaluated tick (intersection.py:860-861)"""
+        if self._live and self._owner._have_force:
+            return (float(self._owner._fx[self._index]), float(self._owner._fy[self._index]))
+        return self._force
+
+    @force.setter
+    def force(self, value):
+        self._force = (float(value[0]), float(value[1]))
+        if self._live:
+            self._owner._fx[self._index], self._owner._fy[self._index] = self._force
+
+    @property
+    def drawing(self):
+        return self._drawing
+
+    @drawing.setter
+    def drawing(self, value):
+        self._drawing = value
+        if self._owner is not None:
+            self._owner._drawn_stale = True
+
+    @property
+    def F(self):
+        """magnitudes of the total force, one entry per evaluated tick (intersection.py:862)"""
+        if self._owner is not None:
+            self._owner._fold_force_log(self)
+        return self._F
+
+    @F.setter
+    def F(self, value):
+        self._F = list(value)
 
     # ------------------------------------------------------------------ engine plumbing
     def _pod(self, priority_rule=0):
@@ -110,7 +177,6 @@ class Vehicle:
         self._s_shadow[:] = s_row
         self.destpointer = int(ptr)
         self.znav[:] = znav_row
-        self.dest = self.destqueue[self.destpointer, :]
 
     def _advance_history(self, Fx, Fy):
         self.i = (self.i + 1) % self.traj.shape[1]                     # vehicle.py:1279-1282 (see DESIGN D5)
@@ -138,7 +204,6 @@ class Vehicle:
         s, ptr, zn, _ = e.state(with_nav=True)
         self.destpointer = int(ptr[0])
         self.znav[:] = zn[0]
-        self.dest = self.destqueue[self.destpointer, :]
         return float(fx[0]), float(fy[0])
 
     def step(self, F1=0, F2=0):
@@ -171,13 +236,11 @@ class Vehicle:
         if reset or self.destqueue is None:
             self.destqueue = np.c_[x, y, stop]
             self.destpointer = 0
-            self.dest = [x[0], y[0], stop[0]]
         else:
             self.destqueue = np.vstack((self.destqueue, np.c_[x, y, stop]))
         self._queue_dirty = True
-        self._queue_reset = bool(reset)
         if self._owner is not None:
-            self._owner._mark_queue_dirty(self)
+            self._owner._mark_queue_dirty(self, -1 if reset else None)
 
     def stop(self, stoptype=0, stopdest=None):
         """vehicle.py:459-503, stoptype 0: stop at the next destination in the queue (sets its stop flag; the
@@ -186,7 +249,6 @@ class Vehicle:
         if stoptype != 0:
             raise NotImplementedError("only stoptype 0 (stop at the next destination) is mirrored")
         self.destqueue[self.destpointer, 2] = 1.0
-        self.dest = self.destqueue[self.destpointer, :]
         self._queue_edit()
 
     def go(self, gotype=0):
@@ -194,7 +256,6 @@ class Vehicle:
         if gotype != 0:
             raise NotImplementedError("only gotype 0 (clear the stop flag of the current destination) is mirrored")
         self.destqueue[self.destpointer, 2] = 0.0
-        self.dest = self.destqueue[self.destpointer, :]
         self._queue_edit()
 
     def _queue_edit(self):
@@ -202,7 +263,7 @@ class Vehicle:
         self._queue_dirty = True
         self._queue_keep_ptr = True
         if self._owner is not None:
-            self._queue_synced = -2
+            self._owner._mark_queue_dirty(self, -2)
 
     def setSplineDestinations(self, x, y, npoints, stop=False, reset=False):
         """vehicle.py:649-693 (host-side convenience; uses scipy like the reference)."""
