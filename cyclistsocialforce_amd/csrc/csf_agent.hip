@@ -760,6 +760,30 @@ void launch_agent(const Dev &d, int phases, hipStream_t st) {
     }
 }
 
+// csf_get_tick: everything the host mirror refreshes after a tick, packed for one transfer
+__global__ void snapshot_kernel(const Dev d, double *out) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = d.n;
+    if (a >= n) return;
+    const int ns = d.ns;
+    for (int c = 0; c < ns; c++) out[a * ns + c] = d.s[(int64_t)c * d.cap + a];
+    double *F = out + n * ns;
+    F[a] = d.F[a];
+    F[n + a] = d.F[d.cap + a];
+    int32_t *ptr = (int32_t *)(F + 2 * n);
+    ptr[a] = d.ptr[a];
+    uint8_t *zn = (uint8_t *)(ptr + n);
+    const int z = d.znav[a] & 3;
+    zn[3 * a + 0] = z == 0;
+    zn[3 * a + 1] = z == 1;
+    zn[3 * a + 2] = z == 2;
+}
+
+void launch_snapshot(const Dev &d, double *out, hipStream_t st) {
+    if (d.n <= 0) return;
+    hipLaunchKernelGGL(snapshot_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, st, d, out);
+}
+
 void launch_records(const Dev &d, hipStream_t st) {
     if (d.n_pad <= 0) return;
     hipLaunchKernelGGL(records_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);

@@ -89,6 +89,9 @@ void launch_pair(const Dev &d, hipStream_t st);
 void launch_road(const Dev &d, hipStream_t st);
 void launch_agent(const Dev &d, int phases, hipStream_t st);
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state
+// csf_get_tick: row-major state [n, ns], Fx [n], Fy [n] (doubles), destination pointers [n] (int32), navigation state
+// one-hot [n, 3] (bytes), packed behind each other in `out` (host-mapped)
+void launch_snapshot(const Dev &d, double *out, hipStream_t st);
 // csf_bin.hip: spatial binning of the source records (Hilbert order) and per-batch bounding circles
 size_t bin_temp_bytes(int64_t n_pad);
 int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,

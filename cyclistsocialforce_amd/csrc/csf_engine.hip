@@ -115,6 +115,9 @@ struct csf_engine {
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, part, froad, kat2;
     double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
+    void *snap_host = nullptr;  // csf_get_tick: pinned, device-mapped staging buffer
+    double *snap_dev = nullptr;
+    size_t snap_bytes = 0;
     DevBuf<uint64_t> trace;   // CSF_TRACE_BLOCKS (measurement aid)
     size_t trace_words = 0;
 
@@ -641,6 +644,7 @@ int csf_destroy(csf_engine *e) {
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
     e->sort_vals.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
+    if (e->snap_host) (void)hipHostFree(e->snap_host);
     if (e->main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);
     delete e;
@@ -1045,6 +1049,44 @@ int csf_get_state(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav
 static int get_F(csf_engine *e, int comp, double *out) {
     if (!out) return CSF_OK;
     HIPCHK(e, hipMemcpy(out, e->F.p + (size_t)comp * e->cap, (size_t)e->d.n * sizeof(double), hipMemcpyDeviceToHost));
+    return CSF_OK;
+}
+
+int csf_get_tick(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy, int64_t *tick) {
+    if (!e) return CSF_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);  // a never-stepped engine still answers from a consistent device copy
+    if (rc) return rc;
+    const int64_t n = e->d.n;
+    const int ns = e->d.ns;
+    if (tick) *tick = e->d.tick;
+    if (n == 0) return csf_sync(e);
+    const size_t need = (size_t)n * ((size_t)(ns + 2) * sizeof(double) + sizeof(int32_t) + 3);
+    if (need > e->snap_bytes) {
+        if (e->snap_host) {
+            HIPCHK(e, hipStreamSynchronize(e->main));
+            HIPCHK(e, hipHostFree(e->snap_host));
+            e->snap_host = nullptr;
+            e->snap_bytes = 0;
+        }
+        const size_t want = std::max<size_t>(need * 2, 4096);
+        HIPCHK(e, hipHostMalloc(&e->snap_host, want, hipHostMallocMapped));
+        HIPCHK(e, hipHostGetDevicePointer((void **)&e->snap_dev, e->snap_host, 0));
+        e->snap_bytes = want;
+    }
+    launch_snapshot(e->d, e->snap_dev, e->main);
+    HIPCHK(e, hipGetLastError());
+    rc = csf_sync(e);
+    if (rc) return rc;
+    const double *S = (const double *)e->snap_host;
+    const double *F = S + (size_t)n * ns;
+    const int32_t *P = (const int32_t *)(F + 2 * (size_t)n);
+    const uint8_t *Z = (const uint8_t *)(P + n);
+    if (s_out) std::memcpy(s_out, S, (size_t)n * ns * sizeof(double));
+    if (Fx) std::memcpy(Fx, F, (size_t)n * sizeof(double));
+    if (Fy) std::memcpy(Fy, F + n, (size_t)n * sizeof(double));
+    if (dest_ptr) std::memcpy(dest_ptr, P, (size_t)n * sizeof(int32_t));
+    if (znav) std::memcpy(znav, Z, (size_t)n * 3);
     return CSF_OK;
 }
 

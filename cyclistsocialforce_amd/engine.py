@@ -160,6 +160,20 @@ class Engine:
         self._ck(self._lib.csf_get_state(self._h, _ptr(s), _ptr(ptr), _ptr(zn), C.byref(tick)))
         return s, ptr, zn.astype(bool), tick.value
 
+    def tick_snapshot(self, forces=True):
+        """state [n, n_states], destination pointers, one-hot navigation state, total forces and the tick count in one
+        device-to-host transfer (csf_get_tick)"""
+        n = self.n
+        s = np.zeros((n, self.ns))
+        ptr = np.zeros(n, dtype=np.int32)
+        zn = np.zeros((n, 3), dtype=np.uint8)
+        fx = np.zeros(n) if forces else None
+        fy = np.zeros(n) if forces else None
+        tick = C.c_int64(0)
+        self._ck(self._lib.csf_get_tick(self._h, _ptr(s), _ptr(ptr), _ptr(zn), None if fx is None else _ptr(fx),
+                                        None if fy is None else _ptr(fy), C.byref(tick)))
+        return s, ptr, zn.astype(bool), fx, fy, tick.value
+
     @property
     def tick(self):
         t = C.c_int64(0)

@@ -173,7 +173,8 @@ class SocialForceIntersection:
         self._fx = self._fy = None
         self._have_force = False
         self._ti = None           # vehicle.i [capacity]
-        self._traj = None         # vehicle.traj [rows, n_states, traj_len]; vehicle.traj are views
+        self._traj = None         # vehicle.traj, stored [traj_len, rows, n_states] (a tick writes one contiguous slab);
+                                  # vehicle.traj are transposed views [n_states, traj_len]
         self._dirty_queues = {}   # vehicle -> None (rows appended) | -1 (queue replaced) | -2 (rows edited in place)
         self._drawn = []          # vehicles with a drawing / saveForces (the only per-tick Python loop)
         self._drawn_stale = True
@@ -251,7 +252,7 @@ class SocialForceIntersection:
             for a in (self._S, self._shadow, self._vd, self._ptr, self._zn, self._fx, self._fy, self._ti):
                 a[:m] = a[keep]
         if self._traj is not None and m:
-            self._traj[:m] = self._traj[keep]
+            self._traj[:, :m] = self._traj[:, keep]
         for new, v in enumerate(self.vehicles):
             v._index = new
             if v._live:
@@ -267,7 +268,7 @@ class SocialForceIntersection:
         k = v._index
         v.s = self._S[k]
         v.znav = self._zn[k]
-        v.traj = self._traj[k]
+        v.traj = self._traj[:, k, :].T
 
     def _detach(self, v):
         """the vehicle leaves with private copies of everything it saw through the mirror"""
@@ -317,25 +318,28 @@ class SocialForceIntersection:
         first = new[0]._index
         e.add_agents(s0, vd)
         # vehicle.traj rows of the bulk history (grown geometrically; every vehicle of an engine shares t_s)
-        shape = new[0].traj.shape
+        ns, T = new[0].traj.shape
         n = len(self.vehicles)
-        if self._traj is None or self._traj.shape[0] < n:
-            grown = np.zeros((max(n, 2 * (0 if self._traj is None else self._traj.shape[0])),) + shape)
+        if self._traj is None or self._traj.shape[1] < n:
+            grown = np.zeros((T, max(n, 2 * (0 if self._traj is None else self._traj.shape[1])), ns))
             if self._traj is not None:
-                grown[: self._traj.shape[0]] = self._traj
+                grown[:, : self._traj.shape[1]] = self._traj
             self._traj = grown
             for v in self.vehicles:
                 if v._live:
-                    v.traj = self._traj[v._index]
-        for k, v in enumerate(new):
-            if v.traj.shape != self._traj.shape[1:]:
+                    v.traj = self._traj[:, v._index, :].T
+        for v in new:
+            if v.traj.shape != (ns, T):
                 raise NotImplementedError("all road users of one intersection share t_s (one engine per vehicle class)")
+        for c in range(0, len(new), 512):            # adopt the vehicles' own histories, a slab of rows at a time
+            blk = new[c:c + 512]
+            self._traj[:, first + c:first + c + len(blk), :] = np.stack([v.traj for v in blk]).transpose(2, 0, 1)
+        for k, v in enumerate(new):
             r = first + k
             self._S[r] = v.s
             self._shadow[r] = v.s
             self._vd[r] = vd[k]
             self._zn[r] = v.znav
-            self._traj[r] = v.traj
             st = (v.i, v.destpointer, v.force)
             v._live = True
             v.i, v.destpointer, v.force = st
@@ -415,12 +419,11 @@ class SocialForceIntersection:
         """One read-back of the device's view into the bulk mirror (vehicle.s, znav, traj are views of it)."""
         e = self._engine
         n = len(self.vehicles)
-        s, ptr, zn, _ = e.state(with_nav=True)
+        s, ptr, zn, fx, fy, _ = e.tick_snapshot(forces=forces)
         self._S[:n] = s
         self._shadow[:n] = s
         self._ptr[:n] = ptr
         self._zn[:n] = zn
-        fx, fy = e.forces() if forces else (None, None)
         if forces:
             self._fx[:n] = fx                                         # intersection.py:860-862
             self._fy[:n] = fy
@@ -428,9 +431,12 @@ class SocialForceIntersection:
         if advance:
             if forces:
                 self._log_forces(fx, fy)
-            T = self._traj.shape[2]
-            self._ti[:n] = (self._ti[:n] + advance) % T               # vehicle.py:1279-1282 (see DESIGN D5)
-            self._traj[np.arange(n), :, self._ti[:n]] = self._S[:n]
+            T = self._traj.shape[0]
+            ti = self._ti[:n] = (self._ti[:n] + advance) % T          # vehicle.py:1279-1282 (see DESIGN D5)
+            if n and (ti == ti[0]).all():
+                self._traj[ti[0], :n] = self._S[:n]                   # the usual case: everyone joined at tick 0
+            else:
+                self._traj[ti, np.arange(n)] = self._S[:n]
             if self._drawn_stale:
                 self._drawn = [v for v in self.vehicles if v.drawing is not None or v.saveForces]
                 self._drawn_stale = False

@@ -141,6 +141,13 @@ int csf_dest_force(csf_engine *e, double *Fx, double *Fy);
 /* s_out [n, n_states]; dest_ptr [n] (destpointer), znav [n,3] one-hot, tick = ticks since creation.
  * Any output pointer may be NULL. */
 int csf_get_state(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, int64_t *tick);
+/* Everything the host mirror of SocialForceIntersection.step() refreshes after a tick (intersection.py:860-862,
+ * 660-677; vehicle.py:1279-1282), in ONE device-to-host transfer: csf_get_state + csf_get_forces cost nine separate
+ * copies of ~12 us each, which dominated the per-tick call at the reference's own population sizes (3 - 30
+ * cyclists).  A kernel packs the row-major state, destination pointers, navigation state and total forces into a
+ * pinned staging buffer; any output pointer may be NULL. */
+int csf_get_tick(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy,
+                 int64_t *tick);
 /* total force of the last evaluated tick (vehicle.force, intersection.py:860-861) */
 int csf_get_forces(csf_engine *e, double *Fx, double *Fy);
 /* parts of it: destination force and clamped repulsive sum (before road edges) */

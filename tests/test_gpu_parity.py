@@ -402,3 +402,25 @@ def test_far_field_cull_bound(amd, monkeypatch):
     d2 = np.hypot(x2 - x0, y2 - y0).max()
     print(f"far radius {r1:.1f} m (eps 2^-24), {r2:.1f} m (eps 1e-3); max omitted {np.hypot(x1 - x0, y1 - y0).max():.2e} / {d2:.2e}")
     assert d2 <= 1e-3 * f0 + 8 * np.finfo(np.float32).eps * scale
+
+
+def test_tick_snapshot_equals_separate_readbacks(amd):
+    """csf_get_tick (one transfer) returns exactly what csf_get_state + csf_get_forces return."""
+    for model, n in (("twod", 300), ("invpend", 65), ("planarpoint", 1)):
+        x, y, psi, v, off, dq = synthetic_population(n, 60.0)
+        ns = orc.N_STATES[MODELS[model]]
+        s0 = np.zeros((n, ns)); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
+        e = make_engine(amd, model, s0, 5.0, off, dq)
+        s, ptr, zn, fx, fy, tick = e.tick_snapshot()          # before any tick: the uploaded state
+        assert tick == 0 and np.array_equal(s, e.state())
+        e.step(7)
+        s, ptr, zn, fx, fy, tick = e.tick_snapshot()
+        s2, ptr2, zn2, tick2 = e.state(with_nav=True)
+        fx2, fy2 = e.forces()
+        assert tick == tick2 == 7
+        assert np.array_equal(s, s2) and np.array_equal(ptr, ptr2) and np.array_equal(zn, zn2)
+        assert np.array_equal(fx, fx2) and np.array_equal(fy, fy2)
+        s3, _, _, fx3, fy3, _ = e.tick_snapshot(forces=False)
+        assert fx3 is None and fy3 is None and np.array_equal(s3, s2)
+    empty = amd.Engine(amd.pod("twod"), 4)
+    assert empty.tick_snapshot()[0].shape == (0, 5)

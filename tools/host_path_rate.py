@@ -45,6 +45,12 @@ def array_path(n, box, ticks):
     dt = time.perf_counter() - t0
     print(f"Engine.step(1) + state() read-back          N={n:6d}: {dt / ticks * 1e3:8.3f} ms/tick  {n * ticks / dt:12.0f} agent-steps/s")
     t0 = time.perf_counter()
+    for _ in range(ticks):
+        e.step(1)
+        e.tick_snapshot()
+    dt = time.perf_counter() - t0
+    print(f"Engine.step(1) + tick_snapshot() (1 transfer) N={n:6d}: {dt / ticks * 1e3:8.3f} ms/tick  {n * ticks / dt:12.0f} agent-steps/s")
+    t0 = time.perf_counter()
     e.step(ticks, sync=True)
     dt = time.perf_counter() - t0
     print(f"Engine.step(K), state resident              N={n:6d}: {dt / ticks * 1e3:8.3f} ms/tick  {n * ticks / dt:12.0f} agent-steps/s")
@@ -53,5 +59,6 @@ def array_path(n, box, ticks):
 if __name__ == "__main__":
     mirror_path(3, 30.0, 700)
     mirror_path(1024, 200.0, 100)
+    mirror_path(16384, 200.0, 50)
     array_path(1024, 200.0, 500)
     array_path(16384, 200.0, 300)
