@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void bounds_kernel(const Dev d) {
 
 size_t bin_temp_bytes(int64_t n_pad) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                        (const int32_t *)nullptr, (int32_t *)nullptr, (int)n_pad);
     return bytes;
 }
