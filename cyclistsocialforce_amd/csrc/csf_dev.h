@@ -64,6 +64,7 @@ struct Dev {
     float4 *recs;      // [n_pad] the records in binned order (single device: written by the agent kernel beside
                        // rec, so that the pair kernel's tile fill is one coalesced load instead of perm -> rec)
     int32_t recs_valid;
+    int32_t recv_binned;   // the pair kernel takes its receivers in binned order too and skips far tiles (large populations)
     float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
     float4 *bnd_next;  // written by the pair kernel for the next tick (from this tick's records + bnd_margin)
     float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
@@ -71,6 +72,7 @@ struct Dev {
     float2 *froad;     // [cap]
     float4 *rv;        // [nv_pad] road vertices (x-ox, y-oy, -F0, -(sigma+1)/2)
     int64_t nv, nv_pad;
+    int32_t road_np;   // sigma + 1 when every road edge shares one integer sigma in 1..5, else 0 (road_kernel)
 
     double *F;         // [6][cap] Fx, Fy, Fdest_x, Fdest_y, Frep_x, Frep_y
     uint32_t *status;

@@ -185,7 +185,7 @@ __device__ __forceinline__ void load_receivers(const Dev &d, int64_t j0, Recv (&
 // reduced together: each of the first three butterfly steps hands half of the values to the partner lane, the
 // last three steps finish the one value a lane is left with.  10 shuffles instead of 48; fixed order.
 __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane, const float (&ax)[RPW],
-                                             const float (&ay)[RPW]) {
+                                             const float (&ay)[RPW], const int32_t *perm = nullptr) {
     static_assert(RPW == 4, "the reduction below is written for eight values");
     float v[8] = {ax[0], ay[0], ax[1], ay[1], ax[2], ay[2], ax[3], ay[3]};
     float w[4];
@@ -208,8 +208,9 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
     // lane 8*k holds value index 4*bit5 + 2*bit4 + bit3
     const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     const int u = idx >> 1;
-    if ((lane & 7) == 0 && j0 + u < d.hi) {
-        float *dst = (float *)&d.part[(int64_t)blockIdx.y * d.cap + j0 + u];
+    if ((lane & 7) == 0 && j0 + u < d.hi) {   // perm: the receivers are positions of the binned order (BINR)
+        const int64_t a = perm ? (int64_t)perm[j0 + u] : j0 + u;
+        float *dst = (float *)&d.part[(int64_t)blockIdx.y * d.cap + a];
         dst[idx & 1] = z;
     }
 }
@@ -240,7 +241,10 @@ __device__ __forceinline__ v2f lds_pair(const float *a, int i0, int i1) {
 // decides every borderline source: these two leave the results identical with and without CLASSIFY.
 // A batch is also skipped when all of it lies beyond the far-field radius k.rfar (csf_engine.hip: far_radius),
 // where the contributions are below the resolution of the fp32 column sum.
-template <bool P2R, bool CLASSIFY>
+// BINR (large unsharded populations): the RECEIVERS of a workgroup are 16 consecutive positions of the binned order as
+// well, i.e. neighbours in space, so a whole tile of 1024 sources that lies beyond the far-field radius of the
+// group's bounding circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).
+template <bool P2R, bool CLASSIFY, bool BINR>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
@@ -295,12 +299,29 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     };
     // first tile and the workgroup's 16 receiver records travel together: one global round trip, not two
     if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
-    fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
+    if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
     if (threadIdx.x < WPB * RPW) {
         const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
-        rrec[threadIdx.x] = d.rec[j < d.hi ? j : d.hi - 1];  // clamp: results of the duplicates are not stored
+        const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
+        rrec[threadIdx.x] = BINR ? d.recs[jc] : d.rec[jc];   // BINR: j is a position of the binned order
     }
     __syncthreads();
+    float gx = 0.f, gy = 0.f, gr = 0.f;   // BINR: bounding circle of the workgroup's receivers (the same in every wave)
+    if (BINR) {
+        const float4 q = rrec[lane & 15];
+        float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, o, WAVE));
+            x1 = fmaxf(x1, __shfl_xor(x1, o, WAVE));
+            y0 = fminf(y0, __shfl_xor(y0, o, WAVE));
+            y1 = fmaxf(y1, __shfl_xor(y1, o, WAVE));
+        }
+        const float w = x1 - x0, h = y1 - y0;
+        gx = 0.5f * (x0 + x1), gy = 0.5f * (y0 + y1);
+        gr = 0.5f * fast_sqrt(w * w + h * h) * 1.0001f + 1e-4f;   // rounded up: must contain
+    }
+    bool filled = false;
     for (int64_t base = ibeg; base < iend; base += TILE2) {
         const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
         const int nb = cnt >> 6;
@@ -308,7 +329,18 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         ax[0] += tx[lane] + rrec[wave * RPW].x;
         continue;
 #endif
-        if (base != ibeg) {
+        if (BINR) {
+            // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
+            // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
+            const float4 bb = d.bnd[(base >> 6) + ((lane & 15) < nb ? (lane & 15) : 0)];
+            const float ex = bb.x - gx, ey = bb.y - gy;
+            const float reach = k.rfar + bb.z + gr;
+            if (__ballot(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
+            if (filled) __syncthreads();
+            fill_tile(base, cnt);
+            __syncthreads();
+            filled = true;
+        } else if (base != ibeg) {
             __syncthreads();
             fill_tile(base, cnt);
             __syncthreads();
@@ -393,7 +425,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             if (qlen > 0) pop(u, std::false_type{});
         }
     }
-    reduce_store(d, j0, lane, ax, ay);
+    reduce_store(d, j0, lane, ax, ay, BINR ? d.perm : nullptr);
     if (d.trace && lane == 0) {   // tools/block_trace.py: when did every wave run, and where
         uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave);
         o[0] = t_start;
@@ -453,38 +485,64 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
 }
 
 // intersection.py:226-242: F = sum_k -F0 r_k^-sigma (v_k - p)/r_k over the polyline vertices.
-// Same mapping: vertices in the lanes, receivers wave-uniform.
+// Same mapping: vertices in the lanes (two per lane, packed arithmetic), receivers wave-uniform.  NP = sigma + 1 when
+// every edge shares one small integer sigma (the reference's defaults: 3; the curve scenario: 2): r^-(sigma+1) is then
+// a power of rsq(r^2), one transcendental per pair instead of log2 + exp2.  NP = 0: per-vertex exponent.
+// A receiver exactly on a vertex (r = 0; the reference divides by zero there) gets no force from it.
+template <int NP>
 __global__ __launch_bounds__(BLOCK) void road_kernel(const Dev d) {
-    __shared__ float4 tile[TILE];
+    __shared__ float vx[TILE], vy[TILE], vf[TILE], vw[NP ? 1 : TILE];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
     Recv r[RPW];
     load_receivers(d, j0, r);
-    float ax[RPW], ay[RPW];
+    v2f ax[RPW], ay[RPW];
 #pragma unroll
-    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.f;
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = v2f{0.f, 0.f};
     for (int64_t base = 0; base < d.nv_pad; base += TILE) {
-        int cnt = (int)((d.nv_pad - base) < TILE ? (d.nv_pad - base) : TILE);
+        const int cnt = (int)((d.nv_pad - base) < TILE ? (d.nv_pad - base) : TILE);  // multiple of 64
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += BLOCK) tile[t] = d.rv[base + t];
+        for (int t = threadIdx.x; t < cnt; t += BLOCK) {
+            const float4 v = d.rv[base + t];  // (x, y, -F0, -(sigma+1)/2); padding has F0 = 0
+            vx[t] = v.x;
+            vy[t] = v.y;
+            vf[t] = v.z;
+            if (!NP) vw[t] = v.w;
+        }
         __syncthreads();
-        for (int t = lane; t < cnt; t += WAVE) {
-            float4 v = tile[t];  // (x, y, -F0, -(sigma+1)/2); padding has F0 = 0
+        for (int t = lane; t < cnt; t += 2 * WAVE) {
+            const bool two = t + WAVE < cnt;
+            const int t2 = two ? t + WAVE : t;
+            const v2f px = lds_pair(vx, t, t2), py = lds_pair(vy, t, t2);
+            v2f pf = lds_pair(vf, t, t2);
+            pf.y = two ? pf.y : 0.0f;
+            v2f pw{0.f, 0.f};
+            if (!NP) pw = lds_pair(vw, t, t2);
 #pragma unroll
             for (int u = 0; u < RPW; u++) {
-                float ex = v.x - r[u].x, ey = v.y - r[u].y;      // :235-236 (numerators)
-                float r2 = ex * ex + ey * ey;                    // :231-234
-                float m = v.z * fast_exp2(v.w * fast_log2(r2));  // -F0 r^-(sigma+1)    :238
-                m = r2 > 0.f ? m : 0.f;
-                ax[u] += m * ex;                                 // :239-240
-                ay[u] += m * ey;
+                const v2f ex = px - r[u].x, ey = py - r[u].y;       // :235-236 (numerators)
+                const v2f r2 = ex * ex + ey * ey;                   // :231-234
+                v2f m;
+                if (NP) {
+                    v2f inv = rsq2(r2);
+                    inv = __builtin_elementwise_min(inv, v2f{1e6f, 1e6f});   // r = 0: finite, times ex = ey = 0
+                    const v2f i2 = inv * inv;
+                    m = NP == 2 ? i2 : NP == 3 ? i2 * inv : NP == 4 ? i2 * i2 : NP == 5 ? i2 * i2 * inv : i2 * i2 * i2;
+                } else {
+                    v2f lg = pw * v2f{fast_log2(r2.x), fast_log2(r2.y)};
+                    lg = __builtin_elementwise_min(lg, v2f{120.f, 120.f});   // r = 0: finite, times ex = ey = 0
+                    m = v2f{fast_exp2(lg.x), fast_exp2(lg.y)};
+                }
+                m = m * pf;                                         // -F0 r^-(sigma+1)    :238
+                ax[u] = m * ex + ax[u];                             // :239-240
+                ay[u] = m * ey + ay[u];
             }
         }
     }
 #pragma unroll
     for (int u = 0; u < RPW; u++) {
-        float sx = ax[u], sy = ay[u];
+        float sx = ax[u].x + ax[u].y, sy = ay[u].x + ay[u].y;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             sx += __shfl_xor(sx, o, WAVE);
@@ -545,18 +603,29 @@ void launch_pair(const Dev &d, hipStream_t st) {
     } else if (d.pair_variant == 1) {
         if (p2r) hipLaunchKernelGGL((pair_kernel<false, true>), g, b, 0, st, d);
         else hipLaunchKernelGGL((pair_kernel<false, false>), g, b, 0, st, d);
+    } else if (d.classify && d.recv_binned) {
+        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, true, true>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_cull_kernel<false, true, true>), g, b, 0, st, d);
     } else if (d.classify) {
-        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, true>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_cull_kernel<false, true>), g, b, 0, st, d);
+        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, true, false>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_cull_kernel<false, true, false>), g, b, 0, st, d);
     } else {
-        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, false>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_cull_kernel<false, false>), g, b, 0, st, d);
+        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, false, false>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_cull_kernel<false, false, false>), g, b, 0, st, d);
     }
 }
 
 void launch_road(const Dev &d, hipStream_t st) {
     if (d.hi <= d.lo || d.nv == 0) return;
-    hipLaunchKernelGGL(road_kernel, recv_grid(d, 1), dim3(BLOCK), 0, st, d);
+    const dim3 g = recv_grid(d, 1), b(BLOCK);
+    switch (d.road_np) {
+    case 2: hipLaunchKernelGGL(road_kernel<2>, g, b, 0, st, d); break;
+    case 3: hipLaunchKernelGGL(road_kernel<3>, g, b, 0, st, d); break;
+    case 4: hipLaunchKernelGGL(road_kernel<4>, g, b, 0, st, d); break;
+    case 5: hipLaunchKernelGGL(road_kernel<5>, g, b, 0, st, d); break;
+    case 6: hipLaunchKernelGGL(road_kernel<6>, g, b, 0, st, d); break;
+    default: hipLaunchKernelGGL(road_kernel<0>, g, b, 0, st, d); break;
+    }
 }
 
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,

@@ -424,3 +424,40 @@ def test_tick_snapshot_equals_separate_readbacks(amd):
         assert fx3 is None and fy3 is None and np.array_equal(s3, s2)
     empty = amd.Engine(amd.pod("twod"), 4)
     assert empty.tick_snapshot()[0].shape == (0, 5)
+
+
+@pytest.mark.parametrize("sigmas", [(2.0, 2.0, 2.0), (3.0, 3.0, 3.0), (1.0, 1.0, 1.0), (5.0, 5.0, 5.0),
+                                    (2.0, 3.0, 2.5), (0.5, 4.0, 6.0)])
+def test_road_force_exponent_paths_vs_oracle(amd, sigmas):
+    """RoadEdge.calcRepulsiveForce (intersection.py:226-242): the road kernel takes r^-(sigma+1) as a power of
+    rsq(r^2) when every edge shares one integer sigma and through log2/exp2 otherwise; both against the oracle,
+    with vertex counts that leave odd and even numbers of 64-vertex batches and a receiver exactly on a vertex."""
+    rng = np.random.default_rng(5)
+    counts = (70, 64, 131)
+    verts = np.vstack([np.c_[np.linspace(0, 40, c), 8.0 * k + rng.normal(0, 0.05, c)] for k, c in enumerate(counts)])
+    off = np.r_[0, np.cumsum(counts)]
+    F0 = np.array([0.15, 0.05, 0.3])
+    sg = np.array(sigmas)
+    x = rng.uniform(-5, 45, 400); y = rng.uniform(-4, 22, 400)
+    # fp32 records resolve 4e-6 m here and r^-(sigma+1) amplifies that by (sigma+1)/r: keep receivers >= 0.5 m away
+    clear = np.min(np.hypot(x[:, None] - verts[None, :, 0], y[:, None] - verts[None, :, 1]), axis=1) >= 0.5
+    x, y = x[clear][:96], y[clear][:96]
+    n = x.size
+    x[0], y[0] = verts[10]                                       # r = 0 for one vertex: that vertex adds nothing
+    s0 = np.c_[x, y, np.zeros(n), np.full(n, 4.0)]
+    e = amd.Engine(amd.pod("planarpoint", f_0=0.0), n)
+    e.add_agents(s0, 5.0)
+    e.set_road(off, verts, F0, sg)
+    fx, fy = e.calc_forces()
+    fdx, fdy, _, _ = e.force_parts()
+    keep = np.ones(len(verts), bool); keep[10] = False
+    rx, ry = orc.road_force(verts, off, F0, sg, x[1:], y[1:])
+    scale = np.maximum(np.hypot(rx, ry), 1e-6)
+    assert np.max(np.abs(fx[1:] - fdx[1:] - rx) / scale) < 5e-5
+    assert np.max(np.abs(fy[1:] - fdy[1:] - ry) / scale) < 5e-5
+    # the receiver on vertex 10: the oracle over the other vertices of that edge and the other edges
+    v2 = verts[keep]; off2 = off.copy(); off2[1:] -= 1
+    r0x, r0y = orc.road_force(v2, off2, F0, sg, x[:1], y[:1])
+    # (its two neighbours on the edge, 0.58 m away, pull with O(1) each and nearly cancel: absolute tolerance)
+    assert np.isfinite(fx[0]) and abs(fx[0] - fdx[0] - r0x[0]) < 2e-5
+    assert np.isfinite(fy[0]) and abs(fy[0] - fdy[0] - r0y[0]) < 2e-5
