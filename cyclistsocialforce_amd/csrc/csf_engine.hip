@@ -207,9 +207,13 @@ double far_radius(double kappa, int64_t n, double far_eps) {
     return std::log((double)n / far_eps) / kappa;
 }
 
-void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
+double far_eps() {
     const char *fe = getenv("CSF_FAR_EPS");
-    e->d.pc.rfar = (float)far_radius(e->far_kappa, e->d.n, fe ? atof(fe) : 5.9604644775390625e-8);
+    return fe ? atof(fe) : 5.9604644775390625e-8;   // 2^-24
+}
+
+void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
+    e->d.pc.rfar = (float)far_radius(e->far_kappa, e->d.n, far_eps());
 }
 
 void derive_consts(csf_engine *e) {
@@ -1252,7 +1256,8 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi) {
 int csf_far_radius(const csf_engine *e, double *radius_m) {
     if (!e || !radius_m) return CSF_E_ARG;
     const bool binned = e->d.pair_variant == 0 && e->d.p.model != CSF_BICYCLE && e->d.n >= BIN_MIN_AGENTS;
-    *radius_m = binned ? (double)e->d.pc.rfar : (double)INFINITY;  // no bounding circles, no cull
+    // (computed here rather than read back: the kernel's copy is refreshed with the next upload of the population)
+    *radius_m = binned ? (double)(float)far_radius(e->far_kappa, e->d.n, far_eps()) : (double)INFINITY;  // no circles, no cull
     return CSF_OK;
 }
 

@@ -461,3 +461,30 @@ def test_road_force_exponent_paths_vs_oracle(amd, sigmas):
     # (its two neighbours on the edge, 0.58 m away, pull with O(1) each and nearly cancel: absolute tolerance)
     assert np.isfinite(fx[0]) and abs(fx[0] - fdx[0] - r0x[0]) < 2e-5
     assert np.isfinite(fy[0]) and abs(fy[0] - fdy[0] - r0y[0]) < 2e-5
+
+
+@pytest.mark.parametrize("model", ["twod", "invpend"])
+def test_full_size_ticks_vs_oracle(amd, model):
+    """BASELINE configs 1 and 3 at their full size (16 384 agents, 200 m box): a few whole ticks against the CPU oracle,
+    which evaluates every pair in fp64 (the engine runs with its far-field cull on)."""
+    n, box, ticks = 16384, 200.0, 3
+    x, y, psi, v, off, dq = synthetic_population(n, box)
+    ns = orc.N_STATES[MODELS[model]]
+    s0 = np.zeros((n, ns)); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
+    e = make_engine(amd, model, s0, 5.0, off, dq)
+    assert np.isfinite(e.far_radius()) and e.far_radius() < box * 2 ** 0.5
+    pop = orc.Population(orc.default_params(model), s0, 5.0, off, dq)
+    e.step(ticks); pop.step(ticks)
+    got, ref = e.state(), pop.state()
+    moved = np.abs(ref[:, :2] - s0[:, :2]).max()
+    err = np.abs(got[:, :2] - ref[:, :2]).max()
+    print(f"{model} N={n}: max |dpos| after {ticks} ticks = {err:.3e} m (agents moved up to {moved:.3f} m)")
+    assert err < 1e-4 * moved                                   # 1e-4 relative to the distance covered
+    fx, fy = e.forces(); ox, oy = pop.forces()
+    scale = np.hypot(ox, oy).max()
+    df = np.abs(np.c_[fx - ox, fy - oy]).max(axis=1)
+    print(f"   force error / max force: median {np.median(df) / scale:.2e}, 99.9 % {np.percentile(df, 99.9) / scale:.2e}, "
+          f"max {df.max() / scale:.2e}")
+    # a few of the 2.7e8 pairs are centimetres apart, where the 4e-6 m resolution of the fp32 records shows
+    assert np.median(df) < 2e-6 * scale and np.percentile(df, 99.9) < 1e-4 * scale and df.max() < 5e-4 * scale
+    assert (e.status() == 0).all()
