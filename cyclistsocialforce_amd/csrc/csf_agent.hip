@@ -490,18 +490,22 @@ __device__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, 
     for (int r = 0; r < 5; r++)
 #pragma unroll
         for (int c = 0; c < 6; c++) E[r][c] = (r == c ? 1.0 : 0.0) + M[r][c] * (1.0 / 12);
+    // M has 12 non-zero entries (rows 0, 2, 4 one each, row 3 three, row 1 six): the products M E are written out
+    const double m01 = M[0][1], m23 = M[2][3], m40 = M[4][0], m30 = M[3][0], m31 = M[3][1], m32 = M[3][2];
     for (int k = 11; k >= 1; k--) {
         double T[5][6];
         const double ik = 1.0 / k;
 #pragma unroll
-        for (int r = 0; r < 5; r++)
+        for (int c = 0; c < 6; c++) {
+            double r1 = (c == 5) ? M[1][5] : 0.0;  // M[:,5] * E[5][c], E row 5 = e5
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double acc = (c == 5) ? M[r][5] : 0.0;  // M[:,5] * E[5][c], E row 5 = e5
-#pragma unroll
-                for (int q = 0; q < 5; q++) acc += M[r][q] * E[q][c];
-                T[r][c] = (r == c ? 1.0 : 0.0) + acc * ik;
-            }
+            for (int q = 0; q < 5; q++) r1 += M[1][q] * E[q][c];
+            T[0][c] = (c == 0 ? 1.0 : 0.0) + (m01 * E[1][c]) * ik;
+            T[1][c] = (c == 1 ? 1.0 : 0.0) + r1 * ik;
+            T[2][c] = (c == 2 ? 1.0 : 0.0) + (m23 * E[3][c]) * ik;
+            T[3][c] = (c == 3 ? 1.0 : 0.0) + (m30 * E[0][c] + m31 * E[1][c] + m32 * E[2][c]) * ik;
+            T[4][c] = (c == 4 ? 1.0 : 0.0) + (m40 * E[0][c]) * ik;
+        }
 #pragma unroll
         for (int r = 0; r < 5; r++)
 #pragma unroll
