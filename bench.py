@@ -135,6 +135,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     pair_ms, agent_ms, launches = eng.profile_read()
+    gather_ms = eng.profile_gather()
     eng.profile(0)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -173,6 +174,7 @@ def main():
                 "unit": "GB/s", "frac": alg_bytes / pair_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
                 "launch_us": pair_s * 1e6, "agent_kernel_us": agent_ms * 1e3 / max(launches, 1),
+                "all_gather_us": gather_ms * 1e3 / max(launches, 1),
                 "note": "algorithmic bytes = 16 B x N sources per receiver (SURVEY.md 8(d)); served from LDS/L2, "
                         "so the kernel is VALU-bound: see valu.  Algorithmic = what the reference evaluates (every "
                         "pair); the kernel skips pairs outside the field of view and beyond the far-field radius",

@@ -24,7 +24,7 @@ SYMBOLS = (
     "csf_calc_forces", "csf_apply_forces", "csf_replay_forces", "csf_dest_force", "csf_get_state", "csf_get_forces",
     "csf_get_force_parts", "csf_status", "csf_enable_history", "csf_get_history", "csf_pair_force",
     "csf_comm_unique_id", "csf_comm_init", "csf_shard_range", "csf_profile_enable", "csf_profile_read",
-    "csf_far_radius", "csf_get_tick",
+    "csf_far_radius", "csf_get_tick", "csf_profile_gather",
 )
 
 
@@ -107,6 +107,7 @@ def load():
     L.csf_profile_enable.argtypes = [vp, i32]
     L.csf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i64)]
     L.csf_far_radius.argtypes = [vp, C.POINTER(C.c_double)]
+    L.csf_profile_gather.argtypes = [vp, C.POINTER(C.c_double)]
     L.csf_get_tick.argtypes = [vp, dp, vp, vp, dp, dp, C.POINTER(i64)]
     if L.csf_abi_version() != 1:
         raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 1")

@@ -115,6 +115,8 @@ struct csf_engine {
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, part, froad, kat2;
     double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
+    double last_gather_ms = 0.0;  // all-gather time accumulated by the last csf_profile_read
+    bool ev_gather_recorded = false;
     void *snap_host = nullptr;  // csf_get_tick: pinned, device-mapped staging buffer
     double *snap_dev = nullptr;
     size_t snap_bytes = 0;
@@ -871,8 +873,8 @@ static int enqueue_tick(csf_engine *e) {
     hipEvent_t *pe = nullptr;
     if (e->profile > 0 && e->d.tick % e->profile == 0) {
         size_t base = e->ev.size();
-        e->ev.resize(base + 3);
-        for (int k = 0; k < 3; k++) HIPCHK(e, hipEventCreate(&e->ev[base + k]));
+        e->ev.resize(base + 4);
+        for (int k = 0; k < 4; k++) HIPCHK(e, hipEventCreate(&e->ev[base + k]));
         pe = &e->ev[base];
     }
     const bool overlap = sharded && comm_second_stream();
@@ -899,7 +901,12 @@ static int enqueue_tick(csf_engine *e) {
     d.tick++;
     if (sharded) {
         if (overlap) HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
-        return all_gather_records(e);
+        int rc = all_gather_records(e);
+        if (rc) return rc;
+    }
+    if (pe && sharded) {   // after the collective (unsharded: no fourth record, an event costs ~3 us of launch gap)
+        HIPCHK(e, hipEventRecord(pe[3], overlap ? e->comm : e->main));
+        e->ev_gather_recorded = true;
     }
     return CSF_OK;
 }
@@ -1271,21 +1278,31 @@ int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *
     if (!e) return CSF_E_ARG;
     int rc = csf_sync(e);
     if (rc) return rc;
-    double pm = 0, am = 0;
+    double pm = 0, am = 0, gm = 0;
     int64_t cnt = 0;
-    for (size_t k = 0; k + 2 < e->ev.size(); k += 3) {
-        float a = 0, b = 0;
+    for (size_t k = 0; k + 3 < e->ev.size(); k += 4) {
+        float a = 0, b = 0, c = 0;
         HIPCHK(e, hipEventElapsedTime(&a, e->ev[k], e->ev[k + 1]));
         HIPCHK(e, hipEventElapsedTime(&b, e->ev[k + 1], e->ev[k + 2]));
+        if (e->ev_gather_recorded) HIPCHK(e, hipEventElapsedTime(&c, e->ev[k + 2], e->ev[k + 3]));
         pm += a;
         am += b;
+        gm += c;
         cnt++;
     }
+    e->last_gather_ms = gm;
+    e->ev_gather_recorded = false;
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     e->ev.clear();
     if (pair_ms) *pair_ms = pm;
     if (agent_ms) *agent_ms = am;
     if (launches) *launches = cnt;
+    return CSF_OK;
+}
+
+int csf_profile_gather(const csf_engine *e, double *gather_ms) {
+    if (!e || !gather_ms) return CSF_E_ARG;
+    *gather_ms = e->last_gather_ms;
     return CSF_OK;
 }
 

@@ -249,3 +249,9 @@ class Engine:
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
         self._ck(self._lib.csf_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def profile_gather(self):
+        """all-gather milliseconds accumulated over the launches of the last profile_read() (sharded engines)"""
+        g = C.c_double(0)
+        self._ck(self._lib.csf_profile_gather(self._h, C.byref(g)))
+        return g.value

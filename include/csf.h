@@ -190,6 +190,9 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi);
  * number of sampled launches (reset on read). */
 int csf_profile_enable(csf_engine *e, int32_t on);
 int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *launches);
+/* milliseconds between the end of the agent kernel and the end of the RCCL all-gather, accumulated over the launches
+ * of the last csf_profile_read (0 for an unsharded engine) */
+int csf_profile_gather(const csf_engine *e, double *gather_ms);
 
 /* Far-field radius of the pair kernel (metres; +inf when the cull is off).  The repulsive field of
  * vehicle.py:1560-1648 decays at least like f_0 exp(-kappa rho); sources beyond
