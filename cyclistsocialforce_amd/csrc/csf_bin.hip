@@ -88,6 +88,18 @@ int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals
     return (int)hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_out, vals, d.perm, (int)d.n_pad, 0, 32, st);
 }
 
+__global__ void receiver_keys_kernel(const Dev d, uint32_t *keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.hi - d.lo) keys[i] = (uint32_t)d.pos[d.lo + i];
+}
+
+int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st) {
+    const int64_t m = d.hi - d.lo;
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(receiver_keys_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, keys);
+    return (int)hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, (uint32_t *)rlist_out, (int)m, 0, 32, st);
+}
+
 void launch_identity_perm(const Dev &d, hipStream_t st) {
     if (d.n_pad <= 0) return;
     hipLaunchKernelGGL(identity_perm_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);

@@ -65,6 +65,7 @@ struct Dev {
                        // rec, so that the pair kernel's tile fill is one coalesced load instead of perm -> rec)
     int32_t recs_valid;
     int32_t recv_binned;   // the pair kernel takes its receivers in binned order too and skips far tiles (large populations)
+    const int32_t *rlist;  // recv_binned on a shard: binned positions of this rank's receivers, ascending (NULL: all of them)
     float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
     float4 *bnd_next;  // written by the pair kernel for the next tick (from this tick's records + bnd_margin)
     float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
@@ -101,6 +102,8 @@ int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals
 void launch_identity_perm(const Dev &d, hipStream_t st);
 void launch_sorted_copy(const Dev &d, hipStream_t st);  // pos[] and recs[] from perm[] and rec[]
 void launch_bounds(const Dev &d, hipStream_t st);
+// binned positions of the receivers [lo, hi) of this rank in ascending order (the rank's receivers as neighbours in space)
+int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st);
 
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
                      int apply_fov, float2 *out, hipStream_t st);

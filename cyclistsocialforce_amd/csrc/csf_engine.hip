@@ -109,7 +109,7 @@ struct csf_engine {
     DevBuf<float4> rec, recs, rv, kat4, bnd, bnd2;
     DevBuf<int32_t> pos;
     bool bounds_fresh = false;   // d.bnd describes the current records (else: recompute before the pair kernel)
-    DevBuf<int32_t> perm, sort_vals;
+    DevBuf<int32_t> perm, sort_vals, rlist;
     DevBuf<uint32_t> sort_keys, sort_keys_out;
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
@@ -289,6 +289,7 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->sort_vals.alloc(nrec));
+    HIPCHK(e, e->rlist.alloc(nrec));
     HIPCHK(e, e->sort_keys.alloc(nrec));
     HIPCHK(e, e->sort_keys_out.alloc(nrec));
     HIPCHK(e, e->sort_tmp.alloc(bin_temp_bytes((int64_t)nrec) + 256));
@@ -378,10 +379,9 @@ void set_shard(csf_engine *e) {
         split = blocks > 0 ? (1024 + blocks - 1) / blocks : 1;
     }
     split = std::max<int64_t>(1, std::min<int64_t>({split, (int64_t)MAX_SPLIT, units}));
-    // large unsharded populations run the far-tile-skipping variant (rebin: recv_binned): most tiles of a chunk are
+    // large populations run the far-tile-skipping variant (rebin: recv_binned): most tiles of a chunk are
     // skipped unloaded, and longer chunks amortise the workgroup's start-up (config 4: 7.3 ms at 64 chunks, 6.2 at 8-16)
-    if (e->world <= 1 && e->nccl == nullptr && d.lo == 0 && d.hi == d.n && d.n_pad >= 65536 && d.p.model != CSF_BICYCLE)
-        split = std::min<int64_t>(split, 16);
+    if (d.n_pad >= 65536 && d.p.model != CSF_BICYCLE) split = std::min<int64_t>(split, 16);
     if (const char *ov = getenv("CSF_NSPLIT")) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoi(ov), (int64_t)MAX_SPLIT, units}));
     d.n_split = (int32_t)split;
 }
@@ -405,10 +405,17 @@ int rebin(csf_engine *e) {
     // gathered records before every pair launch of a sharded run (enqueue_tick)
     d.recs_valid = binned;
     if (d.recs_valid) launch_sorted_copy(d, e->main);
-    {   // receivers in binned order + far-tile skipping: every record local, and enough tiles for it to pay
-        static const char *ov = getenv("CSF_RECV_BINNED");
-        const bool whole = e->world <= 1 && e->nccl == nullptr && d.lo == 0 && d.hi == d.n;
-        d.recv_binned = binned && whole && std::isfinite(d.pc.rfar) && (ov ? atoi(ov) != 0 : d.n_pad >= 65536);
+    {   // receivers in binned order + far-tile skipping, where there are enough tiles for it to pay.  A rank that owns
+        // an index block [lo, hi) takes ITS receivers in binned order: their positions, sorted
+        const char *ov = getenv("CSF_RECV_BINNED");
+        const bool whole = d.lo == 0 && d.hi == d.n;
+        d.recv_binned = binned && d.recs_valid && std::isfinite(d.pc.rfar) && (ov ? atoi(ov) != 0 : d.n_pad >= 65536);
+        d.rlist = nullptr;
+        if (d.recv_binned && !whole) {
+            int rc = launch_receiver_list(d, e->sort_keys.p, e->rlist.p, e->sort_tmp.p, e->sort_tmp.n, e->main);
+            if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the receiver positions failed (%d)", rc);
+            d.rlist = e->rlist.p;
+        }
     }
     e->ticks_since_rebin = 0;
     e->bounds_fresh = false;
@@ -666,7 +673,7 @@ int csf_destroy(csf_engine *e) {
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
-    e->sort_vals.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
+    e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);
     if (e->main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);

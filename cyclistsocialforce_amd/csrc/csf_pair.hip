@@ -185,7 +185,7 @@ __device__ __forceinline__ void load_receivers(const Dev &d, int64_t j0, Recv (&
 // reduced together: each of the first three butterfly steps hands half of the values to the partner lane, the
 // last three steps finish the one value a lane is left with.  10 shuffles instead of 48; fixed order.
 __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane, const float (&ax)[RPW],
-                                             const float (&ay)[RPW], const int32_t *perm = nullptr) {
+                                             const float (&ay)[RPW], const int *agent_of = nullptr) {
     static_assert(RPW == 4, "the reduction below is written for eight values");
     float v[8] = {ax[0], ay[0], ax[1], ay[1], ax[2], ay[2], ax[3], ay[3]};
     float w[4];
@@ -208,8 +208,9 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
     // lane 8*k holds value index 4*bit5 + 2*bit4 + bit3
     const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     const int u = idx >> 1;
-    if ((lane & 7) == 0 && j0 + u < d.hi) {   // perm: the receivers are positions of the binned order (BINR)
-        const int64_t a = perm ? (int64_t)perm[j0 + u] : j0 + u;
+    // agent_of (BINR): agent index of each of the wave's receivers, -1 for none (LDS); else the receivers are j0 + u
+    const int64_t a = agent_of ? (int64_t)agent_of[u] : (j0 + u < d.hi ? j0 + u : -1);
+    if ((lane & 7) == 0 && a >= 0) {
         float *dst = (float *)&d.part[(int64_t)blockIdx.y * d.cap + a];
         dst[idx & 1] = z;
     }
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
     __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave: drained after each receiver
     __shared__ float4 rrec[WPB * RPW];
+    __shared__ int ragent[BINR ? WPB * RPW : 1];   // BINR: agent index of every receiver of the workgroup (-1: none)
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
@@ -303,7 +305,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     if (threadIdx.x < WPB * RPW) {
         const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
         const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
-        rrec[threadIdx.x] = BINR ? d.recs[jc] : d.rec[jc];   // BINR: j is a position of the binned order
+        if (BINR) {  // receiver slot jc - lo of this rank -> position of the binned order -> agent
+            const int64_t p = d.rlist ? (int64_t)d.rlist[jc - d.lo] : jc;
+            rrec[threadIdx.x] = d.recs[p];
+            ragent[threadIdx.x] = j < d.hi ? d.perm[p] : -1;
+        } else {
+            rrec[threadIdx.x] = d.rec[jc];
+        }
     }
     __syncthreads();
     float gx = 0.f, gy = 0.f, gr = 0.f;   // BINR: bounding circle of the workgroup's receivers (the same in every wave)
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             if (qlen > 0) pop(u, std::false_type{});
         }
     }
-    reduce_store(d, j0, lane, ax, ay, BINR ? d.perm : nullptr);
+    reduce_store(d, j0, lane, ax, ay, BINR ? &ragent[wave * RPW] : nullptr);
     if (d.trace && lane == 0) {   // tools/block_trace.py: when did every wave run, and where
         uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave);
         o[0] = t_start;

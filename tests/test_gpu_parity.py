@@ -488,3 +488,35 @@ def test_full_size_ticks_vs_oracle(amd, model):
     # a few of the 2.7e8 pairs are centimetres apart, where the 4e-6 m resolution of the fp32 records shows
     assert np.median(df) < 2e-6 * scale and np.percentile(df, 99.9) < 1e-4 * scale and df.max() < 5e-4 * scale
     assert (e.status() == 0).all()
+
+
+def test_binned_receivers_and_far_tile_skip_are_exact(amd, monkeypatch):
+    """Large populations take their receivers in binned order and skip tiles of sources that lie beyond the far-field
+    radius of a whole receiver group without loading them (csf_pair.hip, BINR); a rank of a sharded run does the same
+    with the binned order of ITS receivers.  Neither changes which terms enter a column sum."""
+    n, box = 8192, 700.0
+    x, y, psi, v, off, dq = synthetic_population(n, box)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+
+    def rep(binned, shard=None):
+        monkeypatch.setenv("CSF_RECV_BINNED", "1" if binned else "0")
+        if shard is None:
+            monkeypatch.delenv("CSF_FAKE_SHARD", raising=False)
+        else:
+            monkeypatch.setenv("CSF_FAKE_SHARD", shard)
+        e = make_engine(amd, "twod", s0, 1e6, off, dq)       # |F_dest| = 1e6: the clamp never acts
+        e.calc_forces()
+        lo, hi = e.shard_range()
+        _, _, rx, ry = e.force_parts()
+        return lo, hi, rx, ry
+
+    _, _, x0, y0 = rep(False)
+    assert np.abs(x0).max() > 0
+    _, _, x1, y1 = rep(True)
+    assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+    for shard in ("0/4", "3/4", "2/3"):
+        lo, hi, xs, ys = rep(True, shard)
+        assert 0 <= lo < hi <= n and hi - lo < n
+        # (a shard splits the sources into a different number of chunks: the same terms, another fp32 summation order)
+        scale = np.hypot(x0, y0).max()
+        assert np.abs(xs[lo:hi] - x0[lo:hi]).max() < 2e-6 * scale and np.abs(ys[lo:hi] - y0[lo:hi]).max() < 2e-6 * scale, shard
