@@ -182,30 +182,40 @@ __device__ __forceinline__ void load_receivers(const Dev &d, int64_t j0, Recv (&
 }
 
 // column sum (intersection.py:841-843) of the 2 x RPW per-lane accumulators of a wave.  The eight values are
-// reduced together: each of the first three butterfly steps hands half of the values to the partner lane, the
-// last three steps finish the one value a lane is left with.  10 shuffles instead of 48; fixed order.
+// reduced together: each of the first three butterfly steps hands half of the values to the partner lanes, the last
+// three finish the one value a lane is left with.  gfx950 lane exchanges, no LDS and no address arithmetic
+// (__shfl_xor costs four VALU instructions and a ds_bpermute each): v_permlane32_swap / v_permlane16_swap exchange the
+// upper half (odd rows) of one register with the lower half (even rows) of another, so one swap and one add
+// reduce two values across the halves; DPP modifiers on the adds do the rest.  Fixed order: bit-reproducible.
+__device__ __forceinline__ float swap_add32(float a, float b) {   // lanes < 32: a over both halves; lanes >= 32: b
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {   // even rows of 16: a over the row pair; odd rows: b
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp(float x) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_ROW_ROR8 = 0x128, DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141;
+
 __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane, const float (&ax)[RPW],
                                              const float (&ay)[RPW], const int *agent_of = nullptr) {
     static_assert(RPW == 4, "the reduction below is written for eight values");
-    float v[8] = {ax[0], ay[0], ax[1], ay[1], ax[2], ay[2], ax[3], ay[3]};
-    float w[4];
-    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+    const float v[8] = {ax[0], ay[0], ax[1], ay[1], ax[2], ay[2], ax[3], ay[3]};
+    float w[4], y[2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float send = h5 ? v[i] : v[i + 4], keep = h5 ? v[i + 4] : v[i];
-        w[i] = keep + __shfl_xor(send, 32, WAVE);
-    }
-    float y[2];
+    for (int i = 0; i < 4; i++) w[i] = swap_add32(v[i], v[i + 4]);
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const float send = h4 ? w[i] : w[i + 2], keep = h4 ? w[i + 2] : w[i];
-        y[i] = keep + __shfl_xor(send, 16, WAVE);
-    }
-    float z = (h3 ? y[1] : y[0]) + __shfl_xor(h3 ? y[0] : y[1], 8, WAVE);
-    z += __shfl_xor(z, 4, WAVE);
-    z += __shfl_xor(z, 2, WAVE);
-    z += __shfl_xor(z, 1, WAVE);
-    // lane 8*k holds value index 4*bit5 + 2*bit4 + bit3
+    for (int i = 0; i < 2; i++) y[i] = swap_add16(w[i], w[i + 2]);
+    const bool h3 = lane & 8;
+    float z = (h3 ? y[1] : y[0]) + dpp<DPP_ROW_ROR8>(h3 ? y[0] : y[1]);
+    z += dpp<DPP_XOR1>(z);
+    z += dpp<DPP_XOR2>(z);
+    z += dpp<DPP_HALF_MIRROR>(z);
+    // every lane of a group of 8 holds value index 4*bit5 + 2*bit4 + bit3 of the lane number
     const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     const int u = idx >> 1;
     // agent_of (BINR): agent index of each of the wave's receivers, -1 for none (LDS); else the receivers are j0 + u
