@@ -241,6 +241,10 @@ typedef const volatile __attribute__((address_space(3))) float *lds_vfp;   // vo
 __device__ __forceinline__ v2f lds_pair(const float *a, int i0, int i1) {
     return v2f{*(lds_vfp)(a + i0), *(lds_vfp)(a + i1)};
 }
+// the same with BYTE offsets (what the queue stores: no shift between the queue read and the tile read)
+__device__ __forceinline__ v2f lds_pair_b(const float *a, int o0, int o1) {
+    return v2f{*(lds_vfp)((const char *)a + o0), *(lds_vfp)((const char *)a + o1)};
+}
 
 // ---- culling kernel (TwoD field): classify batches -> test -> ballot -> LDS queue -> packed field ---------
 // CLASSIFY: the records are streamed in spatially binned order (csf_bin.hip) and every batch of 64 carries a
@@ -259,7 +263,8 @@ template <bool P2R, bool CLASSIFY, bool BINR>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
-    __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave: drained after each receiver
+    __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave, drained after each receiver; holds BYTE offsets
+                                                 // into the tile arrays (4 x index <= 4092)
     __shared__ float4 rrec[WPB * RPW];
     __shared__ int ragent[BINR ? WPB * RPW : 1];   // BINR: agent index of every receiver of the workgroup (-1: none)
     const int lane = threadIdx.x & (WAVE - 1);
@@ -293,8 +298,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         int i1 = queue[wave][(qhead + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
         if (!FULL) i0 = v0 ? i0 : 0, i1 = v1 ? i1 : 0;
-        field_twod_x2<FULL>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
-                            lds_pair(ts, i0, i1), v0, v1, ax[u], ay[u]);
+        field_twod_x2<FULL>(k, ru, lds_pair_b(tx, i0, i1), lds_pair_b(ty, i0, i1), lds_pair_b(tc, i0, i1),
+                            lds_pair_b(ts, i0, i1), v0, v1, ax[u], ay[u]);
         qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
         qlen = __builtin_amdgcn_readfirstlane(qlen - n);
     };
@@ -420,17 +425,17 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             while (cand) {
                 const int b = __builtin_ctz(cand);
                 cand &= cand - 1u;
-                const int t = (b << 6) + lane;
+                const int tb = (b << 8) + 4 * lane;   // byte offset of this lane's record in the tile arrays
                 if ((inside >> b) & 1u) {
-                    queue[wave][(qhead + qlen + lane) & (QCAP - 1)] = (unsigned short)t;
+                    queue[wave][(qhead + qlen + lane) & (QCAP - 1)] = (unsigned short)tb;
                     qlen = __builtin_amdgcn_readfirstlane(qlen + WAVE);
                 } else {
-                    const float dx = ru.x - tx[t], dy = ru.y - ty[t];
+                    const float dx = ru.x - *(const float *)((const char *)tx + tb), dy = ru.y - *(const float *)((const char *)ty + tb);
                     const bool in = tracked<P2R>(k.chs, ru, dx, dy, dx * dx + dy * dy);
                     const unsigned long long m = __ballot(in);
                     if (in) {
                         const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)t;
+                        queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)tb;
                     }
                     qlen = __builtin_amdgcn_readfirstlane(qlen + __builtin_popcountll(m));
                 }
