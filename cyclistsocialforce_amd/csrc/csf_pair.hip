@@ -383,7 +383,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
             const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
             const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
-            const float sb = fabsf(rc * ey - rs * ex) * invD;
+            const float off = rc * ey - rs * ex;                      // centre's offset from the heading line, left > 0
+            const float sb = fabsf(off) * invD;
             const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
             const bool fov = apart & (k.fov_classify != 0);
             // outside: the heading misses the circle (|beta| > alpha) and cos(|beta| - alpha) < cos(hfov/2)
@@ -391,8 +392,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             // resolution of the fp32 column sum (csf_engine.hip: far_radius)
             const float reach = k.rfar + bb.z;
             const bool far = D2 > reach * reach;
-            const bool out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
-            const bool in = !P2R & fov & !far & ((cb * ca - sb * sa) > k.ch + 1e-4f);  // cos(|beta| + alpha) > cos(hfov/2)
+            bool out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
+            bool in = fov & !far & ((cb * ca - sb * sa) > k.ch + 1e-4f);               // cos(|beta| + alpha) > cos(hfov/2)
+            if (P2R) {  // priority to the right (intersection.py:739-741): sources to the left are ignored
+                const float clear = bb.z * 1.0001f + 1e-4f;
+                out = out | (off > clear);      // the whole circle is to the left of the heading line
+                in = in & (off < -clear);       // ... to the right of it
+            }
             const bool valid = (lane & 15) < nb;
             cand_all = __ballot(valid & !out);
             inside_all = __ballot(valid & in);
