@@ -17,11 +17,11 @@ struct PairConsts {
     float lf0;                         // log2(f_0); Bicycle field: log2(p_0 / p_decay) (vehicle.py:1101, 1132)
     float kexp;                        // log2(e)
     float chs;                         // -cos^2(hfov/2) for hfov <= pi, +cos^2 beyond (intersection.py:733-736)
-    float ch;                          // cos(hfov/2) (batch classification, hfov <= pi only)
+    float ch;                          // cos(hfov/2) (batch classification)
     float ipd;                         // Bicycle field: 1 / p_decay (vehicle.py:1095-1099)
     int32_t p2r;                       // intersection.py:739-741
     int32_t f0_zero;                   // vehicle.py:1592-1593
-    int32_t fov_classify;              // hfov <= pi: whole batches can be classified against the field-of-view cone
+    int32_t fov_classify;              // whole batches are classified against the field-of-view cone
     float rfar;                        // sources farther than this add less than far_eps * f_0 / n in magnitude (inf: off)
 };
 

@@ -248,7 +248,7 @@ __device__ __forceinline__ v2f lds_pair_b(const float *a, int o0, int o1) {
 
 // ---- culling kernel (TwoD field): classify batches -> test -> ballot -> LDS queue -> packed field ---------
 // CLASSIFY: the records are streamed in spatially binned order (csf_bin.hip) and every batch of 64 carries a
-// bounding circle.  Per receiver and tile, lane b classifies batch b against the field-of-view cone (hfov <= pi):
+// bounding circle.  Per receiver and tile, lane b classifies batch b against the field-of-view cone:
 //   outside (smallest bearing in the circle > hfov/2)  -> skipped without touching its records,
 //   inside  (largest bearing in the circle  < hfov/2)  -> all 64 lanes queued without per-lane tests,
 //   else                                               -> exact per-lane test (intersection.py:690-745).
@@ -393,7 +393,9 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             const float reach = k.rfar + bb.z;
             const bool far = D2 > reach * reach;
             bool out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
-            bool in = fov & !far & ((cb * ca - sb * sa) > k.ch + 1e-4f);               // cos(|beta| + alpha) > cos(hfov/2)
+            // inside: cos(|beta| + alpha) > cos(hfov/2) with |beta| + alpha < pi (beyond, the circle reaches across the
+            // rear axis and the cosine is no longer monotone: hfov > pi)
+            bool in = fov & !far & ((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f);
             if (P2R) {  // priority to the right (intersection.py:739-741): sources to the left are ignored
                 const float clear = bb.z * 1.0001f + 1e-4f;
                 out = out | (off > clear);      // the whole circle is to the left of the heading line
