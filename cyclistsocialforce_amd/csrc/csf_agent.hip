@@ -626,7 +626,9 @@ __device__ __forceinline__ void write_record(const Dev &d, int64_t a, double x, 
     if (d.p.model == CSF_BICYCLE) {                           // vehicle.py:1062-1064 (v <= 0: e := 0)
         double e = 0.0;
         if (v > 0.0) e = fmin(pow(v / d.p.v_max_riding[1], 0.1), 0.7);
-        d.rec2[a] = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
+        const float2 q2 = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
+        d.rec2[a] = q2;
+        if (d.recs_valid) d.recs2[d.pos[a]] = q2;
     }
 }
 

@@ -63,6 +63,7 @@ struct Dev {
     int32_t *pos;      // [n_pad] inverse of perm (record index -> position)
     float4 *recs;      // [n_pad] the records in binned order (single device: written by the agent kernel beside
                        // rec, so that the pair kernel's tile fill is one coalesced load instead of perm -> rec)
+    float2 *recs2;     // [n_pad] Bicycle field: rec2 in binned order
     int32_t recs_valid;
     int32_t recv_binned;   // the pair kernel takes its receivers in binned order too and skips far tiles (large populations)
     const int32_t *rlist;  // recv_binned on a shard: binned positions of this rank's receivers, ascending (NULL: all of them)

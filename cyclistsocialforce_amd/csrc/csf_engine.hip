@@ -113,7 +113,7 @@ struct csf_engine {
     DevBuf<uint32_t> sort_keys, sort_keys_out;
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
-    DevBuf<float2> rec2, part, froad, kat2;
+    DevBuf<float2> rec2, recs2, part, froad, kat2;
     double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
     double last_gather_ms = 0.0;  // all-gather time accumulated by the last csf_profile_read
     bool ev_gather_recorded = false;
@@ -283,6 +283,7 @@ int alloc_all(csf_engine *e) {
     size_t nrec = (cap + 64 * 64 + 63) / 64 * 64;
     HIPCHK(e, e->rec.alloc(nrec));
     HIPCHK(e, e->rec2.alloc(nrec));
+    HIPCHK(e, e->recs2.alloc(nrec));
     HIPCHK(e, e->perm.alloc(nrec));
     HIPCHK(e, e->pos.alloc(nrec));
     HIPCHK(e, e->recs.alloc(nrec));
@@ -329,6 +330,7 @@ int alloc_all(csf_engine *e) {
     d.froad = e->froad.p;
     d.rec = e->rec.p;
     d.rec2 = e->rec2.p;
+    d.recs2 = e->recs2.p;
     d.perm = e->perm.p;
     d.pos = e->pos.p;
     d.recs = e->recs.p;
@@ -392,7 +394,7 @@ constexpr int64_t BIN_MIN_AGENTS = 1024;
 // (re)build the spatially binned order of the records; decides whether batches are classified this tick
 int rebin(csf_engine *e) {
     Dev &d = e->d;
-    const bool binned = d.pair_variant == 0 && d.p.model != CSF_BICYCLE && d.n >= BIN_MIN_AGENTS;
+    const bool binned = d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS;
     d.classify = binned;
     update_far_radius(e);
     if (binned) {
@@ -671,7 +673,7 @@ int csf_destroy(csf_engine *e) {
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qoff.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
-    e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release();
+    e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);

@@ -515,6 +515,108 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
     reduce_store(d, j0, lane, ax, ay);
 }
 
+// ---- Bicycle field on binned records: whole batches outside the field of view are skipped --------------------
+// The older elliptic field (vehicle.py:1054-1147) costs ~30 instructions per pair, so there is no sifting and no
+// queue here: batches are classified exactly as in pair_cull_kernel (bounding circle against the field-of-view cone,
+// priority-to-the-right side test), the outside ones (62 % at hfov = 2 pi / 3) are skipped, the others are evaluated
+// lane by lane, with the exact mask of intersection.py:690-745 unless the whole batch is inside.
+// The field decays like exp(-0.084 rho) at worst (p_decay = 5 m): no far-field cull.
+template <bool P2R>
+__global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
+    __shared__ float4 tile[TILE];
+    __shared__ float2 tile2[TILE];
+    __shared__ float4 tbnd[TILE / WAVE];
+    __shared__ float4 rrec[WPB * RPW];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
+    int64_t ibeg, iend;
+    source_chunk(d, ibeg, iend);
+    if (d.bnd_next != nullptr && blockIdx.y == 0) {   // the next tick's bounding circles (see pair_cull_kernel)
+        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_pad; b += (int64_t)gridDim.x * WPB)
+            batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
+    }
+    if (ibeg >= iend) return;
+    if (threadIdx.x < WPB * RPW) {
+        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
+        rrec[threadIdx.x] = d.rec[j < d.hi ? j : d.hi - 1];  // clamp: results of the duplicates are not stored
+    }
+    float ax[RPW], ay[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f;
+    PairConsts k = d.pc;
+    asm volatile("" : "+v"(k.lf0), "+v"(k.kexp), "+v"(k.chs), "+v"(k.ipd));
+    static_assert(TILE / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
+    for (int64_t base = ibeg; base < iend; base += TILE) {
+        const int cnt = (int)((iend - base) < TILE ? (iend - base) : TILE);  // multiple of 64
+        const int nb = cnt >> 6;
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += BLOCK) {
+            tile[t] = d.recs[base + t];
+            tile2[t] = d.recs2[base + t];
+        }
+        if ((int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
+        __syncthreads();
+        unsigned long long cand_all, inside_all;
+        {
+            const float4 rl = rrec[wave * RPW + (lane >> 4)];
+            const float rc = rl.z, rs = rl.w;
+            const float4 bb = tbnd[lane & 15];
+            const float ex = bb.x - rl.x, ey = bb.y - rl.y;           // receiver -> centre of the batch
+            const float D2 = ex * ex + ey * ey;
+            const float invD = fast_rsq(fmaxf(D2, 1e-30f));
+            const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
+            const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
+            const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
+            const float off = rc * ey - rs * ex;                      // centre's offset from the heading line, left > 0
+            const float sb = fabsf(off) * invD;
+            const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
+            bool out = apart & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f);
+            bool in = apart & ((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f);
+            if (P2R) {
+                const float clear = bb.z * 1.0001f + 1e-4f;
+                out = out | (off > clear);
+                in = in & (off < -clear);
+            }
+            const bool valid = (lane & 15) < nb;
+            cand_all = __ballot(valid & !out);
+            inside_all = __ballot(valid & in);
+        }
+#pragma unroll
+        for (int u = 0; u < RPW; u++) {
+            Recv r;
+            {
+                const float4 q = rrec[wave * RPW + u];
+                r.x = q.x, r.y = q.y, r.c = q.z, r.s = q.w;
+                asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.c), "+v"(r.s));
+            }
+            unsigned cand = (unsigned)(cand_all >> (16 * u)) & 0xFFFFu;
+            const unsigned inside = (unsigned)(inside_all >> (16 * u)) & 0xFFFFu;
+            while (cand) {
+                const int b = __builtin_ctz(cand);
+                cand &= cand - 1u;
+                const int t = (b << 6) + lane;
+                const float4 q = tile[t];
+                const float2 qb = tile2[t];
+                const float dx = r.x - q.x, dy = r.y - q.y;          // vehicle.py:1615-1616
+                float r2 = dx * dx + dy * dy;
+                float F, gx, gy;
+                if ((inside >> b) & 1u) {                            // (uniform) every source of the batch is tracked
+                    field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
+                } else {
+                    const bool in = tracked<P2R>(k.chs, r, dx, dy, r2);
+                    r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
+                    field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
+                    F = in ? F : 0.0f;
+                }
+                ax[u] += F * gx;
+                ay[u] += F * gy;
+            }
+        }
+    }
+    reduce_store(d, j0, lane, ax, ay);
+}
+
 // intersection.py:226-242: F = sum_k -F0 r_k^-sigma (v_k - p)/r_k over the polyline vertices.
 // Same mapping: vertices in the lanes (two per lane, packed arithmetic), receivers wave-uniform.  NP = sigma + 1 when
 // every edge shares one small integer sigma (the reference's defaults: 3; the curve scenario: 2): r^-(sigma+1) is then
@@ -628,7 +730,10 @@ void launch_pair(const Dev &d, hipStream_t st) {
     if (d.hi <= d.lo) return;
     const dim3 g = recv_grid(d, d.n_split), b(BLOCK);
     const bool p2r = d.pc.p2r != 0;
-    if (d.p.model == CSF_BICYCLE) {
+    if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
+        if (p2r) hipLaunchKernelGGL((pair_bike_kernel<true>), g, b, 0, st, d);
+        else hipLaunchKernelGGL((pair_bike_kernel<false>), g, b, 0, st, d);
+    } else if (d.p.model == CSF_BICYCLE) {
         if (p2r) hipLaunchKernelGGL((pair_kernel<true, true>), g, b, 0, st, d);
         else hipLaunchKernelGGL((pair_kernel<true, false>), g, b, 0, st, d);
     } else if (d.pair_variant == 1) {

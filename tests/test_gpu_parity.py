@@ -520,3 +520,31 @@ def test_binned_receivers_and_far_tile_skip_are_exact(amd, monkeypatch):
         # (a shard splits the sources into a different number of chunks: the same terms, another fp32 summation order)
         scale = np.hypot(x0, y0).max()
         assert np.abs(xs[lo:hi] - x0[lo:hi]).max() < 2e-6 * scale and np.abs(ys[lo:hi] - y0[lo:hi]).max() < 2e-6 * scale, shard
+
+
+@pytest.mark.parametrize("hfov,rule", [(np.pi * 2 / 3, 0), (np.pi * 2 / 3, 1), (4.0, 0), (2 * np.pi, 0)])
+def test_bicycle_field_on_binned_records_vs_oracle(amd, hfov, rule):
+    """The older elliptic field (vehicle.py:1054-1147) at N >= 1024: binned records, batches outside the field of view
+    skipped whole (pair_bike_kernel); column sums of one evaluation and a short run against the oracle."""
+    n, box = 2048, 120.0
+    x, y, psi, v, off, dq = synthetic_population(n, box, seed=3)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    e = make_engine(amd, "bicycle", s0, 1e6, off, dq, rule=rule, hfov=float(hfov))
+    e.calc_forces()
+    _, _, rx, ry = e.force_parts()
+    p = orc.default_params("bicycle", priority_rule=rule, hfov=float(hfov))
+    pop = orc.Population(p, s0, 1e6, off, dq)
+    pop.calc_forces_range(0, n)
+    _, _, ox, oy = pop.force_parts()
+    scale = max(np.hypot(ox, oy).max(), 1.0)
+    err = np.abs(np.c_[rx - ox, ry - oy]).max() / scale
+    print(f"bicycle hfov={hfov:.3f} rule={rule}: max |dF_rep| / max|F_rep| = {err:.2e}")
+    assert err < 5e-5
+    e2 = make_engine(amd, "bicycle", s0, 5.0, off, dq, rule=rule, hfov=float(hfov))
+    pop2 = orc.Population(p, s0, 5.0, off, dq)
+    e2.step(40); pop2.step(40)                                    # crosses a re-binning (every 32 ticks)
+    dev = np.abs(e2.state()[:, :2] - pop2.state()[:, :2]).max(axis=1)
+    # a source that crosses a receiver's field-of-view boundary can do so one tick apart in fp32 and fp64 (DESIGN D6);
+    # the force jumps there, and that one receiver then follows a different path (seen with hfov = 4.0: 1 of 2048)
+    assert np.percentile(dev, 99.5) < 1e-4 * box and (dev > 1e-4 * box).sum() <= 3
+    assert (e2.status() == 0).all()
