@@ -22,6 +22,7 @@ struct PairConsts {
     int32_t p2r;                       // intersection.py:739-741
     int32_t f0_zero;                   // vehicle.py:1592-1593
     int32_t fov_classify;              // whole batches are classified against the field-of-view cone
+    int32_t full_circle;               // hfov >= 2 pi: every bearing is inside the field of view
     float rfar;                        // sources farther than this add less than far_eps * f_0 / n in magnitude (inf: off)
 };
 

@@ -243,6 +243,7 @@ void derive_consts(csf_engine *e) {
         k.ipd = 0.f;
         k.f0_zero = p.f_0 == 0.0;
     }
+    k.full_circle = p.hfov >= 2 * PI_;
     k.fov_classify = 1;   // any field of view: csf_pair.hip guards the wide ones (set to 0 to fall back to exact tests)
     e->far_kappa = far_kappa(p);
     update_far_radius(e);

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             bool out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
             // inside: cos(|beta| + alpha) > cos(hfov/2) with |beta| + alpha < pi (beyond, the circle reaches across the
             // rear axis and the cosine is no longer monotone: hfov > pi)
-            bool in = fov & !far & ((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f);
+            bool in = fov & !far & ((((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f)) | (k.full_circle != 0));
             if (P2R) {  // priority to the right (intersection.py:739-741): sources to the left are ignored
                 const float clear = bb.z * 1.0001f + 1e-4f;
                 out = out | (off > clear);      // the whole circle is to the left of the heading line
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
             const float sb = fabsf(off) * invD;
             const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
             bool out = apart & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f);
-            bool in = apart & ((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f);
+            bool in = apart & ((((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f)) | (k.full_circle != 0));
             if (P2R) {
                 const float clear = bb.z * 1.0001f + 1e-4f;
                 out = out | (off > clear);
