@@ -149,6 +149,13 @@ class Engine:
 
     # -- read-back --------------------------------------------------------------------------
     def state(self, with_nav=False):
+        """[n, n_states] state (and destination pointers, one-hot navigation state, tick count): one packed transfer
+        (csf_get_tick; csf_get_state copies component by component)"""
+        s, ptr, zn, _, _, tick = self.tick_snapshot(forces=False)
+        return (s, ptr, zn, tick) if with_nav else s
+
+    def state_by_component(self, with_nav=False):
+        """the same through csf_get_state"""
         n = self.n
         s = np.zeros((n, self.ns))
         if not with_nav:

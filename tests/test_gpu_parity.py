@@ -412,10 +412,10 @@ def test_tick_snapshot_equals_separate_readbacks(amd):
         s0 = np.zeros((n, ns)); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
         e = make_engine(amd, model, s0, 5.0, off, dq)
         s, ptr, zn, fx, fy, tick = e.tick_snapshot()          # before any tick: the uploaded state
-        assert tick == 0 and np.array_equal(s, e.state())
+        assert tick == 0 and np.array_equal(s, e.state_by_component())
         e.step(7)
         s, ptr, zn, fx, fy, tick = e.tick_snapshot()
-        s2, ptr2, zn2, tick2 = e.state(with_nav=True)
+        s2, ptr2, zn2, tick2 = e.state_by_component(with_nav=True)
         fx2, fy2 = e.forces()
         assert tick == tick2 == 7
         assert np.array_equal(s, s2) and np.array_equal(ptr, ptr2) and np.array_equal(zn, zn2)

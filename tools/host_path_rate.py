@@ -41,9 +41,9 @@ def array_path(n, box, ticks):
     t0 = time.perf_counter()
     for _ in range(ticks):
         e.step(1)
-        e.state()
+        e.state_by_component()
     dt = time.perf_counter() - t0
-    print(f"Engine.step(1) + state() read-back          N={n:6d}: {dt / ticks * 1e3:8.3f} ms/tick  {n * ticks / dt:12.0f} agent-steps/s")
+    print(f"Engine.step(1) + csf_get_state read-back    N={n:6d}: {dt / ticks * 1e3:8.3f} ms/tick  {n * ticks / dt:12.0f} agent-steps/s")
     t0 = time.perf_counter()
     for _ in range(ticks):
         e.step(1)
