@@ -246,6 +246,41 @@ __device__ __forceinline__ v2f lds_pair_b(const float *a, int o0, int o1) {
     return v2f{*(lds_vfp)((const char *)a + o0), *(lds_vfp)((const char *)a + o1)};
 }
 
+// Classification of one batch of 64 binned source records (bounding circle bb = centre, radius) against one receiver rl
+// = (x, y, cos psi, sin psi).  out: no source of the batch can be tracked (or all are beyond the far-field radius);
+// in: every source is tracked and none is far.  Both keep a 1e-4 margin and need the receiver outside the circle, so
+// whatever they leave undecided goes to the exact per-lane test (intersection.py:690-745).
+//   outside: the heading misses the circle (|beta| > alpha) and cos(|beta| - alpha) < cos(hfov/2)
+//   inside:  cos(|beta| + alpha) > cos(hfov/2) with |beta| + alpha < pi (beyond, the circle reaches across the rear
+//            axis and the cosine is no longer monotone: hfov > pi); any circle when hfov >= 2 pi
+//   priority to the right (intersection.py:739-741): a circle wholly to the left of the heading line is outside,
+//            and only one wholly to the right can be inside
+//   far:     every source is beyond the radius at which the field has decayed below the resolution of the fp32
+//            column sum (csf_engine.hip: far_radius; +inf for the Bicycle field)
+template <bool P2R>
+__device__ __forceinline__ void classify_batch(const PairConsts &k, const float4 rl, const float4 bb, bool &out, bool &in) {
+    const float rc = rl.z, rs = rl.w;
+    const float ex = bb.x - rl.x, ey = bb.y - rl.y;           // receiver -> centre of the batch
+    const float D2 = ex * ex + ey * ey;
+    const float invD = fast_rsq(fmaxf(D2, 1e-30f));
+    const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
+    const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
+    const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
+    const float off = rc * ey - rs * ex;                      // centre's offset from the heading line, left > 0
+    const float sb = fabsf(off) * invD;
+    const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
+    const bool fov = apart & (k.fov_classify != 0);
+    const float reach = k.rfar + bb.z;
+    const bool far = D2 > reach * reach;
+    out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
+    in = fov & !far & ((((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f)) | (k.full_circle != 0));
+    if (P2R) {
+        const float clear = bb.z * 1.0001f + 1e-4f;
+        out = out | (off > clear);
+        in = in & (off < -clear);
+    }
+}
+
 // ---- culling kernel (TwoD field): classify batches -> test -> ballot -> LDS queue -> packed field ---------
 // CLASSIFY: the records are streamed in spatially binned order (csf_bin.hip) and every batch of 64 carries a
 // bounding circle.  Per receiver and tile, lane b classifies batch b against the field-of-view cone:
@@ -373,34 +408,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         static_assert(TILE2 / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
         unsigned long long cand_all = ~0ull, inside_all = 0ull;
         if (CLASSIFY) {
-            const int grp = lane >> 4;
-            const float4 rl = rrec[wave * RPW + grp];
-            const float rx = rl.x, ry = rl.y, rc = rl.z, rs = rl.w;
-            const float4 bb = tbnd[lane & 15];
-            const float ex = bb.x - rx, ey = bb.y - ry;               // receiver -> centre of the batch
-            const float D2 = ex * ex + ey * ey;
-            const float invD = fast_rsq(fmaxf(D2, 1e-30f));
-            const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
-            const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
-            const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
-            const float off = rc * ey - rs * ex;                      // centre's offset from the heading line, left > 0
-            const float sb = fabsf(off) * invD;
-            const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
-            const bool fov = apart & (k.fov_classify != 0);
-            // outside: the heading misses the circle (|beta| > alpha) and cos(|beta| - alpha) < cos(hfov/2)
-            // far: every source of the batch is beyond the radius at which the field has decayed below the
-            // resolution of the fp32 column sum (csf_engine.hip: far_radius)
-            const float reach = k.rfar + bb.z;
-            const bool far = D2 > reach * reach;
-            bool out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
-            // inside: cos(|beta| + alpha) > cos(hfov/2) with |beta| + alpha < pi (beyond, the circle reaches across the
-            // rear axis and the cosine is no longer monotone: hfov > pi)
-            bool in = fov & !far & ((((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f)) | (k.full_circle != 0));
-            if (P2R) {  // priority to the right (intersection.py:739-741): sources to the left are ignored
-                const float clear = bb.z * 1.0001f + 1e-4f;
-                out = out | (off > clear);      // the whole circle is to the left of the heading line
-                in = in & (off < -clear);       // ... to the right of it
-            }
+            bool out, in;
+            classify_batch<P2R>(k, rrec[wave * RPW + (lane >> 4)], tbnd[lane & 15], out, in);
             const bool valid = (lane & 15) < nb;
             cand_all = __ballot(valid & !out);
             inside_all = __ballot(valid & in);
@@ -559,25 +568,8 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
         __syncthreads();
         unsigned long long cand_all, inside_all;
         {
-            const float4 rl = rrec[wave * RPW + (lane >> 4)];
-            const float rc = rl.z, rs = rl.w;
-            const float4 bb = tbnd[lane & 15];
-            const float ex = bb.x - rl.x, ey = bb.y - rl.y;           // receiver -> centre of the batch
-            const float D2 = ex * ex + ey * ey;
-            const float invD = fast_rsq(fmaxf(D2, 1e-30f));
-            const float sa = fminf(bb.z * invD, 1.0f);                // sin of the circle's half angle
-            const float ca = fast_sqrt(fmaxf(1.0f - sa * sa, 0.0f));
-            const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
-            const float off = rc * ey - rs * ex;                      // centre's offset from the heading line, left > 0
-            const float sb = fabsf(off) * invD;
-            const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
-            bool out = apart & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f);
-            bool in = apart & ((((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f)) | (k.full_circle != 0));
-            if (P2R) {
-                const float clear = bb.z * 1.0001f + 1e-4f;
-                out = out | (off > clear);
-                in = in & (off < -clear);
-            }
+            bool out, in;
+            classify_batch<P2R>(k, rrec[wave * RPW + (lane >> 4)], tbnd[lane & 15], out, in);
             const bool valid = (lane & 15) < nb;
             cand_all = __ballot(valid & !out);
             inside_all = __ballot(valid & in);
