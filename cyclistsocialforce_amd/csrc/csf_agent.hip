@@ -48,6 +48,8 @@ struct Agent {
     double zv0, zd0, zd1;
     int32_t ti;
     uint32_t st;
+    double cpsi, spsi;  // cos / sin of psi when the integrator has just computed them (cs_fresh), for the fp32 record
+    bool cs_fresh;
 };
 
 __device__ __forceinline__ double qx(const Dev &d, const Agent &g, int k) { return d.q[g.qb + k]; }
@@ -425,8 +427,10 @@ __device__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) 
     delta = clampd(delta, -p.delta_max, p.delta_max);         // :1257
     v = clampd(v, p.v_max_riding[0], p.v_max_riding[1]);      // :1258
     double psi = limit_angle(g.psi + p.t_s * v * tan(delta) / p.l);  // :1260-1262
-    g.y += p.t_s * v * sin(psi);                              // :1264
-    g.x += p.t_s * v * cos(psi);                              // :1265
+    sincos(psi, &g.spsi, &g.cpsi);                            // once: the next tick's record needs the same two
+    g.cs_fresh = true;
+    g.y += p.t_s * v * g.spsi;                                // :1264
+    g.x += p.t_s * v * g.cpsi;                                // :1265
     g.psi = psi;
     g.v = v;
     g.delta = delta;
@@ -619,8 +623,10 @@ __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
 }
 
 // fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677
-__device__ __forceinline__ void write_record(const Dev &d, int64_t a, double x, double y, double psi, double v) {
-    const float4 q = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)cos(psi), (float)sin(psi));
+__device__ __forceinline__ void write_record(const Dev &d, int64_t a, double x, double y, double psi, double v,
+                                             bool cs_fresh = false, double c = 0.0, double s = 0.0) {
+    if (!cs_fresh) sincos(psi, &s, &c);
+    const float4 q = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)c, (float)s);
     d.rec[a] = q;
     if (d.recs_valid) d.recs[d.pos[a]] = q;                   // the copy in binned order (csf_bin.hip)
     if (d.p.model == CSF_BICYCLE) {                           // vehicle.py:1062-1064 (v <= 0: e := 0)
@@ -655,6 +661,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     g.zd1 = d.znp[2 * cap + a];
     g.ti = d.ti[a];
     g.st = d.status[a];
+    g.cs_fresh = false;
 
     double fdx, fdy;
     if (phases & PH_DEST) {
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         d.s[4 * cap + a] = g.delta;
         d.s[5 * cap + a] = g.theta;
         d.ti[a] = g.ti;
-        write_record(d, a, g.x, g.y, g.psi, g.v);
+        write_record(d, a, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi);
         if (d.hist != nullptr) {
             int64_t t1 = d.tick + 1;
             if (t1 % d.hist_stride == 0) {
