@@ -387,6 +387,8 @@ void set_shard(csf_engine *e) {
     if (d.n_pad >= 65536 && d.p.model != CSF_BICYCLE) split = std::min<int64_t>(split, 16);
     if (const char *ov = getenv("CSF_NSPLIT")) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoi(ov), (int64_t)MAX_SPLIT, units}));
     d.n_split = (int32_t)split;
+    d.dyn_recv = 1;   // receivers handed to the waves of a workgroup one at a time (csf_pair.hip, DYN; 0: four per wave)
+    if (const char *ov = getenv("CSF_DYN_RECV")) d.dyn_recv = atoi(ov) != 0;
 }
 
 constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long

@@ -294,7 +294,11 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // BINR (large unsharded populations): the RECEIVERS of a workgroup are 16 consecutive positions of the binned order as
 // well, i.e. neighbours in space, so a whole tile of 1024 sources that lies beyond the far-field radius of the
 // group's bounding circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).
-template <bool P2R, bool CLASSIFY, bool BINR>
+// DYN (small receiver blocks, i.e. shards of a small population: launch_pair): the 16 receivers of the workgroup are
+// handed to its waves one at a time through an LDS counter instead of four per wave.  With few workgroups the kernel
+// ends with its longest single wave (a lone wave issues one dependent instruction every ~8 cycles); sharing the
+// receivers shortens that wave.  At full size the SIMDs are issue-bound either way and the variant is not used.
+template <bool P2R, bool CLASSIFY, bool BINR, bool DYN>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
@@ -302,6 +306,9 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                                                  // into the tile arrays (4 x index <= 4092)
     __shared__ float4 rrec[WPB * RPW];
     __shared__ int ragent[BINR ? WPB * RPW : 1];   // BINR: agent index of every receiver of the workgroup (-1: none)
+    __shared__ unsigned bmask[DYN ? WPB * RPW : 1];   // DYN: candidate | inside << 16 batch masks of every receiver
+    __shared__ float racc[2][DYN ? WPB * RPW : 1];    // DYN: column sums of the workgroup's receivers
+    __shared__ int next_recv;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
@@ -348,6 +355,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             ts[t] = q.w;
         }
         if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
+        if (DYN && threadIdx.x == BLOCK - 1) next_recv = 0;
     };
     // first tile and the workgroup's 16 receiver records travel together: one global round trip, not two
     if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
@@ -362,6 +370,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         } else {
             rrec[threadIdx.x] = d.rec[jc];
         }
+        if (DYN) racc[0][threadIdx.x] = racc[1][threadIdx.x] = 0.0f;
     }
     __syncthreads();
     float gx = 0.f, gy = 0.f, gr = 0.f;   // BINR: bounding circle of the workgroup's receivers (the same in every wave)
@@ -413,17 +422,32 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             const bool valid = (lane & 15) < nb;
             cand_all = __ballot(valid & !out);
             inside_all = __ballot(valid & in);
+            if (DYN) {
+                if (lane < RPW)
+                    bmask[wave * RPW + lane] = ((unsigned)(cand_all >> (16 * lane)) & 0xFFFFu) |
+                                               (((unsigned)(inside_all >> (16 * lane)) & 0xFFFFu) << 16);
+                __syncthreads();
+            }
         }
-#pragma unroll
-        for (int u = 0; u < RPW; u++) {
+#pragma unroll DYN ? 1 : RPW
+        for (int uu = 0; uu < (DYN ? WPB * RPW : RPW); uu++) {
+            int ur = wave * RPW + uu;                 // receiver within the workgroup
+            if (DYN) {
+                int got = 0;
+                if (lane == 0) got = atomicAdd(&next_recv, 1);
+                ur = __builtin_amdgcn_readfirstlane(got);
+                if (ur >= WPB * RPW) break;
+            }
+            const int u = DYN ? 0 : uu;               // accumulator slot
             {
-                const float4 q = rrec[wave * RPW + u];
+                const float4 q = rrec[ur];
                 ru.x = q.x, ru.y = q.y, ru.c = q.z, ru.s = q.w;
                 asm volatile("" : "+v"(ru.x), "+v"(ru.y), "+v"(ru.c), "+v"(ru.s));  // stay in VGPRs, not SGPRs
             }
             const unsigned live = nb >= 16 ? 0xFFFFu : ((1u << nb) - 1u);
-            unsigned cand = (unsigned)(cand_all >> (16 * u)) & live;
-            const unsigned inside = (unsigned)(inside_all >> (16 * u)) & live;
+            const unsigned bm = (DYN && CLASSIFY) ? (unsigned)__builtin_amdgcn_readfirstlane((int)bmask[ur]) : 0u;
+            unsigned cand = ((DYN && CLASSIFY) ? (bm & 0xFFFFu) : (unsigned)(cand_all >> (16 * u))) & live;
+            const unsigned inside = ((DYN && CLASSIFY) ? (bm >> 16) : (unsigned)(inside_all >> (16 * u))) & live;
             // batches that are entirely inside the field of view need neither the test nor the queue: two at a
             // time they go straight into the packed field evaluation (one batch per half of the register pairs)
             {
@@ -463,9 +487,29 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             // the queue holds indices into this tile for this receiver: drain it before either changes
             while (qlen >= CHUNK) pop(u, std::true_type{});
             if (qlen > 0) pop(u, std::false_type{});
+            if (DYN) {  // column sum of this receiver: x in the lower half of the wave, y in the upper, then within halves
+                float v = swap_add32(ax[0], ay[0]);
+                v += dpp<DPP_ROW_ROR8>(v);
+                v += dpp<DPP_XOR1>(v);
+                v += dpp<DPP_XOR2>(v);
+                v += dpp<DPP_HALF_MIRROR>(v);                              // every lane: the sum of its row of 16
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                v = __uint_as_float(r[0]) + __uint_as_float(r[1]);          // rows 0+1 (x) in lanes < 32, rows 2+3 (y) beyond
+                if ((lane & 31) == 0) racc[lane >> 5][ur] += v;  // one wave per receiver and tile: fixed order, no atomics
+                ax[0] = ay[0] = 0.0f;
+            }
         }
     }
-    reduce_store(d, j0, lane, ax, ay, BINR ? &ragent[wave * RPW] : nullptr);
+    if (DYN) {
+        __syncthreads();
+        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
+        if (threadIdx.x < WPB * RPW && j < d.hi) {
+            const int64_t a = BINR ? (int64_t)ragent[threadIdx.x] : j;
+            d.part[(int64_t)blockIdx.y * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
+        }
+    } else {
+        reduce_store(d, j0, lane, ax, ay, BINR ? &ragent[wave * RPW] : nullptr);
+    }
     if (d.trace && lane == 0) {   // tools/block_trace.py: when did every wave run, and where
         uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave);
         o[0] = t_start;
@@ -718,6 +762,27 @@ static dim3 recv_grid(const Dev &d, int split) {
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
 
+template <bool P2R, bool CLASSIFY, bool BINR>
+static void launch_cull_dyn(const Dev &d, hipStream_t st) {
+    const dim3 g = recv_grid(d, d.n_split), b(BLOCK);
+    if (d.dyn_recv) hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), g, b, 0, st, d);
+    else hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), g, b, 0, st, d);
+}
+
+static void launch_cull(const Dev &d, hipStream_t st) {
+    const bool p2r = d.pc.p2r != 0;
+    if (d.classify && d.recv_binned) {
+        if (p2r) launch_cull_dyn<true, true, true>(d, st);
+        else launch_cull_dyn<false, true, true>(d, st);
+    } else if (d.classify) {
+        if (p2r) launch_cull_dyn<true, true, false>(d, st);
+        else launch_cull_dyn<false, true, false>(d, st);
+    } else {
+        if (p2r) launch_cull_dyn<true, false, false>(d, st);
+        else launch_cull_dyn<false, false, false>(d, st);
+    }
+}
+
 void launch_pair(const Dev &d, hipStream_t st) {
     if (d.hi <= d.lo) return;
     const dim3 g = recv_grid(d, d.n_split), b(BLOCK);
@@ -731,15 +796,8 @@ void launch_pair(const Dev &d, hipStream_t st) {
     } else if (d.pair_variant == 1) {
         if (p2r) hipLaunchKernelGGL((pair_kernel<false, true>), g, b, 0, st, d);
         else hipLaunchKernelGGL((pair_kernel<false, false>), g, b, 0, st, d);
-    } else if (d.classify && d.recv_binned) {
-        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, true, true>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_cull_kernel<false, true, true>), g, b, 0, st, d);
-    } else if (d.classify) {
-        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, true, false>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_cull_kernel<false, true, false>), g, b, 0, st, d);
     } else {
-        if (p2r) hipLaunchKernelGGL((pair_cull_kernel<true, false, false>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_cull_kernel<false, false, false>), g, b, 0, st, d);
+        launch_cull(d, st);
     }
 }
 
