@@ -38,7 +38,8 @@ struct Dev {
     int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
     int32_t back;      // int(1 / t_s) — vehicle.py:1487
     int32_t n_split;   // source chunks of the pair kernel
-    int32_t dyn_recv;  // cull kernel: receivers handed to the waves of a workgroup dynamically (small receiver blocks)
+    int32_t dyn_recv;  // cull kernel: receivers handed to the waves of a workgroup dynamically
+    int32_t rpb;       // ... and receivers per workgroup then: 16 or 32
     int32_t pair_variant;  // 0: cull-first kernel on binned records (default), 1: evaluate-then-mask, 2: cull-first, unbinned
     int32_t classify;      // the records are binned and every batch of 64 carries a bounding circle
     double ox, oy;     // origin of the fp32 source records

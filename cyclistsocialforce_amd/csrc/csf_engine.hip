@@ -389,6 +389,10 @@ void set_shard(csf_engine *e) {
     d.n_split = (int32_t)split;
     d.dyn_recv = 1;   // receivers handed to the waves of a workgroup one at a time (csf_pair.hip, DYN; 0: four per wave)
     if (const char *ov = getenv("CSF_DYN_RECV")) d.dyn_recv = atoi(ov) != 0;
+    // 32 receivers per workgroup where that still leaves thousands of workgroups (N = 16 384 unsharded: 8192): measured
+    // better from 8192 receivers up, worse for the few workgroups of small populations and 4-way shards
+    d.rpb = nloc >= 8192 ? 32 : 16;
+    if (const char *ov = getenv("CSF_RPB")) d.rpb = atoi(ov) == 32 ? 32 : 16;
 }
 
 constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long

@@ -298,16 +298,19 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // handed to its waves one at a time through an LDS counter instead of four per wave.  With few workgroups the kernel
 // ends with its longest single wave (a lone wave issues one dependent instruction every ~8 cycles); sharing the
 // receivers shortens that wave.  At full size the SIMDs are issue-bound either way and the variant is not used.
-template <bool P2R, bool CLASSIFY, bool BINR, bool DYN>
+// RPB: receivers of a workgroup, 16, or 32 where the grid stays large enough (DYN only: with dynamic hand-out a
+// workgroup of twice the receivers shares one tile fill and one start-up between them: 146 -> 141 us at N = 16 384)
+template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
+    static_assert(RPB == WPB * RPW || (DYN && !BINR && RPB % (WPB * RPW) == 0), "wider workgroups need the dynamic hand-out");
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
     __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave, drained after each receiver; holds BYTE offsets
                                                  // into the tile arrays (4 x index <= 4092)
-    __shared__ float4 rrec[WPB * RPW];
-    __shared__ int ragent[BINR ? WPB * RPW : 1];   // BINR: agent index of every receiver of the workgroup (-1: none)
-    __shared__ unsigned bmask[DYN ? WPB * RPW : 1];   // DYN: candidate | inside << 16 batch masks of every receiver
-    __shared__ float racc[2][DYN ? WPB * RPW : 1];    // DYN: column sums of the workgroup's receivers
+    __shared__ float4 rrec[RPB];
+    __shared__ int ragent[BINR ? RPB : 1];   // BINR: agent index of every receiver of the workgroup (-1: none)
+    __shared__ unsigned bmask[DYN ? RPB : 1];   // DYN: candidate | inside << 16 batch masks of every receiver
+    __shared__ float racc[2][DYN ? RPB : 1];    // DYN: column sums of the workgroup's receivers
     __shared__ int next_recv;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -360,8 +363,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // first tile and the workgroup's 16 receiver records travel together: one global round trip, not two
     if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
     if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
-    if (threadIdx.x < WPB * RPW) {
-        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
+    if (threadIdx.x < RPB) {
+        const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
         const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
         if (BINR) {  // receiver slot jc - lo of this rank -> position of the binned order -> agent
             const int64_t p = d.rlist ? (int64_t)d.rlist[jc - d.lo] : jc;
@@ -417,26 +420,29 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         static_assert(TILE2 / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
         unsigned long long cand_all = ~0ull, inside_all = 0ull;
         if (CLASSIFY) {
-            bool out, in;
-            classify_batch<P2R>(k, rrec[wave * RPW + (lane >> 4)], tbnd[lane & 15], out, in);
-            const bool valid = (lane & 15) < nb;
-            cand_all = __ballot(valid & !out);
-            inside_all = __ballot(valid & in);
-            if (DYN) {
-                if (lane < RPW)
-                    bmask[wave * RPW + lane] = ((unsigned)(cand_all >> (16 * lane)) & 0xFFFFu) |
-                                               (((unsigned)(inside_all >> (16 * lane)) & 0xFFFFu) << 16);
-                __syncthreads();
+            constexpr int PASSES = RPB / (WPB * RPW);   // four receivers x 16 batches per pass
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ps++) {
+                const int r0 = (wave * PASSES + ps) * RPW;   // first receiver of this pass
+                bool out, in;
+                classify_batch<P2R>(k, rrec[r0 + (lane >> 4)], tbnd[lane & 15], out, in);
+                const bool valid = (lane & 15) < nb;
+                cand_all = __ballot(valid & !out);
+                inside_all = __ballot(valid & in);
+                if (DYN && lane < RPW)
+                    bmask[r0 + lane] = ((unsigned)(cand_all >> (16 * lane)) & 0xFFFFu) |
+                                       (((unsigned)(inside_all >> (16 * lane)) & 0xFFFFu) << 16);
             }
+            if (DYN) __syncthreads();
         }
 #pragma unroll DYN ? 1 : RPW
-        for (int uu = 0; uu < (DYN ? WPB * RPW : RPW); uu++) {
+        for (int uu = 0; uu < (DYN ? RPB : RPW); uu++) {
             int ur = wave * RPW + uu;                 // receiver within the workgroup
             if (DYN) {
                 int got = 0;
                 if (lane == 0) got = atomicAdd(&next_recv, 1);
                 ur = __builtin_amdgcn_readfirstlane(got);
-                if (ur >= WPB * RPW) break;
+                if (ur >= RPB) break;
             }
             const int u = DYN ? 0 : uu;               // accumulator slot
             {
@@ -502,8 +508,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     }
     if (DYN) {
         __syncthreads();
-        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
-        if (threadIdx.x < WPB * RPW && j < d.hi) {
+        const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
+        if (threadIdx.x < RPB && j < d.hi) {
             const int64_t a = BINR ? (int64_t)ragent[threadIdx.x] : j;
             d.part[(int64_t)blockIdx.y * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
         }
@@ -756,17 +762,23 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
     out[t] = make_float2(fx, fy);
 }
 
-static dim3 recv_grid(const Dev &d, int split) {
+static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
     int64_t nloc = d.hi - d.lo;
-    int64_t per_block = (int64_t)WPB * RPW;
+    int64_t per_block = per_block_recv;
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
 
 template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st) {
-    const dim3 g = recv_grid(d, d.n_split), b(BLOCK);
-    if (d.dyn_recv) hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), g, b, 0, st, d);
-    else hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), g, b, 0, st, d);
+    const dim3 b(BLOCK);
+    if constexpr (!BINR) {
+        if (d.dyn_recv && d.rpb == 32) {
+            hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, false, true, 32>), recv_grid(d, d.n_split, 32), b, 0, st, d);
+            return;
+        }
+    }
+    if (d.dyn_recv) hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), recv_grid(d, d.n_split), b, 0, st, d);
+    else hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), recv_grid(d, d.n_split), b, 0, st, d);
 }
 
 static void launch_cull(const Dev &d, hipStream_t st) {
