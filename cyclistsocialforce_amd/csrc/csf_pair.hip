@@ -302,7 +302,7 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // workgroup of twice the receivers shares one tile fill and one start-up between them: 146 -> 141 us at N = 16 384)
 template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
-    static_assert(RPB == WPB * RPW || (DYN && !BINR && RPB % (WPB * RPW) == 0), "wider workgroups need the dynamic hand-out");
+    static_assert(RPB == WPB * RPW || (DYN && RPB % (WPB * RPW) == 0 && RPB <= WAVE), "wider workgroups need the dynamic hand-out");
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
     __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave, drained after each receiver; holds BYTE offsets
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     __syncthreads();
     float gx = 0.f, gy = 0.f, gr = 0.f;   // BINR: bounding circle of the workgroup's receivers (the same in every wave)
     if (BINR) {
-        const float4 q = rrec[lane & 15];
+        const float4 q = rrec[lane & (RPB - 1)];
         float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
+        for (int o = RPB / 2; o > 0; o >>= 1) {
             x0 = fminf(x0, __shfl_xor(x0, o, WAVE));
             x1 = fmaxf(x1, __shfl_xor(x1, o, WAVE));
             y0 = fminf(y0, __shfl_xor(y0, o, WAVE));
@@ -771,11 +771,9 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
 template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st) {
     const dim3 b(BLOCK);
-    if constexpr (!BINR) {
-        if (d.dyn_recv && d.rpb == 32) {
-            hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, false, true, 32>), recv_grid(d, d.n_split, 32), b, 0, st, d);
-            return;
-        }
+    if (d.dyn_recv && d.rpb == 32) {
+        hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32>), recv_grid(d, d.n_split, 32), b, 0, st, d);
+        return;
     }
     if (d.dyn_recv) hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), recv_grid(d, d.n_split), b, 0, st, d);
     else hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), recv_grid(d, d.n_split), b, 0, st, d);
