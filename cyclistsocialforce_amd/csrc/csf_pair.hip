@@ -580,15 +580,16 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
 // priority-to-the-right side test), the outside ones (62 % at hfov = 2 pi / 3) are skipped, the others are evaluated
 // lane by lane, with the exact mask of intersection.py:690-745 unless the whole batch is inside.
 // The field decays like exp(-0.084 rho) at worst (p_decay = 5 m): no far-field cull.
-template <bool P2R>
+// RW receivers per wave: 4, or 8 where the grid stays large (one tile fill for twice the receivers)
+template <bool P2R, int RW>
 __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     __shared__ float4 tile[TILE];
     __shared__ float2 tile2[TILE];
     __shared__ float4 tbnd[TILE / WAVE];
-    __shared__ float4 rrec[WPB * RPW];
+    __shared__ float4 rrec[WPB * RW];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
+    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RW;
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
     if (d.bnd_next != nullptr && blockIdx.y == 0) {   // the next tick's bounding circles (see pair_cull_kernel)
@@ -596,16 +597,16 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
     if (ibeg >= iend) return;
-    if (threadIdx.x < WPB * RPW) {
-        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RPW + threadIdx.x;
+    if (threadIdx.x < WPB * RW) {
+        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RW + threadIdx.x;
         rrec[threadIdx.x] = d.rec[j < d.hi ? j : d.hi - 1];  // clamp: results of the duplicates are not stored
     }
-    float ax[RPW], ay[RPW];
+    float ax[RW], ay[RW];
 #pragma unroll
-    for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f;
+    for (int u = 0; u < RW; u++) ax[u] = ay[u] = 0.0f;
     PairConsts k = d.pc;
     asm volatile("" : "+v"(k.lf0), "+v"(k.kexp), "+v"(k.chs), "+v"(k.ipd));
-    static_assert(TILE / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
+    static_assert(TILE / WAVE <= 16 && RW % 4 == 0, "one classification pass covers 4 receivers x 16 batches");
     for (int64_t base = ibeg; base < iend; base += TILE) {
         const int cnt = (int)((iend - base) < TILE ? (iend - base) : TILE);  // multiple of 64
         const int nb = cnt >> 6;
@@ -616,24 +617,27 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
         }
         if ((int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
         __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < RW / 4; ps++) {
         unsigned long long cand_all, inside_all;
         {
             bool out, in;
-            classify_batch<P2R>(k, rrec[wave * RPW + (lane >> 4)], tbnd[lane & 15], out, in);
+            classify_batch<P2R>(k, rrec[wave * RW + 4 * ps + (lane >> 4)], tbnd[lane & 15], out, in);
             const bool valid = (lane & 15) < nb;
             cand_all = __ballot(valid & !out);
             inside_all = __ballot(valid & in);
         }
 #pragma unroll
-        for (int u = 0; u < RPW; u++) {
+        for (int uq = 0; uq < 4; uq++) {
+            const int u = 4 * ps + uq;
             Recv r;
             {
-                const float4 q = rrec[wave * RPW + u];
+                const float4 q = rrec[wave * RW + u];
                 r.x = q.x, r.y = q.y, r.c = q.z, r.s = q.w;
                 asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.c), "+v"(r.s));
             }
-            unsigned cand = (unsigned)(cand_all >> (16 * u)) & 0xFFFFu;
-            const unsigned inside = (unsigned)(inside_all >> (16 * u)) & 0xFFFFu;
+            unsigned cand = (unsigned)(cand_all >> (16 * uq)) & 0xFFFFu;
+            const unsigned inside = (unsigned)(inside_all >> (16 * uq)) & 0xFFFFu;
             while (cand) {
                 const int b = __builtin_ctz(cand);
                 cand &= cand - 1u;
@@ -655,8 +659,14 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
                 ay[u] += F * gy;
             }
         }
+        }
     }
-    reduce_store(d, j0, lane, ax, ay);
+#pragma unroll
+    for (int h = 0; h < RW / 4; h++) {
+        const float bx4[4] = {ax[4 * h], ax[4 * h + 1], ax[4 * h + 2], ax[4 * h + 3]};
+        const float by4[4] = {ay[4 * h], ay[4 * h + 1], ay[4 * h + 2], ay[4 * h + 3]};
+        reduce_store(d, j0 + 4 * h, lane, bx4, by4);
+    }
 }
 
 // intersection.py:226-242: F = sum_k -F0 r_k^-sigma (v_k - p)/r_k over the polyline vertices.
@@ -798,8 +808,14 @@ void launch_pair(const Dev &d, hipStream_t st) {
     const dim3 g = recv_grid(d, d.n_split), b(BLOCK);
     const bool p2r = d.pc.p2r != 0;
     if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
-        if (p2r) hipLaunchKernelGGL((pair_bike_kernel<true>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_bike_kernel<false>), g, b, 0, st, d);
+        if (d.rpb == 32) {
+            const dim3 g8 = recv_grid(d, d.n_split, 32);
+            if (p2r) hipLaunchKernelGGL((pair_bike_kernel<true, 8>), g8, b, 0, st, d);
+            else hipLaunchKernelGGL((pair_bike_kernel<false, 8>), g8, b, 0, st, d);
+        } else {
+            if (p2r) hipLaunchKernelGGL((pair_bike_kernel<true, 4>), g, b, 0, st, d);
+            else hipLaunchKernelGGL((pair_bike_kernel<false, 4>), g, b, 0, st, d);
+        }
     } else if (d.p.model == CSF_BICYCLE) {
         if (p2r) hipLaunchKernelGGL((pair_kernel<true, true>), g, b, 0, st, d);
         else hipLaunchKernelGGL((pair_kernel<true, false>), g, b, 0, st, d);

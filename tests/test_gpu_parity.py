@@ -351,10 +351,12 @@ def test_single_rank_communicator_path(amd):
     np.testing.assert_array_equal(e.state(), ref.state())
 
 
+@pytest.mark.parametrize("rpb", [16, 32])
 @pytest.mark.parametrize("hfov,rule", [(0.6, 0), (np.pi * 2 / 3, 1), (np.pi, 0), (4.0, 0), (4.0, 1), (2 * np.pi, 0)])
-def test_field_of_view_variants_vs_oracle(amd, hfov, rule):
+def test_field_of_view_variants_vs_oracle(amd, monkeypatch, hfov, rule, rpb):
     """Narrow, half-plane, wide and full-circle fields of view, with and without priority-to-the-right
     (intersection.py:733-741), on a binned population (N >= 1024: batch classification where it applies)."""
+    monkeypatch.setenv("CSF_RPB", str(rpb))      # receivers per workgroup (32 is chosen from 8192 receivers up)
     n, box = 1600, 90.0
     x, y, psi, v, off, dq = synthetic_population(n, box, seed=11)
     s0 = np.c_[x, y, psi, v, np.zeros(n)]
@@ -522,10 +524,12 @@ def test_binned_receivers_and_far_tile_skip_are_exact(amd, monkeypatch):
         assert np.abs(xs[lo:hi] - x0[lo:hi]).max() < 2e-6 * scale and np.abs(ys[lo:hi] - y0[lo:hi]).max() < 2e-6 * scale, shard
 
 
-@pytest.mark.parametrize("hfov,rule", [(np.pi * 2 / 3, 0), (np.pi * 2 / 3, 1), (4.0, 0), (2 * np.pi, 0)])
-def test_bicycle_field_on_binned_records_vs_oracle(amd, hfov, rule):
+@pytest.mark.parametrize("hfov,rule,rpb", [(np.pi * 2 / 3, 0, 16), (np.pi * 2 / 3, 1, 16), (4.0, 0, 16), (2 * np.pi, 0, 16),
+                                           (np.pi * 2 / 3, 0, 32), (np.pi * 2 / 3, 1, 32)])
+def test_bicycle_field_on_binned_records_vs_oracle(amd, monkeypatch, hfov, rule, rpb):
     """The older elliptic field (vehicle.py:1054-1147) at N >= 1024: binned records, batches outside the field of view
     skipped whole (pair_bike_kernel); column sums of one evaluation and a short run against the oracle."""
+    monkeypatch.setenv("CSF_RPB", str(rpb))      # receivers per workgroup (32 is chosen from 8192 receivers up)
     n, box = 2048, 120.0
     x, y, psi, v, off, dq = synthetic_population(n, box, seed=3)
     s0 = np.c_[x, y, psi, v, np.zeros(n)]
