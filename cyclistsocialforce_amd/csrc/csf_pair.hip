@@ -5,10 +5,11 @@
 // 1054-1147) and the column sum of intersection.py:841-843;  RoadEdge.calcRepulsiveForce
 // (intersection.py:226-242) for the static-obstacle term.
 //
-// Mapping (CDNA4, 64-wide waves): SOURCES sit in the lanes, RECEIVERS are wave-uniform.  One wave owns
-// RPW receivers; the workgroup streams the fp32 source records (x, y, cos psi, sin psi) through an LDS tile
-// that all of its waves share; each lane accumulates its sources' contribution and one butterfly of
-// wavefront shuffles per receiver forms the column sum.  No atomics: the result is bit-reproducible.
+// Mapping (CDNA4, 64-wide waves): SOURCES sit in the lanes, RECEIVERS are wave-uniform.  A workgroup owns 16 or 32
+// receivers and streams the fp32 source records (x, y, cos psi, sin psi) of one chunk through an LDS tile that its four
+// waves share; the waves take the receivers one at a time (an LDS counter), each lane accumulates its sources'
+// contribution, and gfx950 lane exchanges (v_permlane32/16_swap, DPP adds) form the column sum of a receiver, which is
+// added to an LDS accumulator in a fixed order.  No atomics on the sums: the result is bit-reproducible.
 //
 // The kernel is VALU-issue bound (tools/valu_ubench.hip: ~3-4.5 cycles per wave64 fp32 instruction, ~8.3 per
 // transcendental, v_pk_* at ~4.7 for two results), so the work is organised to issue as little as possible:
@@ -20,6 +21,8 @@
 //   2. TWO PAIRS PER LANE in the field evaluation, written on float2 so that hipcc emits v_pk_fma_f32 /
 //      v_pk_mul_f32 / v_pk_add_f32.
 //   3. Wave-uniform operands are kept in VGPRs (an SGPR operand makes a VALU instruction slower here).
+//   4. WHOLE BATCHES of 64 spatially binned records are classified first from their bounding circle (csf_bin.hip):
+//      outside the field of view or beyond the far-field radius -> skipped, inside -> evaluated without the test.
 // The math is trig-free: every angle of the reference enters only through sin/cos, which are dot and cross
 // products of unit vectors here.
 #include <type_traits>
