@@ -8,10 +8,23 @@ synthetic population of SURVEY.md §8(d): N agents uniform in a 200 m x 200 m sq
 speeds in [3, 6] m/s, three destinations straight ahead.  For N > 1 the driver launches this file under
 torch.distributed.run (one rank per GPU); the population is index-sharded, N stays 16,384 ("strong").
 Rank 0 prints ONE JSON line.  The CPU oracle is used only for the `cpu_baseline` leg (N = 1, rank 0).
+
+What the line reports beside `value`:
+  roofline      the dominant kernel (the all-pairs kernel) against the fp32 vector peak: 100 op-equivalents per pair
+                 x the pairs the launch actually EVALUATES (counted on the device, csf_count_pairs:
+                pairs masked by the field of view are evaluated neither here nor by the reference) / the kernel's mean
+                duration from HIP events on its own stream over the timed region.  `traffic` is the HBM bytes per launch
+                from the committed rocprofv3 --pmc passes of this kernel, `hbm_frac` the physical HBM fraction.
+  algorithmic   SURVEY.md §8(d)'s byte/flop rates over ALL N x n_loc pairs (what BASELINE.json's "HBM GB/s fraction" is
+                quoted on).  These are rates of a stream that is served from LDS, not fractions of a peak.
+  preroll_ticks untimed ticks before the W warm-up ticks: a fresh process starts with the GPU in a low power state and
+                the first ticks run slower (profiles/r2_tick_sequence.json); `warmup` is left as passed.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -21,37 +34,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (same guide)
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (same guide): 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz
 OPS_PER_PAIR = 100.0         # fp32 op-equivalents per pair evaluation
 
 
-def synthetic_population(n, box, seed=0):
+def synthetic_population(n, box, seed=0, reach=(50.0, 99.0, 100.0)):
+    """uniform positions and headings, speeds in [3, 6] m/s, destinations straight ahead at `reach`
+    metres (the default three of §8(d) last ~2 000 ticks at 5 m/s; long runs pass more, tools/large_configs.py)."""
     rng = np.random.default_rng(seed)
     x = rng.uniform(0, box, n)
     y = rng.uniform(0, box, n)
     psi = rng.uniform(-np.pi, np.pi, n)
     v = rng.uniform(3, 6, n)
-    d = np.array([50.0, 99.0, 100.0])
-    dq = np.zeros((n, 4, 3))
+    d = np.asarray(reach, dtype=float)
+    k = d.size + 1
+    dq = np.zeros((n, k, 3))
     dq[:, 0, 0] = x
     dq[:, 0, 1] = y
     dq[:, 1:, 0] = x[:, None] + d[None, :] * np.cos(psi)[:, None]
     dq[:, 1:, 1] = y[:, None] + d[None, :] * np.sin(psi)[:, None]
     s0 = np.c_[x, y, psi, v, np.zeros(n)]
-    return s0, np.arange(n + 1) * 4, dq.reshape(-1, 3)
+    return s0, np.arange(n + 1) * k, dq.reshape(-1, 3)
 
 
-def measured_traffic():
-    """HBM bytes per launch of the pair kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE are collected in their own runs, tools/pmc_passes.sh; bench.py cannot run under rocprofv3 itself)."""
-    import glob
+def tiled_curve_road(box, pitch=100.0):
+    """scenarios/curve-scenario.py:63-81 geometry repeated on a `pitch` grid:
+    (offsets, vertices, F0, sigma) as csf_set_road_vertices takes them."""
+    from cyclistsocialforce_amd import parameters
+    from cyclistsocialforce_amd.intersection import (CurvedRoadSegment, RoadSegmentCollection, StraightRoadSegment,
+                                                     flatten_road_elements)
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pair_kernel_pmc.json")))
-    if not files:
+    rp = parameters.RoadElementParameters(sigma=2.0, F_0=0.15)
+    els = []
+    for gx in np.arange(0, box, pitch):
+        for gy in np.arange(0, box, pitch):
+            s1 = StraightRoadSegment(np.array((gx + 10.0, gy + 5.0, np.pi / 2)), 5, 25, params=rp, ds=0.1)
+            s2 = CurvedRoadSegment(s1.x1, 5, 10, np.pi / 2, "right", params=rp, ds=0.1)
+            s3 = CurvedRoadSegment(s2.x1, 5, 10, np.pi / 2, "left", params=rp, ds=0.1)
+            s4 = StraightRoadSegment(s3.x1, 5, 20, params=rp, ds=0.1)
+            els.append(RoadSegmentCollection((s1, s2, s3, s4)))
+    return flatten_road_elements(els)
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
+    collected in their own runs, tools/pmc_passes.sh; bench.py cannot run under rocprofv3 itself).  The newest file by
+    (round, version) whose recorded kernel name matches is taken."""
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_v*_pair_kernel_pmc.json")):
+        m = re.match(r"r(\d+)_v(\d+)_", os.path.basename(path))
+        if not m:
+            continue
+        with open(path) as fh:
+            rec = json.load(fh)
+        if kernel.split("<")[0] not in rec.get("kernel", ""):
+            continue
+        key = (int(m.group(1)), int(m.group(2)))
+        if best is None or key > best[0]:
+            best = (key, rec, path)
+    if best is None:
         return None, None
-    with open(files[-1]) as fh:
-        rec = json.load(fh)
-    return rec.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    return best[1].get("hbm_bytes_per_launch"), os.path.relpath(best[2], ROOT)
 
 
 def cpu_baseline(n, box, ticks):
@@ -78,6 +121,10 @@ def main():
     ap.add_argument("--agents", type=int, default=16384)
     ap.add_argument("--box", type=float, default=200.0)
     ap.add_argument("--model", default="twod", choices=["twod", "bicycle", "invpend", "planarpoint"])
+    ap.add_argument("--road", default="none", choices=["none", "curve-tiles"],
+                    help="static-obstacle infrastructure (BASELINE config 5): the curve scenario tiled on a 100 m grid")
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="untimed ticks before the warm-up (reported as preroll_ticks); default: about 0.1 s of them")
     ap.add_argument("--cpu-ticks", type=int, default=6, help="ticks of the CPU baseline sample (0 = skip)")
     ap.add_argument("--every-pair-steps", type=int, default=200,
                     help="ticks of the secondary run with the far-field cull switched off (0 = skip)")
@@ -111,9 +158,17 @@ def main():
         s0 = np.c_[s0, np.zeros(n)]
     elif args.model == "planarpoint":
         s0 = s0[:, :4]
-    eng = Engine(parameters.default_pod(args.model), n, device=local_rank)
-    eng.add_agents(s0, 5.0)
-    eng.set_dest_queue(np.arange(n), off, dq, reset=True)
+    road = tiled_curve_road(box) if args.road == "curve-tiles" else None
+
+    def populate():
+        e = Engine(parameters.default_pod(args.model), n, device=local_rank)
+        e.add_agents(s0, 5.0)
+        e.set_dest_queue(np.arange(n), off, dq, reset=True)
+        if road is not None:
+            e.set_road(*road)
+        return e
+
+    eng = populate()
     if world > 1:
         shard_engine(eng, dist, rank, world)
     elif rehearse:
@@ -127,15 +182,36 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # pre-roll: one tick to see how long a tick is at this size, then ~0.1 s worth of ticks (every rank the same count)
+    preroll = args.preroll
+    if preroll < 0:
+        eng.step(2, sync=True)
+        t0 = time.perf_counter()
+        eng.step(4, sync=True)
+        tick_s = (time.perf_counter() - t0) / 4
+        preroll = int(min(1000, max(0, 0.1 / max(tick_s, 1e-6))))
+        if dist is not None:
+            t = torch.tensor([preroll], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            preroll = int(t.item())
+        eng.step(preroll)
+        preroll += 6
+    else:
+        eng.step(preroll)
+    fence()
+
     eng.step(args.warmup)
     fence()
-    eng.profile(8)   # HIP events around the pair kernel on every 8th tick of the timed region
+    # the kernels' own start / end time stamps (hipExtLaunchKernelGGL events on the engine's stream); at least 16
+    # sampled launches, every 8th tick in long runs
+    every = max(1, min(8, args.steps // 16))
+    eng.profile(every)
     t0 = time.perf_counter()
     eng.step(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    pair_ms, agent_ms, launches = eng.profile_read()
-    gather_ms = eng.profile_gather()
+    samples = eng.profile_samples()
+    prof = eng.profile_kernels()
     eng.profile(0)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -146,49 +222,62 @@ def main():
     lo, hi = eng.shard_range()
     st = eng.state()[lo:hi]
     healthy = bool(np.isfinite(st).all() and (eng.status()[lo:hi] == 0).all())
+    evaluated, kernel = eng.count_pairs()     # one extra launch on the final snapshot, outside the timed region
 
     if rank == 0:
         value = n * args.steps / dt
         n_loc = hi - lo
-        pair_s = pair_ms * 1e-3 / max(launches, 1)
+        mean_s = {k: ms * 1e-3 / max(c, 1) for k, (ms, c) in prof.items()}     # mean duration of each kernel
+        pair_s, road_s, agent_s, launches = mean_s["pair"], mean_s["road"], mean_s["agent"], prof["pair"][1]
+        pairs_all = float(n) * n_loc
         alg_bytes = 16.0 * n * n_loc + 8.0 * n_loc          # source records consumed + partial sums written
-        pairs = float(n) * n_loc
-        traffic, traffic_src = measured_traffic() if (world == 1 and n == 16384 and args.model == "twod") else (None, None)
+        traffic, traffic_src = measured_traffic(kernel) if (world == 1 and n == 16384 and args.model == "twod") else (None, None)
         rfar = eng.far_radius()
         far_note = ("every pair evaluated" if not np.isfinite(rfar) else
                     f"batches of sources beyond {rfar:.1f} m skipped: together they add < 2^-24 f_0 to a receiver "
                     f"(DESIGN.md D8; CSF_FAR_EPS=0 evaluates every pair)")
+        roof = {"bound": "valu", "kernel": kernel, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "launch_us": pair_s * 1e6, "launches_sampled": int(launches), "pairs_evaluated": evaluated,
+                "pairs_all": pairs_all, "traffic": traffic, "traffic_source": traffic_src}
+        if evaluated is not None and pair_s > 0:
+            roof["achieved"] = OPS_PER_PAIR * evaluated / pair_s / 1e12
+            roof["frac"] = roof["achieved"] / VALU_PEAK_TFLOPS
+            roof["note"] = ("100 fp32 op-equivalents x pairs evaluated by one launch (device counter) / mean kernel "
+                            "duration; the stream of source records is served from LDS/L2, HBM is not the roof (hbm_frac)")
+        else:
+            roof["achieved"] = roof["frac"] = None
+            roof["note"] = "this engine's pair kernel does not count its evaluations"
+        if traffic is not None and pair_s > 0:
+            roof["hbm_frac"] = traffic / pair_s / 1e9 / HBM_PEAK_GBS
+        if samples.size:
+            roof["launch_us_min_med_max"] = [float(samples.min()), float(np.median(samples)), float(samples.max())]
         out = {
             "metric": "agent-steps/sec at N=16k TwoDBicycle", "value": value, "unit": "agent-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_ticks": preroll,
+            "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{n} {args.model} agents, uniform random in {box:g} m x {box:g} m, "
-                                   f"all pairs, t_s=0.01", "agents": n, "rider_model": args.model,
-                       "far_field": far_note,
+                                   f"all pairs, t_s=0.01" + (", curve-scenario road tiled on a 100 m grid" if road else ""),
+                       "agents": n, "rider_model": args.model, "far_field": far_note,
+                       "road_vertices": 0 if road is None else int(road[1].shape[0]),
                        "parallelism": f"index-sharded x{world}, RCCL all-gather of fp32 records per tick"
                        if world > 1 else "single GPU"},
             "healthy": healthy,
-            "roofline": {
-                "bound": "hbm", "kernel": "pair_kernel", "achieved": alg_bytes / pair_s / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg_bytes / pair_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes,
-                "launch_us": pair_s * 1e6, "agent_kernel_us": agent_ms * 1e3 / max(launches, 1),
-                "all_gather_us": gather_ms * 1e3 / max(launches, 1),
-                "note": "algorithmic bytes = 16 B x N sources per receiver (SURVEY.md 8(d)); served from LDS/L2, "
-                        "so the kernel is VALU-bound: see valu.  Algorithmic = what the reference evaluates (every "
-                        "pair); the kernel skips pairs outside the field of view and beyond the far-field radius",
-            },
-            "valu": {"achieved": OPS_PER_PAIR * pairs / pair_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": OPS_PER_PAIR * pairs / pair_s / 1e12 / VALU_PEAK_TFLOPS,
-                     "pairs_per_s": pairs / pair_s},
+            "roofline": roof,
+            "kernels_us": {"pair": pair_s * 1e6, "road": road_s * 1e6, "agent": agent_s * 1e6,
+                           "all_gather": mean_s["gather"] * 1e6, "tick": dt / args.steps * 1e6,
+                           "sampled_launches": {k: c for k, (_, c) in prof.items()}},
+            "algorithmic": {"bytes_per_launch": alg_bytes, "GBps": alg_bytes / pair_s / 1e9 if pair_s > 0 else None,
+                            "x_hbm_peak": alg_bytes / pair_s / 1e9 / HBM_PEAK_GBS if pair_s > 0 else None,
+                            "pairs_per_s": pairs_all / pair_s if pair_s > 0 else None,
+                            "note": "SURVEY.md 8(d): 16 B x N sources per receiver over ALL pairs, evaluated or masked; "
+                                    "a rate, not a fraction of a peak (the stream never leaves LDS/L2)"},
         }
         if world == 1 and not rehearse and np.isfinite(rfar) and args.every_pair_steps > 0:
             # the same population with the far-field cull off (reported beside the headline, never as `value`)
             os.environ["CSF_FAR_EPS"] = "0"
-            ex = Engine(parameters.default_pod(args.model), n, device=local_rank)
-            ex.add_agents(s0, 5.0)
-            ex.set_dest_queue(np.arange(n), off, dq, reset=True)
+            ex = populate()
             ex.step(40, sync=True)
             t0 = time.perf_counter()
             ex.step(args.every_pair_steps, sync=True)
@@ -198,7 +287,7 @@ def main():
             out["every_pair"] = {"value": n * args.every_pair_steps / dte, "unit": "agent-steps/s",
                                  "ms_per_step": dte / args.every_pair_steps * 1e3, "steps": args.every_pair_steps,
                                  "note": "CSF_FAR_EPS=0: no batch is skipped for distance"}
-        if world == 1 and args.cpu_ticks > 0:
+        if world == 1 and args.cpu_ticks > 0 and args.model == "twod" and road is None:
             out["cpu_baseline"] = cpu_baseline(n, box, args.cpu_ticks)
         print(json.dumps(out), flush=True)
     if dist is not None:

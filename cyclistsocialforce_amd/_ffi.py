@@ -24,7 +24,9 @@ SYMBOLS = (
     "csf_calc_forces", "csf_apply_forces", "csf_replay_forces", "csf_dest_force", "csf_get_state", "csf_get_forces",
     "csf_get_force_parts", "csf_status", "csf_enable_history", "csf_get_history", "csf_pair_force",
     "csf_comm_unique_id", "csf_comm_init", "csf_shard_range", "csf_profile_enable", "csf_profile_read",
-    "csf_far_radius", "csf_get_tick", "csf_profile_gather",
+    "csf_far_radius", "csf_get_tick", "csf_profile_gather", "csf_profile_kernels", "csf_profile_samples",
+    "csf_count_pairs", "csf_comm_init_loopback", "csf_step_group", "csf_untracked", "csf_update_destination",
+    "csf_update_nav_state", "csf_set_dest_pointer",
 )
 
 
@@ -109,6 +111,16 @@ def load():
     L.csf_far_radius.argtypes = [vp, C.POINTER(C.c_double)]
     L.csf_profile_gather.argtypes = [vp, C.POINTER(C.c_double)]
     L.csf_get_tick.argtypes = [vp, dp, vp, vp, dp, dp, C.POINTER(i64)]
+    pd = C.POINTER(C.c_double)
+    L.csf_profile_kernels.argtypes = [vp, pd, C.POINTER(i64)]
+    L.csf_profile_samples.argtypes = [vp, dp, i64, C.POINTER(i64)]
+    L.csf_count_pairs.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_char_p)]
+    L.csf_comm_init_loopback.argtypes = [C.POINTER(vp), i32]
+    L.csf_step_group.argtypes = [C.POINTER(vp), i32, i64]
+    L.csf_untracked.argtypes = [vp, vp]
+    L.csf_update_destination.argtypes = [vp, i64, vp]
+    L.csf_update_nav_state.argtypes = [vp, i64, vp, vp, dp, dp]
+    L.csf_set_dest_pointer.argtypes = [vp, i64, vp, vp]
     if L.csf_abi_version() != 1:
         raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 1")
     _lib = L

@@ -761,16 +761,67 @@ __global__ void records_kernel(const Dev d) {
     write_record(d, a, d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);
 }
 
-void launch_agent(const Dev &d, int phases, hipStream_t st) {
+void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo) return;
     static const int bs = getenv("CSF_AGENT_BLOCK") ? atoi(getenv("CSF_AGENT_BLOCK")) : 64;   // 256 waves on 256 CUs: 0.6 us less than 64 workgroups of 4
     dim3 g((unsigned)((d.hi - d.lo + bs - 1) / bs)), b(bs);
     switch (d.p.model) {
-    case CSF_BICYCLE: hipLaunchKernelGGL(agent_kernel<CSF_BICYCLE>, g, b, 0, st, d, phases); break;
-    case CSF_TWOD: hipLaunchKernelGGL(agent_kernel<CSF_TWOD>, g, b, 0, st, d, phases); break;
-    case CSF_INVPEND: hipLaunchKernelGGL(agent_kernel<CSF_INVPEND>, g, b, 0, st, d, phases); break;
-    default: hipLaunchKernelGGL(agent_kernel<CSF_PLANARPOINT>, g, b, 0, st, d, phases); break;
+    case CSF_BICYCLE: hipExtLaunchKernelGGL(agent_kernel<CSF_BICYCLE>, g, b, 0, st, t0, t1, 0, d, phases); break;
+    case CSF_TWOD: hipExtLaunchKernelGGL(agent_kernel<CSF_TWOD>, g, b, 0, st, t0, t1, 0, d, phases); break;
+    case CSF_INVPEND: hipExtLaunchKernelGGL(agent_kernel<CSF_INVPEND>, g, b, 0, st, t0, t1, 0, d, phases); break;
+    default: hipExtLaunchKernelGGL(agent_kernel<CSF_PLANARPOINT>, g, b, 0, st, t0, t1, 0, d, phases); break;
     }
+}
+
+// Vehicle.updateDestination (vehicle.py:545-594) and Vehicle.updateNavState(stop) (vehicle.py:354-457) on their own, for
+// the listed agents: the host mirror's methods of the same name run them here (what & 1: queue pointer, what & 2: navigation
+// state machine, desired speed and distance to vd_out / ddest_out).  stop[k] >= 0 overrides the stop flag of the current
+// destination for this call, as the reference's explicit `stop` argument does.
+__global__ void nav_kat_kernel(const Dev d, const int32_t *idx, int64_t m, int what, const int32_t *stop, double *vd_out,
+                               double *ddest_out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int64_t a = idx[k], cap = d.cap;
+    Agent g;
+    g.a = a;
+    g.x = d.s[a];
+    g.y = d.s[cap + a];
+    g.v = d.s[3 * cap + a];
+    g.vdes = d.vdes[a];
+    g.qb = d.qoff[a];
+    g.K = (int32_t)(d.qoff[a + 1] - g.qb);
+    g.ptr = d.ptr[a];
+    g.zn = d.znav[a] & 3;
+    g.zv0 = d.znp[a];
+    g.zd0 = d.znp[cap + a];
+    g.zd1 = d.znp[2 * cap + a];
+    g.st = d.status[a];
+    if (what & 1) {
+        update_destination(d, g);
+        d.ptr[a] = g.ptr;
+    }
+    if (what & 2) {
+        const int64_t row = 2 * d.qcap + g.qb + g.ptr;
+        const double flag = d.q[row];
+        const bool forced = stop != nullptr && stop[k] >= 0;
+        if (forced) d.q[row] = stop[k] ? 1.0 : 0.0;          // this thread is the only reader of its agent's rows
+        double ddest;
+        const double vd = update_nav(d, g, ddest);
+        if (forced) d.q[row] = flag;
+        d.znav[a] = (uint8_t)g.zn;
+        d.znp[a] = g.zv0;
+        d.znp[cap + a] = g.zd0;
+        d.znp[2 * cap + a] = g.zd1;
+        d.status[a] = g.st;
+        vd_out[k] = vd;
+        ddest_out[k] = ddest;
+    }
+}
+
+void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const int32_t *stop, double *vd_out,
+                    double *ddest_out, hipStream_t st) {
+    if (m <= 0) return;
+    hipLaunchKernelGGL(nav_kat_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d, idx, m, what, stop, vd_out, ddest_out);
 }
 
 // csf_get_tick: everything the host mirror refreshes after a tick, packed for one transfer

@@ -2,6 +2,7 @@
 // (csf_pair.hip), the per-agent kernel (csf_agent.hip) and the host engine (csf_engine.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/csf.h"
@@ -37,7 +38,8 @@ struct Dev {
     int32_t ns;        // states per agent
     int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
     int32_t back;      // int(1 / t_s) — vehicle.py:1487
-    int32_t n_split;   // source chunks of the pair kernel
+    int32_t n_split;   // source chunks of the pair kernel (every one of them holds sources: csf_engine.hip set_shard)
+    int32_t chunk_units;  // batches of 64 records per source chunk
     int32_t dyn_recv;  // cull kernel: receivers handed to the waves of a workgroup dynamically
     int32_t rpb;       // ... and receivers per workgroup then: 16 or 32
     int32_t pair_variant;  // 0: cull-first kernel on binned records (default), 1: evaluate-then-mask, 2: cull-first, unbinned
@@ -86,15 +88,19 @@ struct Dev {
     int64_t replay_tick;        // the replay
     double *hist;      // opt-in history [hist_cap][n][ns]
     int32_t hist_stride, hist_cap;
+    unsigned long long *pair_count;  // csf_count_pairs: pair evaluations of the launch are added here (NULL: not counted)
     uint64_t *trace;   // CSF_TRACE_BLOCKS: (start, end, hw id) of every pair-kernel workgroup of the last tick, else NULL
 };
 
 enum : int { PH_DEST = 1, PH_COMBINE = 2, PH_INTEGRATE = 4, PH_FIXSPEED = 8 };
 
 // launchers implemented in csf_pair.hip / csf_agent.hip
-void launch_pair(const Dev &d, hipStream_t st);
-void launch_road(const Dev &d, hipStream_t st);
-void launch_agent(const Dev &d, int phases, hipStream_t st);
+// t0 / t1 (may be NULL): HIP events that receive the start / end time stamp of the kernel itself (hipExtLaunchKernelGGL:
+// taken from the dispatch packet, no extra barrier packet in the stream as with hipEventRecord)
+void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_road(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+const char *pair_kernel_name(const Dev &d);           // the kernel launch_pair() takes for this engine
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state
 // csf_get_tick: row-major state [n, ns], Fx [n], Fy [n] (doubles), destination pointers [n] (int32), navigation state
 // one-hot [n, 3] (bytes), packed behind each other in `out` (host-mapped)
@@ -109,6 +115,9 @@ void launch_bounds(const Dev &d, hipStream_t st);
 // binned positions of the receivers [lo, hi) of this rank in ascending order (the rank's receivers as neighbours in space)
 int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st);
 
+void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st);   // get_untracked_foes as the reference's matrix
+void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const int32_t *stop, double *vd_out,
+                    double *ddest_out, hipStream_t st);
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
                      int apply_fov, float2 *out, hipStream_t st);
 

@@ -128,9 +128,25 @@ struct csf_engine {
     ncclComm_t nccl = nullptr;
     bool gather_pending = false;
 
-    // profiling
-    int profile = 0;             // 0 off, k > 0: HIP events around the pair kernel on every k-th tick
-    std::vector<hipEvent_t> ev;  // triples: pair begin, pair end, agent end
+    // loopback rehearsal of the sharded path: `world` engines of one process on one device share a stream and exchange
+    // their record blocks with device-to-device copies where the ranks of a real run call ncclAllGather
+    std::vector<csf_engine *> group;
+    bool loopback = false;
+    bool owns_main = true;
+
+    // profiling: a fixed pool of event slots, recycled in order (the oldest slot is resolved into the running sums
+    // before it is reused, so stepping with profiling left on holds a bounded number of events)
+    int profile = 0;             // 0 off, k > 0: time the kernels of every k-th tick
+    struct ProfSlot {
+        hipEvent_t ev[8] = {};   // pair, road, agent: start / end of the kernel itself; all-gather: recorded around it
+        bool pair = false, road = false, agent = false, gather = false;
+    };
+    std::vector<ProfSlot> prof_pool;
+    size_t prof_issued = 0, prof_resolved = 0;
+    double prof_ms[4] = {0, 0, 0, 0};   // pair, road, agent, gather
+    int64_t prof_cnt[4] = {0, 0, 0, 0}; // launches behind each sum
+    int64_t prof_ticks = 0;             // sampled ticks issued (the kernels beside the pair kernel are timed on every 8th)
+    std::vector<float> prof_pair_us;    // per sampled launch (at most PROF_KEEP of them)
 };
 
 namespace {
@@ -386,7 +402,13 @@ void set_shard(csf_engine *e) {
     // skipped unloaded, and longer chunks amortise the workgroup's start-up (config 4: 7.3 ms at 64 chunks, 6.2 at 8-16)
     if (d.n_pad >= 65536 && d.p.model != CSF_BICYCLE) split = std::min<int64_t>(split, 16);
     if (const char *ov = getenv("CSF_NSPLIT")) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoi(ov), (int64_t)MAX_SPLIT, units}));
+    // no empty chunk: with per = ceil(units / split) units per chunk only ceil(units / per) chunks hold sources (n = 1040:
+    // 17 units, split 16 -> per 2 -> 9 chunks).  A workgroup of an empty chunk would leave its slot of d.part untouched,
+    // and the combine phase would add whatever an earlier population layout left there.
+    const int64_t per = (units + split - 1) / split;
+    split = (units + per - 1) / per;
     d.n_split = (int32_t)split;
+    d.chunk_units = (int32_t)per;
     d.dyn_recv = 1;   // receivers handed to the waves of a workgroup one at a time (csf_pair.hip, DYN; 0: four per wave)
     if (const char *ov = getenv("CSF_DYN_RECV")) d.dyn_recv = atoi(ov) != 0;
     // 32 receivers per workgroup where that still leaves thousands of workgroups (N = 16 384 unsharded: 8192): measured
@@ -554,6 +576,7 @@ int upload_all(csf_engine *e) {
     d.rv = e->rv.p;
     set_shard(e);
     if ((size_t)d.n_pad > e->rec.n) return fail(e, CSF_E_CAPACITY, "record buffer too small for this shard layout");
+    HIPCHK(e, hipMemsetAsync(e->part.p, 0, e->part.n * sizeof(float2), e->main));   // a new layout starts from clean partial sums
     launch_records(d, e->main);
     int rrc = rebin(e);
     if (rrc) return rrc;
@@ -565,6 +588,10 @@ int upload_all(csf_engine *e) {
 }
 
 int prepare_mutation(csf_engine *e) {
+    // a rank integrates only its own block: its fp64 copy of the other blocks goes stale with the first tick, and an
+    // upload would rebuild their records from it
+    if ((e->world > 1 || e->loopback) && e->device_ahead)
+        return fail(e, CSF_E_STATE, "a sharded population cannot be changed from the host once ticks have run");
     int rc = download_all(e);
     if (rc) return rc;
     e->dirty = true;
@@ -598,6 +625,46 @@ int all_gather_records(csf_engine *e) {
         e->gather_pending = true;
     }
     return CSF_OK;
+}
+
+constexpr size_t PROF_SLOTS = 256, PROF_KEEP = 1 << 16;
+
+// oldest outstanding slot -> running sums (waits for its last event)
+int prof_resolve_one(csf_engine *e) {
+    csf_engine::ProfSlot &sl = e->prof_pool[e->prof_resolved % PROF_SLOTS];
+    const int last = sl.gather ? 7 : sl.agent ? 5 : sl.road ? 3 : sl.pair ? 1 : -1;
+    if (last >= 0) HIPCHK(e, hipEventSynchronize(sl.ev[last]));
+    const bool have[4] = {sl.pair, sl.road, sl.agent, sl.gather};
+    for (int k = 0; k < 4; k++) {
+        if (!have[k]) continue;
+        float ms = 0;
+        HIPCHK(e, hipEventElapsedTime(&ms, sl.ev[2 * k], sl.ev[2 * k + 1]));
+        e->prof_ms[k] += ms;
+        e->prof_cnt[k]++;
+        if (k == 0 && e->prof_pair_us.size() < PROF_KEEP) e->prof_pair_us.push_back(ms * 1e3f);
+    }
+    e->prof_resolved++;
+    return CSF_OK;
+}
+
+int prof_make_pool(csf_engine *e) {
+    if (!e->prof_pool.empty()) return CSF_OK;
+    e->prof_pool.resize(PROF_SLOTS);
+    for (auto &sl : e->prof_pool)
+        for (auto &ev : sl.ev) HIPCHK(e, hipEventCreate(&ev));
+    return CSF_OK;
+}
+
+// a free slot for this tick (NULL with *rc == 0: profiling is off for it)
+csf_engine::ProfSlot *prof_slot(csf_engine *e, int *rc) {
+    *rc = CSF_OK;
+    if (e->profile <= 0 || e->d.tick % e->profile != 0) return nullptr;
+    if ((*rc = prof_make_pool(e))) return nullptr;
+    if (e->prof_issued - e->prof_resolved >= PROF_SLOTS && (*rc = prof_resolve_one(e))) return nullptr;
+    csf_engine::ProfSlot *sl = &e->prof_pool[e->prof_issued % PROF_SLOTS];
+    sl->pair = sl->road = sl->agent = sl->gather = false;
+    e->prof_issued++;
+    return sl;
 }
 
 int wait_gather(csf_engine *e) {
@@ -674,7 +741,9 @@ int csf_destroy(csf_engine *e) {
         e->trace.release();
     }
     if (e->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(e->nccl);
-    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    for (auto &sl : e->prof_pool)
+        for (hipEvent_t ev : sl.ev)
+            if (ev) (void)hipEventDestroy(ev);
     if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
@@ -684,8 +753,13 @@ int csf_destroy(csf_engine *e) {
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);
-    if (e->main) (void)hipStreamDestroy(e->main);
+    if (e->main && e->owns_main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);
+    for (csf_engine *m : e->group)          // the others of a loopback group lose this member (and its stream, if it was the owner)
+        if (m != e) {
+            m->group.clear();
+            if (e->owns_main && m->main == e->main) m->main = nullptr;
+        }
     delete e;
     return CSF_OK;
 }
@@ -885,44 +959,62 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
 //   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)
 static int enqueue_tick(csf_engine *e) {
     Dev &d = e->d;
-    const bool sharded = e->world > 1 || e->nccl != nullptr;  // a 1-rank communicator rehearses the sharded path
-    hipEvent_t *pe = nullptr;
-    if (e->profile > 0 && e->d.tick % e->profile == 0) {
-        size_t base = e->ev.size();
-        e->ev.resize(base + 4);
-        for (int k = 0; k < 4; k++) HIPCHK(e, hipEventCreate(&e->ev[base + k]));
-        pe = &e->ev[base];
-    }
-    const bool overlap = sharded && comm_second_stream();
+    const bool sharded = e->world > 1 || e->nccl != nullptr || e->loopback;  // a 1-rank communicator rehearses the sharded path
+    int rc = CSF_OK;
+    csf_engine::ProfSlot *ps = prof_slot(e, &rc);
+    if (rc) return rc;
+    // time stamps cost a few microseconds of launch gap per kernel: the pair kernel (what the roofline is computed from)
+    // takes them on every sampled tick, the other kernels on every 8th of those
+    csf_engine::ProfSlot *po = (ps && (e->prof_ticks++ % 8 == 0)) ? ps : nullptr;
+    const bool overlap = sharded && !e->loopback && comm_second_stream();
     if (overlap) {
         launch_agent(d, PH_DEST, e->main);
-        int rc = wait_gather(e);
-        if (rc) return rc;
+        if ((rc = wait_gather(e))) return rc;
     }
-    {
-        int rc = bounds_before_pair(e);
-        if (rc) return rc;
-    }
+    if ((rc = bounds_before_pair(e))) return rc;
     // sharded: the other ranks' records arrived in index order; a coalesced tile fill from the binned copy saves the
     // pair kernel 5 - 7 us at every shard size, the copy costs ~3 us
     if (sharded && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
-    if (pe) HIPCHK(e, hipEventRecord(pe[0], e->main));
-    if (d.n > 1) launch_pair(d, e->main);
+    if (d.n > 1 && d.hi > d.lo) {
+        launch_pair(d, e->main, ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr);
+        if (ps) ps->pair = true;
+    }
     bounds_after_pair(e, true);
-    if (pe) HIPCHK(e, hipEventRecord(pe[1], e->main));
-    launch_road(d, e->main);
-    launch_agent(d, overlap ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main);
-    if (pe) HIPCHK(e, hipEventRecord(pe[2], e->main));
+    if (d.nv > 0 && d.hi > d.lo) {
+        launch_road(d, e->main, po ? po->ev[2] : nullptr, po ? po->ev[3] : nullptr);
+        if (po) po->road = true;
+    }
+    launch_agent(d, overlap ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main,
+                 po ? po->ev[4] : nullptr, po ? po->ev[5] : nullptr);
+    if (po) po->agent = true;
     HIPCHK(e, hipGetLastError());
     d.tick++;
-    if (sharded) {
+    if (sharded && !e->loopback) {
         if (overlap) HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
-        int rc = all_gather_records(e);
-        if (rc) return rc;
+        hipStream_t cs = overlap ? e->comm : e->main;
+        if (po) HIPCHK(e, hipEventRecord(po->ev[6], cs));
+        if ((rc = all_gather_records(e))) return rc;
+        if (po) {
+            HIPCHK(e, hipEventRecord(po->ev[7], cs));
+            po->gather = true;
+        }
     }
-    if (pe && sharded) {   // after the collective (unsharded: no fourth record, an event costs ~3 us of launch gap)
-        HIPCHK(e, hipEventRecord(pe[3], overlap ? e->comm : e->main));
-        e->ev_gather_recorded = true;
+    return CSF_OK;
+}
+
+// the loopback "all-gather": every member's own record block is copied into the record arrays of the others
+static int loopback_exchange(csf_engine *const *g, int world) {
+    for (int r = 0; r < world; r++) {
+        csf_engine *src = g[r];
+        const size_t shard = (size_t)(src->d.n_pad / world);
+        for (int p = 0; p < world; p++) {
+            if (p == r) continue;
+            HIPCHK(g[p], hipMemcpyAsync(g[p]->rec.p + r * shard, src->rec.p + r * shard, shard * sizeof(float4),
+                                        hipMemcpyDeviceToDevice, src->main));
+            if (src->d.p.model == CSF_BICYCLE)
+                HIPCHK(g[p], hipMemcpyAsync(g[p]->rec2.p + r * shard, src->rec2.p + r * shard, shard * sizeof(float2),
+                                            hipMemcpyDeviceToDevice, src->main));
+        }
     }
     return CSF_OK;
 }
@@ -931,6 +1023,7 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
     if (!e) return CSF_E_ARG;
     if (n_ticks < 0) return fail(e, CSF_E_ARG, "n_ticks must be >= 0");
     HIPCHK(e, hipSetDevice(e->device));
+    if (e->loopback) return fail(e, CSF_E_STATE, "members of a loopback group are stepped with csf_step_group");
     if (e->world > 1 && !e->nccl) return fail(e, CSF_E_STATE, "csf_comm_init must run before csf_step when world > 1");
     int rc = upload_all(e);
     if (rc) return rc;
@@ -964,7 +1057,7 @@ int csf_calc_forces(csf_engine *e) {
     if (rc) return rc;
     rc = bounds_before_pair(e);
     if (rc) return rc;
-    if ((e->world > 1 || e->nccl != nullptr) && e->d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(e->d, e->main);
+    if ((e->world > 1 || e->nccl != nullptr || e->loopback) && e->d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(e->d, e->main);
     if (e->d.n > 1) launch_pair(e->d, e->main);
     bounds_after_pair(e, false);                     // the records do not move: recompute next time
     launch_road(e->d, e->main);
@@ -1237,6 +1330,81 @@ int csf_pair_force(csf_engine *e, const double *src, int64_t m, const double *x,
     return CSF_OK;
 }
 
+int csf_untracked(csf_engine *e, uint8_t *out) {
+    if (!e) return CSF_E_ARG;
+    if (!out) return fail(e, CSF_E_ARG, "csf_untracked: NULL output");
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);
+    if (rc) return rc;
+    const int64_t n = e->d.n;
+    if (n == 0) return CSF_OK;
+    if (n > 46340) return fail(e, CSF_E_ARG, "csf_untracked: the n x n matrix is limited to n <= 46340");
+    if ((rc = wait_gather(e))) return rc;
+    DevBuf<uint8_t> buf;
+    HIPCHK(e, buf.alloc((size_t)(n * n)));
+    launch_untracked(e->d, buf.p, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    HIPCHK(e, hipMemcpy(out, buf.p, (size_t)(n * n), hipMemcpyDeviceToHost));
+    buf.release();
+    return CSF_OK;
+}
+
+static int nav_kat(csf_engine *e, int64_t n, const int32_t *idx, int what, const int32_t *stop, double *vd, double *ddest) {
+    if (n < 0 || (n > 0 && !idx)) return fail(e, CSF_E_ARG, "bad agent list");
+    for (int64_t k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);
+    if (rc) return rc;
+    if (n == 0) return CSF_OK;
+    DevBuf<int32_t> di, ds;
+    DevBuf<double> out;
+    HIPCHK(e, di.alloc((size_t)n));
+    HIPCHK(e, out.alloc((size_t)(2 * n)));
+    HIPCHK(e, hipMemcpy(di.p, idx, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (stop) {
+        HIPCHK(e, ds.alloc((size_t)n));
+        HIPCHK(e, hipMemcpy(ds.p, stop, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    launch_nav_kat(e->d, di.p, n, what, stop ? ds.p : nullptr, out.p, out.p + n, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    e->device_ahead = true;
+    if (vd) HIPCHK(e, hipMemcpy(vd, out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (ddest) HIPCHK(e, hipMemcpy(ddest, out.p + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    di.release();
+    ds.release();
+    out.release();
+    return CSF_OK;
+}
+
+int csf_update_destination(csf_engine *e, int64_t n, const int32_t *idx) {
+    if (!e) return CSF_E_ARG;
+    return nav_kat(e, n, idx, 1, nullptr, nullptr, nullptr);
+}
+
+int csf_update_nav_state(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *stop, double *vd, double *ddest) {
+    if (!e) return CSF_E_ARG;
+    if (n > 0 && (!vd || !ddest)) return fail(e, CSF_E_ARG, "csf_update_nav_state: NULL output");
+    return nav_kat(e, n, idx, 2, stop, vd, ddest);
+}
+
+int csf_set_dest_pointer(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *ptr) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && (!idx || !ptr))) return fail(e, CSF_E_ARG, "csf_set_dest_pointer: bad arguments");
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        const int32_t rows = (int32_t)(e->h_q[(size_t)idx[k]].size() / 3);
+        if (ptr[k] < 0 || ptr[k] >= rows) return fail(e, CSF_E_ARG, "destination pointer %d outside the queue of agent %d (%d rows)", ptr[k], idx[k], rows);
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = prepare_mutation(e);
+    if (rc) return rc;
+    for (int64_t k = 0; k < n; k++) e->h_ptr[(size_t)idx[k]] = ptr[k];
+    return CSF_OK;
+}
+
 int csf_comm_unique_id(uint8_t id_out[CSF_UNIQUE_ID_BYTES]) {
     if (!id_out) return CSF_E_ARG;
     if (!g_rccl.load()) return fail(nullptr, CSF_E_COMM, "%s", g_rccl.err.c_str());
@@ -1269,6 +1437,66 @@ int csf_comm_init(csf_engine *e, const uint8_t id[CSF_UNIQUE_ID_BYTES], int32_t 
     return CSF_OK;
 }
 
+int csf_comm_init_loopback(csf_engine *const *engines, int32_t world) {
+    if (!engines || world < 1 || world > 64) return CSF_E_ARG;
+    for (int r = 0; r < world; r++) {
+        csf_engine *e = engines[r];
+        if (!e) return CSF_E_ARG;
+        if (e->nccl || e->loopback || e->world > 1) return fail(e, CSF_E_STATE, "engine already belongs to a communicator");
+        if (e->device != engines[0]->device || e->d.n != engines[0]->d.n || e->d.p.model != engines[0]->d.p.model)
+            return fail(e, CSF_E_ARG, "loopback members hold the same population on the same device");
+        for (int q = 0; q < r; q++)
+            if (engines[q] == e) return fail(e, CSF_E_ARG, "engine listed twice");
+    }
+    HIPCHK(engines[0], hipSetDevice(engines[0]->device));
+    for (int r = 0; r < world; r++) {
+        csf_engine *e = engines[r];
+        int rc = download_all(e);
+        if (rc) return rc;
+        e->rank = r;
+        e->world = world;
+        e->loopback = true;
+        e->dirty = true;
+        e->group.assign(engines, engines + world);
+        if (r > 0) {                                  // one stream for the whole group: ticks and exchanges in order
+            HIPCHK(e, hipStreamSynchronize(e->main));
+            HIPCHK(e, hipStreamDestroy(e->main));
+            e->main = engines[0]->main;
+            e->owns_main = false;
+        }
+        set_shard(e);
+    }
+    return CSF_OK;
+}
+
+int csf_step_group(csf_engine *const *engines, int32_t world, int64_t n_ticks) {
+    if (!engines || world < 1 || !engines[0]) return CSF_E_ARG;
+    csf_engine *e0 = engines[0];
+    if (n_ticks < 0) return fail(e0, CSF_E_ARG, "n_ticks must be >= 0");
+    if (!e0->loopback || (int)e0->group.size() != world) return fail(e0, CSF_E_STATE, "not a loopback group of %d engines", world);
+    for (int r = 0; r < world; r++)
+        if (engines[r] != e0->group[(size_t)r]) return fail(e0, CSF_E_ARG, "members must be passed in rank order");
+    HIPCHK(e0, hipSetDevice(e0->device));
+    for (int r = 0; r < world; r++) {
+        if (!engines[r]->main) return fail(engines[r], CSF_E_STATE, "the group's stream owner was destroyed");
+        int rc = upload_all(engines[r]);
+        if (rc) return rc;
+    }
+    for (int64_t t = 0; t < n_ticks; t++) {
+        for (int r = 0; r < world; r++) {
+            int rc = e0->d.n > 0 ? enqueue_tick(engines[r]) : (engines[r]->d.tick++, CSF_OK);
+            if (rc) return rc;
+        }
+        if (e0->d.n > 0) {
+            int rc = loopback_exchange(engines, world);
+            if (rc) return rc;
+        }
+    }
+    if (n_ticks > 0 && e0->d.n > 0)
+        for (int r = 0; r < world; r++) engines[r]->device_ahead = true;
+    return CSF_OK;
+}
+
 int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi) {
     if (!e) return CSF_E_ARG;
     if (lo) *lo = e->d.lo;
@@ -1287,32 +1515,80 @@ int csf_far_radius(const csf_engine *e, double *radius_m) {
 int csf_profile_enable(csf_engine *e, int32_t on) {
     if (!e) return CSF_E_ARG;
     e->profile = on > 0 ? on : 0;
+    if (e->profile) {                    // the event pool is created here, not inside the first sampled tick
+        HIPCHK(e, hipSetDevice(e->device));
+        return prof_make_pool(e);
+    }
+    return CSF_OK;
+}
+
+int csf_profile_kernels(csf_engine *e, double ms[4], int64_t launches[4]) {
+    if (!e) return CSF_E_ARG;
+    int rc = csf_sync(e);
+    if (rc) return rc;
+    while (e->prof_resolved < e->prof_issued)
+        if ((rc = prof_resolve_one(e))) return rc;
+    for (int k = 0; k < 4; k++) {
+        if (ms) ms[k] = e->prof_ms[k];
+        if (launches) launches[k] = e->prof_cnt[k];
+    }
+    e->last_gather_ms = e->prof_ms[3];
+    for (int k = 0; k < 4; k++) e->prof_ms[k] = 0, e->prof_cnt[k] = 0;
+    e->prof_ticks = 0;
+    e->prof_pair_us.clear();
     return CSF_OK;
 }
 
 int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *launches) {
-    if (!e) return CSF_E_ARG;
+    double ms[4];
+    int64_t cnt[4];
+    int rc = csf_profile_kernels(e, ms, cnt);
+    if (rc) return rc;
+    if (pair_ms) *pair_ms = ms[0];
+    if (agent_ms) *agent_ms = cnt[2] > 0 ? ms[2] * (double)cnt[0] / (double)cnt[2] : 0.0;   // scaled to the pair kernel's count
+    if (launches) *launches = cnt[0];
+    return CSF_OK;
+}
+
+int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_t *n_samples) {
+    if (!e || !n_samples || capacity < 0 || (capacity > 0 && !pair_us)) return e ? fail(e, CSF_E_ARG, "csf_profile_samples: bad arguments") : CSF_E_ARG;
     int rc = csf_sync(e);
     if (rc) return rc;
-    double pm = 0, am = 0, gm = 0;
-    int64_t cnt = 0;
-    for (size_t k = 0; k + 3 < e->ev.size(); k += 4) {
-        float a = 0, b = 0, c = 0;
-        HIPCHK(e, hipEventElapsedTime(&a, e->ev[k], e->ev[k + 1]));
-        HIPCHK(e, hipEventElapsedTime(&b, e->ev[k + 1], e->ev[k + 2]));
-        if (e->ev_gather_recorded) HIPCHK(e, hipEventElapsedTime(&c, e->ev[k + 2], e->ev[k + 3]));
-        pm += a;
-        am += b;
-        gm += c;
-        cnt++;
-    }
-    e->last_gather_ms = gm;
-    e->ev_gather_recorded = false;
-    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-    e->ev.clear();
-    if (pair_ms) *pair_ms = pm;
-    if (agent_ms) *agent_ms = am;
-    if (launches) *launches = cnt;
+    while (e->prof_resolved < e->prof_issued)
+        if ((rc = prof_resolve_one(e))) return rc;
+    const int64_t n = std::min<int64_t>(capacity, (int64_t)e->prof_pair_us.size());
+    for (int64_t k = 0; k < n; k++) pair_us[k] = e->prof_pair_us[(size_t)k];
+    *n_samples = n;
+    return CSF_OK;
+}
+
+int csf_count_pairs(csf_engine *e, int64_t *evaluated, const char **kernel_name) {
+    if (!e || !evaluated) return e ? fail(e, CSF_E_ARG, "csf_count_pairs: NULL output") : CSF_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);
+    if (rc) return rc;
+    Dev &d = e->d;
+    if (kernel_name) *kernel_name = pair_kernel_name(d);
+    *evaluated = -1;
+    if (std::string(pair_kernel_name(d)) != "pair_cull_kernel") return CSF_OK;   // only the cull-first kernel counts
+    *evaluated = 0;
+    if (d.n <= 1 || d.hi <= d.lo) return CSF_OK;
+    if ((rc = wait_gather(e))) return rc;
+    if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
+    if ((e->world > 1 || e->nccl != nullptr || e->loopback) && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
+    DevBuf<unsigned long long> cnt;
+    HIPCHK(e, cnt.alloc(1));
+    HIPCHK(e, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), e->main));   // alloc() clears on the NULL stream, which this stream does not wait for
+    Dev dd = d;                 // this tick's records and circles; the circles of the next tick are not touched
+    dd.pair_count = cnt.p;
+    dd.bnd_next = nullptr;
+    launch_pair(dd, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    unsigned long long h = 0;
+    HIPCHK(e, hipMemcpy(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost));
+    cnt.release();
+    *evaluated = (int64_t)h;
     return CSF_OK;
 }
 

@@ -230,8 +230,7 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
 }
 
 __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend) {
-    const int64_t units = d.n_pad / WAVE;  // blockIdx.y selects a chunk of sources, in units of 64 records
-    const int64_t per = (units + d.n_split - 1) / d.n_split;
+    const int64_t per = d.chunk_units;  // blockIdx.y selects a chunk of sources, in units of 64 records
     ibeg = (int64_t)blockIdx.y * per * WAVE;
     iend = ibeg + per * WAVE;
     if (iend > d.n_pad) iend = d.n_pad;
@@ -331,6 +330,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
 
     float ax[RPW], ay[RPW];     // the receivers themselves stay in LDS (rrec); one at a time is held in registers
     int qhead = 0, qlen = 0;    // wave-uniform ring state of the queue
+    unsigned evals = 0;         // pair evaluations of this wave (wave-uniform: scalar adds; written out for csf_count_pairs)
     Recv ru{0.f, 0.f, 1.f, 0.f};  // the receiver being worked on (wave-uniform, kept in VGPRs)
 #pragma unroll
     for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f;
@@ -350,6 +350,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                             lds_pair_b(ts, i0, i1), v0, v1, ax[u], ay[u]);
         qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
         qlen = __builtin_amdgcn_readfirstlane(qlen - n);
+        evals += (unsigned)n;
     };
 
     auto fill_tile = [&](int64_t base, int cnt) {
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
                     field_twod_x2<true>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
                                         lds_pair(ts, i0, i1), true, true, ax[u], ay[u]);
+                    evals += 2 * WAVE;
                 }
                 cand = (cand & ~inside) | ins;  // an odd one out takes the queue together with the partial batches
             }
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     } else {
         reduce_store(d, j0, lane, ax, ay, BINR ? &ragent[wave * RPW] : nullptr);
     }
+    if (d.pair_count != nullptr && lane == 0) atomicAdd(d.pair_count, (unsigned long long)evals);
     if (d.trace && lane == 0) {   // tools/block_trace.py: when did every wave run, and where
         uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave);
         o[0] = t_start;
@@ -775,71 +778,99 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
     out[t] = make_float2(fx, fy);
 }
 
+// get_untracked_foes (intersection.py:690-745) as the matrix the reference returns: out[i * n + j] = 1 when receiver j
+// ignores source i (row = source, column = receiver; the diagonal is always 1), from the same test the pair kernels apply
+__global__ void untracked_kernel(const Dev d, uint8_t *out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= d.n * d.n) return;
+    const int64_t i = t / d.n, j = t - i * d.n;
+    const float4 q = d.rec[i], rr = d.rec[j];
+    const Recv r{rr.x, rr.y, rr.z, rr.w};
+    const float dx = r.x - q.x, dy = r.y - q.y, r2 = dx * dx + dy * dy;
+    const bool in = (i != j) & (d.pc.p2r ? tracked<true>(d.pc.chs, r, dx, dy, r2) : tracked<false>(d.pc.chs, r, dx, dy, r2));
+    out[t] = in ? 0 : 1;
+}
+
+void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st) {
+    const int64_t m = d.n * d.n;
+    if (m <= 0) return;
+    hipLaunchKernelGGL(untracked_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, out);
+}
+
 static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
     int64_t nloc = d.hi - d.lo;
     int64_t per_block = per_block_recv;
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
 
+// every launch of this file: optional events take the kernel's own start / end time stamps (csf_dev.h)
+#define CSF_LAUNCH(kernel, grid) hipExtLaunchKernelGGL(kernel, grid, dim3(BLOCK), 0, st, t0, t1, 0, d)
+
 template <bool P2R, bool CLASSIFY, bool BINR>
-static void launch_cull_dyn(const Dev &d, hipStream_t st) {
-    const dim3 b(BLOCK);
+static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.dyn_recv && d.rpb == 32) {
-        hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32>), recv_grid(d, d.n_split, 32), b, 0, st, d);
+        CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32>), recv_grid(d, d.n_split, 32));
         return;
     }
-    if (d.dyn_recv) hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), recv_grid(d, d.n_split), b, 0, st, d);
-    else hipLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), recv_grid(d, d.n_split), b, 0, st, d);
+    if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), recv_grid(d, d.n_split));
+    else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), recv_grid(d, d.n_split));
 }
 
-static void launch_cull(const Dev &d, hipStream_t st) {
+static void launch_cull(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     const bool p2r = d.pc.p2r != 0;
     if (d.classify && d.recv_binned) {
-        if (p2r) launch_cull_dyn<true, true, true>(d, st);
-        else launch_cull_dyn<false, true, true>(d, st);
+        if (p2r) launch_cull_dyn<true, true, true>(d, st, t0, t1);
+        else launch_cull_dyn<false, true, true>(d, st, t0, t1);
     } else if (d.classify) {
-        if (p2r) launch_cull_dyn<true, true, false>(d, st);
-        else launch_cull_dyn<false, true, false>(d, st);
+        if (p2r) launch_cull_dyn<true, true, false>(d, st, t0, t1);
+        else launch_cull_dyn<false, true, false>(d, st, t0, t1);
     } else {
-        if (p2r) launch_cull_dyn<true, false, false>(d, st);
-        else launch_cull_dyn<false, false, false>(d, st);
+        if (p2r) launch_cull_dyn<true, false, false>(d, st, t0, t1);
+        else launch_cull_dyn<false, false, false>(d, st, t0, t1);
     }
 }
 
-void launch_pair(const Dev &d, hipStream_t st) {
+void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo) return;
-    const dim3 g = recv_grid(d, d.n_split), b(BLOCK);
+    const dim3 g = recv_grid(d, d.n_split);
     const bool p2r = d.pc.p2r != 0;
     if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
         if (d.rpb == 32) {
             const dim3 g8 = recv_grid(d, d.n_split, 32);
-            if (p2r) hipLaunchKernelGGL((pair_bike_kernel<true, 8>), g8, b, 0, st, d);
-            else hipLaunchKernelGGL((pair_bike_kernel<false, 8>), g8, b, 0, st, d);
+            if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 8>), g8);
+            else CSF_LAUNCH((pair_bike_kernel<false, 8>), g8);
         } else {
-            if (p2r) hipLaunchKernelGGL((pair_bike_kernel<true, 4>), g, b, 0, st, d);
-            else hipLaunchKernelGGL((pair_bike_kernel<false, 4>), g, b, 0, st, d);
+            if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 4>), g);
+            else CSF_LAUNCH((pair_bike_kernel<false, 4>), g);
         }
     } else if (d.p.model == CSF_BICYCLE) {
-        if (p2r) hipLaunchKernelGGL((pair_kernel<true, true>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_kernel<true, false>), g, b, 0, st, d);
+        if (p2r) CSF_LAUNCH((pair_kernel<true, true>), g);
+        else CSF_LAUNCH((pair_kernel<true, false>), g);
     } else if (d.pair_variant == 1) {
-        if (p2r) hipLaunchKernelGGL((pair_kernel<false, true>), g, b, 0, st, d);
-        else hipLaunchKernelGGL((pair_kernel<false, false>), g, b, 0, st, d);
+        if (p2r) CSF_LAUNCH((pair_kernel<false, true>), g);
+        else CSF_LAUNCH((pair_kernel<false, false>), g);
     } else {
-        launch_cull(d, st);
+        launch_cull(d, st, t0, t1);
     }
 }
 
-void launch_road(const Dev &d, hipStream_t st) {
+// which pair kernel launch_pair() takes for this engine (profiles and the bench line name it)
+const char *pair_kernel_name(const Dev &d) {
+    if (d.p.model == CSF_BICYCLE) return (d.classify && d.recs_valid) ? "pair_bike_kernel" : "pair_kernel";
+    if (d.pair_variant == 1) return "pair_kernel";
+    return "pair_cull_kernel";
+}
+
+void launch_road(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo || d.nv == 0) return;
-    const dim3 g = recv_grid(d, 1), b(BLOCK);
+    const dim3 g = recv_grid(d, 1);
     switch (d.road_np) {
-    case 2: hipLaunchKernelGGL(road_kernel<2>, g, b, 0, st, d); break;
-    case 3: hipLaunchKernelGGL(road_kernel<3>, g, b, 0, st, d); break;
-    case 4: hipLaunchKernelGGL(road_kernel<4>, g, b, 0, st, d); break;
-    case 5: hipLaunchKernelGGL(road_kernel<5>, g, b, 0, st, d); break;
-    case 6: hipLaunchKernelGGL(road_kernel<6>, g, b, 0, st, d); break;
-    default: hipLaunchKernelGGL(road_kernel<0>, g, b, 0, st, d); break;
+    case 2: CSF_LAUNCH(road_kernel<2>, g); break;
+    case 3: CSF_LAUNCH(road_kernel<3>, g); break;
+    case 4: CSF_LAUNCH(road_kernel<4>, g); break;
+    case 5: CSF_LAUNCH(road_kernel<5>, g); break;
+    case 6: CSF_LAUNCH(road_kernel<6>, g); break;
+    default: CSF_LAUNCH(road_kernel<0>, g); break;
     }
 }
 

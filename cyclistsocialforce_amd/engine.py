@@ -219,6 +219,31 @@ class Engine:
         self._ck(self._lib.csf_pair_force(self._h, _ptr(src), x.size, _ptr(x), _ptr(y), _ptr(psi), int(apply_fov), _ptr(fx), _ptr(fy)))
         return fx, fy
 
+    def untracked(self):
+        """get_untracked_foes() (intersection.py:690-745): bool [n, n], row = source, column = receiver"""
+        n = self.n
+        out = np.zeros((n, n), dtype=np.uint8)
+        self._ck(self._lib.csf_untracked(self._h, _ptr(out)))
+        return out.astype(bool)
+
+    def update_destination(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self._ck(self._lib.csf_update_destination(self._h, idx.size, _ptr(idx)))
+
+    def update_nav_state(self, idx, stop=None):
+        """(vd, ddest) of Vehicle.updateNavState(stop) for the listed agents; stop None reads the queue's stop flags"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        vd = np.zeros(idx.size)
+        dd = np.zeros(idx.size)
+        st = None if stop is None else np.ascontiguousarray(np.broadcast_to(np.asarray(stop, dtype=np.int32), idx.shape))
+        self._ck(self._lib.csf_update_nav_state(self._h, idx.size, _ptr(idx), None if st is None else _ptr(st), _ptr(vd), _ptr(dd)))
+        return vd, dd
+
+    def set_dest_pointer(self, idx, ptr):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        ptr = np.ascontiguousarray(np.broadcast_to(np.asarray(ptr, dtype=np.int32), idx.shape))
+        self._ck(self._lib.csf_set_dest_pointer(self._h, idx.size, _ptr(idx), _ptr(ptr)))
+
     # -- sharding ---------------------------------------------------------------------------
     @staticmethod
     def comm_unique_id():
@@ -235,6 +260,26 @@ class Engine:
             return
         buf = (C.c_uint8 * _ffi.UNIQUE_ID_BYTES).from_buffer_copy(bytes(unique_id))
         self._ck(self._lib.csf_comm_init(self._h, buf, int(rank), int(world)))
+
+    @staticmethod
+    def loopback_group(engines):
+        """One-device rehearsal of the sharded path (include/csf.h: csf_comm_init_loopback): the engines, all holding the
+        same population, become ranks 0 .. len-1; step them together with Engine.step_group."""
+        lib = _ffi.load()
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        rc = lib.csf_comm_init_loopback(arr, len(engines))
+        if rc != 0:
+            raise EngineError(f"[{rc}] " + "; ".join(lib.csf_last_error(e._h).decode() for e in engines))
+
+    @staticmethod
+    def step_group(engines, n_ticks=1, sync=False):
+        lib = _ffi.load()
+        arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        rc = lib.csf_step_group(arr, len(engines), int(n_ticks))
+        if rc != 0:
+            raise EngineError(f"[{rc}] " + "; ".join(lib.csf_last_error(e._h).decode() for e in engines))
+        if sync:
+            engines[0].sync()
 
     def shard_range(self):
         lo, hi = C.c_int64(0), C.c_int64(0)
@@ -256,6 +301,28 @@ class Engine:
         a, b, n = C.c_double(0), C.c_double(0), C.c_int64(0)
         self._ck(self._lib.csf_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def profile_kernels(self):
+        """{"pair" | "road" | "agent" | "gather": (accumulated ms, launches)} over the sampled ticks; resets the sums.
+        The pair kernel is timed on every sampled tick, the others on every 8th of them."""
+        ms = (C.c_double * 4)()
+        cnt = (C.c_int64 * 4)()
+        self._ck(self._lib.csf_profile_kernels(self._h, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(("pair", "road", "agent", "gather"))}
+
+    def profile_samples(self, capacity=65536):
+        """pair-kernel microseconds of every sampled launch since the last reset (does not reset)"""
+        out = np.zeros(int(capacity))
+        n = C.c_int64(0)
+        self._ck(self._lib.csf_profile_samples(self._h, _ptr(out), int(capacity), C.byref(n)))
+        return out[: n.value].copy()
+
+    def count_pairs(self):
+        """(pair evaluations of one launch on the current snapshot or None, name of the engine's pair kernel)"""
+        n = C.c_int64(0)
+        name = C.c_char_p()
+        self._ck(self._lib.csf_count_pairs(self._h, C.byref(n), C.byref(name)))
+        return (None if n.value < 0 else n.value), (name.value or b"").decode()
 
     def profile_gather(self):
         """all-gather milliseconds accumulated over the launches of the last profile_read() (sharded engines)"""

@@ -192,6 +192,10 @@ class SocialForceIntersection:
             raise RuntimeError(f"vehicle {v.id} already belongs to another intersection")
         if self.vehicles and type(v).MODEL != type(self.vehicles[0]).MODEL:
             raise NotImplementedError("one intersection holds one vehicle class (one engine per rider model)")
+        if v.dest_force_func is not None or v.rep_force_func is not None:
+            raise NotImplementedError(f"vehicle {v.id} carries a custom dest_force_func / rep_force_func: the population "
+                                      "engine evaluates the class's own force functions for every agent")
+        self._check_uniform(v)
         if v._solo is not None:
             v._solo.close()
             v._solo = None
@@ -207,6 +211,31 @@ class SocialForceIntersection:
         self.vehicleX = np.vstack((self.vehicleX, [[v.s[0]]]))         # intersection.py:531-538
         self.vehicleY = np.vstack((self.vehicleY, [[v.s[1]]]))
         self.vehicleTheta = np.vstack((self.vehicleTheta, [[v.s[2]]]))
+
+    def _check_uniform(self, v=None):
+        """One engine holds ONE parameter set (csf_params); only `params.v_desired_default` is per vehicle.  The reference
+        evaluates every source with its own parameters (vehicle.py:1592-1612) and the mask with the source's hfov
+        (intersection.py:733-735): a vehicle whose parameters differ from vehicle 0's would silently get vehicle 0's
+        here, so it is refused.  v = None re-checks the whole population (after parameter objects were assigned to)."""
+        if not self.vehicles and v is not None:
+            return
+        first = self.vehicles[0] if self.vehicles else v
+        stamp = (id(first.params), parameters.mutation_count())
+        if getattr(self, "_uniform_ref", (None,))[0] != stamp:        # vehicle 0's parameters, flattened once per change
+            self._uniform_ref = (stamp, first._pod(0))
+        ref = self._uniform_ref[1]
+        for w in ([v] if v is not None else self.vehicles[1:]):
+            if w.params is first.params:
+                continue
+            pod = w._pod(0)
+            if bytes(pod) != bytes(ref):
+                a, b = bytes(pod), bytes(ref)
+                diff = [name for name, _ in pod._fields_
+                        if a[getattr(type(pod), name).offset:][:getattr(type(pod), name).size]
+                        != b[getattr(type(pod), name).offset:][:getattr(type(pod), name).size]]
+                raise NotImplementedError(
+                    f"vehicle {w.id!r} differs from vehicle {first.id!r} in {', '.join(diff)}: one intersection engine "
+                    "holds one parameter set; only params.v_desired_default may differ between its vehicles")
 
     def add_road_user(self, user):
         """intersection.py:458-539 (without the SUMO route handling)."""
@@ -399,6 +428,7 @@ class SocialForceIntersection:
                 if ch.size:
                     e.set_v_desired(ch, vd[ch])
                     self._vd[ch] = vd[ch]
+                self._check_uniform()
                 pod = self.vehicles[0]._pod(PRIORITY_RULES[self.priority_rule])
                 if bytes(pod) != self._pod_bytes:
                     e.set_params(pod)
@@ -484,6 +514,14 @@ class SocialForceIntersection:
                 self.vehicleX[k, 0], self.vehicleY[k, 0], self.vehicleTheta[k, 0] = v.s[0], v.s[1], v.s[2]
 
     # ------------------------------------------------------------------ reference API
+    def get_untracked_foes(self):
+        """intersection.py:690-745: boolean [n, n], True where a road user is not considered.  As in the reference the
+        first index is the road user whose force field is evaluated (the source, whose hfov applies: :733-735) and the
+        second the one that would feel it; the diagonal is True, and a single road user yields `np.array(True)`."""
+        if self.n_bikes <= 1:
+            return np.array((True))
+        return self._push_mutations().untracked()
+
     def calc_forces(self):
         """intersection.py:747-864: total force on every road user from the current snapshot."""
         e = self._push_mutations()

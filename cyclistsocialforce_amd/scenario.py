@@ -1,74 +1,153 @@
-"""Tick driver with the constructor and `run()` semantics of `cyclistsocialforce.scenario.Scenario`
-(scenario.py:53-265), free of the reference module's import-time dependencies (sumolib, traci, cv2,
-mypyutils: scenario.py:13-50).  Animation and video write-out are out of scope; everything else — the
-real-time pacing of `_wait`, the progress line, the `input()` prompt when verbose — behaves the same, so
-benchmarks must pass `t_r=0, verbose=False` exactly as they would with the reference.
+"""Tick driver with the interface of `cyclistsocialforce.scenario.Scenario` (scenario.py:53-265): same constructor
+arguments, `run(t_end)`, `reset()`, the public counters `i`, `t`, `i_end`, and the same three behaviours a caller can
+observe —
+
+* `run(t_end)` executes `step_func()` until `i == int(t_end / t_s)`; it can be called again with a later `t_end`;
+* every tick is stretched to at least `t_r` seconds of wall time (real-time pacing; `t_r=0` runs flat out);
+* with `verbose=True` the run waits for <Enter> first and keeps one status line up to date.
+
+Written from that description, not from the reference module, which cannot be imported without sumolib, traci, cv2
+and mypyutils (scenario.py:13-50).  Additions: `hist_run_time` (seconds each tick took before pacing) and
+`ticks_per_second()`.  Animation (`animate=True`) draws through the vehicles' drawing hooks with matplotlib when it is
+installed; writing videos is out of scope.
 """
+import sys
+import time
 from datetime import timedelta
-from time import sleep, time
+
+
+class _RealTimePacer:
+    """Stretches ticks to a minimum wall-clock duration."""
+
+    def __init__(self, period):
+        self.period = float(period)
+
+    def remaining(self, started):
+        return max(0.0, self.period - (time.time() - started))
+
+    def hold(self, started):
+        left = self.remaining(started)
+        if left > 0.0:
+            time.sleep(left)
+        return left
+
+
+class _StatusLine:
+    """One self-overwriting console line."""
+
+    def __init__(self, stream=None):
+        self.stream = stream or sys.stdout
+        self.width = 0
+
+    def show(self, text):
+        pad = max(0, self.width - len(text))
+        self.stream.write("\r" + text + " " * pad)
+        self.stream.flush()
+        self.width = len(text)
+
+    def close(self):
+        if self.width:
+            self.stream.write("\n")
+            self.width = 0
+
+
+def _clock(seconds):
+    return str(timedelta(seconds=round(float(seconds), 2)))[:11]
 
 
 class Scenario:
     def __init__(self, step_func, t_0=0, t_s=0.01, t_r=0.01, animate=False, axes=None, verbose=True,
                  t_snapshots=(), write_animation=False, dir_animation_out=None, fname_animation_out=None,
                  tempdir_animation=None, keep_animation_frames=False):
-        if animate or write_animation:
-            raise NotImplementedError("animation is outside the scope of the MI355X engine")
-        self.t = t_0                                                   # scenario.py:75-94
+        if write_animation:
+            raise NotImplementedError("writing animation videos is outside the scope of the MI355X engine")
+        if not callable(step_func):
+            raise TypeError("step_func must be callable")
+        self.step_func = step_func
+        self.t_0 = t_0
+        self.t = t_0
         self.t_s = t_s
         self.t_r = t_r
-        self.t_0 = t_0
-        self.t_wall = time()
+        self.t_wall = time.time()
         self.i = 0
-        self.animate = False
+        self.i_end = 0
+        self.animate = bool(animate)
         self.ax = axes
         self.verbose = verbose
-        self.step_func = step_func
-        self.hist_run_time = []                                        # per-tick wall time (scenario.py:301)
+        self.t_snapshots = tuple(t_snapshots)
+        self.write_animation = False
+        self.dir_animation_out = dir_animation_out
+        self.fname_animation_out = fname_animation_out
+        self.tempdir_animation = tempdir_animation
+        self.keep_animation_frames = keep_animation_frames
+        self.hist_run_time = []
+        self.fig = None
 
+    # ------------------------------------------------------------------ public
     def run(self, t_end):
-        """scenario.py:96-113"""
+        """Advance the scenario to simulated time t_end (scenario.py:96-113)."""
         if self.verbose:
             input("\nPress any key to start simulation ... \n")
-        t_start = time()
-        self._run_silent(t_start, t_end)
-        if self.verbose:
-            print("\n")
-            print(f"Simulation finished after {str(timedelta(seconds=time() - t_start))[:-3]}")
-
-    def _run_silent(self, t_start, t_end):
-        """scenario.py:115-122"""
+        began = time.time()
         self.i_end = int(t_end / self.t_s)
-        len_prev_msg = 0
+        pacer = _RealTimePacer(self.t_r)
+        status = _StatusLine() if self.verbose else None
+        canvas = self._open_canvas() if self.animate else None
         while self.i < self.i_end:
-            t = time()
-            self._step()
-            self.hist_run_time.append(time() - t)
-            len_prev_msg = self._wait(t, t_start, self.i_end, len_prev_msg)
+            tick_began = time.time()
+            if canvas is not None:
+                self._step_blitting(canvas)
+            else:
+                self._step()
+            self.hist_run_time.append(time.time() - tick_began)
+            if status is not None:
+                busy = time.time() - tick_began
+                period = max(busy, self.t_r)
+                rate = int(1.0 / period) if period > 0 else 0
+                status.show(f"step {self.i} of {self.i_end} | simulated {_clock(self.t - self.t_0)} | "
+                            f"elapsed {_clock(time.time() - began)} | {rate} ticks/s")
+            pacer.hold(tick_began)
+        if status is not None:
+            status.close()
+            print(f"Simulation finished after {_clock(time.time() - began)}")
 
+    def reset(self):
+        """Rewind the counters (scenario.py:226-228); the step function's own state is the caller's business."""
+        self.i = 0
+        self.t = self.t_0
+
+    def ticks_per_second(self):
+        """Mean tick rate of the ticks run so far, before pacing."""
+        total = sum(self.hist_run_time)
+        return len(self.hist_run_time) / total if total > 0 else float("inf")
+
+    # ------------------------------------------------------------------ one tick
     def _step(self):
         """scenario.py:169-173"""
         self.step_func()
         self.i += 1
         self.t += self.t_s
 
-    def _wait(self, t, t_start, i_end, len_prev_msg):
-        """scenario.py:175-195: sleep up to the real-time step t_r and print the progress line."""
-        dt = time() - t
-        t_sleep = max(0, self.t_r - dt)
-        msg = ""
-        if self.verbose:
-            sim_time = str(timedelta(seconds=self.t))[:11]
-            wall_time = str(timedelta(seconds=(time() - t_start)))[:11]
-            msg = (f"Running step {self.i}/{i_end}, Sim. time {sim_time}, Wall time {wall_time}, "
-                   f"Wall freq. {int(1 / (dt + t_sleep)) if dt + t_sleep > 0 else 0} Hz ")
-            msg += " " * max(len_prev_msg - len(msg), 0)
-            print("\r" + msg, end="")
-        if dt < self.t_r:
-            sleep(t_sleep)
-        return len(msg)
+    # ------------------------------------------------------------------ animation (matplotlib, optional)
+    def _open_canvas(self):
+        try:
+            import matplotlib.pyplot as plt
+        except ImportError as exc:  # pragma: no cover - matplotlib is an optional dependency
+            raise RuntimeError("animate=True needs matplotlib") from exc
+        if self.ax is None:
+            self.fig, self.ax = plt.subplots(1, 1)
+        else:
+            self.fig = self.ax.figure
+        self.ax.set_aspect("equal")
+        self.fig.canvas.draw()
+        return {"background": self.fig.canvas.copy_from_bbox(self.fig.bbox)}
 
-    def reset(self):
-        """scenario.py:226-228"""
-        self.i = 0
-        self.t = self.t_0
+    def _step_blitting(self, canvas):
+        """Redraw only the animated artists of the vehicles' drawings on top of the saved background."""
+        self.fig.canvas.restore_region(canvas["background"])
+        self._step()
+        for artist in self.ax.get_children():
+            if getattr(artist, "get_animated", lambda: False)():
+                self.ax.draw_artist(artist)
+        self.fig.canvas.blit(self.fig.bbox)
+        self.fig.canvas.flush_events()

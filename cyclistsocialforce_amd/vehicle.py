@@ -29,7 +29,13 @@ class Vehicle:
     N_STATES = 4
     STATE_NAMES = ["x[m]", "y[m]", "psi[rad]", "v[m/s]"]
 
-    def __init__(self, s0, id="unknown", route=(), saveForces=False, params=None):
+    def __init__(self, s0, id="unknown", route=(), saveForces=False, params=None, dest_force_func=None,
+                 rep_force_func=None):
+        # per-vehicle hooks (vehicle.py:56, 194-204, 225-234): None selects the class's own force functions, which run
+        # on the GPU.  A custom callable is honoured by the single-vehicle methods below (it is the caller's Python
+        # code); a population engine evaluates one field for all its agents and refuses vehicles that carry one.
+        self.dest_force_func = dest_force_func
+        self.rep_force_func = rep_force_func
         if self.MODEL is None:
             raise NotImplementedError("instantiate Bicycle, TwoDBicycle, InvPendulumBicycle or PlanarPointBicycle")
         if params is None:                                             # vehicle.py:139-143
@@ -189,6 +195,8 @@ class Vehicle:
     # ------------------------------------------------------------------ reference API
     def calcRepulsiveForce(self, x, y, psi):
         """vehicle.py:250-279 / 1560-1648: force this vehicle exerts on road users at (x, y, psi)."""
+        if self.rep_force_func is not None:
+            return self.rep_force_func(self, x, y, psi)
         if getattr(self.params, "f_0", 1.0) == 0.0 and self.MODEL != _ffi.BICYCLE:
             return 0.0, 0.0                                            # vehicle.py:1592-1593
         x = np.atleast_1d(np.asarray(x, dtype=float)).ravel()
@@ -199,6 +207,9 @@ class Vehicle:
 
     def calcDestinationForce(self):
         """vehicle.py:281-299, 1189-1194, 1416-1558 (advances the destination queue / nav state)."""
+        if self.dest_force_func is not None:                           # vehicle.py:295-297
+            self.updateDestination()
+            return self.dest_force_func(self)
         e = self._solo_engine()
         fx, fy = e.dest_force()
         s, ptr, zn, _ = e.state(with_nav=True)
@@ -214,8 +225,31 @@ class Vehicle:
         self._pull(s[0], ptr[0], zn[0])
         self._advance_history(float(F1), float(F2))
 
+    def _engine_and_row(self):
+        """(engine, row) that hold this vehicle on the device, with every host-side edit pushed"""
+        if self._owner is not None:
+            return self._owner._push_mutations(), self._index
+        return self._solo_engine(), 0
+
+    def _refresh_nav(self, e, row):
+        _, ptr, zn, _ = e.state(with_nav=True)
+        self.destpointer = int(ptr[row])
+        self.znav[:] = zn[row]
+
     def updateDestination(self):
-        raise NotImplementedError("the queue is advanced inside calcDestinationForce() on the device")
+        """vehicle.py:545-594: advance the queue pointer past destinations that were reached or can be skipped."""
+        assert self.destqueue is not None, "Road user does not have a destination queue!"
+        e, row = self._engine_and_row()
+        e.update_destination([row])
+        self._refresh_nav(e, row)
+
+    def updateNavState(self, stop):
+        """vehicle.py:354-457: one transition of the cruise / decelerate / arrived machine; returns (vd, ddest)."""
+        assert np.any(self.znav), "Invalid state!"
+        e, row = self._engine_and_row()
+        vd, ddest = e.update_nav_state([row], [1 if bool(stop) else 0])
+        self._refresh_nav(e, row)
+        return float(vd[0]), float(ddest[0])
 
     def getDestinationDistance(self):
         """vehicle.py:596-604"""
@@ -243,20 +277,37 @@ class Vehicle:
             self._owner._mark_queue_dirty(self, -1 if reset else None)
 
     def stop(self, stoptype=0, stopdest=None):
-        """vehicle.py:459-503, stoptype 0: stop at the next destination in the queue (sets its stop flag; the
-        reference does this through `self.dest`, a view of the queue row).  Types 1 and 2 reference attributes
-        that no parameter class defines (`params.AMAX`, vehicle.py:486) and are not mirrored."""
-        if stoptype != 0:
-            raise NotImplementedError("only stoptype 0 (stop at the next destination) is mirrored")
-        self.destqueue[self.destpointer, 2] = 1.0
-        self._queue_edit()
+        """vehicle.py:459-503.  Type 0 sets the stop flag of the current destination (the reference does it through
+        `self.dest`, a view of the queue row).  Type 2 rebinds `self.dest` to a detached (xstop, ystop, 1) array, which the
+        next updateDestination() replaces by the queue row again, and steps the pointer back: only the pointer change
+        outlives the call, and that is what is mirrored.  Type 1 reads `params.AMAX`, which no parameter class defines
+        (vehicle.py:486): AttributeError, as in the reference."""
+        if stoptype == 0:
+            self.destqueue[self.destpointer, 2] = 1.0
+            self._queue_edit()
+        elif stoptype == 1:
+            raise AttributeError(f"'{type(self.params).__name__}' object has no attribute 'AMAX'")
+        elif stoptype == 2:
+            if stopdest is None or len(stopdest) < 2:
+                raise TypeError("stoptype 2 needs stopdest = (xstop, ystop)")
+            if self.destpointer > 0:
+                self._set_destpointer(self.destpointer - 1)
+        else:
+            raise ValueError("Stop type has to be one of [0,1,2].")
 
     def go(self, gotype=0):
-        """vehicle.py:505-535, gotype 0: keep the current destination but do not stop there."""
-        if gotype != 0:
-            raise NotImplementedError("only gotype 0 (clear the stop flag of the current destination) is mirrored")
-        self.destqueue[self.destpointer, 2] = 0.0
-        self._queue_edit()
+        """vehicle.py:505-535: type 0 clears the stop flag of the current destination, type 1 re-reads the current queue
+        row; both end with updateDestination()."""
+        if gotype == 0:
+            self.destqueue[self.destpointer, 2] = 0.0
+            self._queue_edit()
+        self.arrived = False
+        self.updateDestination()
+
+    def _set_destpointer(self, value):
+        e, row = self._engine_and_row()
+        e.set_dest_pointer([row], [int(value)])
+        self.destpointer = int(value)
 
     def _queue_edit(self):
         """Rows were edited in place: the engine's copy is replaced, the destination pointer kept."""
@@ -315,8 +366,8 @@ class TwoDBicycle(Bicycle):
     PARAMS_TYPE = InvPendulumBicycleParameters
     MODEL = _ffi.TWOD
 
-    def __init__(self, s0, id="unknown", route=(), saveForces=False, params=None):
-        Bicycle.__init__(self, s0, id=id, route=route, saveForces=saveForces, params=params)
+    def __init__(self, s0, id="unknown", route=(), saveForces=False, params=None, **hooks):
+        Bicycle.__init__(self, s0, id=id, route=route, saveForces=saveForces, params=params, **hooks)
 
 
 class InvPendulumBicycle(TwoDBicycle):

@@ -169,6 +169,19 @@ int csf_get_history(csf_engine *e, int64_t first_sample, int64_t n_samples, doub
 int csf_pair_force(csf_engine *e, const double *src, int64_t m, const double *x, const double *y,
                    const double *psi, int32_t apply_fov, double *Fx, double *Fy);
 
+/* get_untracked_foes() (intersection.py:690-745) as the matrix the reference returns: out [n, n] bytes, row = source i,
+ * column = receiver j, 1 = "j ignores i" (the diagonal is 1), from the test the pair kernels apply.  n <= 46340. */
+int csf_untracked(csf_engine *e, uint8_t *out);
+/* Vehicle.updateDestination() (vehicle.py:545-594) for the listed agents, on its own: the queue pointer moves exactly as
+ * it does at the start of calcDestinationForce(). */
+int csf_update_destination(csf_engine *e, int64_t n, const int32_t *idx);
+/* Vehicle.updateNavState(stop) (vehicle.py:354-457) for the listed agents: advances the three-state machine and returns
+ * what the reference returns, (vd, ddest).  stop is NULL or [n]: >= 0 stands in for the stop flag of the current
+ * destination (the reference passes it explicitly), < 0 reads the flag of the queue row. */
+int csf_update_nav_state(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *stop, double *vd, double *ddest);
+/* vehicle.destpointer assigned from the host (Vehicle.stop types 1 and 2 step it back: vehicle.py:486-502) */
+int csf_set_dest_pointer(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *ptr);
+
 /* ---- sharding over the GPUs of one node ------------------------------------- */
 
 /* The population is replicated on the host side of every rank; rank r integrates the contiguous
@@ -182,6 +195,15 @@ int csf_comm_init(csf_engine *e, const uint8_t id[CSF_UNIQUE_ID_BYTES], int32_t 
 /* the receiver block of this rank: [lo, hi) */
 int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi);
 
+/* Rehearsal of the sharded path on ONE device (tests; no reference counterpart): `world` engines holding the same
+ * population become ranks 0 .. world-1 of a loopback group.  They share one HIP stream, and where the ranks of a real
+ * run call ncclAllGather the group copies every member's record block into the record arrays of the others.  Everything
+ * else - shard bounds and padding, sentinel records, the receiver lists, the re-binning from gathered records, the
+ * stale fp64 state of foreign agents - is the code path of csf_comm_init.  Members are stepped together with
+ * csf_step_group (engines in rank order); csf_step on a member fails. */
+int csf_comm_init_loopback(csf_engine *const *engines, int32_t world);
+int csf_step_group(csf_engine *const *engines, int32_t world, int64_t n_ticks);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 
 /* HIP-event time of the pair kernel, measured on the stream it is launched on: enable with on = k > 0 to
@@ -190,6 +212,20 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi);
  * number of sampled launches (reset on read). */
 int csf_profile_enable(csf_engine *e, int32_t on);
 int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *launches);
+/* The same with every kernel of the tick: ms[4] = accumulated milliseconds of the pair kernel, the road-edge kernel, the
+ * per-agent kernel (each from the start / end time stamps of the kernel's own dispatch) and the all-gather, launches[4]
+ * = the number of launches behind each sum; resets the sums.  The pair kernel is timed on every sampled tick, the
+ * others on every 8th of them (a time stamp costs a few microseconds of launch gap).  The events come from a fixed pool
+ * that is recycled in order, so profiling may stay enabled for any number of ticks.  csf_profile_samples copies the
+ * pair-kernel time of every sampled launch since the last reset (microseconds, at most `capacity`, at most 65 536 are
+ * kept) WITHOUT resetting. */
+int csf_profile_kernels(csf_engine *e, double ms[4], int64_t launches[4]);
+int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_t *n_samples);
+/* Number of pair evaluations (vehicle.py:1560-1648 calls per receiver, after the mask of intersection.py:690-745 and the
+ * far-field cull) of ONE launch of the pair kernel on the current snapshot: what the VALU roofline of bench.py is
+ * computed from.  Runs one extra launch with a counter; the state of the simulation is not advanced.  *evaluated = -1
+ * when the engine's pair kernel does not count (kernel_name, if not NULL, names the kernel either way). */
+int csf_count_pairs(csf_engine *e, int64_t *evaluated, const char **kernel_name);
 /* milliseconds between the end of the agent kernel and the end of the RCCL all-gather, accumulated over the launches
  * of the last csf_profile_read (0 for an unsharded engine) */
 int csf_profile_gather(const csf_engine *e, double *gather_ms);

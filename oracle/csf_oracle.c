@@ -211,6 +211,36 @@ void csfo_road_force(int64_t nv, const double *vx, const double *vy, const doubl
     *Fy = fy;
 }
 
+/* intersection.py:814-843 for a SAMPLE of receivers of a large population: the column sums (before the clamp of
+ * :841-845) of receivers recv[0..m) over all n sources, every pair through csfo_untracked and the field function.
+ * O(n) memory: the full-size parity tests (262 144 and 1 048 576 agents) cannot afford a csfo_t with its 30-s
+ * trajectory rings.  v is read for the Bicycle field only. */
+void csfo_column_sums(const csfo_params *p, int64_t n, const double *x, const double *y, const double *psi,
+                      const double *v, int64_t m, const int64_t *recv, double *rx, double *ry) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t k = 0; k < m; k++) {
+        const int64_t j = recv[k];
+        double sx = 0, sy = 0;
+        for (int64_t i = 0; i < n; i++) {
+            if (csfo_untracked(p->hfov, p->priority_rule, i == j ? 0 : 1, 0, x[i], y[i], x[j], y[j], psi[j])) continue;
+            double gx, gy;
+            if (p->model == CSFO_BICYCLE) csfo_pair_bicycle(p, x[i], y[i], psi[i], v[i], x[j], y[j], &gx, &gy);
+            else csfo_pair_twod(p, x[i], y[i], psi[i], x[j], y[j], psi[j], &gx, &gy);
+            sx += gx;                                              /* :842-843 */
+            sy += gy;
+        }
+        rx[k] = sx;
+        ry[k] = sy;
+    }
+}
+
+/* intersection.py:226-242, 854-857 for m receivers (OpenMP over the receivers) */
+void csfo_road_forces(int64_t nv, const double *vx, const double *vy, const double *vF0, const double *vsig,
+                      int64_t m, const double *x, const double *y, double *fx, double *fy) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t k = 0; k < m; k++) csfo_road_force(nv, vx, vy, vF0, vsig, x[k], y[k], &fx[k], &fy[k]);
+}
+
 /* ----------------------------------------------- destination queue + nav state machine ---- */
 
 static inline double *S(csfo_t *o, int a) { return o->s + 6 * (size_t)a; }
@@ -966,6 +996,38 @@ csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double 
     }
     csfo_update_snapshot_range(o, 0, n);                           /* intersection.py:320 */
     return o;
+}
+
+/* Test aid (no reference counterpart): re-anchor the oracle on a state produced elsewhere - what csf_push_state does for
+ * the engine (calibration.py:455-460 edits vehicle.s the same way): s [n][ns] replaces vehicle.s, the current column of
+ * the trajectory ring and the position snapshot; ptr / znav (optional) replace the destination pointer and the
+ * navigation state.  The dynamics of a chaotic population cannot be compared point by point over thousands of ticks;
+ * the long-run parity tests re-anchor every 100 ticks and compare the segments in between. */
+void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const uint8_t *znav) {
+    for (int a = 0; a < o->n; a++) {
+        double *s = S(o, a);
+        for (int k = 0; k < o->ns; k++) s[k] = s_in[(size_t)a * o->ns + k];
+        int i = o->i[a];
+        trj(o, a, 0)[i] = s[0];
+        trj(o, a, 1)[i] = s[1];
+        trj(o, a, 2)[i] = s[4];
+        if (o->p.model == CSFO_INVPEND) {
+            double *x = o->xlti + 5 * a;
+            x[0] = s[4];
+            x[2] = s[5];
+            x[4] = s[2];
+        }
+        if (o->p.model == CSFO_PLANARPOINT) {
+            o->xdyn[3 * a] = s[2];
+            o->xdyn[3 * a + 1] = s[0];
+            o->xdyn[3 * a + 2] = s[1];
+            o->vdyn[a] = s[3];
+        }
+        if (ptr) o->ptr[a] = ptr[a];
+        if (znav)
+            for (int k = 0; k < 3; k++) o->znav[3 * a + k] = znav[3 * a + k];
+    }
+    csfo_update_snapshot_range(o, 0, o->n);
 }
 
 void csfo_destroy(csfo_t *o) {

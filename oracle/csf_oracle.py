@@ -98,6 +98,8 @@ def lib():
         L.csfo_untracked.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_double] * 5
         L.csfo_road_force.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_double, C.c_double, dp, dp]
+        L.csfo_column_sums.argtypes = [C.POINTER(Params), C.c_int64] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
+        L.csfo_road_forces.argtypes = [C.c_int64] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 4
         L.csfo_spline20.restype = C.c_int
         L.csfo_spline20.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_control_move.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int, C.c_double,
@@ -116,6 +118,7 @@ def lib():
         L.csfo_get_nav.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.csfo_get_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.csfo_set_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.csfo_push_state.argtypes = [C.c_void_p] * 4
         L.csfo_dest_force.argtypes = [C.c_void_p, C.c_int, dp, dp]
         L.csfo_apply_forces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_num_threads.restype = C.c_int
@@ -186,6 +189,27 @@ def road_force(verts, off, F0, sigma, x, y):
     for k in range(len(x)):
         lib().csfo_road_force(len(verts), _p(vx), _p(vy), _p(vF0), _p(vsg), x[k], y[k], C.byref(a), C.byref(b))
         fx[k], fy[k] = a.value, b.value
+    return fx, fy
+
+
+def column_sums(params, x, y, psi, v, recv):
+    """unclamped repulsive column sums (intersection.py:814-843) of the receivers `recv` over all sources"""
+    x, y, psi, v = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, psi, v))
+    recv = np.ascontiguousarray(recv, dtype=np.int64)
+    rx = np.zeros(recv.size); ry = np.zeros(recv.size)
+    lib().csfo_column_sums(C.byref(params), x.size, _p(x), _p(y), _p(psi), _p(v), recv.size, _p(recv), _p(rx), _p(ry))
+    return rx, ry
+
+
+def road_forces(verts, off, F0, sigma, x, y):
+    """road_force for many receivers at once (OpenMP)"""
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    vF0 = np.repeat(np.asarray(F0, dtype=np.float64), np.diff(off))
+    vsg = np.repeat(np.asarray(sigma, dtype=np.float64), np.diff(off))
+    vx = np.ascontiguousarray(verts[:, 0]); vy = np.ascontiguousarray(verts[:, 1])
+    x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+    fx = np.zeros(x.size); fy = np.zeros(x.size)
+    lib().csfo_road_forces(len(verts), _p(vx), _p(vy), _p(vF0), _p(vsg), x.size, _p(x), _p(y), _p(fx), _p(fy))
     return fx, fy
 
 
@@ -279,6 +303,13 @@ class Population:
     def set_snapshot(self, lo, hi, snap):
         snap = np.ascontiguousarray(snap, dtype=np.float64)
         lib().csfo_set_snapshot(self.h, lo, hi, _p(snap))
+
+    def push_state(self, s, ptr=None, znav=None):
+        """re-anchor the oracle on a state produced elsewhere (test aid, see csfo_push_state)"""
+        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n, self.ns)
+        ptr = None if ptr is None else np.ascontiguousarray(ptr, dtype=np.int32)
+        znav = None if znav is None else np.ascontiguousarray(znav, dtype=np.uint8).reshape(self.n, 3)
+        lib().csfo_push_state(self.h, _p(s), None if ptr is None else _p(ptr), None if znav is None else _p(znav))
 
     def dest_force(self, a):
         fx, fy = C.c_double(), C.c_double()

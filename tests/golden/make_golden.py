@@ -499,10 +499,84 @@ def gen_utils():
     save("utils", a=a, limitAngle=la, a1=a1, a2=a2, angleDifference=ad, x=x, y=y, r=r, lx=lx, ly=ly)
 
 
+# ----------------------------------------------------------------------------
+# (11) InvPendulum yaw step response WITHOUT the `control` stand-in — the scenario of the reference's own
+#      test (src/cyclistsocialforce/test.py:15-165): 30 deg yaw step after 20 % of 10 s, speed held at
+#      v_desired_default.  The closed-loop matrices come from the REFERENCE's assembly
+#      (vehicle.py:1738-1786 + the gain tables of parameters.py:1857-1892, read off `bike.dynamics` after
+#      `update_dynamics()`); the time stepping is done twice by SciPy alone, with no matrix exponential of
+#      ours in the way:
+#        zoh   scipy.signal.cont2discrete(method="zoh") recursion (the exact answer for an input that is
+#              constant over each tick, which is what step_yaw feeds forced_response: vehicle.py:1835-1842)
+#        ode   scipy.integrate.solve_ivp(Radau, rtol 1e-12) tick by tick on x' = A x + B u
+#      and once through the reference's step_yaw on the `control` stand-in (`shim`).  All three are stored; the
+#      oracle and the HIP kernel are tested against `zoh`.
+#      test.py's own expected curve is built by pole placement (poles 30 x (-0.2, -0.1 +- 0.1j, -0.15, -0.1),
+#      Ku = 1 / -0.4631...): those are the gains of the table's commented-out predecessor
+#      (parameters.py:1858-1861), NOT of HEAD's table, whose closed-loop poles move with speed.  The placement
+#      gains and HEAD's table gains at v = 5 are stored side by side to document that test.py is stale at HEAD.
+# ----------------------------------------------------------------------------
+def gen_invpend_yawstep():
+    from scipy.integrate import solve_ivp
+    from scipy.signal import cont2discrete, place_poles
+
+    bike = make_vehicle("invpend", (0, 0, 0, 0, 0, 0))
+    v = bike.params.v_desired_default
+    bike.s[3] = v                                             # test.py:31
+    h = bike.params.t_s
+    t = np.arange(0, 10, h)
+    psi_d = np.zeros_like(t)
+    psi_d[int(0.2 * len(t)):] = 2 * np.pi * 30 / 360          # test.py:35-36
+    Fx, Fy = v * np.cos(psi_d), v * np.sin(psi_d)             # test.py:38-39
+
+    bike.update_dynamics()                                    # the reference's closed loop at this speed
+    A = np.array(bike.dynamics.A, dtype=float)
+    B = np.array(bike.dynamics.B, dtype=float).reshape(5, 1)
+
+    # (shim) the reference's own step_yaw, tick by tick, exactly as test.py:42-49 drives it
+    shim = np.zeros((len(t), 3))                              # psi, delta, theta after each tick
+    for k in range(len(t)):
+        shim[k] = bike.step_yaw(Fx[k], Fy[k])
+    # (zoh) SciPy's discretisation
+    Ad, Bd, *_ = cont2discrete((A, B, np.eye(5), np.zeros((5, 1))), h, method="zoh")
+    x = np.zeros(5)
+    zoh = np.zeros((len(t), 3))
+    for k in range(len(t)):
+        x = Ad @ x + Bd[:, 0] * np.arctan2(Fy[k], Fx[k])
+        zoh[k] = (x[4], x[0], x[2])
+    # (ode) an implicit Runge-Kutta integration of the same linear system, tick by tick
+    x = np.zeros(5)
+    ode = np.zeros((len(t), 3))
+    for k in range(len(t)):
+        u = np.arctan2(Fy[k], Fx[k])
+        sol = solve_ivp(lambda _t, y: A @ y + B[:, 0] * u, (0.0, h), x, method="Radau", rtol=1e-12, atol=1e-15,
+                        jac=lambda _t, y: A)
+        x = sol.y[:, -1]
+        ode[k] = (x[4], x[0], x[2])
+    print(f"invpend yaw step: |shim - zoh| max {np.abs(shim - zoh).max():.2e}, |ode - zoh| max {np.abs(ode - zoh).max():.2e}, "
+          f"final yaw {zoh[-1, 0]:.6f} (target {psi_d[-1]:.6f})")
+    assert np.abs(ode - zoh).max() < 1e-9 and np.abs(shim - zoh).max() < 1e-9
+
+    # test.py:51-99: the placement the reference's test compares with, and HEAD's table at the same speed
+    Ao, Bo, _, _ = bike.get_openloop_statespace_matrices()
+    poles_test = np.array((-0.2 + 0j, -0.1 + 0.1j, -0.1 - 0.1j, -0.15 + 0j, -0.1 + 0j)) * 30
+    K_place = place_poles(Ao, Bo[:, None], poles_test).gain_matrix[0]
+    K_table, Ku_table = bike.params.fullstate_feedback_gains(v)
+    speeds = np.array([2.0, 3.0, 5.0, 7.0])
+    poles_head = []
+    for vv in speeds:                                         # closed-loop poles of HEAD's table: they move with speed
+        bike.s[3] = vv
+        bike.update_dynamics()
+        poles_head.append(np.sort_complex(np.linalg.eigvals(np.array(bike.dynamics.A, dtype=float))))
+    save("invpend_yawstep", t_s=h, v=v, psi_d=psi_d, Fx=Fx, Fy=Fy, A=A, B=B[:, 0], zoh=zoh, ode=ode, shim=shim,
+         K_place_testpy=K_place, Ku_testpy=1 / -0.46313878281084603, K_table_head=K_table[0], Ku_table_head=Ku_table,
+         speeds=speeds, poles_head=np.array(poles_head))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils"]
+    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep"]
     gens = {"pair": gen_pair_fields, "masks": gen_masks_and_totals, "control": gen_control_move,
             "dest": gen_dest_force, "pp": gen_planarpoint_steps, "road": gen_road,
-            "traj": gen_trajectories, "utils": gen_utils}
+            "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep}
     for w in which:
         gens[w]()

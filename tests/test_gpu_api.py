@@ -212,3 +212,70 @@ def test_stop_and_go():
     assert a.destpointer == ptr_stop        # stopping vehicles do not advance their queue (vehicle.py:567-568)
     assert a.znav[2] and a.s[3] == 0.0 and np.hypot(*(a.s[:2] - target)) < 2.5
     assert b.s[0] > 100 and abs(b.s[1] - 500) < 1e-6 and target is not None
+
+
+def test_untracked_foes_and_queue_methods(golden):
+    """Members of the reference API that run single pieces of the tick: get_untracked_foes (intersection.py:690-745),
+    Vehicle.updateDestination (vehicle.py:545-594), updateNavState (vehicle.py:354-457), stop types 1 / 2, go type 1."""
+    g = golden("masks_totals")
+    for tag in ("n16", "n16_p2r"):
+        s0 = g[f"{tag}_s0"]
+        bikes = [TwoDBicycle(tuple(r), id=str(k)) for k, r in enumerate(s0)]
+        ins = SocialForceIntersection(bikes, priority_rule="p2r" if int(g[f"{tag}_p2r"]) else "unregulated")
+        U = ins.get_untracked_foes()
+        assert U.shape == (16, 16) and U.dtype == bool
+        np.testing.assert_array_equal(U, g[f"{tag}_untracked0"])
+    assert SocialForceIntersection([TwoDBicycle((0, 0, 0, 5, 0))]).get_untracked_foes() == np.array(True)
+    # queue pointer: 1.5 m from the first destination -> advances; the next-next one is closer -> jumps again
+    a = TwoDBicycle((0, 0, 0, 5, 0), id="a")
+    a.setDestinations((1.5, 30.0, 31.0, 90.0), (0.0, 0.0, 0.0, 0.0), reset=True)
+    a.updateDestination()
+    assert a.destpointer == 1
+    a.s[0] = 29.5                                         # within d_arrived_inter of (30, 0) and closer to (31, 0) than to it
+    a.updateDestination()
+    assert a.destpointer == 3 or a.destpointer == 2
+    # navigation state machine through its three states with an explicit stop argument
+    b = TwoDBicycle((0, 0, 0, 5, 0), id="b")
+    b.setDestinations((40.0,), (0.0,), reset=True)
+    vd, dd = b.updateNavState(False)
+    assert vd == b.params.v_desired_default and abs(dd - 40.0) < 1e-12 and b.znav.tolist() == [True, False, False]
+    b.s[0] = 34.0                                         # 6 m to go at 5 m/s: inside the braking distance
+    vd, dd = b.updateNavState(True)
+    assert b.znav.tolist() == [False, True, False] and 0 < vd < 5.0 and abs(dd - 6.0) < 1e-12
+    b.s[0], b.s[3] = 39.0, 0.05
+    vd, dd = b.updateNavState(True)
+    assert b.znav.tolist() == [False, False, True] and vd == 0.0
+    # stop type 1 fails as in the reference (no params.AMAX), type 2 steps the pointer back, go(1) re-evaluates the queue
+    c = TwoDBicycle((0, 0, 0, 5, 0), id="c")
+    c.setDestinations((1.0, 50.0, 100.0), (0.0, 0.0, 0.0), reset=True)
+    c.updateDestination()
+    assert c.destpointer == 1
+    with pytest.raises(AttributeError, match="AMAX"):
+        c.stop(1)
+    c.stop(2, (10.0, 0.0))
+    assert c.destpointer == 0
+    c.go(1)
+    assert c.destpointer == 1
+    with pytest.raises(ValueError):
+        c.stop(3)
+    # the same through an intersection (the population engine)
+    d1, d2 = TwoDBicycle((0, 0, 0, 5, 0), id="d1"), TwoDBicycle((0, 50, 0, 5, 0), id="d2")
+    d1.setDestinations((1.0, 60.0, 120.0), (0.0, 0.0, 0.0), reset=True)
+    d2.setDestinations((60.0, 120.0), (50.0, 50.0), reset=True)
+    ins = SocialForceIntersection((d1, d2))
+    ins.step()
+    d1.updateDestination()
+    assert d1.destpointer == 1 and d2.destpointer == 0
+    ins.step()
+    assert np.isfinite(d1.s).all()
+
+
+def test_custom_force_hooks_on_single_vehicles():
+    """vehicle.py:194-204, 250-299: a vehicle built with its own dest_force_func / rep_force_func calls them."""
+    seen = []
+    v = TwoDBicycle((0, 0, 0, 5, 0), id="h", dest_force_func=lambda veh: (seen.append(veh.id), (1.0, 2.0))[1],
+                    rep_force_func=lambda veh, x, y, psi: (np.zeros_like(x) + 3.0, np.zeros_like(x)))
+    v.setDestinations((30.0, 60.0), (0.0, 0.0))
+    assert v.calcDestinationForce() == (1.0, 2.0) and seen == ["h"]
+    fx, fy = v.calcRepulsiveForce(np.array([1.0, 2.0]), np.array([0.0, 0.0]), np.array([0.0, 0.0]))
+    assert fx.tolist() == [3.0, 3.0] and fy.tolist() == [0.0, 0.0]

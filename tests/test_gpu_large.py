@@ -1,0 +1,340 @@
+"""Parity of the HIP path at the sizes of BASELINE.json configs 2, 4 and 5, of the sharded engine path (rehearsed on one
+device with a loopback exchange), and of the population-change path.  All tests need a real MI355X and go through the
+C ABI (libcsf_hip.so); the CPU oracle is the checker.
+
+Tolerances: the all-pairs sum runs in fp32 -> column sums 1e-4 of max(1, |F|) against the fp64 oracle, trajectories 1e-4
+of the box; two engine runs that add the same terms in another order: 2e-6 of the largest force.
+"""
+import numpy as np
+import pytest
+
+from oracle import csf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3}
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from cyclistsocialforce_amd import engine, parameters
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.Engine = engine.Engine
+    ns.pod = parameters.default_pod
+    return ns
+
+
+def population(n, box, seed=0, reach=(50.0, 99.0, 100.0)):
+    import bench
+
+    s0, off, dq = bench.synthetic_population(n, box, seed=seed, reach=reach)
+    return s0, off, dq
+
+
+def make_engine(amd, model, s0, vdes, off, dq, rule=0, **over):
+    s0 = np.asarray(s0, dtype=float)
+    n = s0.shape[0]
+    e = amd.Engine(amd.pod(model, priority_rule=rule, **over), n)
+    e.add_agents(s0, vdes)
+    e.set_dest_queue(np.arange(n), off, dq, reset=True)
+    return e
+
+
+# --------------------------------------------------------------------------- BASELINE config 4
+
+def test_config4_262144_twod_column_sums(amd, monkeypatch):
+    """262 144 TwoDBicycle in 800 m (BASELINE config 4 on one device): the kernel variant that only runs from 65 536
+    agents up (receivers in binned order, far tiles skipped unloaded, at most 16 source chunks).  One calc_forces():
+    (a) 96 strided receivers against the oracle's column sums over all 262 144 sources (every pair, fp64);
+    (b) bit-reproducible; (c) the same sums with receivers in index order (CSF_RECV_BINNED=0)."""
+    n, box = 262144, 800.0
+    s0, off, dq = population(n, box)
+    big = 1e6                                            # |F_dest| = v_desired on tick 0: the clamp never acts
+
+    def rep():
+        e = make_engine(amd, "twod", s0, big, off, dq)
+        e.calc_forces()
+        r = e.far_radius()
+        _, _, rx, ry = e.force_parts()
+        cnt, name = e.count_pairs()
+        e.close()
+        return r, rx, ry, cnt, name
+
+    monkeypatch.delenv("CSF_RECV_BINNED", raising=False)
+    r1, x1, y1, cnt, name = rep()
+    assert np.isfinite(r1) and r1 < box and name == "pair_cull_kernel"
+    assert 0 < cnt < 0.10 * n * n                        # the far-field cull and the field of view leave a few per cent
+    recv = np.arange(37, n, n // 96)[:96]
+    p = orc.default_params("twod")
+    ox, oy = orc.column_sums(p, s0[:, 0], s0[:, 1], s0[:, 2], s0[:, 3], recv)
+    scale = np.maximum(1.0, np.hypot(ox, oy))
+    err = np.maximum(np.abs(x1[recv] - ox), np.abs(y1[recv] - oy)) / scale
+    print(f"config 4: far radius {r1:.1f} m, {cnt:.3e} pairs evaluated of {n * n:.3e}; "
+          f"max column-sum error {err.max():.2e} (|F| up to {np.hypot(ox, oy).max():.2f})")
+    assert err.max() < 1e-4                                                            # (a)
+    _, x2, y2, cnt2, _ = rep()
+    assert np.array_equal(x1, x2) and np.array_equal(y1, y2) and cnt2 == cnt            # (b)
+    monkeypatch.setenv("CSF_RECV_BINNED", "0")
+    _, x3, y3, _, _ = rep()
+    assert np.array_equal(x1, x3) and np.array_equal(y1, y3)                            # (c)
+
+
+# --------------------------------------------------------------------------- BASELINE config 5
+
+def test_config5_1048576_planarpoint_with_road(amd):
+    """1 048 576 PlanarPointBicycle in 1600 m + the curve-scenario road tiled on a 100 m grid (391 680 vertices):
+    one calc_forces(); 64 strided receivers against the oracle for the pair term (intersection.py:814-843) AND the
+    road-edge term (intersection.py:226-242, 854-857)."""
+    import bench
+
+    n, box = 1048576, 1600.0
+    s0, off, dq = population(n, box)
+    s0 = s0[:, :4]
+    road = bench.tiled_curve_road(box)
+    roff, verts, F0, sg = road
+    assert verts.shape[0] > 300000
+    e = make_engine(amd, "planarpoint", s0, 1e6, off, dq)
+    e.set_road(roff, verts, F0, sg)
+    fx, fy = e.calc_forces()
+    fdx, fdy, frx, fry = e.force_parts()
+    assert np.isfinite(fx).all() and np.isfinite(fy).all() and (e.status() == 0).all()
+    e.close()
+    recv = np.arange(11, n, n // 64)[:64]
+    # agents closer than 0.3 m to a vertex: the fp32 record (6e-5 m at 800 m from the origin) is amplified by
+    # (sigma + 1) / r in r^-(sigma+1); they are checked with the absolute bound that resolution implies
+    p = orc.default_params("planarpoint")
+    ox, oy = orc.column_sums(p, s0[:, 0], s0[:, 1], s0[:, 2], s0[:, 3], recv)
+    scale = np.maximum(1.0, np.hypot(ox, oy))
+    perr = np.maximum(np.abs(frx[recv] - ox), np.abs(fry[recv] - oy)) / scale
+    rx, ry = orc.road_forces(verts, roff, F0, sg, s0[recv, 0], s0[recv, 1])
+    gx, gy = fx[recv] - fdx[recv] - frx[recv], fy[recv] - fdy[recv] - fry[recv]
+    dmin = np.array([np.sqrt(((verts - s0[j, :2]) ** 2).sum(axis=1).min()) for j in recv])
+    rscale = np.maximum(np.hypot(rx, ry), 1e-3)
+    # relative error bound from the position resolution: d|F|/|F| <= (sigma + 1) dr / r with dr = 1.2e-4 m
+    bound = 5e-5 + 3 * 1.2e-4 / np.maximum(dmin, 1e-3)
+    rerr = np.maximum(np.abs(gx - rx), np.abs(gy - ry)) / rscale
+    print(f"config 5: pair column sums max err {perr.max():.2e}; road term max err {rerr.max():.2e} "
+          f"(closest vertex {dmin.min():.2f} m, |F_road| up to {np.hypot(rx, ry).max():.3f})")
+    assert perr.max() < 1e-4
+    assert (rerr < bound).all(), (rerr / bound).max()
+
+
+# --------------------------------------------------------------------------- BASELINE config 2, full length
+
+def test_config2_1024_twod_10000_ticks(amd):
+    """1 024 TwoDBicycle in 200 m x 200 m for the full 10 000 ticks (three laps of the 3000-column trajectory ring),
+    destinations every 50 m out to 650 m so that the route outlasts the run (SURVEY.md §8(d) generator, longer reach).
+
+    The dynamics of this population is chaotic: the fp64 oracle run twice from initial positions 4e-6 m apart (the
+    resolution of an fp32 coordinate at 100 m) is 0.35 m apart for 1 % of the agents after 1 000 ticks and metres apart
+    for half of them after 2 000 (tools/chaos_sensitivity.py, profiles/r2_chaos_sensitivity.txt).  No two
+    implementations that differ by a rounding can agree point by point over 10 000 ticks, so the engine runs its 10 000
+    ticks without interruption and the oracle SHADOWS it: every 100 ticks the oracle is re-anchored on the engine's
+    state, both advance 100 ticks, and the two segments must agree to 1e-4 of the box."""
+    n, box, ticks, seg = 1024, 200.0, 10000, 100
+    reach = tuple(50.0 * k for k in range(1, 14))
+    s0, off, dq = population(n, box, reach=reach)
+    e = make_engine(amd, "twod", s0, 5.0, off, dq)
+    pop = orc.Population(orc.default_params("twod"), s0, 5.0, off, dq)
+    worst, worst_v, ptr_mismatch = 0.0, 0.0, 0
+    for k in range(ticks // seg):
+        e.step(seg)
+        pop.step(seg)
+        got, gptr, gzn, tick = e.state(with_nav=True)
+        ref = pop.state()
+        optr, ozn, _, ost = pop.nav()
+        dev = np.hypot(got[:, 0] - ref[:, 0], got[:, 1] - ref[:, 1])
+        worst = max(worst, dev.max())
+        worst_v = max(worst_v, np.abs(got[:, 3] - ref[:, 3]).max())
+        ptr_mismatch += int((gptr != optr).sum())
+        assert dev.max() < 1e-4 * box, (k, dev.max())
+        assert np.array_equal(gzn, ozn) and (ost == 0).all()
+        pop.push_state(got, gptr, gzn)                      # re-anchor: the next segment starts from the engine's state
+        if k % 10 == 9:
+            print(f"  tick {tick}: worst segment deviation so far {worst:.2e} m, speed {worst_v:.2e} m/s; "
+                  f"moved {np.hypot(*(got[:, :2] - s0[:, :2]).T).mean():.0f} m")
+    assert tick == ticks and (e.status() == 0).all()           # nobody ran out of route (no CSF_ST_SPLINE)
+    assert worst_v < 5e-3
+    # a destination is passed one tick apart at most a handful of times (the 2 m arrival test on positions 1e-5 m apart)
+    assert ptr_mismatch <= 5
+    print(f"config 2: worst deviation of a 100-tick segment {worst:.3e} m = {worst / box:.2e} of the box; "
+          f"{ptr_mismatch} pointer mismatches at segment ends")
+
+
+# --------------------------------------------------------------------------- population changes
+
+def test_partial_sums_after_population_changes(amd):
+    """add_road_user / remove_road_user change the number of source chunks; every chunk slot the combine phase adds
+    must have been written by the current layout (n = 1040: 17 batches of 64 -> 9 chunks of 2, not 16)."""
+    n0, box = 1024, 60.0
+    s0, off, dq = population(n0 + 600, box, seed=7)
+    dq3 = dq.reshape(-1, 4, 3)
+    big = 1e6                                             # straight routes: |F_dest| = v_desired, the clamp never acts
+
+    def fresh_parts(state, keep):
+        f = make_engine(amd, "twod", state, big, np.arange(len(keep) + 1) * 4, dq3[keep].reshape(-1, 3))
+        f.calc_forces()
+        out = f.force_parts()[2:]
+        f.close()
+        return out
+
+    e = amd.Engine(amd.pod("twod"), n0 + 600)
+    e.add_agents(s0[:n0], big)
+    e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, dq3[:n0].reshape(-1, 3), reset=True)
+    e.step(3)
+    keep = list(range(n0))
+    for grow, drop in ((16, 0), (0, 500), (584, 0), (0, 3), (0, 1000)):
+        if grow:
+            new = list(range(max(keep) + 1, max(keep) + 1 + grow))
+            e.add_agents(s0[new], big)
+            e.set_dest_queue(np.arange(len(keep), len(keep) + grow), np.arange(grow + 1) * 4, dq3[new].reshape(-1, 3), reset=True)
+            keep += new
+        if drop:
+            idx = np.sort(np.random.default_rng(drop).choice(len(keep), drop, replace=False))
+            e.remove_agents(idx)
+            gone = set(idx.tolist())
+            keep = [a for k, a in enumerate(keep) if k not in gone]
+        state = e.state()
+        assert state.shape[0] == len(keep)
+        e.calc_forces()
+        _, _, rx, ry = e.force_parts()
+        fx, fy = fresh_parts(state, keep)
+        scale = max(np.hypot(fx, fy).max(), 1.0)
+        err = max(np.abs(rx - fx).max(), np.abs(ry - fy).max()) / scale
+        print(f"  n = {len(keep)}: max |dF_rep| / max |F_rep| against a fresh engine = {err:.2e}")
+        assert err < 2e-6, len(keep)
+        e.step(2)                                           # and on: the next change starts from a stepped engine
+    assert np.isfinite(e.state()).all()
+
+
+# --------------------------------------------------------------------------- the sharded path, one device
+
+def gather_blocks(engines):
+    """every member's own receiver block is authoritative"""
+    n = engines[0].n
+    out = np.zeros((n, engines[0].ns))
+    F = np.zeros((n, 2))
+    for e in engines:
+        lo, hi = e.shard_range()
+        out[lo:hi] = e.state()[lo:hi]
+        fx, fy = e.forces()
+        F[lo:hi, 0], F[lo:hi, 1] = fx[lo:hi], fy[lo:hi]
+    return out, F
+
+
+@pytest.mark.parametrize("model,world,n,binned", [("twod", 2, 3001, "0"), ("twod", 4, 3001, "1"), ("twod", 3, 2500, "1"),
+                                                   ("bicycle", 2, 2049, "0"), ("bicycle", 4, 3001, "0"),
+                                                   ("invpend", 2, 1100, "0"), ("twod", 2, 700, "0")])
+def test_sharded_engine_loopback(amd, monkeypatch, model, world, n, binned):
+    """csf_comm_init's code path end to end - shard bounds padded to 64 x world, sentinel records in the holes, receiver
+    lists of a rank (binned = 1), the binned record copy rebuilt after every exchange, re-binning from gathered records
+    (48 ticks: across the re-sort at tick 32), foreign fp64 state going stale - with the all-gather replaced by
+    device-to-device copies between `world` engines of this process (csf_comm_init_loopback).  Against the unsharded
+    engine (the same terms in another summation order) and against the oracle."""
+    monkeypatch.setenv("CSF_RECV_BINNED", binned)
+    box, ticks = 110.0, 48
+    s0, off, dq = population(n, box, seed=5)
+    ns = orc.N_STATES[MODELS[model]]
+    s = np.zeros((n, ns)); s[:, :4] = s0[:, :4]
+    ref = make_engine(amd, model, s, 5.0, off, dq)
+    members = [make_engine(amd, model, s, 5.0, off, dq) for _ in range(world)]
+    amd.Engine.loopback_group(members)
+    size = -(-(-(-n // world)) // 64) * 64
+    for r, m in enumerate(members):
+        assert m.shard_range() == (min(n, r * size), min(n, (r + 1) * size))
+    with pytest.raises(Exception):
+        members[0].step(1)                                  # members are stepped as a group
+    pop = orc.Population(orc.default_params(model), s, 5.0, off, dq)
+    for chunk in (1, 30, 17):                               # 48 ticks in uneven calls
+        ref.step(chunk)
+        amd.Engine.step_group(members, chunk)
+        pop.step(chunk)
+    got, F = gather_blocks(members)
+    want = ref.state()
+    fx, fy = ref.forces()
+    fscale = max(np.hypot(fx, fy).max(), 1.0)
+    dF = max(np.abs(F[:, 0] - fx).max(), np.abs(F[:, 1] - fy).max()) / fscale
+    dpos = np.abs(got[:, :2] - want[:, :2]).max()
+    dorc = np.abs(got[:, :2] - pop.state()[:, :2]).max()
+    print(f"{model} x{world} n={n}: vs unsharded |dF|/max|F| {dF:.2e}, |dpos| {dpos:.2e} m; vs oracle |dpos|/box {dorc / box:.2e}")
+    assert dpos < 2e-5 and dF < 5e-5
+    assert dorc < 1e-4 * box
+    for m in members:
+        lo, hi = m.shard_range()
+        assert (m.status()[lo:hi] == 0).all()
+        with pytest.raises(Exception):
+            m.push_state([0], s[:1])                        # a sharded population is frozen on the host side
+    for m in members[::-1]:
+        m.close()
+
+
+def test_loopback_first_tick_matches_unsharded_closely(amd):
+    """one calc_forces() on a 4-way loopback group against the unsharded engine: the same terms, another fp32 summation
+    order (2e-6 of the largest force)"""
+    n, box, world = 5000, 150.0, 4
+    s0, off, dq = population(n, box, seed=2)
+    ref = make_engine(amd, "twod", s0, 1e6, off, dq)
+    ref.calc_forces()
+    _, _, rx, ry = ref.force_parts()
+    members = [make_engine(amd, "twod", s0, 1e6, off, dq) for _ in range(world)]
+    amd.Engine.loopback_group(members)
+    scale = np.hypot(rx, ry).max()
+    for m in members:
+        m.calc_forces()
+        lo, hi = m.shard_range()
+        _, _, mx, my = m.force_parts()
+        assert max(np.abs(mx[lo:hi] - rx[lo:hi]).max(), np.abs(my[lo:hi] - ry[lo:hi]).max()) < 2e-6 * scale
+
+
+# --------------------------------------------------------------------------- measurement plumbing
+
+def test_profiling_event_pool_is_bounded(amd):
+    """csf_profile_enable left on for more ticks than the pool has slots (256): the slots are recycled, every sampled
+    launch is accounted for, and the per-launch samples are available until the sums are read."""
+    n = 2048
+    s0, off, dq = population(n, 80.0)
+    e = make_engine(amd, "twod", s0, 5.0, off, dq)
+    e.profile(1)
+    e.step(700, sync=True)
+    samples = e.profile_samples()
+    prof = e.profile_kernels()
+    assert prof["pair"][1] == 700 and samples.size == 700
+    assert prof["agent"][1] == 88                              # the other kernels: every 8th sampled tick
+    assert prof["pair"][0] > 0 and prof["agent"][0] > 0 and prof["road"] == (0.0, 0) and prof["gather"] == (0.0, 0)
+    assert abs(samples.sum() * 1e-3 - prof["pair"][0]) < 1e-3 * prof["pair"][0]
+    e.profile(3)
+    e.step(30, sync=True)
+    assert e.profile_kernels()["pair"][1] == 10
+    e.profile(0)
+    e.step(5, sync=True)
+    assert e.profile_kernels()["pair"][1] == 0
+    cntp, name = e.count_pairs()
+    assert name == "pair_cull_kernel" and 0 < cntp < n * n
+    b = make_engine(amd, "bicycle", s0, 5.0, off, dq)
+    assert b.count_pairs() == (None, "pair_bike_kernel")
+
+
+# --------------------------------------------------------------------------- A11 pinned without the control shim
+
+def test_invpend_yaw_step_vs_scipy_fixture(amd, golden):
+    """InvPendulumBicycle.step_yaw on the device (csf_agent.hip: invpend_step_yaw, scaled Taylor + squaring) against the
+    yaw step response of the reference's own test scenario (src/cyclistsocialforce/test.py:15-165) computed with SciPy
+    alone on the reference's closed-loop matrices (tests/golden/invpend_yawstep.npz: cont2discrete('zoh'), cross-checked
+    with a Radau integration).  Tolerance: the reference test's assert_allclose default, rtol 1e-7."""
+    g = golden("invpend_yawstep")
+    v = float(g["v"])
+    e = amd.Engine(amd.pod("invpend"), 1)
+    e.add_agents(np.array([[0.0, 0, 0, v, 0, 0]]), v)
+    T = g["Fx"].size
+    S = e.replay_forces(g["Fx"][:, None], g["Fy"][:, None], fix_speed=True)
+    assert S.shape == (T, 1, 6)
+    got = S[:, 0, [2, 4, 5]]                                # psi, delta, theta after each tick
+    err = np.abs(got - g["zoh"]).max()
+    print(f"invpend yaw step on the device: max |d(psi, delta, theta)| = {err:.2e}")
+    np.testing.assert_allclose(got, g["zoh"], rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(S[:, 0, 3], v, rtol=0, atol=1e-12)
+    assert (e.status() == 0).all()

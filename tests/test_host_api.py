@@ -164,15 +164,63 @@ def test_utils_against_golden(golden):
     assert utils.thresh(5.0, (-1.0, 2.0)) == 2.0
 
 
-def test_scenario_driver():
+def test_scenario_driver(capsys, monkeypatch):
+    """Constructor / run() / reset() semantics of scenario.py:59-122, 169-195, 226-228."""
     calls = []
     scn = Scenario(lambda: calls.append(1), t_s=0.01, t_r=0, verbose=False)
     scn.run(0.25)
-    assert len(calls) == 25 and scn.i == 25 and abs(scn.t - 0.25) < 1e-12 and len(scn.hist_run_time) == 25
+    assert len(calls) == 25 and scn.i == 25 and scn.i_end == 25 and abs(scn.t - 0.25) < 1e-12
+    assert len(scn.hist_run_time) == 25 and scn.ticks_per_second() > 0
+    scn.run(0.30)                                    # run() continues to a later end time
+    assert len(calls) == 30
+    scn.run(0.10)                                    # an earlier one is already reached
+    assert len(calls) == 30
     scn.reset()
     assert scn.i == 0 and scn.t == 0
+    paced = Scenario(lambda: None, t_s=0.01, t_r=0.02, verbose=False)     # real-time pacing: >= t_r per tick
+    import time
+    t0 = time.time()
+    paced.run(0.05)
+    assert time.time() - t0 >= 5 * 0.02 * 0.95
+    monkeypatch.setattr("builtins.input", lambda *_: "")                   # verbose waits for <Enter> and reports
+    Scenario(lambda: None, t_s=0.01, t_r=0, verbose=True).run(0.03)
+    out = capsys.readouterr().out
+    assert "3 of 3" in out and "finished" in out
     with pytest.raises(NotImplementedError):
-        Scenario(lambda: None, animate=True)
+        Scenario(lambda: None, write_animation=True)
+    with pytest.raises(TypeError):
+        Scenario(None)
+
+
+def test_one_parameter_set_per_intersection():
+    """One engine = one csf_params: vehicles whose parameters differ from vehicle 0's (anything but v_desired_default)
+    are refused instead of silently receiving vehicle 0's values (vehicle.py:1592-1612, intersection.py:733-735)."""
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import TwoDBicycle
+
+    a = TwoDBicycle((0, 0, 0, 5, 0), id="a")
+    b = TwoDBicycle((0, 5, 0, 5, 0), id="b")
+    b.params.v_desired_default = 4.0                 # the per-vehicle parameter
+    ins = SocialForceIntersection((a, b))
+    c = TwoDBicycle((0, 9, 0, 5, 0), id="c")
+    c.params.f_0 = 3.0
+    with pytest.raises(NotImplementedError, match="f_0"):
+        ins.add_road_user(c)
+    assert ins.n_bikes == 2 and c._owner is None
+    d = TwoDBicycle((0, 9, 0, 5, 0), id="d")
+    d.params.sigma_0 = 0.6
+    with pytest.raises(NotImplementedError, match="sigma_0"):
+        SocialForceIntersection((a2 := TwoDBicycle((1, 1, 0, 5, 0), id="a2"), d))
+    shared = TwoDBicycle((0, 12, 0, 5, 0), id="s", params=a.params)       # sharing vehicle 0's object is fine
+    ins.add_road_user(shared)
+    hooked = TwoDBicycle((0, 15, 0, 5, 0), id="h", dest_force_func=lambda v: (0.0, 0.0))
+    with pytest.raises(NotImplementedError, match="dest_force_func"):
+        ins.add_road_user(hooked)
+    assert hooked.calcDestinationForce.__self__ is hooked and a2 is not None
+    # a later assignment on a member's parameters is caught by the re-check before the next tick
+    b.params.f_0 = 5.0
+    with pytest.raises(NotImplementedError, match="f_0"):
+        ins._check_uniform()
 
 
 def test_shard_bounds_cover_the_population():

@@ -10,15 +10,15 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import synthetic_population  # noqa: E402
+from bench import synthetic_population, tiled_curve_road  # noqa: E402
 from cyclistsocialforce_amd import parameters  # noqa: E402
 from cyclistsocialforce_amd.engine import Engine  # noqa: E402
-from cyclistsocialforce_amd.intersection import (CurvedRoadSegment, RoadSegmentCollection, StraightRoadSegment,  # noqa: E402
-                                                 flatten_road_elements)
+
+LONG_REACH = tuple(50.0 * k for k in range(1, 14))   # waypoints every 50 m out to 650 m: outlasts 10 000 ticks at 5 m/s
 
 
-def run(name, model, n, box, ticks, road=None, warm=2):
-    s0, off, dq = synthetic_population(n, box)
+def run(name, model, n, box, ticks, road=None, warm=2, reach=(50.0, 99.0, 100.0)):
+    s0, off, dq = synthetic_population(n, box, reach=reach)
     if model == "invpend":
         s0 = np.c_[s0, np.zeros(n)]
     elif model == "planarpoint":
@@ -29,36 +29,28 @@ def run(name, model, n, box, ticks, road=None, warm=2):
     if road is not None:
         e.set_road(*road)
     e.step(warm, sync=True)
+    e.profile(max(1, ticks // 64))
     t0 = time.perf_counter()
     e.step(ticks, sync=True)
     dt = time.perf_counter() - t0
+    prof = {k: ms * 1e3 / max(c, 1) for k, (ms, c) in e.profile_kernels().items()}     # mean microseconds per launch
+    e.profile(0)
     s = e.state()
     st = e.status()
+    evaluated, kernel = e.count_pairs()
     print(json.dumps({"config": name, "model": model, "agents": n, "box_m": box, "ticks": ticks,
                       "ms_per_tick": dt / ticks * 1e3, "agent_steps_per_s": n * ticks / dt,
                       "finite": bool(np.isfinite(s).all()), "status_flags": int((st != 0).sum()),
-                      "road_vertices": 0 if road is None else int(road[1].shape[0])}), flush=True)
+                      "road_vertices": 0 if road is None else int(road[1].shape[0]),
+                      "pair_kernel": kernel, "pair_us": prof["pair"], "road_us": prof["road"],
+                      "agent_us": prof["agent"], "pairs_evaluated": evaluated}), flush=True)
     e.close()
-
-
-def tiled_curve_road(box, pitch=100.0):
-    """scenarios/curve-scenario.py:63-81 geometry repeated on a `pitch` grid."""
-    rp = parameters.RoadElementParameters(sigma=2.0, F_0=0.15)
-    els = []
-    for gx in np.arange(0, box, pitch):
-        for gy in np.arange(0, box, pitch):
-            s1 = StraightRoadSegment(np.array((gx + 10.0, gy + 5.0, np.pi / 2)), 5, 25, params=rp, ds=0.1)
-            s2 = CurvedRoadSegment(s1.x1, 5, 10, np.pi / 2, "right", params=rp, ds=0.1)
-            s3 = CurvedRoadSegment(s2.x1, 5, 10, np.pi / 2, "left", params=rp, ds=0.1)
-            s4 = StraightRoadSegment(s3.x1, 5, 20, params=rp, ds=0.1)
-            els.append(RoadSegmentCollection((s1, s2, s3, s4)))
-    return flatten_road_elements(els)
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["2", "3", "4", "5"]
     if "2" in which:
-        run("2: 1,024 TwoDBicycle, 10,000 steps", "twod", 1024, 200.0, 10000)
+        run("2: 1,024 TwoDBicycle, 10,000 steps", "twod", 1024, 200.0, 10000, reach=LONG_REACH)
     if "3" in which:
         run("3: 16,384 InvertedPendulumBicycle", "invpend", 16384, 200.0, 1000)
     if "4" in which:
