@@ -26,7 +26,7 @@ SYMBOLS = (
     "csf_comm_unique_id", "csf_comm_init", "csf_shard_range", "csf_profile_enable", "csf_profile_read",
     "csf_far_radius", "csf_get_tick", "csf_profile_gather", "csf_profile_kernels", "csf_profile_samples",
     "csf_count_pairs", "csf_comm_init_loopback", "csf_step_group", "csf_untracked", "csf_update_destination",
-    "csf_update_nav_state", "csf_set_dest_pointer",
+    "csf_update_nav_state", "csf_set_dest_pointer", "csf_set_incremental",
 )
 
 
@@ -114,13 +114,14 @@ def load():
     pd = C.POINTER(C.c_double)
     L.csf_profile_kernels.argtypes = [vp, pd, C.POINTER(i64)]
     L.csf_profile_samples.argtypes = [vp, dp, i64, C.POINTER(i64)]
-    L.csf_count_pairs.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_char_p)]
+    L.csf_count_pairs.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_char_p)]   # int64 counts[4]
     L.csf_comm_init_loopback.argtypes = [C.POINTER(vp), i32]
     L.csf_step_group.argtypes = [C.POINTER(vp), i32, i64]
     L.csf_untracked.argtypes = [vp, vp]
     L.csf_update_destination.argtypes = [vp, i64, vp]
     L.csf_update_nav_state.argtypes = [vp, i64, vp, vp, dp, dp]
     L.csf_set_dest_pointer.argtypes = [vp, i64, vp, vp]
+    L.csf_set_incremental.argtypes = [vp, i32]
     if L.csf_abi_version() != 1:
         raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 1")
     _lib = L

@@ -52,10 +52,10 @@ struct Agent {
     bool cs_fresh;
 };
 
-__device__ __forceinline__ double qx(const Dev &d, const Agent &g, int k) { return d.q[g.qb + k]; }
-__device__ __forceinline__ double qy(const Dev &d, const Agent &g, int k) { return d.q[d.qcap + g.qb + k]; }
+__device__ __forceinline__ double qx(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k)]; }
+__device__ __forceinline__ double qy(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k) + 1]; }
 __device__ __forceinline__ bool qstop(const Dev &d, const Agent &g, int k) {
-    return d.q[2 * d.qcap + g.qb + k] != 0.0;
+    return d.q[3 * (g.qb + k) + 2] != 0.0;
 }
 
 // vehicle.py:596-604
@@ -642,6 +642,7 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
     const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= d.hi) return;
+    if (!d.alive[a]) return;                                   // a slot left behind by csf_remove_agents
     const int64_t cap = d.cap;
     Agent g;
     g.a = a;
@@ -652,8 +653,8 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     g.delta = d.s[4 * cap + a];
     g.theta = d.s[5 * cap + a];
     g.vdes = d.vdes[a];
-    g.qb = d.qoff[a];
-    g.K = (int32_t)(d.qoff[a + 1] - g.qb);
+    g.qb = d.qbeg[a];
+    g.K = d.qlen[a];
     g.ptr = d.ptr[a];
     g.zn = d.znav[a] & 3;
     g.zv0 = d.znp[a];
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         double rx = 0, ry = 0;
         Fx = fdx;
         Fy = fdy;
-        if (d.n > 1) {                                        // intersection.py:813, 825, 849-851
+        if (d.n_live > 1) {                                   // intersection.py:813, 825, 849-851
             int c = 0;                                        // fixed order: reproducible
             for (; c + 4 <= d.n_split; c += 4) {              // four independent loads in flight
                 const float2 p0 = d.part[(int64_t)c * cap + a], p1 = d.part[(int64_t)(c + 1) * cap + a];
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
 __global__ void records_kernel(const Dev d) {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= d.n_pad) return;
-    if (a >= d.n) {  // sentinel: far away, contributes exactly 0 (exp2 underflow), never NaN
+    if (a >= d.n || !d.alive[a]) {  // sentinel: far away, contributes exactly 0 (exp2 underflow), never NaN
         d.rec[a] = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
         if (d.p.model == CSF_BICYCLE) d.rec2[a] = make_float2(0.0f, 1.0f);
         return;
@@ -788,8 +789,8 @@ __global__ void nav_kat_kernel(const Dev d, const int32_t *idx, int64_t m, int w
     g.y = d.s[cap + a];
     g.v = d.s[3 * cap + a];
     g.vdes = d.vdes[a];
-    g.qb = d.qoff[a];
-    g.K = (int32_t)(d.qoff[a + 1] - g.qb);
+    g.qb = d.qbeg[a];
+    g.K = d.qlen[a];
     g.ptr = d.ptr[a];
     g.zn = d.znav[a] & 3;
     g.zv0 = d.znp[a];
@@ -801,7 +802,7 @@ __global__ void nav_kat_kernel(const Dev d, const int32_t *idx, int64_t m, int w
         d.ptr[a] = g.ptr;
     }
     if (what & 2) {
-        const int64_t row = 2 * d.qcap + g.qb + g.ptr;
+        const int64_t row = 3 * (g.qb + g.ptr) + 2;
         const double flag = d.q[row];
         const bool forced = stop != nullptr && stop[k] >= 0;
         if (forced) d.q[row] = stop[k] ? 1.0 : 0.0;          // this thread is the only reader of its agent's rows
@@ -826,26 +827,103 @@ void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const
 
 // csf_get_tick: everything the host mirror refreshes after a tick, packed for one transfer
 __global__ void snapshot_kernel(const Dev d, double *out) {
-    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n = d.n;
-    if (a >= n) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // road user i of the population order
+    const int64_t n = d.n_live;
+    if (i >= n) return;
+    const int64_t a = d.order ? d.order[i] : i;
     const int ns = d.ns;
-    for (int c = 0; c < ns; c++) out[a * ns + c] = d.s[(int64_t)c * d.cap + a];
+    for (int c = 0; c < ns; c++) out[i * ns + c] = d.s[(int64_t)c * d.cap + a];
     double *F = out + n * ns;
-    F[a] = d.F[a];
-    F[n + a] = d.F[d.cap + a];
+    F[i] = d.F[a];
+    F[n + i] = d.F[d.cap + a];
     int32_t *ptr = (int32_t *)(F + 2 * n);
-    ptr[a] = d.ptr[a];
+    ptr[i] = d.ptr[a];
     uint8_t *zn = (uint8_t *)(ptr + n);
     const int z = d.znav[a] & 3;
-    zn[3 * a + 0] = z == 0;
-    zn[3 * a + 1] = z == 1;
-    zn[3 * a + 2] = z == 2;
+    zn[3 * i + 0] = z == 0;
+    zn[3 * i + 1] = z == 1;
+    zn[3 * i + 2] = z == 2;
 }
 
 void launch_snapshot(const Dev &d, double *out, hipStream_t st) {
-    if (d.n <= 0) return;
-    hipLaunchKernelGGL(snapshot_kernel, dim3((unsigned)((d.n + 255) / 256)), dim3(256), 0, st, d, out);
+    if (d.n_live <= 0) return;
+    hipLaunchKernelGGL(snapshot_kernel, dim3((unsigned)((d.n_live + 255) / 256)), dim3(256), 0, st, d, out);
+}
+
+// ---- population changes on the device ---------------------------------------------------------------------------------
+// Vehicle.__init__ (vehicle.py:64-204, 1728-1736; dynamics.py:828) for new road users placed into free slots: what
+// csf_add_agents writes into the host mirror, written straight into the device arrays instead, plus the fp32 record.
+// The slot keeps the position of the binned order it had (pos[]): until the next re-binning the new record sits in a
+// batch of far-away neighbours, whose bounding circle the engine recomputes before the next pair launch.
+__global__ void spawn_kernel(const Dev d, const SpawnRec *recs, int64_t m) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const SpawnRec r = recs[k];
+    const int64_t a = r.slot, cap = d.cap;
+    const csf_params &p = d.p;
+    double s[6];
+    for (int c = 0; c < 6; c++) s[c] = c < d.ns ? r.s[c] : 0.0;
+    s[2] = limit_angle(s[2]);                                  // vehicle.py:154-155
+    for (int c = 0; c < 6; c++) d.s[c * cap + a] = s[c];
+    d.vdes[a] = r.vdes;
+    d.qbeg[a] = r.qbeg;
+    d.qlen[a] = r.qlen;
+    d.ptr[a] = 0;
+    d.znav[a] = 0;                                             // vehicle.py:188
+    for (int c = 0; c < 3; c++) d.znp[c * cap + a] = 0.0;
+    d.ti[a] = 0;                                               // vehicle.py:146
+    d.hx[a] = s[0];                                            // traj[:, 0] = s (vehicle.py:159-160)
+    d.hy[a] = s[1];
+    const double delta = d.ns > 4 ? s[4] : 0.0, theta = d.ns > 5 ? s[5] : 0.0;
+    d.lti[0 * cap + a] = delta;                                // vehicle.py:1728
+    d.lti[1 * cap + a] = 0.0;
+    d.lti[2 * cap + a] = theta;
+    d.lti[3 * cap + a] = 0.0;
+    d.lti[4 * cap + a] = s[2];
+    d.zrid[a] = s[3] < p.v_max_walk ? 0 : 1;                   // vehicle.py:1732-1736
+    d.dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
+    d.ppsi[a] = s[2];                                          // dynamics.py:828, 987-993
+    for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
+    d.status[a] = 0;
+    d.alive[a] = 1;
+    write_record(d, a, s[0], s[1], s[2], s[3]);
+}
+
+// remove_road_user (intersection.py:576-634): the slot dies - it is no longer integrated and its record becomes the
+// sentinel that contributes exactly nothing as a source
+__global__ void retire_kernel(const Dev d, const int32_t *slots, int64_t m) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const int64_t a = slots[k];
+    d.alive[a] = 0;
+    const float4 q = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
+    d.rec[a] = q;
+    if (d.recs_valid) d.recs[d.pos[a]] = q;
+    if (d.p.model == CSF_BICYCLE) {
+        d.rec2[a] = make_float2(0.0f, 1.0f);
+        if (d.recs_valid) d.recs2[d.pos[a]] = make_float2(0.0f, 1.0f);
+    }
+}
+
+// Vehicle.setDestinations (vehicle.py:606-647): the queue of a slot now lives at another place of the slab
+__global__ void requeue_kernel(const Dev d, const QueueRec *recs, int64_t m) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const QueueRec r = recs[k];
+    d.qbeg[r.slot] = r.qbeg;
+    d.qlen[r.slot] = r.qlen;
+    const int32_t ptr = r.mode == 1 ? 0 : d.ptr[r.slot];       // vehicle.py:642-645: reset rewinds the pointer
+    d.ptr[r.slot] = ptr < r.qlen ? ptr : r.qlen - 1;
+}
+
+void launch_spawn(const Dev &d, const SpawnRec *recs, int64_t m, hipStream_t st) {
+    if (m > 0) hipLaunchKernelGGL(spawn_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d, recs, m);
+}
+void launch_retire(const Dev &d, const int32_t *slots, int64_t m, hipStream_t st) {
+    if (m > 0) hipLaunchKernelGGL(retire_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d, slots, m);
+}
+void launch_requeue(const Dev &d, const QueueRec *recs, int64_t m, hipStream_t st) {
+    if (m > 0) hipLaunchKernelGGL(requeue_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d, recs, m);
 }
 
 void launch_records(const Dev &d, hipStream_t st) {

@@ -25,13 +25,18 @@ struct PairConsts {
     int32_t fov_classify;              // whole batches are classified against the field-of-view cone
     int32_t full_circle;               // hfov >= 2 pi: every bearing is inside the field of view
     float rfar;                        // sources farther than this add less than far_eps * f_0 / n in magnitude (inf: off)
+    // per-pair reach test of the cull-first kernel (csf_pair.hip: keep_x2): T (sigma_a - sigma_b / 2) and T sigma_b / 2 as
+    // polynomials in s2 = sin^2(psi0 - psi), T = ln(n / far_eps) with a margin for fp32 rounding
+    float tA0, tA1, tB0, tB1;
+    int32_t reach;                     // the reach test is on (far-field cull enabled)
 };
 
 // All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
 struct Dev {
     csf_params p;
     PairConsts pc;
-    int64_t n;         // agents (global population)
+    int64_t n;         // agent SLOTS in use (the highest one + 1); a slot may be dead after csf_remove_agents until it is reused
+    int64_t n_live;    // road users (intersection.py n_bikes)
     int64_t cap;       // SoA stride
     int64_t lo, hi;    // receiver block integrated by this rank
     int64_t n_pad;     // n rounded up to a multiple of 64 (sentinel source records behind n)
@@ -49,9 +54,12 @@ struct Dev {
 
     double *s;         // [6][cap]  x, y, psi, v, delta, theta
     double *vdes;      // [cap]
-    int64_t *qoff;     // [cap+1]
-    double *q;         // [3][qcap] x, y, stop
+    int64_t *qbeg;     // [cap] first row of the agent's destination queue in q
+    int32_t *qlen;     // [cap] rows of it
+    double *q;         // [qcap][3] rows (x, y, stop): a slab, every queue contiguous, new and replaced queues appended
     int64_t qcap;
+    uint8_t *alive;    // [cap] 0: dead slot (sentinel record, not integrated)
+    const int32_t *order;  // [n_live] road user i of the host's population order -> slot
     int32_t *ptr;      // destpointer
     uint8_t *znav;     // 0 cruise, 1 brake, 2 arrived; bit 7: not one-hot
     double *znp;       // [3][cap] latched v0, d0, d1 (vehicle.py:428-430)
@@ -88,7 +96,7 @@ struct Dev {
     int64_t replay_tick;        // the replay
     double *hist;      // opt-in history [hist_cap][n][ns]
     int32_t hist_stride, hist_cap;
-    unsigned long long *pair_count;  // csf_count_pairs: pair evaluations of the launch are added here (NULL: not counted)
+    unsigned long long *pair_count;  // csf_count_pairs: [4] pair evaluations, per-lane tests, full and partial evaluation passes of the launch (NULL: not counted)
     uint64_t *trace;   // CSF_TRACE_BLOCKS: (start, end, hw id) of every pair-kernel workgroup of the last tick, else NULL
 };
 
@@ -115,6 +123,21 @@ void launch_bounds(const Dev &d, hipStream_t st);
 // binned positions of the receivers [lo, hi) of this rank in ascending order (the rank's receivers as neighbours in space)
 int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st);
 
+// population changes on the device (csf_add_agents / csf_remove_agents / csf_set_dest_queue between ticks, without the
+// round trip through the host mirror): see csf_agent.hip
+struct SpawnRec {      // one new road user (Vehicle.__init__, vehicle.py:64-204)
+    int32_t slot, qlen;
+    int64_t qbeg;
+    double s[6], vdes;
+};
+struct QueueRec {      // one replaced destination queue (Vehicle.setDestinations, vehicle.py:606-647)
+    int32_t slot, qlen;
+    int64_t qbeg;
+    int32_t mode, pad;  // 1: pointer rewinds, 0 / 2: pointer kept (clamped to the new length)
+};
+void launch_spawn(const Dev &d, const SpawnRec *recs, int64_t m, hipStream_t st);
+void launch_retire(const Dev &d, const int32_t *slots, int64_t m, hipStream_t st);
+void launch_requeue(const Dev &d, const QueueRec *recs, int64_t m, hipStream_t st);
 void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st);   // get_untracked_foes as the reference's matrix
 void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const int32_t *stop, double *vd_out,
                     double *ddest_out, hipStream_t st);

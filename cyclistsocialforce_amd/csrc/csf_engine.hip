@@ -96,15 +96,25 @@ struct csf_engine {
     std::vector<int32_t> h_ptr, h_ti, h_dgood;
     std::vector<uint8_t> h_znav, h_zrid;
     std::vector<uint32_t> h_status;
-    std::vector<std::vector<double>> h_q;  // per agent: rows of (x, y, stop)
+    std::vector<std::vector<double>> h_q;  // per slot: rows of (x, y, stop) - the host is authoritative for the rows
+    // The population: road user i of the caller's order lives in slot order[i].  Slots are what every device array is
+    // indexed by.  csf_remove_agents on a live device copy only kills slots (they keep a sentinel record), csf_add_agents
+    // reuses them; a full upload compacts the slots back into population order.
+    std::vector<int32_t> order, free_slots;
+    std::vector<uint8_t> h_alive;
+    bool order_dirty = true;               // the device copy of `order` is stale
+    bool incremental = true;               // csf_set_incremental
+    int64_t q_top = 0;                     // rows of the queue slab in use
+    int64_t churn = 0;                     // slots spawned or retired since the last re-binning
     std::vector<double> h_road;            // per vertex (x, y, F0, sigma)
     bool dirty = true;                     // host mirror changed since the last upload
     bool device_ahead = false;             // ticks ran since the last download
 
     DevBuf<double> s, vdes, q, znp, hx, hy, lti, ppsi, F, hist;
-    DevBuf<int64_t> qoff;
-    DevBuf<int32_t> ptr, ti, dgood;
-    DevBuf<uint8_t> znav, zrid;
+    DevBuf<int64_t> qbeg;
+    DevBuf<int32_t> ptr, ti, dgood, qlen, order_dev;
+    DevBuf<uint8_t> znav, zrid, alive;
+    DevBuf<uint8_t> stage;                 // population changes: records on their way to the spawn / retire / requeue kernels
     DevBuf<uint32_t> status;
     DevBuf<float4> rec, recs, rv, kat4, bnd, bnd2;
     DevBuf<int32_t> pos;
@@ -230,8 +240,30 @@ double far_eps() {
     return fe ? atof(fe) : 5.9604644775390625e-8;   // 2^-24
 }
 
+// Per-pair form of the same bound.  A pair adds f_0 exp(-x), x = rho q / sigma (vehicle.py:1628), and may be left out
+// when x > T = ln(n / far_eps): then it is below far_eps f_0 / n like every source beyond the far-field radius.  With
+// X = rho cos(phi) (the receiver along the source's heading), rho^2 q^2 = rho^2 - e^2 X^2 exactly, and
+// sigma = sigma_a - sigma_b |sin(phi/2)| <= sigma_a - sigma_b (1 - cos phi) / 2 because |sin(phi/2)| <= 1; so
+//     rho^2 - e^2 X^2 > T^2 (sigma_a - sigma_b / 2 + (sigma_b / 2) X / rho)^2   implies   x > T.
+// The kernel evaluates this with one rsq per pair (csf_pair.hip: keep_x2); T carries a 0.2 % margin against the fp32
+// rounding of the two sides.  At N = 16 384 in 200 m the test removes three of four pairs that pass the field of view.
 void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
-    e->d.pc.rfar = (float)far_radius(e->far_kappa, e->d.n, far_eps());
+    const double eps = far_eps();
+    PairConsts &k = e->d.pc;
+    k.rfar = (float)far_radius(e->far_kappa, e->d.n, eps);
+    const csf_params &p = e->d.p;
+    const bool on = std::isfinite(k.rfar) && p.model != CSF_BICYCLE && e->d.n >= 1 && p.sigma_2 < p.sigma_0 && p.sigma_3 < p.sigma_1 &&
+                    !(getenv("CSF_REACH") && atoi(getenv("CSF_REACH")) == 0);
+    k.reach = on;
+    if (on) {
+        const double T = std::log((double)e->d.n / eps) * 1.002;
+        k.tA0 = (float)(T * (p.sigma_0 - 0.5 * p.sigma_2));
+        k.tA1 = (float)(T * (p.sigma_1 - 0.5 * p.sigma_3));
+        k.tB0 = (float)(T * 0.5 * p.sigma_2);
+        k.tB1 = (float)(T * 0.5 * p.sigma_3);
+    } else {
+        k.tA0 = k.tA1 = k.tB0 = k.tB1 = 0.f;
+    }
 }
 
 void derive_consts(csf_engine *e) {
@@ -281,7 +313,10 @@ int alloc_all(csf_engine *e) {
     const size_t hl = (size_t)e->d.hist_len;
     HIPCHK(e, e->s.alloc(6 * cap));
     HIPCHK(e, e->vdes.alloc(cap));
-    HIPCHK(e, e->qoff.alloc(cap + 1));
+    HIPCHK(e, e->qbeg.alloc(cap));
+    HIPCHK(e, e->qlen.alloc(cap));
+    HIPCHK(e, e->alive.alloc(cap));
+    HIPCHK(e, e->order_dev.alloc(cap));
     HIPCHK(e, e->ptr.alloc(cap));
     HIPCHK(e, e->znav.alloc(cap));
     HIPCHK(e, e->znp.alloc(3 * cap));
@@ -326,11 +361,15 @@ int alloc_all(csf_engine *e) {
     e->h_zrid.assign(cap, 0);
     e->h_status.assign(cap, 0);
     e->h_q.assign(cap, {});
+    e->h_alive.assign(cap, 0);
     Dev &d = e->d;
     d.cap = (int64_t)cap;
     d.s = e->s.p;
     d.vdes = e->vdes.p;
-    d.qoff = e->qoff.p;
+    d.qbeg = e->qbeg.p;
+    d.qlen = e->qlen.p;
+    d.alive = e->alive.p;
+    d.order = nullptr;
     d.ptr = e->ptr.p;
     d.znav = e->znav.p;
     d.znp = e->znp.p;
@@ -449,6 +488,7 @@ int rebin(csf_engine *e) {
         }
     }
     e->ticks_since_rebin = 0;
+    e->churn = 0;
     e->bounds_fresh = false;
     return CSF_OK;
 }
@@ -456,7 +496,7 @@ int rebin(csf_engine *e) {
 // bounding circles for the pair launch that follows; afterwards the circles emitted by that launch become current
 int bounds_before_pair(csf_engine *e) {
     Dev &d = e->d;
-    if (e->ticks_since_rebin >= REBIN_TICKS) {
+    if (e->ticks_since_rebin >= REBIN_TICKS || 16 * e->churn > d.n) {   // (new road users sit in the batches of the slots they took)
         int rc = rebin(e);
         if (rc) return rc;
     }
@@ -467,7 +507,7 @@ int bounds_before_pair(csf_engine *e) {
 
 void bounds_after_pair(csf_engine *e, bool records_will_move_one_tick) {
     Dev &d = e->d;
-    if (!d.classify || d.n <= 1) {
+    if (!d.classify || d.n_live <= 1) {
         e->bounds_fresh = false;
         return;
     }
@@ -499,32 +539,64 @@ int download_all(csf_engine *e) {
     return CSF_OK;
 }
 
+// slots -> population order on the host mirror (a full upload starts from a population without holes)
+void compact_host(csf_engine *e) {
+    const int64_t n = (int64_t)e->order.size(), cap = e->cap, hl = e->d.hist_len;
+    bool identity = e->free_slots.empty() && n == e->d.n;
+    for (int64_t i = 0; identity && i < n; i++) identity = e->order[(size_t)i] == i;
+    if (!identity) {
+        auto gather = [&](auto &vec, int64_t comps) {
+            auto old = vec;
+            for (int64_t c = 0; c < comps; c++)
+                for (int64_t i = 0; i < n; i++) vec[(size_t)(c * cap + i)] = old[(size_t)(c * cap + e->order[(size_t)i])];
+        };
+        gather(e->h_s, 6); gather(e->h_F, 6); gather(e->h_znp, 3); gather(e->h_lti, 5);
+        gather(e->h_hx, hl); gather(e->h_hy, hl);
+        gather(e->h_vdes, 1); gather(e->h_ppsi, 1); gather(e->h_ptr, 1); gather(e->h_ti, 1); gather(e->h_dgood, 1);
+        gather(e->h_znav, 1); gather(e->h_zrid, 1); gather(e->h_status, 1);
+        std::vector<std::vector<double>> q((size_t)cap);
+        for (int64_t i = 0; i < n; i++) q[(size_t)i] = std::move(e->h_q[(size_t)e->order[(size_t)i]]);
+        e->h_q.swap(q);
+        for (int64_t i = 0; i < n; i++) e->order[(size_t)i] = (int32_t)i;
+        e->free_slots.clear();
+    }
+    std::fill(e->h_alive.begin(), e->h_alive.end(), (uint8_t)0);
+    std::fill(e->h_alive.begin(), e->h_alive.begin() + n, (uint8_t)1);
+    e->d.n = n;
+    e->d.n_live = n;
+    e->order_dirty = true;
+}
+
 int upload_all(csf_engine *e) {
     if (!e->dirty) return CSF_OK;
     Dev &d = e->d;
+    compact_host(e);
     const int64_t n = d.n;
-    // destination queues -> CSR
-    std::vector<int64_t> off((size_t)e->cap + 1, 0);
-    for (int64_t a = 0; a < n; a++) off[a + 1] = off[a] + (int64_t)e->h_q[a].size() / 3;
-    for (int64_t a = n; a < e->cap; a++) off[a + 1] = off[a];
-    int64_t rows = off[n];
-    if ((size_t)(3 * rows) > e->q.n) {
-        size_t want = (size_t)std::max<int64_t>(3 * rows * 2, 3 * 1024);
+    // destination queues -> one slab of rows, every queue contiguous, with room for queues that are replaced later
+    std::vector<int64_t> beg((size_t)e->cap, 0);
+    std::vector<int32_t> len((size_t)e->cap, 0);
+    int64_t rows = 0;
+    for (int64_t a = 0; a < n; a++) {
+        beg[(size_t)a] = rows;
+        len[(size_t)a] = (int32_t)(e->h_q[(size_t)a].size() / 3);
+        rows += len[(size_t)a];
+    }
+    if ((size_t)(3 * rows) > e->q.n || e->q.n == 0) {
+        size_t want = (size_t)std::max<int64_t>(3 * rows * 2, 3 * 4096);
         HIPCHK(e, e->q.alloc(want));
     }
     d.q = e->q.p;
     d.qcap = (int64_t)(e->q.n / 3);
-    std::vector<double> flat(e->q.n, 0.0);
+    e->q_top = rows;
+    std::vector<double> flat((size_t)(3 * rows), 0.0);
     for (int64_t a = 0; a < n; a++) {
-        const std::vector<double> &qa = e->h_q[a];
-        for (size_t k = 0; k < qa.size() / 3; k++) {
-            flat[(size_t)(off[a] + k)] = qa[3 * k];
-            flat[(size_t)(d.qcap + off[a] + k)] = qa[3 * k + 1];
-            flat[(size_t)(2 * d.qcap + off[a] + k)] = qa[3 * k + 2];
-        }
+        const std::vector<double> &qa = e->h_q[(size_t)a];
+        std::copy(qa.begin(), qa.end(), flat.begin() + 3 * beg[(size_t)a]);
     }
     if (!flat.empty()) HIPCHK(e, hipMemcpy(e->q.p, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(e->qoff.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->qbeg.p, beg.data(), beg.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->qlen.p, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->alive.p, e->h_alive.data(), e->h_alive.size(), hipMemcpyHostToDevice));
 #define H2D(vec, buf) HIPCHK(e, hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
     H2D(e->h_s, e->s);
     H2D(e->h_vdes, e->vdes);
@@ -596,6 +668,81 @@ int prepare_mutation(csf_engine *e) {
     if (rc) return rc;
     e->dirty = true;
     return CSF_OK;
+}
+
+// Population changes between ticks go straight to the device arrays (spawn / retire / requeue kernels of csf_agent.hip)
+// when the device copy is current: no download, no upload, no re-sort.  Sharded engines, engines with the opt-in
+// history ring and CSF_INCREMENTAL=0 take the round trip through the host mirror (prepare_mutation / upload_all).
+bool can_patch_device(const csf_engine *e) {
+    static const bool off = getenv("CSF_INCREMENTAL") && atoi(getenv("CSF_INCREMENTAL")) == 0;
+    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
+}
+
+// `bytes` of host data -> the staging buffer at `offset`, in stream order on the main stream
+int stage_put(csf_engine *e, size_t offset, const void *src, size_t bytes) {
+    if (offset + bytes > e->stage.n) {
+        if (offset != 0) return fail(e, CSF_E_STATE, "staging buffer too small");   // sized by stage_reserve first
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        HIPCHK(e, e->stage.alloc(std::max<size_t>(2 * (offset + bytes), 1 << 16)));
+    }
+    HIPCHK(e, hipMemcpyAsync(e->stage.p + offset, src, bytes, hipMemcpyHostToDevice, e->main));
+    return CSF_OK;
+}
+
+int stage_reserve(csf_engine *e, size_t bytes) {
+    if (bytes <= e->stage.n) return CSF_OK;
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    HIPCHK(e, e->stage.alloc(std::max<size_t>(2 * bytes, 1 << 16)));
+    return CSF_OK;
+}
+
+// after slots were spawned or retired on the device: the circles of the batches they sit in are stale, and once a
+// sixteenth of the slots has changed the binned order is renewed at the next tick instead of after REBIN_TICKS
+void after_patch(csf_engine *e, int64_t changed) {
+    e->bounds_fresh = false;
+    e->order_dirty = true;
+    e->churn += changed;
+    e->d.n_live = (int64_t)e->order.size();
+    if (!getenv("CSF_FAKE_SHARD")) e->d.hi = e->d.n;    // (unsharded: the receiver block is every slot)
+    update_far_radius(e);
+}
+
+int sync_order(csf_engine *e) {                         // the device copy of the population order (read-back kernels)
+    Dev &d = e->d;
+    bool identity = (int64_t)e->order.size() == d.n;
+    for (size_t i = 0; identity && i < e->order.size(); i++) identity = e->order[i] == (int32_t)i;
+    if (identity) {
+        d.order = nullptr;
+    } else {
+        if (e->order_dirty)
+            HIPCHK(e, hipMemcpyAsync(e->order_dev.p, e->order.data(), e->order.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->main));
+        d.order = e->order_dev.p;
+    }
+    e->order_dirty = false;
+    return CSF_OK;
+}
+
+// slot-indexed device array (component c at [c * cap + slot]) -> caller's array in population order
+template <class T>
+int read_rows(csf_engine *e, const T *dev, int comps, T *out, bool row_major) {
+    const int64_t n = (int64_t)e->order.size(), ns = e->d.n, cap = e->cap;
+    std::vector<T> tmp((size_t)ns);
+    for (int c = 0; c < comps; c++) {
+        HIPCHK(e, hipMemcpy(tmp.data(), dev + (size_t)c * cap, (size_t)ns * sizeof(T), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) out[row_major ? i * comps + c : c * n + i] = tmp[(size_t)e->order[(size_t)i]];
+    }
+    return CSF_OK;
+}
+
+// entry points that index the device arrays by road user (replay, history, sharding) want slots == population order
+int ensure_compact(csf_engine *e) {
+    bool identity = e->free_slots.empty() && (int64_t)e->order.size() == e->d.n;
+    for (size_t i = 0; identity && i < e->order.size(); i++) identity = e->order[i] == (int32_t)i;
+    if (identity) return CSF_OK;
+    int rc = download_all(e);
+    if (rc) return rc;
+    e->dirty = true;
+    return upload_all(e);
 }
 
 // CSF_COMM_STREAM=second puts the all-gather on a second HIP stream, so that the destination-force phase of the
@@ -747,7 +894,7 @@ int csf_destroy(csf_engine *e) {
     if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
-    e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qoff.release();
+    e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release(); e->stage.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
@@ -764,22 +911,38 @@ int csf_destroy(csf_engine *e) {
     return CSF_OK;
 }
 
-int64_t csf_num_agents(const csf_engine *e) { return e ? e->d.n : 0; }
+int64_t csf_num_agents(const csf_engine *e) { return e ? (int64_t)e->order.size() : 0; }
 int32_t csf_num_states(const csf_engine *e) { return e ? e->d.ns : 0; }
 
 int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired) {
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!s0 || !v_desired))) return fail(e, CSF_E_ARG, "csf_add_agents: bad arguments");
-    if (e->d.n + n > e->cap) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap);
+    if ((int64_t)e->order.size() + n > e->cap) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap);
     if (e->world > 1 && e->nccl) return fail(e, CSF_E_STATE, "population is frozen once the shard communicator exists");
+    if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
-    int rc = prepare_mutation(e);
-    if (rc) return rc;
-    const int ns = e->d.ns;
+    Dev &d = e->d;
+    const int64_t reuse = std::min<int64_t>(n, (int64_t)e->free_slots.size());
+    // straight to the device when its copy is current, the new slots have a place in the binned order (slot < n_pad)
+    // and the start rows fit behind the queues already in the slab
+    const bool patch = can_patch_device(e) && d.n + (n - reuse) <= d.n_pad && e->q_top + n <= d.qcap;
+    if (!patch) {
+        int rc = prepare_mutation(e);
+        if (rc) return rc;
+    }
+    const int ns = d.ns;
     const int64_t cap = e->cap;
-    const csf_params &p = e->d.p;
+    const csf_params &p = d.p;
+    std::vector<SpawnRec> recs(patch ? (size_t)n : 0);
+    std::vector<double> rows(patch ? (size_t)(3 * n) : 0);
     for (int64_t k = 0; k < n; k++) {
-        const int64_t a = e->d.n + k;
+        int64_t a;
+        if (!e->free_slots.empty()) {
+            a = e->free_slots.back();
+            e->free_slots.pop_back();
+        } else {
+            a = d.n++;
+        }
         const double *s = s0 + k * ns;
         for (int c = 0; c < 6; c++) e->h_s[c * cap + a] = c < ns ? s[c] : 0.0;
         e->h_s[2 * cap + a] = limit_angle_h(s[2]);               // vehicle.py:154-155
@@ -802,9 +965,34 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         e->h_ppsi[a] = e->h_s[2 * cap + a];                      // dynamics.py:828, 987-993
         for (int c = 0; c < 6; c++) e->h_F[c * cap + a] = 0.0;
         e->h_status[a] = 0;
+        e->h_alive[a] = 1;
+        e->order.push_back((int32_t)a);
+        if (patch) {                                             // the same, as a record for the spawn kernel
+            SpawnRec &r = recs[(size_t)k];
+            r.slot = (int32_t)a;
+            r.qlen = 1;
+            r.qbeg = e->q_top + k;
+            for (int c = 0; c < 6; c++) r.s[c] = c < ns ? s[c] : 0.0;
+            r.vdes = v_desired[k];
+            rows[(size_t)(3 * k)] = s[0];
+            rows[(size_t)(3 * k + 1)] = s[1];
+            rows[(size_t)(3 * k + 2)] = 0.0;
+        }
     }
-    e->d.n += n;
-    set_shard(e);
+    d.n_live = (int64_t)e->order.size();
+    if (!patch) {
+        set_shard(e);
+        return CSF_OK;
+    }
+    int rc = stage_reserve(e, recs.size() * sizeof(SpawnRec));
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->q.p + 3 * e->q_top, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, e->main));
+    if ((rc = stage_put(e, 0, recs.data(), recs.size() * sizeof(SpawnRec)))) return rc;
+    e->q_top += n;
+    launch_spawn(d, (const SpawnRec *)e->stage.p, n, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));                    // the staged records are host vectors of this call
+    after_patch(e, n);
     return CSF_OK;
 }
 
@@ -813,40 +1001,44 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
     if (n < 0 || (n > 0 && !idx)) return fail(e, CSF_E_ARG, "csf_remove_agents: bad arguments");
     if (e->world > 1 && e->nccl) return fail(e, CSF_E_STATE, "population is frozen once the shard communicator exists");
     HIPCHK(e, hipSetDevice(e->device));
-    std::vector<uint8_t> kill((size_t)e->d.n, 0);
+    const int64_t pop = (int64_t)e->order.size();
+    std::vector<uint8_t> kill((size_t)pop, 0);
     for (int64_t k = 0; k < n; k++) {
-        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        if (idx[k] < 0 || idx[k] >= pop) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
         kill[(size_t)idx[k]] = 1;
     }
-    int rc = prepare_mutation(e);
-    if (rc) return rc;
-    const int64_t cap = e->cap, hl = e->d.hist_len;
-    int64_t w = 0;
-    for (int64_t a = 0; a < e->d.n; a++) {
-        if (kill[(size_t)a]) continue;
-        if (w != a) {
-            for (int c = 0; c < 6; c++) e->h_s[c * cap + w] = e->h_s[c * cap + a];
-            for (int c = 0; c < 6; c++) e->h_F[c * cap + w] = e->h_F[c * cap + a];
-            for (int c = 0; c < 3; c++) e->h_znp[c * cap + w] = e->h_znp[c * cap + a];
-            for (int c = 0; c < 5; c++) e->h_lti[c * cap + w] = e->h_lti[c * cap + a];
-            for (int64_t c = 0; c < hl; c++) {
-                e->h_hx[c * cap + w] = e->h_hx[c * cap + a];
-                e->h_hy[c * cap + w] = e->h_hy[c * cap + a];
-            }
-            e->h_vdes[w] = e->h_vdes[a];
-            e->h_ppsi[w] = e->h_ppsi[a];
-            e->h_ptr[w] = e->h_ptr[a];
-            e->h_ti[w] = e->h_ti[a];
-            e->h_dgood[w] = e->h_dgood[a];
-            e->h_znav[w] = e->h_znav[a];
-            e->h_zrid[w] = e->h_zrid[a];
-            e->h_status[w] = e->h_status[a];
-            e->h_q[w] = std::move(e->h_q[a]);
-        }
-        w++;
+    if (n == 0) return CSF_OK;
+    const bool patch = can_patch_device(e);
+    if (!patch) {
+        int rc = prepare_mutation(e);
+        if (rc) return rc;
     }
-    e->d.n = w;
-    set_shard(e);
+    std::vector<int32_t> slots, keep;
+    keep.reserve((size_t)pop);
+    for (int64_t i = 0; i < pop; i++) {                          // the remaining road users keep their relative order
+        const int32_t a = e->order[(size_t)i];
+        if (!kill[(size_t)i]) {
+            keep.push_back(a);
+            continue;
+        }
+        slots.push_back(a);
+        e->h_alive[(size_t)a] = 0;
+        e->h_q[(size_t)a].clear();
+        e->free_slots.push_back(a);
+    }
+    e->order.swap(keep);
+    e->d.n_live = (int64_t)e->order.size();
+    if (!patch) {                                                // the host mirror is authoritative now: close the holes
+        compact_host(e);
+        set_shard(e);
+        return CSF_OK;
+    }
+    int rc = stage_put(e, 0, slots.data(), slots.size() * sizeof(int32_t));
+    if (rc) return rc;
+    launch_retire(e->d, (const int32_t *)e->stage.p, (int64_t)slots.size(), e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    after_patch(e, (int64_t)slots.size());
     return CSF_OK;
 }
 
@@ -854,24 +1046,54 @@ int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int
                        const double *xyz_stop, int32_t reset) {
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!agent || !offsets || !xyz_stop))) return fail(e, CSF_E_ARG, "csf_set_dest_queue: bad arguments");
+    const int64_t pop = (int64_t)e->order.size();
+    int64_t total = 0;                                           // rows of the queues as they will be
     for (int64_t k = 0; k < n; k++) {
-        if (agent[k] < 0 || agent[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", agent[k]);
+        if (agent[k] < 0 || agent[k] >= pop) return fail(e, CSF_E_ARG, "agent index %d out of range", agent[k]);
         if (offsets[k + 1] < offsets[k]) return fail(e, CSF_E_ARG, "offsets must be non-decreasing");
         if (reset && offsets[k + 1] == offsets[k]) return fail(e, CSF_E_ARG, "reset with an empty queue");
+        total += offsets[k + 1] - offsets[k] + (reset ? 0 : (int64_t)e->h_q[(size_t)e->order[(size_t)agent[k]]].size() / 3);
     }
+    if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
-    int rc = prepare_mutation(e);
-    if (rc) return rc;
+    // on a current device copy the new queues are appended to the slab and the slots pointed at them
+    const bool patch = can_patch_device(e) && e->q_top + total <= e->d.qcap;
+    if (!patch) {
+        int rc = prepare_mutation(e);
+        if (rc) return rc;
+    }
+    std::vector<QueueRec> recs;
+    std::vector<double> rows;
     for (int64_t k = 0; k < n; k++) {
-        std::vector<double> &qa = e->h_q[(size_t)agent[k]];
+        const size_t a = (size_t)e->order[(size_t)agent[k]];
+        std::vector<double> &qa = e->h_q[a];
         if (reset) {                                             // vehicle.py:642-645
             qa.clear();
-            if (reset == 1) e->h_ptr[(size_t)agent[k]] = 0;      // reset == 2: rows edited in place, pointer kept
+            if (reset == 1) e->h_ptr[a] = 0;                     // reset == 2: rows edited in place, pointer kept
         }
         qa.insert(qa.end(), xyz_stop + 3 * offsets[k], xyz_stop + 3 * offsets[k + 1]);  // :646-647
-        const int32_t rows = (int32_t)(qa.size() / 3);
-        if (e->h_ptr[(size_t)agent[k]] >= rows) e->h_ptr[(size_t)agent[k]] = rows - 1;
+        const int32_t nrows = (int32_t)(qa.size() / 3);
+        if (e->h_ptr[a] >= nrows) e->h_ptr[a] = nrows - 1;
+        if (patch) {
+            QueueRec r;
+            r.slot = (int32_t)a;
+            r.qlen = nrows;
+            r.qbeg = e->q_top + (int64_t)(rows.size() / 3);
+            r.mode = reset;
+            r.pad = 0;
+            recs.push_back(r);
+            rows.insert(rows.end(), qa.begin(), qa.end());
+        }
     }
+    if (!patch) return CSF_OK;
+    int rc = stage_reserve(e, recs.size() * sizeof(QueueRec));
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->q.p + 3 * e->q_top, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, e->main));
+    if ((rc = stage_put(e, 0, recs.data(), recs.size() * sizeof(QueueRec)))) return rc;
+    e->q_top += (int64_t)(rows.size() / 3);
+    launch_requeue(e->d, (const QueueRec *)e->stage.p, (int64_t)recs.size(), e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->main));
     return CSF_OK;
 }
 
@@ -891,6 +1113,12 @@ int csf_set_road_vertices(csf_engine *e, int32_t n_edges, const int64_t *offsets
             e->h_road.push_back(F0[k]);
             e->h_road.push_back(sigma[k]);
         }
+    return CSF_OK;
+}
+
+int csf_set_incremental(csf_engine *e, int32_t on) {
+    if (!e) return CSF_E_ARG;
+    e->incremental = on != 0;
     return CSF_OK;
 }
 
@@ -918,9 +1146,9 @@ int csf_set_v_desired(csf_engine *e, int64_t n, const int32_t *idx, const double
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!idx || !v_desired))) return fail(e, CSF_E_ARG, "csf_set_v_desired: bad arguments");
     for (int64_t k = 0; k < n; k++)
-        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        if (idx[k] < 0 || idx[k] >= (int64_t)e->order.size()) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
     HIPCHK(e, hipSetDevice(e->device));
-    for (int64_t k = 0; k < n; k++) e->h_vdes[(size_t)idx[k]] = v_desired[k];
+    for (int64_t k = 0; k < n; k++) e->h_vdes[(size_t)e->order[(size_t)idx[k]]] = v_desired[k];
     if (!e->dirty) {  // device copy is current: patch it in place
         HIPCHK(e, hipStreamSynchronize(e->main));
         HIPCHK(e, hipMemcpy(e->vdes.p, e->h_vdes.data(), (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
@@ -932,14 +1160,14 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!idx || !s))) return fail(e, CSF_E_ARG, "csf_push_state: bad arguments");
     for (int64_t k = 0; k < n; k++)
-        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        if (idx[k] < 0 || idx[k] >= (int64_t)e->order.size()) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
     HIPCHK(e, hipSetDevice(e->device));
     int rc = prepare_mutation(e);
     if (rc) return rc;
     const int ns = e->d.ns;
     const int64_t cap = e->cap;
     for (int64_t k = 0; k < n; k++) {
-        const int64_t a = idx[k];
+        const int64_t a = e->order[(size_t)idx[k]];
         for (int c = 0; c < ns; c++) e->h_s[c * cap + a] = s[k * ns + c];
         // keep the model side-state consistent with the pushed vehicle.s
         e->h_ppsi[a] = e->h_s[2 * cap + a];
@@ -975,7 +1203,7 @@ static int enqueue_tick(csf_engine *e) {
     // sharded: the other ranks' records arrived in index order; a coalesced tile fill from the binned copy saves the
     // pair kernel 5 - 7 us at every shard size, the copy costs ~3 us
     if (sharded && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
-    if (d.n > 1 && d.hi > d.lo) {
+    if (d.n_live > 1 && d.hi > d.lo) {
         launch_pair(d, e->main, ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr);
         if (ps) ps->pair = true;
     }
@@ -1027,7 +1255,7 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
     if (e->world > 1 && !e->nccl) return fail(e, CSF_E_STATE, "csf_comm_init must run before csf_step when world > 1");
     int rc = upload_all(e);
     if (rc) return rc;
-    if (e->d.n == 0) {  // intersection.py:888: nothing to do, time still advances
+    if (e->order.empty()) {  // intersection.py:888: nothing to do, time still advances
         e->d.tick += n_ticks;
         return CSF_OK;
     }
@@ -1052,13 +1280,13 @@ int csf_calc_forces(csf_engine *e) {
     HIPCHK(e, hipSetDevice(e->device));
     int rc = upload_all(e);
     if (rc) return rc;
-    if (e->d.n == 0) return CSF_OK;
+    if (e->order.empty()) return CSF_OK;
     rc = wait_gather(e);
     if (rc) return rc;
     rc = bounds_before_pair(e);
     if (rc) return rc;
     if ((e->world > 1 || e->nccl != nullptr || e->loopback) && e->d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(e->d, e->main);
-    if (e->d.n > 1) launch_pair(e->d, e->main);
+    if (e->d.n_live > 1) launch_pair(e->d, e->main);
     bounds_after_pair(e, false);                     // the records do not move: recompute next time
     launch_road(e->d, e->main);
     launch_agent(e->d, PH_DEST | PH_COMBINE, e->main);
@@ -1074,10 +1302,17 @@ int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy) {
     if (e->world > 1) return fail(e, CSF_E_STATE, "csf_apply_forces is a single-device entry point");
     int rc = upload_all(e);
     if (rc) return rc;
-    if (e->d.n == 0) return CSF_OK;
+    if (e->order.empty()) return CSF_OK;
     HIPCHK(e, hipStreamSynchronize(e->main));
-    HIPCHK(e, hipMemcpy(e->F.p, Fx, (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(e->F.p + e->cap, Fy, (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
+    {   // Fx, Fy are in population order, the device array is indexed by slot
+        std::vector<double> fx((size_t)e->d.n, 0.0), fy((size_t)e->d.n, 0.0);
+        for (size_t i = 0; i < e->order.size(); i++) {
+            fx[(size_t)e->order[i]] = Fx[i];
+            fy[(size_t)e->order[i]] = Fy[i];
+        }
+        HIPCHK(e, hipMemcpy(e->F.p, fx.data(), fx.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->F.p + e->cap, fy.data(), fy.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     launch_agent(e->d, PH_INTEGRATE, e->main);
     HIPCHK(e, hipGetLastError());
     e->bounds_fresh = false;
@@ -1094,6 +1329,7 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
     HIPCHK(e, hipSetDevice(e->device));
     int rc = upload_all(e);
     if (rc) return rc;
+    if ((rc = ensure_compact(e))) return rc;
     const int64_t n = e->d.n, cap = e->cap;
     if (n == 0 || n_ticks == 0) return CSF_OK;
     HIPCHK(e, hipStreamSynchronize(e->main));
@@ -1146,14 +1382,13 @@ int csf_dest_force(csf_engine *e, double *Fx, double *Fy) {
     HIPCHK(e, hipSetDevice(e->device));
     int rc = upload_all(e);
     if (rc) return rc;
-    if (e->d.n == 0) return CSF_OK;
+    if (e->order.empty()) return CSF_OK;
     launch_agent(e->d, PH_DEST, e->main);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
     e->device_ahead = true;
-    HIPCHK(e, hipMemcpy(Fx, e->F.p + 2 * e->cap, (size_t)e->d.n * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(e, hipMemcpy(Fy, e->F.p + 3 * e->cap, (size_t)e->d.n * sizeof(double), hipMemcpyDeviceToHost));
-    return CSF_OK;
+    if ((rc = read_rows(e, e->F.p + 2 * e->cap, 1, Fx, false))) return rc;
+    return read_rows(e, e->F.p + 3 * e->cap, 1, Fy, false);
 }
 
 int csf_get_state(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, int64_t *tick) {
@@ -1163,21 +1398,15 @@ int csf_get_state(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav
     if (rc) return rc;
     rc = csf_sync(e);
     if (rc) return rc;
-    const int64_t n = e->d.n, cap = e->cap;
+    const int64_t n = (int64_t)e->order.size();
     const int ns = e->d.ns;
     if (tick) *tick = e->d.tick;
     if (n == 0) return CSF_OK;
-    if (s_out) {
-        std::vector<double> tmp((size_t)n);
-        for (int c = 0; c < ns; c++) {
-            HIPCHK(e, hipMemcpy(tmp.data(), e->s.p + c * cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-            for (int64_t a = 0; a < n; a++) s_out[a * ns + c] = tmp[(size_t)a];
-        }
-    }
-    if (dest_ptr) HIPCHK(e, hipMemcpy(dest_ptr, e->ptr.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (s_out && (rc = read_rows(e, e->s.p, ns, s_out, true))) return rc;
+    if (dest_ptr && (rc = read_rows(e, e->ptr.p, 1, dest_ptr, false))) return rc;
     if (znav) {
         std::vector<uint8_t> z((size_t)n);
-        HIPCHK(e, hipMemcpy(z.data(), e->znav.p, (size_t)n, hipMemcpyDeviceToHost));
+        if ((rc = read_rows(e, e->znav.p, 1, z.data(), false))) return rc;
         for (int64_t a = 0; a < n; a++) {
             znav[3 * a + 0] = (z[(size_t)a] & 3) == 0;
             znav[3 * a + 1] = (z[(size_t)a] & 3) == 1;
@@ -1189,8 +1418,7 @@ int csf_get_state(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav
 
 static int get_F(csf_engine *e, int comp, double *out) {
     if (!out) return CSF_OK;
-    HIPCHK(e, hipMemcpy(out, e->F.p + (size_t)comp * e->cap, (size_t)e->d.n * sizeof(double), hipMemcpyDeviceToHost));
-    return CSF_OK;
+    return read_rows(e, e->F.p + (size_t)comp * e->cap, 1, out, false);
 }
 
 int csf_get_tick(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy, int64_t *tick) {
@@ -1198,10 +1426,11 @@ int csf_get_tick(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav,
     HIPCHK(e, hipSetDevice(e->device));
     int rc = upload_all(e);  // a never-stepped engine still answers from a consistent device copy
     if (rc) return rc;
-    const int64_t n = e->d.n;
+    const int64_t n = (int64_t)e->order.size();
     const int ns = e->d.ns;
     if (tick) *tick = e->d.tick;
     if (n == 0) return csf_sync(e);
+    if ((rc = sync_order(e))) return rc;
     const size_t need = (size_t)n * ((size_t)(ns + 2) * sizeof(double) + sizeof(int32_t) + 3);
     if (need > e->snap_bytes) {
         if (e->snap_host) {
@@ -1239,7 +1468,7 @@ int csf_get_forces(csf_engine *e, double *Fx, double *Fy) {
         rc = upload_all(e);
         if (rc) return rc;
     }
-    if (e->d.n == 0) return CSF_OK;
+    if (e->order.empty()) return CSF_OK;
     if ((rc = get_F(e, 0, Fx))) return rc;
     return get_F(e, 1, Fy);
 }
@@ -1248,7 +1477,7 @@ int csf_get_force_parts(csf_engine *e, double *Fdest_x, double *Fdest_y, double 
     if (!e) return CSF_E_ARG;
     int rc = csf_sync(e);
     if (rc) return rc;
-    if (e->d.n == 0) return CSF_OK;
+    if (e->order.empty()) return CSF_OK;
     if ((rc = get_F(e, 2, Fdest_x))) return rc;
     if ((rc = get_F(e, 3, Fdest_y))) return rc;
     if ((rc = get_F(e, 4, Frep_x))) return rc;
@@ -1262,9 +1491,8 @@ int csf_status(csf_engine *e, uint32_t *per_agent_flags) {
     if (rc) return rc;
     rc = csf_sync(e);
     if (rc) return rc;
-    if (e->d.n == 0) return CSF_OK;
-    HIPCHK(e, hipMemcpy(per_agent_flags, e->status.p, (size_t)e->d.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return CSF_OK;
+    if (e->order.empty()) return CSF_OK;
+    return read_rows(e, e->status.p, 1, per_agent_flags, false);
 }
 
 int csf_enable_history(csf_engine *e, int32_t stride, int32_t capacity) {
@@ -1273,6 +1501,7 @@ int csf_enable_history(csf_engine *e, int32_t stride, int32_t capacity) {
     HIPCHK(e, hipSetDevice(e->device));
     int rc = csf_sync(e);
     if (rc) return rc;
+    if ((rc = ensure_compact(e))) return rc;              // the ring is indexed by road user: slots == population order
     HIPCHK(e, e->hist.alloc((size_t)capacity * (size_t)e->cap * (size_t)e->d.ns));
     e->d.hist = e->hist.p;
     e->d.hist_stride = stride;
@@ -1336,10 +1565,11 @@ int csf_untracked(csf_engine *e, uint8_t *out) {
     HIPCHK(e, hipSetDevice(e->device));
     int rc = upload_all(e);
     if (rc) return rc;
-    const int64_t n = e->d.n;
+    const int64_t n = (int64_t)e->order.size();
     if (n == 0) return CSF_OK;
     if (n > 46340) return fail(e, CSF_E_ARG, "csf_untracked: the n x n matrix is limited to n <= 46340");
     if ((rc = wait_gather(e))) return rc;
+    if ((rc = sync_order(e))) return rc;
     DevBuf<uint8_t> buf;
     HIPCHK(e, buf.alloc((size_t)(n * n)));
     launch_untracked(e->d, buf.p, e->main);
@@ -1353,7 +1583,7 @@ int csf_untracked(csf_engine *e, uint8_t *out) {
 static int nav_kat(csf_engine *e, int64_t n, const int32_t *idx, int what, const int32_t *stop, double *vd, double *ddest) {
     if (n < 0 || (n > 0 && !idx)) return fail(e, CSF_E_ARG, "bad agent list");
     for (int64_t k = 0; k < n; k++)
-        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        if (idx[k] < 0 || idx[k] >= (int64_t)e->order.size()) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
     HIPCHK(e, hipSetDevice(e->device));
     int rc = upload_all(e);
     if (rc) return rc;
@@ -1362,7 +1592,9 @@ static int nav_kat(csf_engine *e, int64_t n, const int32_t *idx, int what, const
     DevBuf<double> out;
     HIPCHK(e, di.alloc((size_t)n));
     HIPCHK(e, out.alloc((size_t)(2 * n)));
-    HIPCHK(e, hipMemcpy(di.p, idx, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<int32_t> slots((size_t)n);
+    for (int64_t k = 0; k < n; k++) slots[(size_t)k] = e->order[(size_t)idx[k]];
+    HIPCHK(e, hipMemcpy(di.p, slots.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
     if (stop) {
         HIPCHK(e, ds.alloc((size_t)n));
         HIPCHK(e, hipMemcpy(ds.p, stop, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1394,14 +1626,14 @@ int csf_set_dest_pointer(csf_engine *e, int64_t n, const int32_t *idx, const int
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!idx || !ptr))) return fail(e, CSF_E_ARG, "csf_set_dest_pointer: bad arguments");
     for (int64_t k = 0; k < n; k++) {
-        if (idx[k] < 0 || idx[k] >= e->d.n) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
-        const int32_t rows = (int32_t)(e->h_q[(size_t)idx[k]].size() / 3);
+        if (idx[k] < 0 || idx[k] >= (int64_t)e->order.size()) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        const int32_t rows = (int32_t)(e->h_q[(size_t)e->order[(size_t)idx[k]]].size() / 3);
         if (ptr[k] < 0 || ptr[k] >= rows) return fail(e, CSF_E_ARG, "destination pointer %d outside the queue of agent %d (%d rows)", ptr[k], idx[k], rows);
     }
     HIPCHK(e, hipSetDevice(e->device));
     int rc = prepare_mutation(e);
     if (rc) return rc;
-    for (int64_t k = 0; k < n; k++) e->h_ptr[(size_t)idx[k]] = ptr[k];
+    for (int64_t k = 0; k < n; k++) e->h_ptr[(size_t)e->order[(size_t)idx[k]]] = ptr[k];
     return CSF_OK;
 }
 
@@ -1443,7 +1675,7 @@ int csf_comm_init_loopback(csf_engine *const *engines, int32_t world) {
         csf_engine *e = engines[r];
         if (!e) return CSF_E_ARG;
         if (e->nccl || e->loopback || e->world > 1) return fail(e, CSF_E_STATE, "engine already belongs to a communicator");
-        if (e->device != engines[0]->device || e->d.n != engines[0]->d.n || e->d.p.model != engines[0]->d.p.model)
+        if (e->device != engines[0]->device || e->order.size() != engines[0]->order.size() || e->d.p.model != engines[0]->d.p.model)
             return fail(e, CSF_E_ARG, "loopback members hold the same population on the same device");
         for (int q = 0; q < r; q++)
             if (engines[q] == e) return fail(e, CSF_E_ARG, "engine listed twice");
@@ -1484,15 +1716,15 @@ int csf_step_group(csf_engine *const *engines, int32_t world, int64_t n_ticks) {
     }
     for (int64_t t = 0; t < n_ticks; t++) {
         for (int r = 0; r < world; r++) {
-            int rc = e0->d.n > 0 ? enqueue_tick(engines[r]) : (engines[r]->d.tick++, CSF_OK);
+            int rc = !e0->order.empty() ? enqueue_tick(engines[r]) : (engines[r]->d.tick++, CSF_OK);
             if (rc) return rc;
         }
-        if (e0->d.n > 0) {
+        if (!e0->order.empty()) {
             int rc = loopback_exchange(engines, world);
             if (rc) return rc;
         }
     }
-    if (n_ticks > 0 && e0->d.n > 0)
+    if (n_ticks > 0 && !e0->order.empty())
         for (int r = 0; r < world; r++) engines[r]->device_ahead = true;
     return CSF_OK;
 }
@@ -1562,33 +1794,33 @@ int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_
     return CSF_OK;
 }
 
-int csf_count_pairs(csf_engine *e, int64_t *evaluated, const char **kernel_name) {
-    if (!e || !evaluated) return e ? fail(e, CSF_E_ARG, "csf_count_pairs: NULL output") : CSF_E_ARG;
+int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) {
+    if (!e || !counts) return e ? fail(e, CSF_E_ARG, "csf_count_pairs: NULL output") : CSF_E_ARG;
     HIPCHK(e, hipSetDevice(e->device));
     int rc = upload_all(e);
     if (rc) return rc;
     Dev &d = e->d;
     if (kernel_name) *kernel_name = pair_kernel_name(d);
-    *evaluated = -1;
+    for (int k = 0; k < 4; k++) counts[k] = -1;
     if (std::string(pair_kernel_name(d)) != "pair_cull_kernel") return CSF_OK;   // only the cull-first kernel counts
-    *evaluated = 0;
-    if (d.n <= 1 || d.hi <= d.lo) return CSF_OK;
+    for (int k = 0; k < 4; k++) counts[k] = 0;
+    if (d.n_live <= 1 || d.hi <= d.lo) return CSF_OK;
     if ((rc = wait_gather(e))) return rc;
     if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
     if ((e->world > 1 || e->nccl != nullptr || e->loopback) && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
     DevBuf<unsigned long long> cnt;
-    HIPCHK(e, cnt.alloc(1));
-    HIPCHK(e, hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long), e->main));   // alloc() clears on the NULL stream, which this stream does not wait for
+    HIPCHK(e, cnt.alloc(4));
+    HIPCHK(e, hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned long long), e->main));   // alloc() clears on the NULL stream, which this stream does not wait for
     Dev dd = d;                 // this tick's records and circles; the circles of the next tick are not touched
     dd.pair_count = cnt.p;
     dd.bnd_next = nullptr;
     launch_pair(dd, e->main);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
-    unsigned long long h = 0;
-    HIPCHK(e, hipMemcpy(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(e, hipMemcpy(h, cnt.p, sizeof h, hipMemcpyDeviceToHost));
     cnt.release();
-    *evaluated = (int64_t)h;
+    for (int k = 0; k < 4; k++) counts[k] = (int64_t)h[k];
     return CSF_OK;
 }
 

@@ -41,6 +41,9 @@ constexpr int TILE = 1024;           // simple kernels: source records per LDS t
 #ifndef CSF_CULL_WAVES
 #define CSF_CULL_WAVES 7
 #endif
+#ifndef CSF_PREFETCH
+#define CSF_PREFETCH 1       // reach test: request the next two batches before the queue append of the current two (A/B knob)
+#endif
 constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 7 waves/SIMD (72 VGPRs, 12 B spilled) measured best (tools/sweep_cull.sh)
 constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
 constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
@@ -155,6 +158,40 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
     const v2f cx = F * gx, cy = F * gy;
     ax += cx.x + cx.y;
     ay += cy.x + cy.y;
+}
+
+// Reach test for TWO sources per lane (csf_engine.hip: update_far_radius): keep a pair unless its contribution is provably
+// below far_eps f_0 / n,
+//     rho^2 - e^2 X^2 > T^2 (sigma_a - sigma_b / 2 + (sigma_b / 2) X / rho)^2,   X = rho cos(phi) = (dx, dy) . (cos psi0, sin psi0),
+// which needs the three pair scalars (rho^2, X, s2) and one rsq: ~40 % of the cost of the field (vehicle.py:1604-1628),
+// and removes three of four pairs inside the field of view.  FOV adds the exact mask of intersection.py:690-745 for
+// batches that are not wholly inside the field of view.
+template <bool FOV, bool P2R>
+__device__ __forceinline__ void keep_x2(const PairConsts &k, const Recv &r, const v2f qx, const v2f qy, const v2f qc,
+                                        const v2f qs, bool &k0, bool &k1) {
+    const v2f dx = r.x - qx, dy = r.y - qy;
+    const v2f r2 = dx * dx + dy * dy;
+    const v2f X = dx * qc + dy * qs;
+    const v2f srel = qs * r.c - qc * r.s;
+    const v2f s2 = srel * srel;
+    const v2f e = k.e0 - k.e1 * s2, A = k.tA0 + k.tA1 * s2, B = k.tB0 + k.tB1 * s2;
+    const v2f c = X * rsq2(r2);                        // r2 = 0 (the receiver itself): NaN -> kept here, masked by FOV
+    const v2f S = A + B * c;
+    const v2f eX = e * X;
+    const v2f f = (r2 - eX * eX) - S * S;
+    k0 = !(f.x > 0.0f);
+    k1 = !(f.y > 0.0f);
+    if (FOV) {
+        const v2f t = -(dx * r.c + dy * r.s);
+        const v2f g = t * fabs2(t) + k.chs * r2;
+        k0 = k0 & (g.x > 0.0f);
+        k1 = k1 & (g.y > 0.0f);
+        if (P2R) {
+            const v2f side = r.s * dx - r.c * dy;      // rho sin(bearing) > 0: the source is to the left
+            k0 = k0 & !(side.x > 0.0f);
+            k1 = k1 & !(side.y > 0.0f);
+        }
+    }
 }
 
 // vehicle.py:1054-1147: older elliptic field of base Bicycle; q2v = (e, 1/sqrt(1-e^2)) of the source.
@@ -302,9 +339,12 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // receivers shortens that wave.  At full size the SIMDs are issue-bound either way and the variant is not used.
 // RPB: receivers of a workgroup, 16, or 32 where the grid stays large enough (DYN only: with dynamic hand-out a
 // workgroup of twice the receivers shares one tile fill and one start-up between them: 146 -> 141 us at N = 16 384)
-template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW>
+// REACH (with the far-field cull on): every candidate batch goes through the packed reach test keep_x2, two batches at a
+// time, and only the sources it keeps are queued for the field.
+template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     static_assert(RPB == WPB * RPW || (DYN && RPB % (WPB * RPW) == 0 && RPB <= WAVE), "wider workgroups need the dynamic hand-out");
+    static_assert(!REACH || (CLASSIFY && DYN), "the reach test is built into the classified, dynamically handed-out variant");
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
     __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave, drained after each receiver; holds BYTE offsets
@@ -331,12 +371,15 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     float ax[RPW], ay[RPW];     // the receivers themselves stay in LDS (rrec); one at a time is held in registers
     int qhead = 0, qlen = 0;    // wave-uniform ring state of the queue
     unsigned evals = 0;         // pair evaluations of this wave (wave-uniform: scalar adds; written out for csf_count_pairs)
+    unsigned tests = 0;         // ... sources put through the per-lane tests, and full | partial << 16 evaluation passes
+    unsigned pops = 0;
     Recv ru{0.f, 0.f, 1.f, 0.f};  // the receiver being worked on (wave-uniform, kept in VGPRs)
 #pragma unroll
     for (int u = 0; u < RPW; u++) ax[u] = ay[u] = 0.0f;
     PairConsts k = d.pc;
     asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0),
                  "+v"(k.kexp), "+v"(k.chs));
+    if (REACH) asm volatile("" : "+v"(k.tA0), "+v"(k.tA1), "+v"(k.tB0), "+v"(k.tB1));
 
     // pop CHUNK (or, when draining, whatever is left) queued sources of receiver u; the field takes two per lane
     auto pop = [&](int u, auto full) {
@@ -351,6 +394,25 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
         qlen = __builtin_amdgcn_readfirstlane(qlen - n);
         evals += (unsigned)n;
+        pops += FULL ? 1u : 0x10000u;
+    };
+    // the last (at most 64) queued sources of a receiver: one per lane through the unpacked field - about 60 % of the
+    // instructions of a packed evaluation whose second half would be empty
+    auto pop_tail = [&](int u) {
+        const bool v = lane < qlen;
+        const int o = v ? (int)queue[wave][(qhead + lane) & (QCAP - 1)] : 0;
+        const float4 q = make_float4(*(const float *)((const char *)tx + o), *(const float *)((const char *)ty + o),
+                                     *(const float *)((const char *)tc + o), *(const float *)((const char *)ts + o));
+        const float dx = ru.x - q.x, dy = ru.y - q.y;
+        float F, gx, gy;
+        field_twod(k, ru, q, dx, dy, fmaxf(dx * dx + dy * dy, 1e-30f), F, gx, gy);
+        F = v ? F : 0.0f;
+        ax[u] += F * gx;
+        ay[u] += F * gy;
+        evals += (unsigned)qlen;
+        pops += 0x10000u;
+        qhead = __builtin_amdgcn_readfirstlane((qhead + qlen) & (QCAP - 1));
+        qlen = 0;
     };
 
     auto fill_tile = [&](int64_t base, int cnt) {
@@ -458,9 +520,77 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             const unsigned bm = (DYN && CLASSIFY) ? (unsigned)__builtin_amdgcn_readfirstlane((int)bmask[ur]) : 0u;
             unsigned cand = ((DYN && CLASSIFY) ? (bm & 0xFFFFu) : (unsigned)(cand_all >> (16 * u))) & live;
             const unsigned inside = ((DYN && CLASSIFY) ? (bm >> 16) : (unsigned)(inside_all >> (16 * u))) & live;
+            if (REACH) {
+                // Two candidate batches at a time through the packed reach test (+ the exact field-of-view test unless
+                // both are wholly inside); what it keeps is appended to the queue, first batch first.  The kernel is
+                // bound by LDS round trips here, not by VALU issue (rocprof: half of the issue slots idle), so the
+                // records of the NEXT two batches are requested before the queue append of the current two and arrive
+                // while it runs - unless this append fills the queue, because the evaluation pass that follows needs
+                // the registers.
+                unsigned ins = inside;                       // wholly inside, taken in pairs first
+                unsigned rest = cand & ~inside;              // partial batches (+ an odd inside one: the exact test passes all of it)
+                if (__builtin_popcount(ins) & 1) {
+                    const unsigned top = 1u << (31 - __builtin_clz(ins));
+                    ins &= ~top;
+                    rest |= top;
+                }
+                int b1 = 0, b2 = 0;
+                bool two = false, fov = false, have = false;
+                auto next_item = [&]() {                     // wave-uniform: scalar bit operations
+                    unsigned &m = ins ? ins : rest;
+                    have = m != 0u;
+                    if (!have) return;
+                    fov = ins == 0u;
+                    b1 = __builtin_ctz(m);
+                    m &= m - 1u;
+                    two = m != 0u;
+                    b2 = two ? __builtin_ctz(m) : b1;
+                    m &= m - 1u;                             // (0 & anything: stays 0)
+                };
+                v2f sx, sy, sc, ss;
+                auto load_item = [&]() {
+                    const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
+                    sx = lds_pair(tx, i0, i1), sy = lds_pair(ty, i0, i1), sc = lds_pair(tc, i0, i1), ss = lds_pair(ts, i0, i1);
+                };
+                next_item();
+                if (have) load_item();
+                while (have) {
+                    const int o0 = 4 * ((b1 << 6) + lane), o1 = 4 * ((b2 << 6) + lane);   // byte offsets of the two records
+                    bool k0, k1;
+                    if (fov) keep_x2<true, P2R>(k, ru, sx, sy, sc, ss, k0, k1);
+                    else keep_x2<false, P2R>(k, ru, sx, sy, sc, ss, k0, k1);
+                    k1 = k1 & two;
+                    tests += two ? 2u * WAVE : (unsigned)WAVE;
+                    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+                    const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
+                    const bool fills = qlen + n0 + n1 >= CHUNK;
+                    next_item();
+                    if (CSF_PREFETCH && have && !fills) load_item();
+                    if (k0) {
+                        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
+                        queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)o0;
+                    }
+                    if (k1) {
+                        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
+                        queue[wave][(qhead + qlen + n0 + pre) & (QCAP - 1)] = (unsigned short)o1;
+                    }
+                    qlen = __builtin_amdgcn_readfirstlane(qlen + n0 + n1);
+                    if (fills) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        while (qlen >= CHUNK) pop(u, std::true_type{});
+                        if (have) load_item();
+                    } else if (!CSF_PREFETCH && have) {
+                        load_item();
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                cand = 0u;
+            }
             // batches that are entirely inside the field of view need neither the test nor the queue: two at a
             // time they go straight into the packed field evaluation (one batch per half of the register pairs)
-            {
+            if (!REACH) {
                 unsigned ins = inside;
                 while (__builtin_popcount(ins) >= 2) {
                     const int b1 = __builtin_ctz(ins);
@@ -484,6 +614,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 } else {
                     const float dx = ru.x - *(const float *)((const char *)tx + tb), dy = ru.y - *(const float *)((const char *)ty + tb);
                     const bool in = tracked<P2R>(k.chs, ru, dx, dy, dx * dx + dy * dy);
+                    tests += (unsigned)WAVE;
                     const unsigned long long m = __ballot(in);
                     if (in) {
                         const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -497,7 +628,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             }
             // the queue holds indices into this tile for this receiver: drain it before either changes
             while (qlen >= CHUNK) pop(u, std::true_type{});
-            if (qlen > 0) pop(u, std::false_type{});
+            if (qlen > WAVE) pop(u, std::false_type{});
+            else if (qlen > 0) pop_tail(u);
             if (DYN) {  // column sum of this receiver: x in the lower half of the wave, y in the upper, then within halves
                 float v = swap_add32(ax[0], ay[0]);
                 v += dpp<DPP_ROW_ROR8>(v);
@@ -521,7 +653,12 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     } else {
         reduce_store(d, j0, lane, ax, ay, BINR ? &ragent[wave * RPW] : nullptr);
     }
-    if (d.pair_count != nullptr && lane == 0) atomicAdd(d.pair_count, (unsigned long long)evals);
+    if (d.pair_count != nullptr && lane == 0) {
+        atomicAdd(d.pair_count, (unsigned long long)evals);
+        atomicAdd(d.pair_count + 1, (unsigned long long)tests);
+        atomicAdd(d.pair_count + 2, (unsigned long long)(pops & 0xFFFFu));
+        atomicAdd(d.pair_count + 3, (unsigned long long)(pops >> 16));
+    }
     if (d.trace && lane == 0) {   // tools/block_trace.py: when did every wave run, and where
         uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave);
         o[0] = t_start;
@@ -782,9 +919,10 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
 // ignores source i (row = source, column = receiver; the diagonal is always 1), from the same test the pair kernels apply
 __global__ void untracked_kernel(const Dev d, uint8_t *out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= d.n * d.n) return;
-    const int64_t i = t / d.n, j = t - i * d.n;
-    const float4 q = d.rec[i], rr = d.rec[j];
+    const int64_t n = d.n_live;
+    if (t >= n * n) return;
+    const int64_t i = t / n, j = t - i * n;
+    const float4 q = d.rec[d.order ? d.order[i] : i], rr = d.rec[d.order ? d.order[j] : j];
     const Recv r{rr.x, rr.y, rr.z, rr.w};
     const float dx = r.x - q.x, dy = r.y - q.y, r2 = dx * dx + dy * dy;
     const bool in = (i != j) & (d.pc.p2r ? tracked<true>(d.pc.chs, r, dx, dy, r2) : tracked<false>(d.pc.chs, r, dx, dy, r2));
@@ -792,7 +930,7 @@ __global__ void untracked_kernel(const Dev d, uint8_t *out) {
 }
 
 void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st) {
-    const int64_t m = d.n * d.n;
+    const int64_t m = d.n_live * d.n_live;
     if (m <= 0) return;
     hipLaunchKernelGGL(untracked_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, out);
 }
@@ -808,6 +946,11 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
 
 template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
+    if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
+        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
+        else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
+        return;
+    }
     if (d.dyn_recv && d.rpb == 32) {
         CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32>), recv_grid(d, d.n_split, 32));
         return;

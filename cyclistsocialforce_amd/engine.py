@@ -82,6 +82,11 @@ class Engine:
             raise ValueError("offsets must be [n+1] and end at the number of rows")
         self._ck(self._lib.csf_set_dest_queue(self._h, agents.size, _ptr(agents), _ptr(offsets), _ptr(xyz), int(reset)))  # reset: 0 append, 1 replace, 2 replace + keep pointer
 
+    def set_incremental(self, on=True):
+        """population changes after the first tick: straight into the device arrays (True, default) or through the host
+        mirror (include/csf.h: csf_set_incremental)"""
+        self._ck(self._lib.csf_set_incremental(self._h, int(bool(on))))
+
     def set_road(self, offsets, verts, F0, sigma):
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         verts = _f64(verts).reshape(-1, 2)
@@ -317,12 +322,18 @@ class Engine:
         self._ck(self._lib.csf_profile_samples(self._h, _ptr(out), int(capacity), C.byref(n)))
         return out[: n.value].copy()
 
-    def count_pairs(self):
-        """(pair evaluations of one launch on the current snapshot or None, name of the engine's pair kernel)"""
-        n = C.c_int64(0)
+    def count_pairs(self, detail=False):
+        """(pair evaluations of one launch on the current snapshot or None, name of the engine's pair kernel); with
+        detail=True the first item is the dict {evaluated, tested, full_passes, partial_passes}"""
+        n = (C.c_int64 * 4)()
         name = C.c_char_p()
-        self._ck(self._lib.csf_count_pairs(self._h, C.byref(n), C.byref(name)))
-        return (None if n.value < 0 else n.value), (name.value or b"").decode()
+        self._ck(self._lib.csf_count_pairs(self._h, n, C.byref(name)))
+        kernel = (name.value or b"").decode()
+        if n[0] < 0:
+            return None, kernel
+        if detail:
+            return dict(evaluated=n[0], tested=n[1], full_passes=n[2], partial_passes=n[3]), kernel
+        return n[0], kernel
 
     def profile_gather(self):
         """all-gather milliseconds accumulated over the launches of the last profile_read() (sharded engines)"""

@@ -9,14 +9,22 @@ destination queues or the population are pushed to the device before the next ti
 `traj`, `destpointer`, `znav`, `force`, `F` are refreshed after it.  `step_n(k)` runs k ticks without any
 per-tick Python work.
 
-Out of scope: SUMO co-simulation (`activate_sumo_cosimulation=True` raises), matplotlib
-animation (`animate=True` raises), and populations mixing vehicle classes in one intersection.
+SUMO co-simulation: with `activate_sumo_cosimulation=True` the intersection reads its footprint,
+approach lanes and internal lanes from a sumolib-style `net`, finds arrivals and departures on its internal lanes
+through TraCI, gives arriving road users a spline prototype across the junction, and pushes every position back with
+`traci.vehicle.moveToXY` after each tick (intersection.py:341-453, 458-539, 679-688).  `traci` is imported on demand
+or injected (`traci=`), so the seam is testable without a SUMO installation.  Arrivals and departures reach the device
+incrementally (include/csf.h: csf_set_incremental).
+
+Out of scope: matplotlib animation owned by the intersection (`animate=True` raises; drawings are
+attached per vehicle) and populations mixing vehicle classes in one intersection.
 """
 import numpy as np
 
 from . import _ffi, parameters
 from .engine import Engine
 from .parameters import RoadElementParameters
+from .utils import angleSFMtoSUMO, generateSplinePrototype
 from .vehicle import Vehicle
 
 PRIORITY_RULES = {"unregulated": _ffi.UNREGULATED, "p2r": _ffi.P2R}
@@ -132,9 +140,7 @@ class SocialForceIntersection:
 
     def __init__(self, vehicleList, id="", priority_rule="unregulated", animate=False, axes=None,
                  activate_sumo_cosimulation=False, net=None, road_elements=[], bicycle_drawing_kwargs={},
-                 capacity=None, device=0, track_params=True):
-        if activate_sumo_cosimulation:
-            raise NotImplementedError("SUMO co-simulation is outside the scope of the MI355X engine")
+                 capacity=None, device=0, track_params=True, traci=None):
         if animate:
             raise NotImplementedError("matplotlib animation is outside the scope of the MI355X engine; "
                                       "attach drawing objects to the vehicles instead")
@@ -143,7 +149,8 @@ class SocialForceIntersection:
         assert isinstance(id, str), "Intersection ID has to be a string."
         self.bicycle_drawing_kwargs = bicycle_drawing_kwargs
         self.is_first_step = True
-        self.activate_sumo_cosimulation = False
+        self.activate_sumo_cosimulation = bool(activate_sumo_cosimulation)
+        self._traci = traci
         self.id = id
         self.priority_rule = priority_rule
         self.animate = False
@@ -181,8 +188,83 @@ class SocialForceIntersection:
         self._flog = []           # |F| of every evaluated tick since the last fold (vehicle.F)
         self._flog_base = 0
         self._params_seen = -1
-        for v in vehicleList:
+        if self.activate_sumo_cosimulation:
+            self._init_sumo(net)
+        for v in vehicleList:                                  # (as given: the reference plans no route for them, :316-317)
             self._attach(v)
+        if self.activate_sumo_cosimulation:
+            self.update_road_user_positions()                  # intersection.py:320
+
+    # ------------------------------------------------------------------ SUMO co-simulation
+    def _init_sumo(self, net):
+        """intersection.py:341-405: footprint, the last / first two points of every approach / exit lane (sampled from
+        a spline through the lane shape), and the internal lanes on which SUMO hands road users over."""
+        from scipy import interpolate
+
+        if net is None:
+            raise ValueError("activate_sumo_cosimulation=True needs the sumolib net of the scenario (net=...)")
+        if self._traci is None:
+            try:
+                import traci as _traci
+            except ImportError as exc:
+                raise ImportError("SUMO co-simulation needs the `traci` package (or pass traci=...)") from exc
+            self._traci = _traci
+        self.node = net.getNode(self.id)
+        self.shape_vertices = np.asarray(self.node.getShape(), dtype=float)
+        try:
+            from matplotlib import path as pth
+            self.shape = pth.Path(self.shape_vertices, closed=True)
+        except ImportError:                                   # pragma: no cover - matplotlib is optional
+            self.shape = self.shape_vertices
+
+        def lane_ends(edges, order, take):
+            ends = {}
+            for edge in edges:
+                ends[edge.getID()] = []
+                for lane in edge.getLanes():
+                    path = np.asarray(lane.getShape(), dtype=float)
+                    tck, _ = interpolate.splprep((path[:, 0], path[:, 1]), s=0.0, k=min(order, path.shape[0] - 1))
+                    x_i, y_i = interpolate.splev(np.linspace(0, 1, 10), tck)
+                    ends[edge.getID()].append((x_i[take], y_i[take]))
+            return ends
+
+        self.inEdges = lane_ends(self.node.getIncoming(), 5, slice(-2, None))
+        self.outEdges = lane_ends(self.node.getOutgoing(), 3, slice(None, 2))
+        self.internal_lanes, self.internal_lane_ids = [], []
+        for edge in net.getEdges():
+            if edge.getFromNode() == self.node and edge.getToNode() == self.node:
+                for lane in edge.getLanes():
+                    self.internal_lane_ids.append(lane.getID())
+                    self.internal_lanes.append(lane)
+        if not self.internal_lanes:
+            raise ValueError(f"Intersection {self.id} does not have internal lanes! Cyclistsocialforce requires internal "
+                             "lanes to allocate SUMO road users to intersections. Check if the net-file correctly "
+                             "specifies interal lanes for this intersection!")
+
+    def find_entered_exited_roadusers(self):
+        """intersection.py:429-453: ids that appeared on / vanished from the internal lanes during the last SUMO step."""
+        before = self.get_road_user_ids()
+        now = []
+        for lane in self.internal_lane_ids:
+            now += list(self._traci.lane.getLastStepVehicleIDs(lane))
+        return np.setdiff1d(now, before), np.setdiff1d(before, now)
+
+    def _route_prototype(self, user):
+        """intersection.py:471-519: destinations across the junction for a road user that follows a SUMO route."""
+        ecurrent, enext = user.route[0], user.route[1]
+        assert ecurrent in self.inEdges, f"Road user {user.id} arriving on junction {self.id} from unknown edge {ecurrent}!"
+        assert enext in self.outEdges, f"Road user {user.id} requesting to depart junction {self.id} on unknown edge {enext}!"
+        lanes_in = self.inEdges[ecurrent]
+        lane_in = 0
+        if len(lanes_in) > 1:                                  # the closer of the first two approach lanes
+            xs = np.concatenate((lanes_in[0][0], lanes_in[1][0]))
+            ys = np.concatenate((lanes_in[0][1], lanes_in[1][1]))
+            lane_in = int(np.argmin(np.hypot(xs - user.s[0], ys - user.s[1])) / 2)
+        lane_out = np.random.randint(0, len(self.outEdges[enext]))
+        pts = np.vstack((np.array(lanes_in[lane_in]).T, np.array(self.outEdges[enext][lane_out]).T))
+        xp, yp = generateSplinePrototype(pts[:, 0], pts[:, 1], 5)
+        ahead = np.hypot(xp - xp[-1], yp - yp[-1]) < np.hypot(user.s[0] - xp[-1], user.s[1] - yp[-1])
+        user.setDestinations(xp[ahead], yp[ahead], reset=True)  # only the points still in front of the road user
 
     # ------------------------------------------------------------------ population management
     def _attach(self, v):
@@ -238,7 +320,9 @@ class SocialForceIntersection:
                     "holds one parameter set; only params.v_desired_default may differ between its vehicles")
 
     def add_road_user(self, user):
-        """intersection.py:458-539 (without the SUMO route handling)."""
+        """intersection.py:458-539"""
+        if self.activate_sumo_cosimulation and user.follow_route:
+            self._route_prototype(user)
         self._attach(user)
 
     def get_road_user_ids(self):
@@ -512,6 +596,11 @@ class SocialForceIntersection:
         else:
             for k, v in enumerate(self.vehicles):
                 self.vehicleX[k, 0], self.vehicleY[k, 0], self.vehicleTheta[k, 0] = v.s[0], v.s[1], v.s[2]
+        if self.activate_sumo_cosimulation and n:              # intersection.py:679-688: SUMO follows the social-force positions
+            move = self._traci.vehicle.moveToXY
+            angles = angleSFMtoSUMO(self.vehicleTheta[:, 0])
+            for k, v in enumerate(self.vehicles):
+                move(v.id, "", -1, float(self.vehicleX[k, 0]), float(self.vehicleY[k, 0]), angle=float(angles[k]), keepRoute=6)
 
     # ------------------------------------------------------------------ reference API
     def get_untracked_foes(self):

@@ -62,8 +62,20 @@ def angleSUMOtoSFM(theta):
 
 
 def angleSFMtoSUMO(theta):
-    """utils.py:119-121"""
-    t = np.pi / 2 - theta
-    if t < 0:
-        t += TWO_PI
-    return np.rad2deg(t)
+    """utils.py:119-121 (scalars and arrays): SUMO measures the heading in degrees, clockwise from north."""
+    t = np.pi / 2 - np.asarray(theta, dtype=float)
+    t = np.where(t < 0, t + TWO_PI, t)                 # expandAngle, utils.py:142-148
+    out = np.rad2deg(t)
+    return float(out) if out.ndim == 0 else out
+
+
+def generateSplinePrototype(x, y, npoints=5):
+    """trajectory.py:11-41: npoints samples of the interpolating cubic spline through (x, y) - the path a road user is
+    given across a junction under SUMO co-simulation (host-side, once per arrival; uses scipy like the reference)."""
+    from scipy import interpolate
+
+    assert len(x) == len(y), "x and y must be same length!"
+    assert len(x) >= 3, "Provide at least 3 points to calculate a cubic trajectory prototype"
+    tck, _ = interpolate.splprep((x, y), s=0.0)
+    x_p, y_p = interpolate.splev(np.linspace(0, 1, npoints), tck)
+    return x_p, y_p

@@ -89,6 +89,15 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
  * population, any order; the remaining agents keep their relative order. */
 int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
 
+/* How csf_add_agents / csf_remove_agents / csf_set_dest_queue reach the device once ticks have run (the per-tick arrivals
+ * and departures of SUMO co-simulation, intersection.py:429-453, 458-634; scenario.py:376-466).  on != 0 (default): the
+ * change is written straight into the device arrays by small kernels - a removed road user leaves a dead slot with a
+ * sentinel record, a new one takes a free slot, a replaced queue is appended to the queue slab; no download, no upload,
+ * the binned order is renewed once a sixteenth of the slots has changed.  on == 0: every change goes through the host
+ * mirror (download, edit, upload, re-sort), which is also what sharded engines and engines with the history ring do.
+ * The population order seen by every other entry point is the same either way. */
+int csf_set_incremental(csf_engine *e, int32_t on);
+
 /* Vehicle.setDestinations (vehicle.py:606-647) for n agents: CSR (offsets[n+1], xyz_stop[sum,3]);
  * reset = 0 appends to the agent's queue, reset = 1 replaces it and rewinds the pointer, reset = 2 replaces
  * it and keeps the pointer (rows edited in place: Vehicle.stop / Vehicle.go set the stop flag of the current
@@ -221,11 +230,14 @@ int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *
  * kept) WITHOUT resetting. */
 int csf_profile_kernels(csf_engine *e, double ms[4], int64_t launches[4]);
 int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_t *n_samples);
-/* Number of pair evaluations (vehicle.py:1560-1648 calls per receiver, after the mask of intersection.py:690-745 and the
- * far-field cull) of ONE launch of the pair kernel on the current snapshot: what the VALU roofline of bench.py is
- * computed from.  Runs one extra launch with a counter; the state of the simulation is not advanced.  *evaluated = -1
- * when the engine's pair kernel does not count (kernel_name, if not NULL, names the kernel either way). */
-int csf_count_pairs(csf_engine *e, int64_t *evaluated, const char **kernel_name);
+/* What ONE launch of the pair kernel on the current snapshot does (the roofline of bench.py is computed from it):
+ *   counts[0]  pair evaluations - calls of the force field vehicle.py:1560-1648 for a (source, receiver) pair, after the
+ *              mask of intersection.py:690-745, the far-field cull and the per-pair reach test;
+ *   counts[1]  sources put through the per-lane tests (field of view and reach);
+ *   counts[2], counts[3]  full (128 pairs) and partial evaluation passes.
+ * Runs one extra launch with device counters; the state of the simulation is not advanced.  All -1 when the engine's
+ * pair kernel does not count (kernel_name, if not NULL, names the kernel either way). */
+int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name);
 /* milliseconds between the end of the agent kernel and the end of the RCCL all-gather, accumulated over the launches
  * of the last csf_profile_read (0 for an unsharded engine) */
 int csf_profile_gather(const csf_engine *e, double *gather_ms);

@@ -1000,13 +1000,14 @@ csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double 
 
 /* Test aid (no reference counterpart): re-anchor the oracle on a state produced elsewhere - what csf_push_state does for
  * the engine (calibration.py:455-460 edits vehicle.s the same way): s [n][ns] replaces vehicle.s, the current column of
- * the trajectory ring and the position snapshot; ptr / znav (optional) replace the destination pointer and the
- * navigation state.  The dynamics of a chaotic population cannot be compared point by point over thousands of ticks;
+ * the trajectory ring and the position snapshot; ptr / znav / col (optional) replace the destination pointer, the
+ * navigation state and the ring column vehicle.i.  The dynamics of a chaotic population cannot be compared point by point over thousands of ticks;
  * the long-run parity tests re-anchor every 100 ticks and compare the segments in between. */
-void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const uint8_t *znav) {
+void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const uint8_t *znav, const int32_t *col) {
     for (int a = 0; a < o->n; a++) {
         double *s = S(o, a);
         for (int k = 0; k < o->ns; k++) s[k] = s_in[(size_t)a * o->ns + k];
+        if (col) o->i[a] = col[a];                                  /* the ring column vehicle.i (vehicle.py:1279-1280) */
         int i = o->i[a];
         trj(o, a, 0)[i] = s[0];
         trj(o, a, 1)[i] = s[1];

@@ -118,7 +118,7 @@ def lib():
         L.csfo_get_nav.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.csfo_get_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.csfo_set_snapshot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        L.csfo_push_state.argtypes = [C.c_void_p] * 4
+        L.csfo_push_state.argtypes = [C.c_void_p] * 5
         L.csfo_dest_force.argtypes = [C.c_void_p, C.c_int, dp, dp]
         L.csfo_apply_forces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_num_threads.restype = C.c_int
@@ -304,12 +304,13 @@ class Population:
         snap = np.ascontiguousarray(snap, dtype=np.float64)
         lib().csfo_set_snapshot(self.h, lo, hi, _p(snap))
 
-    def push_state(self, s, ptr=None, znav=None):
-        """re-anchor the oracle on a state produced elsewhere (test aid, see csfo_push_state)"""
+    def push_state(self, s, ptr=None, znav=None, col=None):
+        """re-anchor the oracle on a state produced elsewhere (test aid, see csfo_push_state); col = vehicle.i"""
         s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.n, self.ns)
         ptr = None if ptr is None else np.ascontiguousarray(ptr, dtype=np.int32)
         znav = None if znav is None else np.ascontiguousarray(znav, dtype=np.uint8).reshape(self.n, 3)
-        lib().csfo_push_state(self.h, _p(s), None if ptr is None else _p(ptr), None if znav is None else _p(znav))
+        col = None if col is None else np.ascontiguousarray(np.broadcast_to(np.asarray(col, dtype=np.int32), (self.n,)))
+        lib().csfo_push_state(self.h, _p(s), *[None if a is None else _p(a) for a in (ptr, znav, col)])
 
     def dest_force(self, a):
         fx, fy = C.c_double(), C.c_double()

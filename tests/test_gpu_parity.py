@@ -373,10 +373,12 @@ def test_field_of_view_variants_vs_oracle(amd, monkeypatch, hfov, rule, rpb):
     assert err < 5e-5
 
 
-def test_far_field_cull_bound(amd, monkeypatch):
-    """Batches beyond the far-field radius are skipped (include/csf.h: csf_far_radius).  What is left out of a
-    receiver's column sum must stay below eps * f_0; with eps = 0 every pair is evaluated."""
-    n, box = 4096, 500.0
+@pytest.mark.parametrize("n,box", [(4096, 500.0), (16384, 200.0)])
+def test_far_field_cull_bound(amd, monkeypatch, n, box):
+    """Batches beyond the far-field radius are skipped (include/csf.h: csf_far_radius) and, inside it, the per-pair reach
+    test drops every pair whose contribution is provably below eps * f_0 / n (csf_engine.hip: update_far_radius; at
+    N = 16 384 in 200 m: four of five pairs inside the field of view).  What is left out of a receiver's column sum must
+    stay below eps * f_0; with eps = 0 every pair is evaluated."""
     x, y, psi, v, off, dq = synthetic_population(n, box)
     s0 = np.c_[x, y, psi, v, np.zeros(n)]
     f0 = amd.pod("twod").f_0
@@ -395,7 +397,7 @@ def test_far_field_cull_bound(amd, monkeypatch):
     r0, x0, y0 = rep(0.0)
     assert np.isinf(r0)
     r1, x1, y1 = rep(None)                                    # default: eps = 2^-24
-    assert 100.0 < r1 < box                                   # the cull is active in this scene
+    assert 100.0 < r1 < box * 2 ** 0.5                        # the cull is active in this scene
     scale = np.hypot(x0, y0).max()
     bound = 2.0 ** -24 * f0 + 8 * np.finfo(np.float32).eps * scale
     assert np.abs(x1 - x0).max() <= bound and np.abs(y1 - y0).max() <= bound

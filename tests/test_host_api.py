@@ -235,3 +235,48 @@ def test_shard_bounds_cover_the_population():
                 assert size % 64 == 0 and size * world >= n
                 assert all(hi - lo <= size for lo, hi in blocks)
     assert parallel.shard_bounds(16384, 8, 3) == (6144, 8192)
+
+
+def test_sumo_seam_host_side():
+    """intersection.py:341-453, 458-539, 679-688 on duck-typed sumolib / traci stand-ins (tests/sumo_fakes.py): lane
+    end points, internal lanes, the spline prototype of an arriving road user, the TraCI push-back convention."""
+    from sumo_fakes import FakeNet, FakeTraci
+
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.utils import angleSFMtoSUMO, angleSUMOtoSFM
+    from cyclistsocialforce_amd.vehicle import TwoDBicycle
+
+    tr = FakeTraci()
+    ins = SocialForceIntersection([], id="J", activate_sumo_cosimulation=True, net=FakeNet(), traci=tr)
+    assert set(ins.inEdges) == {"W_in", "E_in", "S_in", "N_in"} and set(ins.outEdges) == {"W_out", "E_out", "S_out", "N_out"}
+    (xi, yi), = ins.inEdges["W_in"]                       # the last two samples of the approach lane, towards the node
+    assert xi.shape == (2,) and xi[0] < xi[1] <= -5 + 1e-9 and abs(xi[1] + 5.0) < 1e-9
+    (xo, yo), = ins.outEdges["N_out"]                     # the first two samples of the exit lane
+    assert abs(yo[0] - 5.0) < 1e-9 and yo[1] > yo[0]
+    assert ins.internal_lane_ids == [":J_0_0", ":J_0_1"]
+    with pytest.raises(ValueError, match="internal"):
+        SocialForceIntersection([], id="J", activate_sumo_cosimulation=True, net=FakeNet(internal=False), traci=tr)
+    with pytest.raises(ValueError):
+        SocialForceIntersection([], id="J", activate_sumo_cosimulation=True, traci=tr)
+    # an arrival from the west that leaves to the north: 5-point prototype, only the points ahead of it are kept
+    np.random.seed(0)
+    u = TwoDBicycle((-9.0, -1.6, 0.0, 5.0, 0.0), id="veh0", route=("W_in", "N_out"))
+    ins.add_road_user(u)
+    assert u.destpointer == 0 and 3 <= u.destqueue.shape[0] <= 5
+    assert np.all(np.diff(np.hypot(u.destqueue[:, 0] - u.destqueue[-1, 0], u.destqueue[:, 1] - u.destqueue[-1, 1])) < 0)
+    np.testing.assert_allclose(u.destqueue[-1, :2], [xo[1], yo[1]], atol=1e-9)
+    with pytest.raises(AssertionError, match="unknown edge"):
+        ins.add_road_user(TwoDBicycle((0, 0, 0, 5, 0), id="bad", route=("X_in", "N_out")))
+    # arrivals / departures are read off the internal lanes
+    tr.occupancy = {":J_0_0": ("veh0", "veh7"), ":J_0_1": ("veh9",)}
+    entered, exited = ins.find_entered_exited_roadusers()
+    assert sorted(entered) == ["veh7", "veh9"] and list(exited) == []
+    tr.occupancy = {":J_0_0": ()}
+    entered, exited = ins.find_entered_exited_roadusers()
+    assert list(entered) == [] and list(exited) == ["veh0"]
+    # SUMO's angle convention: degrees, clockwise from north (utils.py:114-121)
+    assert angleSFMtoSUMO(0.0) == 90.0 and angleSFMtoSUMO(np.pi / 2) == 0.0 and abs(angleSFMtoSUMO(-np.pi / 2) - 180.0) < 1e-12
+    for deg in (0.0, 45.0, 90.0, 200.0, 359.0):
+        assert abs(angleSFMtoSUMO(angleSUMOtoSFM(deg)) - deg) < 1e-9
+    ins.update_road_user_positions()                       # pushes (x, y, angle) of every road user: intersection.py:679-688
+    assert tr.moves[-1][1:] == ("veh0", "", -1, -9.0, -1.6, 90.0, 6)
