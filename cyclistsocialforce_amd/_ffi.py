@@ -10,11 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # CSF_LIB selects another build of the same library (kernel A/B measurements, tools/ab.sh)
 LIB_PATH = os.environ.get("CSF_LIB") or os.path.join(HERE, "libcsf_hip.so")
 
-BICYCLE, TWOD, INVPEND, PLANARPOINT = 0, 1, 2, 3
+BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE = 0, 1, 2, 3, 4
 UNREGULATED, P2R = 0, 1
-N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4}
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5}
 UNIQUE_ID_BYTES = 128
-ST_SPLINE, ST_NAN, ST_NAVSTATE = 1, 2, 4
+ST_SPLINE, ST_NAN, ST_NAVSTATE, ST_UNCONTROLLABLE = 1, 2, 4, 8
 
 # every symbol include/csf.h declares (tests check that the library exports all of them)
 SYMBOLS = (
@@ -45,7 +45,7 @@ class Params(C.Structure):
         ("h", C.c_double), ("m", C.c_double), ("i_bike_longlong", C.c_double),
         ("i_steer_vertvert", C.c_double), ("c_steer", C.c_double),
         ("v_max_walk", C.c_double), ("delta_max_walk", C.c_double),
-        ("k_psi", C.c_double),
+        ("k_psi", C.c_double), ("pb_poles", C.c_double * 4),
         ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("reserved", C.c_int32),
     ]
 
@@ -122,7 +122,7 @@ def load():
     L.csf_update_nav_state.argtypes = [vp, i64, vp, vp, dp, dp]
     L.csf_set_dest_pointer.argtypes = [vp, i64, vp, vp]
     L.csf_set_incremental.argtypes = [vp, i32]
-    if L.csf_abi_version() != 1:
-        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 1")
+    if L.csf_abi_version() != 2:
+        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 2")
     _lib = L
     return L

@@ -406,7 +406,7 @@ template <int MODEL>
 __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, double &fy) {
     if (MODEL == CSF_BICYCLE) direct_approach(d, g, fx, fy);  // vehicle.py:1189-1194
     else {
-        if (MODEL == CSF_PLANARPOINT) update_destination(d, g);  // Vehicle.calcDestinationForce :295-297
+        if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) update_destination(d, g);  // Vehicle.calcDestinationForce :295-297
         twod_dest(d, g, fx, fy);
     }
 }
@@ -547,6 +547,8 @@ __device__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, 
     g.theta = limit_angle(xn[2]);                             // :1846
 }
 
+__device__ __forceinline__ int64_t a_idx(int c, int64_t cap, int64_t a) { return (int64_t)c * cap + a; }
+
 template <int MODEL>
 __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
     const csf_params &p = d.p;
@@ -594,6 +596,28 @@ __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) d.lti[k * cap + a] = xl[k];
+    } else if (MODEL == CSF_PLANARBIKE) {                     // PlanarTwoWheelerDynamics.step: dynamics.py:225-258
+        // x = (delta, psi) follows x' = (A - B K_x) x + B K_u psi_d with A = [[0, 0], [v / l, 0]], B = (1, 0)^T, K_x placed
+        // for the class's two poles and K_u from a simulated step response, both re-derived for the current speed every
+        // step (dynamics.py:203-223, 1167-1226).  In z = (v delta / l, psi) the closed loop is the same for every speed
+        // (csf_engine.hip: derive_planarbike), so one precomputed exact step does it.
+        const double a = g.v / p.l;                           // the speed BEFORE the speed update (:228)
+        double del = d.lti[a_idx(0, cap, g.a)], psu = d.ppsi[g.a];   // unwrapped (dynamics.py:195-197, 244)
+        const double psi_d = atan2(Fy, Fx), v_d = sqrt(Fy * Fy + Fx * Fx);   // :231-232
+        if (a > 0.0) {
+            const double z0 = a * del, z1 = psu;
+            del = (d.pb_E[0] * z0 + d.pb_E[1] * z1 + d.pb_G[0] * psi_d) / a;   // :235-244
+            psu = d.pb_E[2] * z0 + d.pb_E[3] * z1 + d.pb_G[1] * psi_d;
+        } else {
+            g.st |= CSF_ST_UNCONTROLLABLE;                    // dynamics.py:1212-1214 asserts; here the yaw loop holds still
+        }
+        d.lti[a_idx(0, cap, g.a)] = del;
+        d.ppsi[g.a] = psu;
+        g.psi = limit_angle(psu);                             // :246-247
+        g.delta = limit_angle(del);
+        g.v = v_d + (g.v - v_d) * d.pb_ev;                    // PPointSpeedDynamics: dynamics.py:156, 175
+        g.y += p.t_s * g.v * sin(g.psi);                      // :251-258
+        g.x += p.t_s * g.v * cos(g.psi);
     } else {                                                  // PlanarPoint: dynamics.py:996-1079
         double vd = sqrt(Fx * Fx + Fy * Fy);                  // :1018
         double acc = clampd(p.k_p_v * (vd - g.v), p.a_max[0], p.a_max[1]);
@@ -770,6 +794,7 @@ void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0, hipEv
     case CSF_BICYCLE: hipExtLaunchKernelGGL(agent_kernel<CSF_BICYCLE>, g, b, 0, st, t0, t1, 0, d, phases); break;
     case CSF_TWOD: hipExtLaunchKernelGGL(agent_kernel<CSF_TWOD>, g, b, 0, st, t0, t1, 0, d, phases); break;
     case CSF_INVPEND: hipExtLaunchKernelGGL(agent_kernel<CSF_INVPEND>, g, b, 0, st, t0, t1, 0, d, phases); break;
+    case CSF_PLANARBIKE: hipExtLaunchKernelGGL(agent_kernel<CSF_PLANARBIKE>, g, b, 0, st, t0, t1, 0, d, phases); break;
     default: hipExtLaunchKernelGGL(agent_kernel<CSF_PLANARPOINT>, g, b, 0, st, t0, t1, 0, d, phases); break;
     }
 }
@@ -850,85 +875,90 @@ void launch_snapshot(const Dev &d, double *out, hipStream_t st) {
     hipLaunchKernelGGL(snapshot_kernel, dim3((unsigned)((d.n_live + 255) / 256)), dim3(256), 0, st, d, out);
 }
 
-// ---- population changes on the device ---------------------------------------------------------------------------------
-// Vehicle.__init__ (vehicle.py:64-204, 1728-1736; dynamics.py:828) for new road users placed into free slots: what
-// csf_add_agents writes into the host mirror, written straight into the device arrays instead, plus the fp32 record.
-// The slot keeps the position of the binned order it had (pos[]): until the next re-binning the new record sits in a
-// batch of far-away neighbours, whose bounding circle the engine recomputes before the next pair launch.
-__global__ void spawn_kernel(const Dev d, const SpawnRec *recs, int64_t m) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    const SpawnRec r = recs[k];
-    const int64_t a = r.slot, cap = d.cap;
-    const csf_params &p = d.p;
-    double s[6];
-    for (int c = 0; c < 6; c++) s[c] = c < d.ns ? r.s[c] : 0.0;
-    s[2] = limit_angle(s[2]);                                  // vehicle.py:154-155
-    for (int c = 0; c < 6; c++) d.s[c * cap + a] = s[c];
-    d.vdes[a] = r.vdes;
-    d.qbeg[a] = r.qbeg;
-    d.qlen[a] = r.qlen;
-    d.ptr[a] = 0;
-    d.znav[a] = 0;                                             // vehicle.py:188
-    for (int c = 0; c < 3; c++) d.znp[c * cap + a] = 0.0;
-    d.ti[a] = 0;                                               // vehicle.py:146
-    d.hx[a] = s[0];                                            // traj[:, 0] = s (vehicle.py:159-160)
-    d.hy[a] = s[1];
-    const double delta = d.ns > 4 ? s[4] : 0.0, theta = d.ns > 5 ? s[5] : 0.0;
-    d.lti[0 * cap + a] = delta;                                // vehicle.py:1728
-    d.lti[1 * cap + a] = 0.0;
-    d.lti[2 * cap + a] = theta;
-    d.lti[3 * cap + a] = 0.0;
-    d.lti[4 * cap + a] = s[2];
-    d.zrid[a] = s[3] < p.v_max_walk ? 0 : 1;                   // vehicle.py:1732-1736
-    d.dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
-    d.ppsi[a] = s[2];                                          // dynamics.py:828, 987-993
-    for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
-    d.status[a] = 0;
-    d.alive[a] = 1;
-    write_record(d, a, s[0], s[1], s[2], s[3]);
-}
-
-// remove_road_user (intersection.py:576-634): the slot dies - it is no longer integrated and its record becomes the
-// sentinel that contributes exactly nothing as a source
-__global__ void retire_kernel(const Dev d, const int32_t *slots, int64_t m) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    const int64_t a = slots[k];
-    d.alive[a] = 0;
-    const float4 q = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
-    d.rec[a] = q;
-    if (d.recs_valid) d.recs[d.pos[a]] = q;
-    if (d.p.model == CSF_BICYCLE) {
-        d.rec2[a] = make_float2(0.0f, 1.0f);
-        if (d.recs_valid) d.recs2[d.pos[a]] = make_float2(0.0f, 1.0f);
-    }
-}
-
-// Vehicle.setDestinations (vehicle.py:606-647): the queue of a slot now lives at another place of the slab
-__global__ void requeue_kernel(const Dev d, const QueueRec *recs, int64_t m) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    const QueueRec r = recs[k];
-    d.qbeg[r.slot] = r.qbeg;
-    d.qlen[r.slot] = r.qlen;
-    const int32_t ptr = r.mode == 1 ? 0 : d.ptr[r.slot];       // vehicle.py:642-645: reset rewinds the pointer
-    d.ptr[r.slot] = ptr < r.qlen ? ptr : r.qlen - 1;
-}
-
-void launch_spawn(const Dev &d, const SpawnRec *recs, int64_t m, hipStream_t st) {
-    if (m > 0) hipLaunchKernelGGL(spawn_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d, recs, m);
-}
-void launch_retire(const Dev &d, const int32_t *slots, int64_t m, hipStream_t st) {
-    if (m > 0) hipLaunchKernelGGL(retire_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d, slots, m);
-}
-void launch_requeue(const Dev &d, const QueueRec *recs, int64_t m, hipStream_t st) {
-    if (m > 0) hipLaunchKernelGGL(requeue_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d, recs, m);
-}
-
 void launch_records(const Dev &d, hipStream_t st) {
     if (d.n_pad <= 0) return;
     hipLaunchKernelGGL(records_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+}
+
+// ---- population changes on the device ---------------------------------------------------------------------------------
+// One launch applies a batch of changes that the engine collected since the last device call (csf_engine.hip:
+// flush_pending).  The items are independent of each other - the host has already dropped a retirement whose slot is
+// spawned into again, folded a new queue of a new road user into its spawn record, and kept only the last queue of a
+// slot - so they run side by side: thread k takes one retirement, one spawn, one queue, or one queue row.  The records
+// are read straight from pinned host memory.
+//
+// spawn: Vehicle.__init__ (vehicle.py:64-204, 1728-1736; dynamics.py:828) for a new road user placed into a free slot:
+//   what csf_add_agents writes into the host mirror on the upload path, plus the fp32 record.  The slot keeps the
+//   position of the binned order it had (pos[]): until the next re-binning the new record sits in a batch of far-away
+//   neighbours, whose bounding circle the engine recomputes before the next pair launch.
+// retire: remove_road_user (intersection.py:576-634): the slot is no longer integrated and its record becomes the
+//   sentinel that contributes exactly nothing as a source.
+// requeue: Vehicle.setDestinations (vehicle.py:606-647): the queue of a slot now lives at another place of the slab.
+__global__ void patch_kernel(const Dev d, const PatchHeader *hp) {
+    const PatchHeader h = *hp;
+    const char *base = (const char *)hp;
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t cap = d.cap;
+    if (k < h.n_retire) {
+        const int64_t a = ((const int32_t *)(base + h.off_retire))[k];
+        d.alive[a] = 0;
+        const float4 q = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
+        d.rec[a] = q;
+        if (d.recs_valid) d.recs[d.pos[a]] = q;
+        if (d.p.model == CSF_BICYCLE) {
+            d.rec2[a] = make_float2(0.0f, 1.0f);
+            if (d.recs_valid) d.recs2[d.pos[a]] = make_float2(0.0f, 1.0f);
+        }
+        return;
+    }
+    k -= h.n_retire;
+    if (k < h.n_spawn) {
+        const SpawnRec r = ((const SpawnRec *)(base + h.off_spawn))[k];
+        const int64_t a = r.slot;
+        const csf_params &p = d.p;
+        double s[6];
+        for (int c = 0; c < 6; c++) s[c] = c < d.ns ? r.s[c] : 0.0;
+        s[2] = limit_angle(s[2]);                                  // vehicle.py:154-155
+        for (int c = 0; c < 6; c++) d.s[c * cap + a] = s[c];
+        d.vdes[a] = r.vdes;
+        d.qbeg[a] = r.qbeg;
+        d.qlen[a] = r.qlen;
+        d.ptr[a] = 0;
+        d.znav[a] = 0;                                             // vehicle.py:188
+        for (int c = 0; c < 3; c++) d.znp[c * cap + a] = 0.0;
+        d.ti[a] = 0;                                               // vehicle.py:146
+        d.hx[a] = s[0];                                            // traj[:, 0] = s (vehicle.py:159-160)
+        d.hy[a] = s[1];
+        const double delta = d.ns > 4 ? s[4] : 0.0, theta = d.ns > 5 ? s[5] : 0.0;
+        d.lti[0 * cap + a] = delta;                                // vehicle.py:1728
+        d.lti[1 * cap + a] = 0.0;
+        d.lti[2 * cap + a] = theta;
+        d.lti[3 * cap + a] = 0.0;
+        d.lti[4 * cap + a] = s[2];
+        d.zrid[a] = s[3] < p.v_max_walk ? 0 : 1;                   // vehicle.py:1732-1736
+        d.dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
+        d.ppsi[a] = s[2];                                          // dynamics.py:828, 987-993
+        for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
+        d.status[a] = 0;
+        d.alive[a] = 1;
+        write_record(d, a, s[0], s[1], s[2], s[3]);
+        return;
+    }
+    k -= h.n_spawn;
+    if (k < h.n_requeue) {
+        const QueueRec r = ((const QueueRec *)(base + h.off_requeue))[k];
+        d.qbeg[r.slot] = r.qbeg;
+        d.qlen[r.slot] = r.qlen;
+        const int32_t ptr = r.mode == 1 ? 0 : d.ptr[r.slot];       // vehicle.py:642-645: reset rewinds the pointer
+        d.ptr[r.slot] = ptr < r.qlen ? ptr : r.qlen - 1;
+        return;
+    }
+    k -= h.n_requeue;
+    if (k < 3 * h.n_rows) d.q[3 * h.q_top + k] = ((const double *)(base + h.off_rows))[k];
+}
+
+void launch_patch(const Dev &d, const PatchHeader *h, int64_t items, hipStream_t st) {
+    if (items > 0) hipLaunchKernelGGL(patch_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, d, h);
 }
 
 }  // namespace csf

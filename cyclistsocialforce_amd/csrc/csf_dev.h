@@ -35,6 +35,9 @@ struct PairConsts {
 struct Dev {
     csf_params p;
     PairConsts pc;
+    // PlanarBicycle (csf_engine.hip: derive_planarbike): one exact step of z' = M z + (1/G, 0)^T u for z = (v delta / l, psi),
+    // M = [[p1 + p2, -p1 p2], [1, 0]]: z+ = pb_E z + pb_G u, the same for every speed; pb_ev = exp(-k_p_v t_s)
+    double pb_E[4], pb_G[2], pb_ev;
     int64_t n;         // agent SLOTS in use (the highest one + 1); a slot may be dead after csf_remove_agents until it is reused
     int64_t n_live;    // road users (intersection.py n_bikes)
     int64_t cap;       // SoA stride
@@ -135,9 +138,13 @@ struct QueueRec {      // one replaced destination queue (Vehicle.setDestination
     int64_t qbeg;
     int32_t mode, pad;  // 1: pointer rewinds, 0 / 2: pointer kept (clamped to the new length)
 };
-void launch_spawn(const Dev &d, const SpawnRec *recs, int64_t m, hipStream_t st);
-void launch_retire(const Dev &d, const int32_t *slots, int64_t m, hipStream_t st);
-void launch_requeue(const Dev &d, const QueueRec *recs, int64_t m, hipStream_t st);
+// one batch of population changes, laid out in one pinned, device-visible host buffer: the header, then the records
+struct PatchHeader {
+    int64_t n_retire, n_spawn, n_requeue, n_rows;   // int32 slots | SpawnRec | QueueRec | rows [n_rows][3] for d.q[q_top ..]
+    int64_t off_retire, off_spawn, off_requeue, off_rows;   // byte offsets from the header
+    int64_t q_top;                                   // first row of the queue slab that the rows go to
+};
+void launch_patch(const Dev &d, const PatchHeader *h, int64_t items, hipStream_t st);
 void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st);   // get_untracked_foes as the reference's matrix
 void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const int32_t *stop, double *vd_out,
                     double *ddest_out, hipStream_t st);
@@ -148,7 +155,10 @@ void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const 
 // box's circumcircle, grown by `margin`
 __device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, float margin, float4 *out) {
     const float4 q = d.rec[d.perm[b * 64 + lane]];
-    float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
+    // sentinel records (padding, holes of a shard, slots left by csf_remove_agents) take no part: they contribute nothing
+    // as sources, and one of them inside a batch would blow its circle up to the whole plane
+    const bool real = fabsf(q.x) < 1e14f;
+    float x0 = real ? q.x : 3e38f, x1 = real ? q.x : -3e38f, y0 = real ? q.y : 3e38f, y1 = real ? q.y : -3e38f;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         x0 = fminf(x0, __shfl_xor(x0, o, 64));
@@ -157,6 +167,10 @@ __device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, 
         y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
     }
     if (lane == 0) {
+        if (x1 < x0) {                       // nothing but sentinels: a circle beyond every far-field radius
+            out[b] = make_float4(1e15f, 1e15f, 0.0f, 0.0f);
+            return;
+        }
         const float w = x1 - x0, h = y1 - y0;
         const float rad = 0.5f * sqrtf(w * w + h * h) * 1.0001f + 1e-4f + margin;  // rounded up: must contain
         out[b] = make_float4(0.5f * (x0 + x1), 0.5f * (y0 + y1), rad, 0.0f);

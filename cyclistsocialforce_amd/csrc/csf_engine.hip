@@ -105,7 +105,7 @@ struct csf_engine {
     bool order_dirty = true;               // the device copy of `order` is stale
     bool incremental = true;               // csf_set_incremental
     int64_t q_top = 0;                     // rows of the queue slab in use
-    int64_t churn = 0;                     // slots spawned or retired since the last re-binning
+    int64_t churn = 0;                     // road users spawned into free slots since the last re-binning
     std::vector<double> h_road;            // per vertex (x, y, F0, sigma)
     bool dirty = true;                     // host mirror changed since the last upload
     bool device_ahead = false;             // ticks ran since the last download
@@ -114,7 +114,26 @@ struct csf_engine {
     DevBuf<int64_t> qbeg;
     DevBuf<int32_t> ptr, ti, dgood, qlen, order_dev;
     DevBuf<uint8_t> znav, zrid, alive;
-    DevBuf<uint8_t> stage;                 // population changes: records on their way to the spawn / retire / requeue kernels
+    // Population changes on a current device copy are collected here and applied by ONE kernel launch at the next
+    // device call (flush_pending).  The kernel reads its records from pinned, device-visible host memory: a ring of four
+    // buffers, each guarded by an event (the kernel that read a buffer has finished long before the ring comes round).
+    struct Pending {
+        std::vector<int32_t> retire;
+        std::vector<SpawnRec> spawn;       // qbeg relative to `rows` until the flush
+        std::vector<QueueRec> requeue;     // the same
+        std::vector<double> rows;          // (x, y, stop) rows of new and replaced queues
+        bool empty() const { return retire.empty() && spawn.empty() && requeue.empty(); }
+    } pend;
+    std::vector<int32_t> pend_spawn_at, pend_requeue_at, pend_retire_at;   // [cap] slot -> index in the lists above, -1
+    std::vector<uint8_t> dev_alive;        // [cap] what d.alive holds on the device (as of the last flush or upload)
+    struct PinnedSlot {
+        void *host = nullptr, *dev = nullptr;
+        size_t bytes = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    };
+    PinnedSlot pinned[4];
+    int pinned_next = 0;
     DevBuf<uint32_t> status;
     DevBuf<float4> rec, recs, rv, kat4, bnd, bnd2;
     DevBuf<int32_t> pos;
@@ -186,7 +205,7 @@ int fail(csf_engine *e, int code, const char *fmt, ...) {
             return fail(e, CSF_E_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r));        \
     } while (0)
 
-const int NS_OF[4] = {5, 5, 6, 4};
+const int NS_OF[5] = {5, 5, 6, 4, 5};
 
 double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, vehicle.py:154-155)
     const double PI = 3.141592653589793238462643383279502884;
@@ -198,7 +217,13 @@ double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, 
 
 int check_params(csf_engine *e, const csf_params *p) {
     if (!p) return fail(e, CSF_E_ARG, "params is NULL");
-    if (p->model < 0 || p->model > 3) return fail(e, CSF_E_ARG, "unknown model %d", p->model);
+    if (p->model < 0 || p->model > 4) return fail(e, CSF_E_ARG, "unknown model %d", p->model);
+    if (p->model == CSF_PLANARBIKE) {
+        const double sum_im = p->pb_poles[1] + p->pb_poles[3], prod_im = p->pb_poles[0] * p->pb_poles[3] + p->pb_poles[1] * p->pb_poles[2];
+        if (std::fabs(sum_im) > 1e-12 || std::fabs(prod_im) > 1e-12 || !(p->pb_poles[0] < 0) || !(p->pb_poles[2] < 0))
+            return fail(e, CSF_E_ARG, "PlanarBicycle needs two stable poles, real or a conjugate pair");
+        if (!(p->l > 0)) return fail(e, CSF_E_ARG, "PlanarBicycle needs a wheelbase l > 0");
+    }
     if (!(p->t_s > 0)) return fail(e, CSF_E_ARG, "t_s must be > 0");
     if (p->traj_len < 2) return fail(e, CSF_E_ARG, "traj_len must be >= 2 (int(30/t_s) in the reference)");
     if (p->priority_rule < 0 || p->priority_rule > 1) return fail(e, CSF_E_ARG, "unknown priority rule");
@@ -266,8 +291,77 @@ void update_far_radius(csf_engine *e) {   // depends on the parameters and on th
     }
 }
 
+// exp(A) of a small dense matrix (n <= 4, row major): scaling and squaring of a degree-18 Taylor polynomial
+void expm_small(int n, const double *A, double *E) {
+    double nrm = 0;
+    for (int i = 0; i < n * n; i++) nrm = std::max(nrm, std::fabs(A[i]));
+    int sq = 0;
+    while (nrm * n > 0.25 && sq < 60) nrm *= 0.5, sq++;
+    const double sc = std::ldexp(1.0, -sq);
+    double M[16], T[16], P[16];
+    for (int i = 0; i < n * n; i++) M[i] = A[i] * sc;
+    for (int i = 0; i < n * n; i++) E[i] = (i / n == i % n) ? 1.0 : 0.0, P[i] = E[i];
+    for (int k = 1; k <= 18; k++) {
+        for (int r = 0; r < n; r++)
+            for (int c = 0; c < n; c++) {
+                double acc = 0;
+                for (int q = 0; q < n; q++) acc += P[r * n + q] * M[q * n + c];
+                T[r * n + c] = acc / k;
+            }
+        for (int i = 0; i < n * n; i++) P[i] = T[i], E[i] += T[i];
+    }
+    for (int it = 0; it < sq; it++) {
+        for (int r = 0; r < n; r++)
+            for (int c = 0; c < n; c++) {
+                double acc = 0;
+                for (int q = 0; q < n; q++) acc += E[r * n + q] * E[q * n + c];
+                T[r * n + c] = acc;
+            }
+        for (int i = 0; i < n * n; i++) E[i] = T[i];
+    }
+}
+
+// PlanarBicycle (dynamics.py:178-258, 1167-1226).  x = (delta, psi), A(v) = [[0, 0], [a, 0]] with a = v / l, B = (1, 0)^T,
+// K_x = (k1, k2) places the class's poles p1, p2: s^2 + k1 s + k2 a = (s - p1)(s - p2), so k1 = -(p1 + p2), k2 = p1 p2 / a.
+// With z = (a delta, psi) the closed loop reads z' = M z + (a, 0)^T u, M = [[-k1, -p1 p2], [1, 0]] - no speed in M.
+// The reference sets K_u = 1 / psi_sim(T), psi_sim the yaw at the end of a simulated response (T = 0 .. 9.99 in steps of
+// 0.01, input 0 for ten samples then 1, first-order hold) of the loop with K_u = 1: psi_sim = a G with G the same response
+// of z' = M z + (1, 0)^T u.  Hence a K_u = 1 / G and the controlled loop is z' = M z + (1 / G, 0)^T psi_d at EVERY speed:
+// one exact step z+ = E z + Gamma psi_d is derived here once; the kernel scales delta by a on the way in and out.
+void derive_planarbike(csf_engine *e) {
+    const csf_params &p = e->d.p;
+    Dev &d = e->d;
+    const double k1 = -(p.pb_poles[0] + p.pb_poles[2]), w2 = p.pb_poles[0] * p.pb_poles[2] - p.pb_poles[1] * p.pb_poles[3];
+    auto step_matrices = [&](double dt, double Ad[4], double Bd0[2], double Bd1[2]) {   // first-order hold, input (1, 0)^T
+        double Mx[16] = {0}, Ex[16];
+        Mx[0] = -k1 * dt; Mx[1] = -w2 * dt; Mx[2] = dt;
+        Mx[4] = dt;
+        Mx[11] = 1.0;
+        expm_small(4, Mx, Ex);
+        Ad[0] = Ex[0]; Ad[1] = Ex[1]; Ad[2] = Ex[4]; Ad[3] = Ex[5];
+        Bd1[0] = Ex[3]; Bd1[1] = Ex[7];
+        Bd0[0] = Ex[2] - Bd1[0]; Bd0[1] = Ex[6] - Bd1[1];
+    };
+    double Ad[4], Bd0[2], Bd1[2];
+    step_matrices(0.01, Ad, Bd0, Bd1);                         // from_pole_placement's own t_s = 0.01, t_end = 10
+    double z0 = 0, z1 = 0;
+    for (int i = 1; i < 1000; i++) {
+        const double u0 = (i - 1) >= 10 ? 1.0 : 0.0, u1 = i >= 10 ? 1.0 : 0.0;
+        const double n0 = Ad[0] * z0 + Ad[1] * z1 + Bd0[0] * u0 + Bd1[0] * u1;
+        const double n1 = Ad[2] * z0 + Ad[3] * z1 + Bd0[1] * u0 + Bd1[1] * u1;
+        z0 = n0, z1 = n1;
+    }
+    const double G = z1;
+    step_matrices(p.t_s, Ad, Bd0, Bd1);                        // forced_response over [0, t_s], input psi_d at both ends
+    for (int i = 0; i < 4; i++) d.pb_E[i] = Ad[i];
+    d.pb_G[0] = (Bd0[0] + Bd1[0]) / G;
+    d.pb_G[1] = (Bd0[1] + Bd1[1]) / G;
+    d.pb_ev = std::exp(-p.k_p_v * p.t_s);                      // dynamics.py:156
+}
+
 void derive_consts(csf_engine *e) {
     const csf_params &p = e->d.p;
+    if (p.model == CSF_PLANARBIKE) derive_planarbike(e);
     PairConsts &k = e->d.pc;
     k.sg0 = (float)p.sigma_0;
     k.sg1 = (float)p.sigma_1;
@@ -362,6 +456,10 @@ int alloc_all(csf_engine *e) {
     e->h_status.assign(cap, 0);
     e->h_q.assign(cap, {});
     e->h_alive.assign(cap, 0);
+    e->pend_spawn_at.assign(cap, -1);
+    e->pend_requeue_at.assign(cap, -1);
+    e->pend_retire_at.assign(cap, -1);
+    e->dev_alive.assign(cap, 0);
     Dev &d = e->d;
     d.cap = (int64_t)cap;
     d.s = e->s.p;
@@ -496,7 +594,12 @@ int rebin(csf_engine *e) {
 // bounding circles for the pair launch that follows; afterwards the circles emitted by that launch become current
 int bounds_before_pair(csf_engine *e) {
     Dev &d = e->d;
-    if (e->ticks_since_rebin >= REBIN_TICKS || 16 * e->churn > d.n) {   // (new road users sit in the batches of the slots they took)
+    // A new road user sits in the batch of the slot it took, among far-away neighbours, and stretches that batch's circle
+    // over the scene until the next re-binning; every stretched batch costs each receiver a per-lane test (measured:
+    // ~0.4 us per batch and tick at N = 16 384) against ~60 us for a re-binning: renew the order once a quarter of the
+    // batches holds a newcomer.  (Retired slots cost nothing: their sentinel records are left out of the circles.)
+    static const int64_t churn_div = getenv("CSF_REBIN_CHURN") ? std::max(1, atoi(getenv("CSF_REBIN_CHURN"))) : 256;
+    if (e->ticks_since_rebin >= REBIN_TICKS || churn_div * e->churn > d.n) {
         int rc = rebin(e);
         if (rc) return rc;
     }
@@ -515,8 +618,12 @@ void bounds_after_pair(csf_engine *e, bool records_will_move_one_tick) {
     e->bounds_fresh = records_will_move_one_tick;   // valid only if exactly one integrate follows
 }
 
+int flush_pending(csf_engine *e);   // collected population changes -> the device (defined with the population entry points)
+
 // device -> host mirror (needed before a structural change once ticks have run)
 int download_all(csf_engine *e) {
+    int frc = flush_pending(e);
+    if (frc) return frc;
     if (!e->device_ahead) return CSF_OK;
     HIPCHK(e, hipStreamSynchronize(e->main));
     if (e->comm) HIPCHK(e, hipStreamSynchronize(e->comm));
@@ -568,7 +675,7 @@ void compact_host(csf_engine *e) {
 }
 
 int upload_all(csf_engine *e) {
-    if (!e->dirty) return CSF_OK;
+    if (!e->dirty) return flush_pending(e);
     Dev &d = e->d;
     compact_host(e);
     const int64_t n = d.n;
@@ -597,6 +704,7 @@ int upload_all(csf_engine *e) {
     HIPCHK(e, hipMemcpy(e->qbeg.p, beg.data(), beg.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->qlen.p, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->alive.p, e->h_alive.data(), e->h_alive.size(), hipMemcpyHostToDevice));
+    e->dev_alive = e->h_alive;
 #define H2D(vec, buf) HIPCHK(e, hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
     H2D(e->h_s, e->s);
     H2D(e->h_vdes, e->vdes);
@@ -678,33 +786,76 @@ bool can_patch_device(const csf_engine *e) {
     return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
 }
 
-// `bytes` of host data -> the staging buffer at `offset`, in stream order on the main stream
-int stage_put(csf_engine *e, size_t offset, const void *src, size_t bytes) {
-    if (offset + bytes > e->stage.n) {
-        if (offset != 0) return fail(e, CSF_E_STATE, "staging buffer too small");   // sized by stage_reserve first
-        HIPCHK(e, hipStreamSynchronize(e->main));
-        HIPCHK(e, e->stage.alloc(std::max<size_t>(2 * (offset + bytes), 1 << 16)));
+// a pinned, device-visible host buffer of `bytes` from the ring; waits only if the ring of four is exhausted
+int stage_acquire(csf_engine *e, size_t bytes, csf_engine::PinnedSlot **out) {
+    csf_engine::PinnedSlot &sl = e->pinned[e->pinned_next];
+    e->pinned_next = (e->pinned_next + 1) % 4;
+    if (sl.busy) {
+        HIPCHK(e, hipEventSynchronize(sl.done));
+        sl.busy = false;
     }
-    HIPCHK(e, hipMemcpyAsync(e->stage.p + offset, src, bytes, hipMemcpyHostToDevice, e->main));
+    if (bytes > sl.bytes) {
+        if (sl.host) HIPCHK(e, hipHostFree(sl.host));
+        sl.host = nullptr;
+        sl.bytes = std::max<size_t>(2 * bytes, 1 << 16);
+        HIPCHK(e, hipHostMalloc(&sl.host, sl.bytes, hipHostMallocMapped));
+        HIPCHK(e, hipHostGetDevicePointer(&sl.dev, sl.host, 0));
+    }
+    if (!sl.done) HIPCHK(e, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    *out = &sl;
     return CSF_OK;
 }
 
-int stage_reserve(csf_engine *e, size_t bytes) {
-    if (bytes <= e->stage.n) return CSF_OK;
-    HIPCHK(e, hipStreamSynchronize(e->main));
-    HIPCHK(e, e->stage.alloc(std::max<size_t>(2 * bytes, 1 << 16)));
-    return CSF_OK;
-}
-
-// after slots were spawned or retired on the device: the circles of the batches they sit in are stale, and once a
-// sixteenth of the slots has changed the binned order is renewed at the next tick instead of after REBIN_TICKS
-void after_patch(csf_engine *e, int64_t changed) {
+// The collected retirements, spawns and queue replacements -> one patch_kernel launch (csf_agent.hip).  Afterwards the
+// circles of the batches the changed slots sit in are stale, and once a sixteenth of the slots has changed the binned
+// order is renewed at the next tick instead of after REBIN_TICKS.
+int flush_pending(csf_engine *e) {
+    csf_engine::Pending &pd = e->pend;
+    if (pd.empty()) return CSF_OK;
+    Dev &d = e->d;
+    const size_t b_ret = pd.retire.size() * sizeof(int32_t), b_sp = pd.spawn.size() * sizeof(SpawnRec),
+                 b_rq = pd.requeue.size() * sizeof(QueueRec), b_rows = pd.rows.size() * sizeof(double);
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    PatchHeader h;
+    h.n_retire = (int64_t)pd.retire.size();
+    h.n_spawn = (int64_t)pd.spawn.size();
+    h.n_requeue = (int64_t)pd.requeue.size();
+    h.n_rows = (int64_t)(pd.rows.size() / 3);
+    h.off_retire = (int64_t)up8(sizeof(PatchHeader));
+    h.off_spawn = h.off_retire + (int64_t)up8(b_ret);
+    h.off_requeue = h.off_spawn + (int64_t)up8(b_sp);
+    h.off_rows = h.off_requeue + (int64_t)up8(b_rq);
+    h.q_top = e->q_top;
+    for (SpawnRec &r : pd.spawn) r.qbeg += e->q_top;          // relative to this batch's rows until now
+    for (QueueRec &r : pd.requeue) r.qbeg += e->q_top;
+    csf_engine::PinnedSlot *pin = nullptr;
+    int rc = stage_acquire(e, (size_t)h.off_rows + b_rows, &pin);
+    if (rc) return rc;
+    char *base = (char *)pin->host;
+    memcpy(base, &h, sizeof h);
+    if (b_ret) memcpy(base + h.off_retire, pd.retire.data(), b_ret);
+    if (b_sp) memcpy(base + h.off_spawn, pd.spawn.data(), b_sp);
+    if (b_rq) memcpy(base + h.off_requeue, pd.requeue.data(), b_rq);
+    if (b_rows) memcpy(base + h.off_rows, pd.rows.data(), b_rows);
+    launch_patch(d, (const PatchHeader *)pin->dev, h.n_retire + h.n_spawn + h.n_requeue + 3 * h.n_rows, e->main);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(pin->done, e->main));
+    pin->busy = true;
+    e->q_top += h.n_rows;
+    for (int32_t a : pd.retire) e->pend_retire_at[(size_t)a] = -1, e->dev_alive[(size_t)a] = 0;
+    for (const SpawnRec &r : pd.spawn) e->pend_spawn_at[(size_t)r.slot] = -1, e->dev_alive[(size_t)r.slot] = 1;
+    for (const QueueRec &r : pd.requeue) e->pend_requeue_at[(size_t)r.slot] = -1;
+    e->churn += h.n_spawn;
+    pd.retire.clear();
+    pd.spawn.clear();
+    pd.requeue.clear();
+    pd.rows.clear();
     e->bounds_fresh = false;
-    e->order_dirty = true;
-    e->churn += changed;
-    e->d.n_live = (int64_t)e->order.size();
-    if (!getenv("CSF_FAKE_SHARD")) e->d.hi = e->d.n;    // (unsharded: the receiver block is every slot)
+    e->device_ahead = true;                                    // the host mirror of the patched slots was not kept up
+    d.n_live = (int64_t)e->order.size();
+    if (!getenv("CSF_FAKE_SHARD")) d.hi = d.n;                 // (unsharded: the receiver block is every slot)
     update_far_radius(e);
+    return CSF_OK;
 }
 
 int sync_order(csf_engine *e) {                         // the device copy of the population order (read-back kernels)
@@ -894,12 +1045,16 @@ int csf_destroy(csf_engine *e) {
     if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
-    e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release(); e->stage.release();
+    e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);
+    for (auto &sl : e->pinned) {
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (e->main && e->owns_main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);
     for (csf_engine *m : e->group)          // the others of a loopback group lose this member (and its stream, if it was the owner)
@@ -923,9 +1078,10 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     HIPCHK(e, hipSetDevice(e->device));
     Dev &d = e->d;
     const int64_t reuse = std::min<int64_t>(n, (int64_t)e->free_slots.size());
-    // straight to the device when its copy is current, the new slots have a place in the binned order (slot < n_pad)
+    // collected for the device when its copy is current, the new slots have a place in the binned order (slot < n_pad)
     // and the start rows fit behind the queues already in the slab
-    const bool patch = can_patch_device(e) && d.n + (n - reuse) <= d.n_pad && e->q_top + n <= d.qcap;
+    const bool patch = can_patch_device(e) && d.n + (n - reuse) <= d.n_pad &&
+                       e->q_top + (int64_t)(e->pend.rows.size() / 3) + n <= d.qcap;
     if (!patch) {
         int rc = prepare_mutation(e);
         if (rc) return rc;
@@ -933,8 +1089,6 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     const int ns = d.ns;
     const int64_t cap = e->cap;
     const csf_params &p = d.p;
-    std::vector<SpawnRec> recs(patch ? (size_t)n : 0);
-    std::vector<double> rows(patch ? (size_t)(3 * n) : 0);
     for (int64_t k = 0; k < n; k++) {
         int64_t a;
         if (!e->free_slots.empty()) {
@@ -944,10 +1098,31 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             a = d.n++;
         }
         const double *s = s0 + k * ns;
-        for (int c = 0; c < 6; c++) e->h_s[c * cap + a] = c < ns ? s[c] : 0.0;
-        e->h_s[2 * cap + a] = limit_angle_h(s[2]);               // vehicle.py:154-155
         e->h_vdes[a] = v_desired[k];
         e->h_q[a].assign({s[0], s[1], 0.0});                     // vehicle.py:183-185
+        e->h_alive[a] = 1;
+        e->order.push_back((int32_t)a);
+        if (patch) {                                             // a record for the patch kernel, which writes the rest
+            if (e->pend_retire_at[(size_t)a] >= 0) {             // the slot was freed in this batch: the spawn resets all of it
+                const int32_t at = e->pend_retire_at[(size_t)a], last = e->pend.retire.back();
+                e->pend.retire[(size_t)at] = last;
+                e->pend_retire_at[(size_t)last] = at;
+                e->pend.retire.pop_back();
+                e->pend_retire_at[(size_t)a] = -1;
+            }
+            SpawnRec r;
+            r.slot = (int32_t)a;
+            r.qlen = 1;
+            r.qbeg = (int64_t)(e->pend.rows.size() / 3);
+            for (int c = 0; c < 6; c++) r.s[c] = c < ns ? s[c] : 0.0;
+            r.vdes = v_desired[k];
+            e->pend.rows.insert(e->pend.rows.end(), {s[0], s[1], 0.0});
+            e->pend_spawn_at[(size_t)a] = (int32_t)e->pend.spawn.size();
+            e->pend.spawn.push_back(r);
+            continue;
+        }
+        for (int c = 0; c < 6; c++) e->h_s[c * cap + a] = c < ns ? s[c] : 0.0;
+        e->h_s[2 * cap + a] = limit_angle_h(s[2]);               // vehicle.py:154-155
         e->h_ptr[a] = 0;
         e->h_znav[a] = 0;                                        // vehicle.py:188
         for (int c = 0; c < 3; c++) e->h_znp[c * cap + a] = 0.0;
@@ -965,34 +1140,10 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         e->h_ppsi[a] = e->h_s[2 * cap + a];                      // dynamics.py:828, 987-993
         for (int c = 0; c < 6; c++) e->h_F[c * cap + a] = 0.0;
         e->h_status[a] = 0;
-        e->h_alive[a] = 1;
-        e->order.push_back((int32_t)a);
-        if (patch) {                                             // the same, as a record for the spawn kernel
-            SpawnRec &r = recs[(size_t)k];
-            r.slot = (int32_t)a;
-            r.qlen = 1;
-            r.qbeg = e->q_top + k;
-            for (int c = 0; c < 6; c++) r.s[c] = c < ns ? s[c] : 0.0;
-            r.vdes = v_desired[k];
-            rows[(size_t)(3 * k)] = s[0];
-            rows[(size_t)(3 * k + 1)] = s[1];
-            rows[(size_t)(3 * k + 2)] = 0.0;
-        }
     }
     d.n_live = (int64_t)e->order.size();
-    if (!patch) {
-        set_shard(e);
-        return CSF_OK;
-    }
-    int rc = stage_reserve(e, recs.size() * sizeof(SpawnRec));
-    if (rc) return rc;
-    HIPCHK(e, hipMemcpyAsync(e->q.p + 3 * e->q_top, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, e->main));
-    if ((rc = stage_put(e, 0, recs.data(), recs.size() * sizeof(SpawnRec)))) return rc;
-    e->q_top += n;
-    launch_spawn(d, (const SpawnRec *)e->stage.p, n, e->main);
-    HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->main));                    // the staged records are host vectors of this call
-    after_patch(e, n);
+    e->order_dirty = true;
+    if (!patch) set_shard(e);
     return CSF_OK;
 }
 
@@ -1013,7 +1164,7 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         int rc = prepare_mutation(e);
         if (rc) return rc;
     }
-    std::vector<int32_t> slots, keep;
+    std::vector<int32_t> keep;
     keep.reserve((size_t)pop);
     for (int64_t i = 0; i < pop; i++) {                          // the remaining road users keep their relative order
         const int32_t a = e->order[(size_t)i];
@@ -1021,24 +1172,29 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
             keep.push_back(a);
             continue;
         }
-        slots.push_back(a);
         e->h_alive[(size_t)a] = 0;
         e->h_q[(size_t)a].clear();
         e->free_slots.push_back(a);
+        if (!patch) continue;
+        if (e->pend_spawn_at[(size_t)a] >= 0) {                  // added and removed within one batch: never reaches the device
+            const int32_t at = e->pend_spawn_at[(size_t)a];
+            const SpawnRec last = e->pend.spawn.back();
+            e->pend.spawn[(size_t)at] = last;
+            e->pend_spawn_at[(size_t)last.slot] = at;
+            e->pend.spawn.pop_back();
+            e->pend_spawn_at[(size_t)a] = -1;
+            if (!e->dev_alive[(size_t)a]) continue;              // dead on the device, or never used: nothing to undo
+        }                                                        // (else: its previous occupant is still alive there)
+        e->pend_retire_at[(size_t)a] = (int32_t)e->pend.retire.size();
+        e->pend.retire.push_back(a);
     }
     e->order.swap(keep);
     e->d.n_live = (int64_t)e->order.size();
+    e->order_dirty = true;
     if (!patch) {                                                // the host mirror is authoritative now: close the holes
         compact_host(e);
         set_shard(e);
-        return CSF_OK;
     }
-    int rc = stage_put(e, 0, slots.data(), slots.size() * sizeof(int32_t));
-    if (rc) return rc;
-    launch_retire(e->d, (const int32_t *)e->stage.p, (int64_t)slots.size(), e->main);
-    HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->main));
-    after_patch(e, (int64_t)slots.size());
     return CSF_OK;
 }
 
@@ -1057,13 +1213,11 @@ int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int
     if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
     // on a current device copy the new queues are appended to the slab and the slots pointed at them
-    const bool patch = can_patch_device(e) && e->q_top + total <= e->d.qcap;
+    const bool patch = can_patch_device(e) && e->q_top + (int64_t)(e->pend.rows.size() / 3) + total <= e->d.qcap;
     if (!patch) {
         int rc = prepare_mutation(e);
         if (rc) return rc;
     }
-    std::vector<QueueRec> recs;
-    std::vector<double> rows;
     for (int64_t k = 0; k < n; k++) {
         const size_t a = (size_t)e->order[(size_t)agent[k]];
         std::vector<double> &qa = e->h_q[a];
@@ -1074,26 +1228,30 @@ int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int
         qa.insert(qa.end(), xyz_stop + 3 * offsets[k], xyz_stop + 3 * offsets[k + 1]);  // :646-647
         const int32_t nrows = (int32_t)(qa.size() / 3);
         if (e->h_ptr[a] >= nrows) e->h_ptr[a] = nrows - 1;
-        if (patch) {
-            QueueRec r;
-            r.slot = (int32_t)a;
+        if (!patch) continue;
+        const int64_t at_rows = (int64_t)(e->pend.rows.size() / 3);
+        e->pend.rows.insert(e->pend.rows.end(), qa.begin(), qa.end());
+        if (e->pend_spawn_at[a] >= 0) {                          // a road user of this batch: its spawn record takes the queue
+            SpawnRec &r = e->pend.spawn[(size_t)e->pend_spawn_at[a]];   // (a new road user's pointer is 0 either way)
+            r.qbeg = at_rows;
             r.qlen = nrows;
-            r.qbeg = e->q_top + (int64_t)(rows.size() / 3);
-            r.mode = reset;
-            r.pad = 0;
-            recs.push_back(r);
-            rows.insert(rows.end(), qa.begin(), qa.end());
+            continue;
+        }
+        QueueRec r;
+        r.slot = (int32_t)a;
+        r.qlen = nrows;
+        r.qbeg = at_rows;
+        r.mode = reset;
+        r.pad = 0;
+        if (e->pend_requeue_at[a] >= 0) {                        // replaced twice in one batch: the last one counts, and a
+            QueueRec &old = e->pend.requeue[(size_t)e->pend_requeue_at[a]];   // rewind requested by either is kept
+            if (old.mode == 1) r.mode = 1;
+            old = r;
+        } else {
+            e->pend_requeue_at[a] = (int32_t)e->pend.requeue.size();
+            e->pend.requeue.push_back(r);
         }
     }
-    if (!patch) return CSF_OK;
-    int rc = stage_reserve(e, recs.size() * sizeof(QueueRec));
-    if (rc) return rc;
-    HIPCHK(e, hipMemcpyAsync(e->q.p + 3 * e->q_top, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, e->main));
-    if ((rc = stage_put(e, 0, recs.data(), recs.size() * sizeof(QueueRec)))) return rc;
-    e->q_top += (int64_t)(rows.size() / 3);
-    launch_requeue(e->d, (const QueueRec *)e->stage.p, (int64_t)recs.size(), e->main);
-    HIPCHK(e, hipGetLastError());
-    HIPCHK(e, hipStreamSynchronize(e->main));
     return CSF_OK;
 }
 
@@ -1171,6 +1329,7 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
         for (int c = 0; c < ns; c++) e->h_s[c * cap + a] = s[k * ns + c];
         // keep the model side-state consistent with the pushed vehicle.s
         e->h_ppsi[a] = e->h_s[2 * cap + a];
+        if (e->d.p.model == CSF_PLANARBIKE) e->h_lti[a] = e->h_s[4 * cap + a];   // dynamics.x[0] = delta
         const int slot = e->h_ti[a] & (e->d.hist_len - 1);
         e->h_hx[(size_t)slot * cap + a] = e->h_s[a];
         e->h_hy[(size_t)slot * cap + a] = e->h_s[cap + a];
@@ -1270,6 +1429,10 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
 int csf_sync(csf_engine *e) {
     if (!e) return CSF_E_ARG;
     HIPCHK(e, hipSetDevice(e->device));
+    {
+        int rc = flush_pending(e);
+        if (rc) return rc;
+    }
     HIPCHK(e, hipStreamSynchronize(e->main));
     HIPCHK(e, hipStreamSynchronize(e->comm));
     return CSF_OK;

@@ -41,9 +41,6 @@ constexpr int TILE = 1024;           // simple kernels: source records per LDS t
 #ifndef CSF_CULL_WAVES
 #define CSF_CULL_WAVES 7
 #endif
-#ifndef CSF_PREFETCH
-#define CSF_PREFETCH 1       // reach test: request the next two batches before the queue append of the current two (A/B knob)
-#endif
 constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 7 waves/SIMD (72 VGPRs, 12 B spilled) measured best (tools/sweep_cull.sh)
 constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
 constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
@@ -521,71 +518,50 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             unsigned cand = ((DYN && CLASSIFY) ? (bm & 0xFFFFu) : (unsigned)(cand_all >> (16 * u))) & live;
             const unsigned inside = ((DYN && CLASSIFY) ? (bm >> 16) : (unsigned)(inside_all >> (16 * u))) & live;
             if (REACH) {
-                // Two candidate batches at a time through the packed reach test (+ the exact field-of-view test unless
-                // both are wholly inside); what it keeps is appended to the queue, first batch first.  The kernel is
-                // bound by LDS round trips here, not by VALU issue (rocprof: half of the issue slots idle), so the
-                // records of the NEXT two batches are requested before the queue append of the current two and arrive
-                // while it runs - unless this append fills the queue, because the evaluation pass that follows needs
-                // the registers.
-                unsigned ins = inside;                       // wholly inside, taken in pairs first
-                unsigned rest = cand & ~inside;              // partial batches (+ an odd inside one: the exact test passes all of it)
-                if (__builtin_popcount(ins) & 1) {
-                    const unsigned top = 1u << (31 - __builtin_clz(ins));
-                    ins &= ~top;
-                    rest |= top;
-                }
-                int b1 = 0, b2 = 0;
-                bool two = false, fov = false, have = false;
-                auto next_item = [&]() {                     // wave-uniform: scalar bit operations
-                    unsigned &m = ins ? ins : rest;
-                    have = m != 0u;
-                    if (!have) return;
-                    fov = ins == 0u;
-                    b1 = __builtin_ctz(m);
-                    m &= m - 1u;
-                    two = m != 0u;
-                    b2 = two ? __builtin_ctz(m) : b1;
-                    m &= m - 1u;                             // (0 & anything: stays 0)
-                };
-                v2f sx, sy, sc, ss;
-                auto load_item = [&]() {
+                // two candidate batches at a time through the packed reach test (+ the exact field-of-view test unless
+                // both are wholly inside); what it keeps is appended to the queue, first batch first.
+                // (A single loop over both kinds of batch pairs with the records of the next pair requested ahead of the
+                // queue append was tried: the compiler spilled 30 registers into the loops and the kernel ran at 180 us.)
+                auto sift2 = [&](int b1, int b2, bool two, auto fov) {
+                    constexpr bool FOV = decltype(fov)::value;
                     const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
-                    sx = lds_pair(tx, i0, i1), sy = lds_pair(ty, i0, i1), sc = lds_pair(tc, i0, i1), ss = lds_pair(ts, i0, i1);
-                };
-                next_item();
-                if (have) load_item();
-                while (have) {
-                    const int o0 = 4 * ((b1 << 6) + lane), o1 = 4 * ((b2 << 6) + lane);   // byte offsets of the two records
                     bool k0, k1;
-                    if (fov) keep_x2<true, P2R>(k, ru, sx, sy, sc, ss, k0, k1);
-                    else keep_x2<false, P2R>(k, ru, sx, sy, sc, ss, k0, k1);
+                    keep_x2<FOV, P2R>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
+                                      lds_pair(ts, i0, i1), k0, k1);
                     k1 = k1 & two;
                     tests += two ? 2u * WAVE : (unsigned)WAVE;
                     const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-                    const int n0 = __builtin_popcountll(m0), n1 = __builtin_popcountll(m1);
-                    const bool fills = qlen + n0 + n1 >= CHUNK;
-                    next_item();
-                    if (CSF_PREFETCH && have && !fills) load_item();
+                    const int n0 = __builtin_popcountll(m0);
                     if (k0) {
                         const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
-                        queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)o0;
+                        queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)(4 * i0);
                     }
                     if (k1) {
                         const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
-                        queue[wave][(qhead + qlen + n0 + pre) & (QCAP - 1)] = (unsigned short)o1;
+                        queue[wave][(qhead + qlen + n0 + pre) & (QCAP - 1)] = (unsigned short)(4 * i1);
                     }
-                    qlen = __builtin_amdgcn_readfirstlane(qlen + n0 + n1);
-                    if (fills) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        while (qlen >= CHUNK) pop(u, std::true_type{});
-                        if (have) load_item();
-                    } else if (!CSF_PREFETCH && have) {
-                        load_item();
-                    }
+                    qlen = __builtin_amdgcn_readfirstlane(qlen + n0 + __builtin_popcountll(m1));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    while (qlen >= CHUNK) pop(u, std::true_type{});
+                };
+                unsigned ins = inside;
+                while (__builtin_popcount(ins) >= 2) {
+                    const int b1 = __builtin_ctz(ins);
+                    ins &= ins - 1u;
+                    const int b2 = __builtin_ctz(ins);
+                    ins &= ins - 1u;
+                    sift2(b1, b2, true, std::false_type{});
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                unsigned rest = (cand & ~inside) | ins;      // partial batches (+ an odd inside one: the exact test passes all of it)
+                while (rest) {
+                    const int b1 = __builtin_ctz(rest);
+                    rest &= rest - 1u;
+                    const bool two = rest != 0u;
+                    const int b2 = two ? __builtin_ctz(rest) : b1;
+                    rest &= rest - 1u;                       // (0 & anything: stays 0)
+                    sift2(b1, b2, two, std::true_type{});
+                }
                 cand = 0u;
             }
             // batches that are entirely inside the field of view need neither the test nor the queue: two at a

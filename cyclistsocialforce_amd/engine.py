@@ -8,9 +8,9 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import BICYCLE, INVPEND, N_STATES, PLANARPOINT, TWOD, EngineError, Params  # noqa: F401
+from ._ffi import BICYCLE, INVPEND, N_STATES, PLANARBIKE, PLANARPOINT, TWOD, EngineError, Params  # noqa: F401
 
-MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT}
+MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE}
 
 
 def _f64(a, shape=None):

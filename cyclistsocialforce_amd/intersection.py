@@ -16,8 +16,10 @@ through TraCI, gives arriving road users a spline prototype across the junction,
 or injected (`traci=`), so the seam is testable without a SUMO installation.  Arrivals and departures reach the device
 incrementally (include/csf.h: csf_set_incremental).
 
-Out of scope: matplotlib animation owned by the intersection (`animate=True` raises; drawings are
-attached per vehicle) and populations mixing vehicle classes in one intersection.
+`animate=True` gives every vehicle a `vizualisation.VehicleDrawing` on the axes passed in (intersection.py:881-885); the
+drawings are refreshed from the host mirror after each tick's read-back.
+
+Out of scope: populations mixing vehicle classes in one intersection, writing animation videos.
 """
 import numpy as np
 
@@ -141,9 +143,8 @@ class SocialForceIntersection:
     def __init__(self, vehicleList, id="", priority_rule="unregulated", animate=False, axes=None,
                  activate_sumo_cosimulation=False, net=None, road_elements=[], bicycle_drawing_kwargs={},
                  capacity=None, device=0, track_params=True, traci=None):
-        if animate:
-            raise NotImplementedError("matplotlib animation is outside the scope of the MI355X engine; "
-                                      "attach drawing objects to the vehicles instead")
+        if animate and axes is None:
+            raise AssertionError("Provide axes for animation!")        # intersection.py:409
         if priority_rule not in PRIORITY_RULES:
             raise ValueError(f"priority_rule must be one of {tuple(PRIORITY_RULES)}")
         assert isinstance(id, str), "Intersection ID has to be a string."
@@ -153,7 +154,7 @@ class SocialForceIntersection:
         self._traci = traci
         self.id = id
         self.priority_rule = priority_rule
-        self.animate = False
+        self.animate = bool(animate)
         self.ax = axes
         self.road_elements = road_elements
         self.hist_n_vecs = []
@@ -323,6 +324,10 @@ class SocialForceIntersection:
         """intersection.py:458-539"""
         if self.activate_sumo_cosimulation and user.follow_route:
             self._route_prototype(user)
+        if self.animate:                                       # intersection.py:521-524
+            if user.drawing is None:
+                user.add_drawing(self.ax, **self.bicycle_drawing_kwargs)
+            user.drawing.set_animated(True)
         self._attach(user)
 
     def get_road_user_ids(self):
@@ -621,6 +626,10 @@ class SocialForceIntersection:
 
     def step(self):
         """intersection.py:866-896: one simulation tick of the whole population."""
+        if self.animate and self.is_first_step:          # intersection.py:881-885: everyone gets a drawing on the first tick
+            for v in self.vehicles:
+                if v.drawing is None:
+                    v.add_drawing(self.ax, animated=True, **self.bicycle_drawing_kwargs)
         self.is_first_step = False
         if self.n_bikes > 0:
             e = self._push_mutations()
@@ -639,7 +648,10 @@ class SocialForceIntersection:
         self.hist_n_vecs.extend([self.n_bikes] * int(n_ticks))
 
     def set_animated(self, animated):
-        """intersection.py:899-915 (no-op: animation is out of scope)."""
+        """intersection.py:899-915: switch every drawing between blitted (animated) and ordinary artists."""
+        for v in self.vehicles:
+            if v.drawing is not None and hasattr(v.drawing, "set_animated"):
+                v.drawing.set_animated(animated)
 
     @property
     def engine(self):

@@ -148,6 +148,12 @@ class VehicleParameters:
             p.k_psi = float(-np.real(np.asarray(poles).flatten()[0]))
         elif gains is not None:
             p.k_psi = float(np.asarray(gains, dtype=float).flatten()[0])
+        if int(model) == _ffi.PLANARBIKE and poles is not None:      # dynamics.py:190: the poles placed every step
+            pl = np.asarray(poles, dtype=complex).flatten()
+            if pl.size != 2 or abs((pl[0] + pl[1]).imag) > 1e-12 or abs((pl[0] * pl[1]).imag) > 1e-12:
+                raise ValueError("PlanarBicycle needs two poles, real or a conjugate pair")
+            p.pb_poles = (_ffi.C.c_double * 4)(pl[0].real, pl[0].imag, pl[1].real, pl[1].imag)
+            p.k_psi = 0.0
         p.model = int(model)
         p.priority_rule = int(priority_rule)
         p.traj_len = int(30 / self.t_s)  # vehicle.py:159
@@ -298,7 +304,17 @@ class InvPendulumBicycleParameters(BicycleParameters):
         return K, K_tau_2, tau_3
 
 
+class PlanarBicycleParameters(BicycleParameters):
+    """parameters.py:1203-1211: BicycleParameters + the desired poles of the steer / yaw loop."""
+
+    def __init__(self, poles=(-1.0141284591434665 + 1.226826644413086j, -1.0141284591434665 - 1.226826644413086j),
+                 **kwargs):
+        BicycleParameters.__init__(self, **kwargs)
+        self.poles = poles
+
+
 PARAMS_OF_MODEL = {
+    _ffi.PLANARBIKE: PlanarBicycleParameters,
     _ffi.BICYCLE: BicycleParameters,
     _ffi.TWOD: InvPendulumBicycleParameters,
     _ffi.INVPEND: InvPendulumBicycleParameters,
@@ -309,5 +325,5 @@ PARAMS_OF_MODEL = {
 def default_pod(model, priority_rule=0, **overrides):
     """csf_params of a vehicle class with the reference's defaults (keyword overrides allowed)."""
     if isinstance(model, str):
-        model = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3}[model]
+        model = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3, "planarbike": 4}[model]
     return PARAMS_OF_MODEL[model](**overrides).to_pod(model, priority_rule)

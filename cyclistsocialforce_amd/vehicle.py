@@ -16,8 +16,8 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine
-from .parameters import (BicycleParameters, InvPendulumBicycleParameters, PlanarPointBicycleParameters,
-                         VehicleParameters)
+from .parameters import (BicycleParameters, InvPendulumBicycleParameters, PlanarBicycleParameters,
+                         PlanarPointBicycleParameters, VehicleParameters)
 from .utils import limitAngle
 
 
@@ -333,10 +333,22 @@ class Vehicle:
             self.setDestinations(x_i, y_i, reset=reset)
 
     def add_drawing(self, ax, drawing=None, **kwargs):
-        """vehicle.py:695-720: only caller-supplied drawings (matplotlib artists are out of scope)."""
+        """vehicle.py:695-720: attach a drawing to this vehicle - the one passed in (anything with
+        update(vehicle, Fdest=, Frep=, Fres=) and set_animated(flag)), else a `vizualisation.VehicleDrawing` on `ax`."""
         if drawing is None:
-            raise NotImplementedError("pass a drawing object with update(vehicle, Fdest=, Frep=, Fres=)")
+            from .vizualisation import VehicleDrawing
+            drawing = VehicleDrawing(ax, self, **kwargs)
         self.drawing = drawing
+
+    def plot_states(self, t_end=None, axes=None):
+        """vehicle.py:734-787"""
+        from .vizualisation import plot_states
+        return plot_states(self, t_end=t_end, axes=axes)
+
+    def plot_forces(self, t_end=None, axes=None, components_to_plot=("magnitude", "direction")):
+        """vehicle.py:789-917"""
+        from .vizualisation import plot_forces
+        return plot_forces(self, t_end=t_end, axes=axes, components_to_plot=components_to_plot)
 
     def update_drawing(self, Fdest=None, Frep=None, Fres=None):
         """vehicle.py:722-732"""
@@ -391,4 +403,19 @@ class PlanarPointBicycle(Vehicle):
     MODEL = _ffi.PLANARPOINT
 
     def __init__(self, s0, **kwargs):
+        Vehicle.__init__(self, s0, **kwargs)
+
+
+class PlanarBicycle(Vehicle):
+    """vehicle.py:2031-2076 — planar two-wheeler: pole-placed steer / yaw loop whose gains follow the speed every step
+    (dynamics.py:178-258, 1167-1226), first-order speed dynamics (dynamics.py:145-175), the TwoD force field and the
+    spline destination force."""
+
+    PARAMS_TYPE = PlanarBicycleParameters
+    MODEL = _ffi.PLANARBIKE
+    N_STATES = 5
+    STATE_NAMES = ["x[m]", "y[m]", "psi[rad]", "v[m/s]", "delta[rad]"]
+
+    def __init__(self, s0, **kwargs):
+        assert len(s0) >= 5, ("s0 has to have at least five elements:", " (x, y, psi, v, delta)!")
         Vehicle.__init__(self, s0, **kwargs)

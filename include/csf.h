@@ -25,11 +25,11 @@
 extern "C" {
 #endif
 
-#define CSF_ABI_VERSION 1
+#define CSF_ABI_VERSION 2
 
 /* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
- * :1991 (PlanarPointBicycle) */
-enum csf_model { CSF_BICYCLE = 0, CSF_TWOD = 1, CSF_INVPEND = 2, CSF_PLANARPOINT = 3 };
+ * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle) */
+enum csf_model { CSF_BICYCLE = 0, CSF_TWOD = 1, CSF_INVPEND = 2, CSF_PLANARPOINT = 3, CSF_PLANARBIKE = 4 };
 
 /* priority rule — intersection.py:263, 739-741 */
 enum csf_priority_rule { CSF_UNREGULATED = 0, CSF_P2R = 1 };
@@ -47,6 +47,7 @@ enum csf_status_code {
 #define CSF_ST_SPLINE 1u   /* vehicle.py:1495-1507: splprep would raise on duplicate points */
 #define CSF_ST_NAN 2u      /* a force became non-finite (vehicle.py:1180-1185 "Isnan!") */
 #define CSF_ST_NAVSTATE 4u /* vehicle.py:416-425: navigation state not one-hot */
+#define CSF_ST_UNCONTROLLABLE 8u /* dynamics.py:1212-1214: PlanarBicycle at v <= 0 ("System not controllable!") */
 
 /* POD mirror of the reference's parameter objects (parameters.py).  One set per engine = per vehicle
  * class; the only per-agent parameter is v_desired_default (csf_add_agents).  Field order is ABI. */
@@ -61,6 +62,8 @@ typedef struct csf_params {
     double h, m, i_bike_longlong, i_steer_vertvert, c_steer, v_max_walk, delta_max_walk;
     /* PlanarPointBicycleParameters — parameters.py:1180-1201 (gain = -Re(pole), dynamics.py:933-940) */
     double k_psi;
+    /* PlanarBicycleParameters — parameters.py:1203-1211: the two desired poles of the steer / yaw loop (re, im, re, im) */
+    double pb_poles[4];
     int32_t model;         /* enum csf_model */
     int32_t priority_rule; /* enum csf_priority_rule */
     int32_t traj_len;      /* columns of the reference's traj ring buffer, int(30 / t_s) — vehicle.py:159 */
@@ -81,7 +84,7 @@ int32_t csf_abi_version(void);
 /* ---- population ------------------------------------------------------------------------------ */
 
 /* Vehicle.__init__ (vehicle.py:64-204) for n agents at once: s0 is [n, n_states] row-major
- * (n_states = 5, 5, 6, 4 by model), v_desired is [n].  Every new agent gets the single-row
+ * (n_states = 5, 5, 6, 4, 5 by model), v_desired is [n].  Every new agent gets the single-row
  * destination queue (x0, y0, 0) of vehicle.py:183-185.  add_road_user: intersection.py:458-539. */
 int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired);
 

@@ -40,6 +40,7 @@
 #define CSFO_TWOD 1
 #define CSFO_INVPEND 2
 #define CSFO_PLANARPOINT 3
+#define CSFO_PLANARBIKE 4
 
 #define CSFO_ST_SPLINE 1u
 #define CSFO_ST_NAN 2u
@@ -59,6 +60,8 @@ typedef struct csfo_params {
     double h, m, i_bike_longlong, i_steer_vertvert, c_steer, v_max_walk, delta_max_walk;
     /* PlanarPointBicycleParameters — parameters.py:1180-1201 (gain = -Re(pole), dynamics.py:933-940) */
     double k_psi;
+    /* PlanarBicycleParameters — parameters.py:1203-1211: the two desired poles (re, im, re, im) */
+    double pb_poles[4];
     int32_t model, priority_rule /* 0 unregulated, 1 p2r */, traj_len /* int(30/t_s) */, reserved;
 } csfo_params;
 
@@ -547,8 +550,9 @@ static void dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
         direct_approach(o, a, Fx, Fy);                             /* vehicle.py:1189-1194 */
         break;
     case CSFO_PLANARPOINT:
+    case CSFO_PLANARBIKE:
         update_destination(o, a);                                  /* vehicle.py:295-297 */
-        twod_dest_force(o, a, Fx, Fy);                             /* vehicle.py:2025 */
+        twod_dest_force(o, a, Fx, Fy);                             /* vehicle.py:2025, 2070 */
         break;
     default:
         twod_dest_force(o, a, Fx, Fy);
@@ -800,6 +804,68 @@ static void planarpoint_step(csfo_t *o, int a, double Fx, double Fy) {
     s[3] = v;
 }
 
+/* ------------------------------------------------------------- PlanarBicycle (f)4 ---- */
+
+/* first-order-hold discretisation python-control's forced_response applies to a continuous system (the block matrix
+ * exponential): x+ = Ad x + Bd0 u_k + Bd1 u_{k+1} for a single-input system with n = 2 states */
+static void foh2(const double Acl[4], const double Bcl[2], double dt, double Ad[4], double Bd0[2], double Bd1[2]) {
+    double M[16] = {0}, E[16];
+    M[0] = Acl[0] * dt; M[1] = Acl[1] * dt; M[2] = Bcl[0] * dt;
+    M[4] = Acl[2] * dt; M[5] = Acl[3] * dt; M[6] = Bcl[1] * dt;
+    M[11] = 1.0;
+    csfo_expm(4, M, E);
+    Ad[0] = E[0]; Ad[1] = E[1]; Ad[2] = E[4]; Ad[3] = E[5];
+    Bd1[0] = E[3]; Bd1[1] = E[7];
+    Bd0[0] = E[2] - Bd1[0]; Bd0[1] = E[6] - Bd1[1];
+}
+
+/* PlanarTwoWheelerDynamics.update (dynamics.py:203-223) -> from_pole_placement (dynamics.py:1167-1226) for
+ * A = [[0, 0], [v / w, 0]], B = [1, 0]^T, C = [0, 1]: K_x by pole placement (a single-input system has exactly one
+ * solution, found here by matching the coefficients of the characteristic polynomial), K_u as the reciprocal of the
+ * output at the end of a simulated response (T = 0, 0.01, ..., 9.99; input 0 for the first ten samples, then 1). */
+void csfo_planarbike_gains(const csfo_params *p, double v, double Kx[2], double *Ku) {
+    const double a10 = v / p->l;
+    const double sum = p->pb_poles[0] + p->pb_poles[2];                                   /* p1 + p2 (real) */
+    const double prod = p->pb_poles[0] * p->pb_poles[2] - p->pb_poles[1] * p->pb_poles[3]; /* Re(p1 p2) */
+    Kx[0] = -sum;
+    Kx[1] = prod / a10;
+    const double Acl[4] = {-Kx[0], -Kx[1], a10, 0.0}, Bcl[2] = {1.0, 0.0};
+    double Ad[4], Bd0[2], Bd1[2];
+    foh2(Acl, Bcl, 0.01, Ad, Bd0, Bd1);
+    double x0 = 0, x1 = 0;
+    for (int i = 1; i < 1000; i++) {                               /* np.arange(10.0, step=0.01): 1000 samples */
+        const double u0 = (i - 1) >= 10 ? 1.0 : 0.0, u1 = i >= 10 ? 1.0 : 0.0;
+        const double n0 = Ad[0] * x0 + Ad[1] * x1 + Bd0[0] * u0 + Bd1[0] * u1;
+        const double n1 = Ad[2] * x0 + Ad[3] * x1 + Bd0[1] * u0 + Bd1[1] * u1;
+        x0 = n0;
+        x1 = n1;
+    }
+    *Ku = 1.0 / x1;                                                /* dynamics.py:1222-1224 */
+}
+
+/* PlanarTwoWheelerDynamics.step (dynamics.py:225-258) + PPointSpeedDynamics.step (dynamics.py:160-175) */
+static void planarbike_step(csfo_t *o, int a, double Fx, double Fy) {
+    const csfo_params *p = &o->p;
+    double *s = S(o, a), *x = o->xdyn + 3 * a;                      /* x = (delta, psi), unwrapped */
+    double Kx[2], Ku;
+    csfo_planarbike_gains(p, s[3], Kx, &Ku);                       /* :228: gains for the current speed */
+    const double psi_d = atan2(Fy, Fx), v_d = sqrt(Fy * Fy + Fx * Fx);   /* :231-232 */
+    const double Acl[4] = {-Kx[0], -Kx[1], s[3] / p->l, 0.0}, Bcl[2] = {Ku, 0.0};
+    double Ad[4], Bd0[2], Bd1[2];
+    foh2(Acl, Bcl, p->t_s, Ad, Bd0, Bd1);                          /* :235-243: input psi_d at both ends of the step */
+    const double n0 = Ad[0] * x[0] + Ad[1] * x[1] + (Bd0[0] + Bd1[0]) * psi_d;
+    const double n1 = Ad[2] * x[0] + Ad[3] * x[1] + (Bd0[1] + Bd1[1]) * psi_d;
+    x[0] = n0;
+    x[1] = n1;
+    s[2] = csfo_limit_angle(x[1]);                                 /* :246-247 */
+    s[4] = csfo_limit_angle(x[0]);
+    s[3] = v_d + (s[3] - v_d) * exp(-p->k_p_v * p->t_s);           /* :156, 175 */
+    const double y = s[1] + p->t_s * s[3] * sin(s[2]);             /* :251-258 */
+    const double xx = s[0] + p->t_s * s[3] * cos(s[2]);
+    s[0] = xx;
+    s[1] = y;
+}
+
 /* --------------------------------------------------------------- population tick ---- */
 
 /* intersection.py:747-864 for receivers [lo, hi) */
@@ -902,6 +968,9 @@ void csfo_integrate_range(csfo_t *o, int lo, int hi) {
         case CSFO_PLANARPOINT:                                     /* vehicle.py:301-328 */
             planarpoint_step(o, a, Fx, Fy);
             break;
+        case CSFO_PLANARBIKE:
+            planarbike_step(o, a, Fx, Fy);
+            break;
         }
         int i = (o->i[a] + 1) % L;                                 /* vehicle.py:1279-1282, D5 */
         o->i[a] = i;
@@ -940,7 +1009,7 @@ csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double 
     csfo_t *o = (csfo_t *)calloc(1, sizeof *o);
     o->p = *p;
     o->n = n;
-    static const int NS[4] = {5, 5, 6, 4};
+    static const int NS[5] = {5, 5, 6, 4, 5};
     o->ns = NS[p->model];
     size_t N = (size_t)(n > 0 ? n : 1), L = (size_t)p->traj_len;
     o->s = (double *)calloc(N * 6, sizeof(double));
@@ -987,6 +1056,10 @@ csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double 
             if (s[3] < p->v_max_walk) o->zrid[2 * a + 1] = 1;
             else o->zrid[2 * a] = 1;
         }
+        if (p->model == CSFO_PLANARBIKE) {                         /* dynamics.py:195-197 */
+            o->xdyn[3 * a] = s[4];
+            o->xdyn[3 * a + 1] = s[2];
+        }
         if (p->model == CSFO_PLANARPOINT) {                        /* dynamics.py:828, 987-993 */
             o->xdyn[3 * a] = s[2];
             o->xdyn[3 * a + 1] = s[0];
@@ -1017,6 +1090,10 @@ void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const ui
             x[0] = s[4];
             x[2] = s[5];
             x[4] = s[2];
+        }
+        if (o->p.model == CSFO_PLANARBIKE) {
+            o->xdyn[3 * a] = s[4];
+            o->xdyn[3 * a + 1] = s[2];
         }
         if (o->p.model == CSFO_PLANARPOINT) {
             o->xdyn[3 * a] = s[2];
@@ -1109,6 +1186,12 @@ void csfo_apply_forces(csfo_t *o, const double *Fx, const double *Fy) {
     csfo_update_snapshot_range(o, 0, o->n);
     o->tick++;
 }
+void csfo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 int csfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

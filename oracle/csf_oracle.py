@@ -12,9 +12,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libcsf_oracle.so")
 
-BICYCLE, TWOD, INVPEND, PLANARPOINT = 0, 1, 2, 3
-MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT}
-N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4}
+BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE = 0, 1, 2, 3, 4
+MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE}
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5}
 
 ST_SPLINE, ST_NAN, ST_NAVSTATE = 1, 2, 4
 
@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("h", C.c_double), ("m", C.c_double), ("i_bike_longlong", C.c_double),
         ("i_steer_vertvert", C.c_double), ("c_steer", C.c_double),
         ("v_max_walk", C.c_double), ("delta_max_walk", C.c_double),
-        ("k_psi", C.c_double),
+        ("k_psi", C.c_double), ("pb_poles", C.c_double * 4),
         ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("reserved", C.c_int32),
     ]
 
@@ -47,12 +47,13 @@ _BICYCLE = dict(_VEHICLE, v_max_riding=(-1.0, 10.0), p_decay=5.0, p_0=30.0, hfov
                 v_max_stop=0.6, l=1.0, l_2=0.5, delta_max=1.4, a_max=(-10.0, 10.0),
                 a_desired_default=(-5.0, 5.0), k_p_v=10.0, k_p_delta=10.0, g=9.81,
                 h=0.0, m=0.0, i_bike_longlong=0.0, i_steer_vertvert=1.0, c_steer=0.0,
-                v_max_walk=0.0, delta_max_walk=0.0, k_psi=0.0)
+                v_max_walk=0.0, delta_max_walk=0.0, k_psi=0.0, pb_poles=(0.0, 0.0, 0.0, 0.0))
 _INVPEND = dict(_BICYCLE, v_max_riding=(-1.0, 7.0), a_max=(-3.0, 1.0), a_desired_default=(-1.0, 0.5),
                 l=1.0, l_2=0.5, h=1.0, m=87.0, i_bike_longlong=3.28, i_steer_vertvert=0.07,
                 c_steer=50.0, v_max_walk=1.5, delta_max_walk=0.174)
 _PLANARPOINT = dict(_BICYCLE, k_psi=2.0)
-DEFAULTS = {BICYCLE: _BICYCLE, TWOD: _INVPEND, INVPEND: _INVPEND, PLANARPOINT: _PLANARPOINT}
+_PLANARBIKE = dict(_BICYCLE, pb_poles=(-1.0141284591434665, 1.226826644413086, -1.0141284591434665, -1.226826644413086))
+DEFAULTS = {BICYCLE: _BICYCLE, TWOD: _INVPEND, INVPEND: _INVPEND, PLANARPOINT: _PLANARPOINT, PLANARBIKE: _PLANARBIKE}
 
 
 def default_params(model, priority_rule=0, **overrides):
@@ -62,7 +63,7 @@ def default_params(model, priority_rule=0, **overrides):
     p = Params()
     for k, v in d.items():
         if isinstance(v, (tuple, list)):
-            setattr(p, k, (C.c_double * 2)(*v))
+            setattr(p, k, (C.c_double * len(v))(*v))
         else:
             setattr(p, k, v)
     p.model = model
@@ -81,10 +82,33 @@ def build(force=False):
 _lib = None
 
 
+def cpu_share():
+    """CPUs this process may really use: the cgroup quota if there is one (a GPU box gives a 1-GPU job 16 of its 128
+    hardware threads), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
+        # OpenMP would start one thread per hardware thread of the host; beyond the CPU share they only spin against
+        # each other (a 1 024-agent tick took 0.25 s instead of 6 ms on a GPU box).  OMP_NUM_THREADS wins if it is set.
+        want = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or cpu_share()
         L = C.CDLL(LIB)
         dp = C.POINTER(C.c_double)
         L.csfo_limit_angle.restype = C.c_double
@@ -105,6 +129,7 @@ def lib():
         L.csfo_control_move.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int, C.c_double,
                                         C.c_double, C.c_void_p]
         L.csfo_expm.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.csfo_planarbike_gains.argtypes = [C.POINTER(Params), C.c_double, C.c_void_p, C.POINTER(C.c_double)]
         L.csfo_create.restype = C.c_void_p
         L.csfo_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_destroy.argtypes = [C.c_void_p]
@@ -122,6 +147,8 @@ def lib():
         L.csfo_dest_force.argtypes = [C.c_void_p, C.c_int, dp, dp]
         L.csfo_apply_forces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_num_threads.restype = C.c_int
+        L.csfo_set_num_threads.argtypes = [C.c_int]
+        L.csfo_set_num_threads(want)
         L.csfo_sizeof_params.restype = C.c_size_t
         assert L.csfo_sizeof_params() == C.sizeof(Params)
         _lib = L
@@ -225,6 +252,14 @@ def control_move(params, s, dest, is_last, Fx, Fy):
     out = np.zeros(5)
     lib().csfo_control_move(C.byref(params), _p(s), _p(dest), int(is_last), float(Fx), float(Fy), _p(out))
     return out
+
+
+def planarbike_gains(params, v):
+    """(K_x [2], K_u) of PlanarTwoWheelerDynamics.update at speed v (dynamics.py:203-223, 1167-1226)"""
+    kx = np.zeros(2)
+    ku = C.c_double()
+    lib().csfo_planarbike_gains(C.byref(params), float(v), _p(kx), C.byref(ku))
+    return kx, ku.value
 
 
 def expm(A):

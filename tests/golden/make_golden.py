@@ -11,10 +11,12 @@ What the import needs:
 * ``sys.modules`` stand-ins for packages that are absent here and only touched at
   import time (pypaperutils, mypyutils, bicycleparameters, controlbehavior) —
   none of them is on the hot path;
-* python-control is absent: a ~20-line ``control`` shim provides ``ss`` and
-  ``forced_response`` (block matrix exponential of a first-order hold, which is
-  the published formula python-control uses for continuous LTI systems).  The
-  InvPendulum vectors are therefore "parity unpinned against python-control";
+* python-control is absent: a ``control`` shim provides ``ss``, ``forced_response`` (block matrix
+  exponential of a first-order hold, which is the published formula python-control uses
+  for continuous LTI systems), ``place`` (scipy.signal.place_poles) and ``ctrb``.  The
+  InvPendulum and PlanarBicycle vectors are therefore "parity unpinned against
+  python-control"; gen_invpend_yawstep checks the shim's time stepping against two
+  SciPy-only integrations of the same matrices;
 * ``TwoDBicycle.__init__`` is broken at reference HEAD (vehicle.py:1359 passes
   keyword-only arguments positionally).  ``_TwoD`` / ``_InvPend`` below repair only
   that call; every *method* that runs is the reference's own;
@@ -104,7 +106,33 @@ def _install_stubs():
         y = C @ x + D @ U
         return T, y, x
 
-    mod("control", ss=_SS, StateSpace=_SS, forced_response=forced_response)
+    class _Response:
+        """what python-control's forced_response returns: unpacks as (t, y[, x]) and has .time / .outputs / .states"""
+
+        def __init__(self, t, y, x, with_states):
+            self.time, self.outputs, self.states, self._with_states = t, y, x, with_states
+
+        def __iter__(self):
+            return iter((self.time, self.outputs, self.states) if self._with_states else (self.time, self.outputs))
+
+    def forced_response_obj(sys_, T=None, U=0.0, X0=0.0, return_x=False, squeeze=None):
+        n = np.atleast_2d(np.asarray(sys_.A, dtype=float)).shape[0]
+        if np.ndim(X0) == 0:
+            X0 = np.full(n, float(X0))
+        t, y, x = forced_response(sys_, T=T, U=U, X0=X0)
+        return _Response(t, y, x, return_x)
+
+    def place(A, B, poles):          # SISO pole placement has one solution: scipy.signal.place_poles finds it
+        from scipy.signal import place_poles
+
+        return place_poles(np.asarray(A, dtype=float), np.asarray(B, dtype=float), np.asarray(poles)).gain_matrix
+
+    def ctrb(A, B):
+        A = np.asarray(A, dtype=float)
+        B = np.asarray(B, dtype=float).reshape(A.shape[0], -1)
+        return np.hstack([np.linalg.matrix_power(A, k) @ B for k in range(A.shape[0])])
+
+    mod("control", ss=_SS, StateSpace=_SS, forced_response=forced_response_obj, place=place, ctrb=ctrb)
 
 
 _install_stubs()
@@ -155,8 +183,9 @@ MODELS = {
     "twod": _TwoD,
     "invpend": _InvPend,
     "planarpoint": rv.PlanarPointBicycle,
+    "planarbike": rv.PlanarBicycle,
 }
-NSTATES = {"bicycle": 5, "twod": 5, "invpend": 6, "planarpoint": 4}
+NSTATES = {"bicycle": 5, "twod": 5, "invpend": 6, "planarpoint": 4, "planarbike": 5}
 
 
 def make_vehicle(model, s0, vdes=None, **kw):
@@ -573,10 +602,44 @@ def gen_invpend_yawstep():
          speeds=speeds, poles_head=np.array(poles_head))
 
 
+# ----------------------------------------------------------------------------
+# (12) PlanarBicycle — vehicle.py:2031-2076, dynamics.py:178-258, 1167-1226: planar two-wheeler with a pole-placed
+#      steer / yaw loop (gains and input gain re-derived from the speed EVERY step, the input gain from a simulated
+#      10-s step response) and first-order speed dynamics; TwoD force field and spline destination force.
+#      Needs `control.place`, `control.ctrb` and the attribute form of `forced_response` from the stand-in.
+# ----------------------------------------------------------------------------
+def gen_planarbike():
+    rng = np.random.default_rng(1212)
+    S, F, O, X, G = [], [], [], [], []
+    for k in range(120):
+        s = (rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-np.pi, np.pi), rng.uniform(0.5, 9), rng.uniform(-0.3, 0.3))
+        v = make_vehicle("planarbike", s)
+        f = (rng.normal(0, 4), rng.normal(0, 4))
+        v.step(f[0], f[1])
+        s1 = v.s.copy()
+        x1 = np.array(v.dynamics.x, dtype=float).copy()
+        gains = np.r_[np.ravel(v.dynamics.gains[0]), np.ravel(v.dynamics.gains[1])]     # of the first step's speed
+        f2 = (rng.normal(0, 4), rng.normal(0, 4))
+        v.step(f2[0], f2[1])
+        S.append(np.r_[s, s1]); F.append(np.r_[f, f2]); O.append(v.s.copy()); X.append(np.r_[x1, v.dynamics.x]); G.append(gains)
+    out = {"steps_s01": np.array(S), "steps_F01": np.array(F), "steps_s2": np.array(O), "steps_x12": np.array(X),
+           "steps_gains": np.array(G)}
+    vs = demo_bikes("planarbike")
+    s0, vdes, off, dq = pop_arrays(vs)
+    St, Ft = run_population(vs, 700, every=10)
+    out.update({"demo_s0": s0, "demo_vdes": vdes, "demo_off": off, "demo_dq": dq, "demo_S": St, "demo_F": Ft})
+    vs = random_population(np.random.default_rng(1313), "planarbike", 12, 25.0)
+    s0, vdes, off, dq = pop_arrays(vs)
+    St, Ft = run_population(vs, 150, every=10)
+    out.update({"dense_s0": s0, "dense_vdes": vdes, "dense_off": off, "dense_dq": dq, "dense_S": St, "dense_F": Ft})
+    save("planarbike", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep"]
+    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike"]
     gens = {"pair": gen_pair_fields, "masks": gen_masks_and_totals, "control": gen_control_move,
             "dest": gen_dest_force, "pp": gen_planarpoint_steps, "road": gen_road,
-            "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep}
+            "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep,
+            "planarbike": gen_planarbike}
     for w in which:
         gens[w]()

@@ -294,19 +294,18 @@ def test_sumo_cosimulation_loop():
     ins = SocialForceIntersection([], id="J", activate_sumo_cosimulation=True, net=FakeNet(), traci=tr, capacity=64)
     arms = {"W": (-1, 0), "E": (1, 0), "S": (0, -1), "N": (0, 1)}
     rng = np.random.default_rng(5)
-    on_junction, born, seen_ids, arrivals = {}, 0, [], 0
+    on_junction, born, seen_ids, arrivals, entry = {}, 0, [], 0, {}
     for tick in range(600):
-        # SUMO's side: a road user enters every 25 ticks, and leaves the internal lanes 9.5 m from the centre
+        # SUMO's side: a road user enters every 25 ticks and is taken back by SUMO 200 ticks later
         if tick % 25 == 0:
             a, b = rng.choice(list(arms), 2, replace=False)
             ax, ay = arms[a]
             heading = np.arctan2(-ay, -ax)
-            on_junction[f"veh{born}"] = dict(route=(a + "_in", b + "_out"),
+            on_junction[f"veh{born}"] = dict(route=(a + "_in", b + "_out"), since=tick,
                                              s=[ax * 9.0 + ay * 1.6, ay * 9.0 - ax * 1.6, heading, 4.0, 0.0])
             born += 1
-        for v in list(ins.vehicles):
-            if np.hypot(v.s[0], v.s[1]) > 9.5 and v.i > 50:
-                on_junction.pop(v.id, None)
+        for vid in [vid for vid, spec in on_junction.items() if tick - spec["since"] >= 200]:
+            del on_junction[vid]
         tr.occupancy = {":J_0_0": tuple(on_junction)}
         # scenario.py:376-437: allocate_road_users
         entered, exited = ins.find_entered_exited_roadusers()
@@ -314,22 +313,24 @@ def test_sumo_cosimulation_loop():
         for vid in entered:
             spec = on_junction[vid]
             ins.add_road_user(TwoDBicycle(tuple(spec["s"]), id=str(vid), route=spec["route"]))
+            entry[str(vid)] = tuple(spec["s"][:2])
             arrivals += 1
         n_before = len(tr.moves)
         ins.step()
         tr.simulationStep()
         moved = tr.moves[n_before:]
         assert [m[1] for m in moved] == ins.get_road_user_ids()          # one moveToXY per road user, in order
+        assert sorted(ins.get_road_user_ids()) == sorted(on_junction)
         for m, v in zip(moved, ins.vehicles):
             assert m[2:4] == ("", -1) and m[7] == 6
             assert m[4] == v.s[0] and m[5] == v.s[1] and abs(m[6] - angleSFMtoSUMO(v.s[2])) < 1e-9
             assert np.isfinite(v.s).all()
         seen_ids += [v.id for v in ins.vehicles if v.id not in seen_ids]
     assert arrivals == 24 and len(seen_ids) == 24
-    assert ins.n_bikes <= 6 and len(ins.hist_n_vecs) == 600 and max(ins.hist_n_vecs) >= 2
-    # everyone who left had crossed the junction: the last position SUMO saw of it is beyond the footprint, on its exit arm
+    assert ins.n_bikes == 8 and len(ins.hist_n_vecs) == 600 and max(ins.hist_n_vecs) == 8
+    # everyone who left had been driven on by the engine: SUMO's last position of it is metres from its entry
     last = {}
     for m in tr.moves:
         last[m[1]] = (m[4], m[5])
     gone = [vid for vid in last if vid not in ins.get_road_user_ids()]
-    assert len(gone) >= 15 and all(np.hypot(*last[vid]) > 9.5 for vid in gone)
+    assert len(gone) == 16 and all(np.hypot(last[vid][0] - entry[vid][0], last[vid][1] - entry[vid][1]) > 2.0 for vid in gone)

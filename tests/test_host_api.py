@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.csf_abi_version() == 1
-    assert ctypes.sizeof(_ffi.Params) == 296
+    assert lib.csf_abi_version() == 2
+    assert ctypes.sizeof(_ffi.Params) == 328
 
 
 def test_engine_fails_loudly_without_gpu():
@@ -119,7 +119,7 @@ def test_intersection_host_bookkeeping():
     assert ins.get_road_user_ids() == ["b", "c"] and ins.vehicleX[0, 0] == 1.0 and a._owner is None
     ins.remove_road_user(1)
     assert ins.get_road_user_ids() == ["b"]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                      # co-simulation needs the net (tests: test_sumo_seam_host_side)
         SocialForceIntersection((), activate_sumo_cosimulation=True)
     with pytest.raises(NotImplementedError):
         SocialForceIntersection((b2 := Bicycle((0, 0, 0, 5, 0)), PlanarPointBicycle((0, 0, 0, 5))))
@@ -280,3 +280,35 @@ def test_sumo_seam_host_side():
         assert abs(angleSFMtoSUMO(angleSUMOtoSFM(deg)) - deg) < 1e-9
     ins.update_road_user_positions()                       # pushes (x, y, angle) of every road user: intersection.py:679-688
     assert tr.moves[-1][1:] == ("veh0", "", -1, -9.0, -1.6, 90.0, 6)
+
+
+def test_visual_hook_drawings():
+    """Vehicle.add_drawing / update_drawing / plot_states / plot_forces on matplotlib's Agg canvas
+    (vehicle.py:695-917); no GPU involved - the drawings read the host mirror."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    from cyclistsocialforce_amd.vehicle import TwoDBicycle
+
+    fig, ax = plt.subplots(1, 1)
+    v = TwoDBicycle((1.0, 2.0, 0.0, 5.0, 0.0), id="a", saveForces=True)
+    v.setDestinations((30.0, 60.0), (2.0, 2.0))
+    v.add_drawing(ax)
+    xy0 = v.drawing.body.get_xy().copy()
+    assert np.allclose(xy0[0], [1.0 + 0.6 * 1.8, 2.0])                    # the nose points along psi = 0
+    v.s[:3] = (4.0, 3.0, np.pi / 2)
+    v.update_drawing(Fres=(0.0, 2.0))
+    assert np.allclose(v.drawing.body.get_xy()[0], [4.0, 3.0 + 0.6 * 1.8])
+    assert np.allclose(v.drawing.force.get_ydata(), [3.0, 3.0 + 0.3 * 2.0])
+    assert list(v.drawing.destinations.get_xdata()) == [1.0, 30.0, 60.0]
+    v.drawing.set_animated(True)
+    assert all(a.get_animated() for a in v.drawing.artists())
+    v.traj[:, 1] = v.s; v.trajF[:, 1] = (0.0, 2.0); v.i = 1
+    axs = v.plot_states(t_end=1.0)
+    assert len(axs) == 5 and len(axs[0].lines) == 1
+    axf = v.plot_forces(components_to_plot=["magnitude", "direction"])
+    assert len(axf) == 2 and np.allclose(axf[0].lines[0].get_ydata(), [2.0])
+    with pytest.raises(ValueError):
+        TwoDBicycle((0, 0, 0, 5, 0)).plot_forces()
+    plt.close("all")

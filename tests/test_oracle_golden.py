@@ -197,3 +197,28 @@ def test_invpend_yaw_step_without_control_shim(golden):
     # (parameters.py:1858-1861 vs 1863-1883): recorded, not asserted equal
     np.testing.assert_allclose(g["K_place_testpy"], [6.26092881, -48.635, -6.92845026, -2.25215286, -2.15918001], rtol=1e-7)
     assert abs(g["K_table_head"][0] - g["K_place_testpy"][0]) > 100
+
+
+def test_planarbike_against_reference(golden):
+    """PlanarBicycle (vehicle.py:2031-2076; dynamics.py:178-258, 1167-1226): gains re-derived from the
+    speed every step, single steps, the 3-bike demo geometry (700 ticks) and a dense population (150 ticks), all captured
+    from the reference (tests/golden/make_golden.py: gen_planarbike)."""
+    g = golden("planarbike")
+    p = orc.default_params("planarbike")
+    s01, F = g["steps_s01"], g["steps_F01"]
+    for k in range(0, s01.shape[0], 7):
+        kx, ku = orc.planarbike_gains(p, s01[k, 3])
+        np.testing.assert_allclose(np.r_[kx, ku], g["steps_gains"][k], rtol=1e-10)
+    n = s01.shape[0]
+    pop = orc.Population(p, s01[:, :5], 5.0, np.arange(n + 1), np.c_[s01[:, 0], s01[:, 1], np.zeros(n)])
+    pop.apply_forces(F[:, 0], F[:, 1])
+    np.testing.assert_allclose(pop.state(), s01[:, 5:], rtol=1e-12, atol=1e-12)
+    pop.apply_forces(F[:, 2], F[:, 3])
+    np.testing.assert_allclose(pop.state(), g["steps_s2"], rtol=1e-12, atol=1e-12)
+    for tag in ("demo", "dense"):
+        pop = orc.Population(p, g[f"{tag}_s0"], g[f"{tag}_vdes"], g[f"{tag}_off"], g[f"{tag}_dq"])
+        S = g[f"{tag}_S"]
+        for k in range(1, S.shape[0]):
+            pop.step(10)
+            np.testing.assert_allclose(pop.state(), S[k], rtol=0, atol=1e-9, err_msg=f"{tag} sample {k}")
+        np.testing.assert_allclose(np.c_[pop.forces()], g[f"{tag}_F"][-1], rtol=0, atol=1e-8)

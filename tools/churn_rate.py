@@ -21,6 +21,14 @@ s0, off, dq = synthetic_population(n, box)
 pool, _, pdq = synthetic_population(8 * n, box, seed=1)
 pdq = pdq.reshape(-1, 4, 3)
 out = {"agents": n, "ticks": ticks, "churn_per_tick": frac}
+k = int(frac * n)
+rng = np.random.default_rng(0)
+kills = [np.sort(rng.choice(n, k, replace=False)).astype(np.int32) for _ in range(ticks)]     # prepared outside the timed loops
+news = [(np.arange(k) + t * k) % (8 * n) for t in range(ticks)]
+new_s = [np.ascontiguousarray(pool[i]) for i in news]
+new_q = [np.ascontiguousarray(pdq[i].reshape(-1, 3)) for i in news]
+tail = np.arange(n - k, n, dtype=np.int32)
+qoff = np.arange(k + 1, dtype=np.int64) * 4
 for label, inc, churn in (("static", True, False), ("incremental", True, True), ("host_mirror", False, True)):
     t_run = ticks if label != "host_mirror" else max(20, ticks // 20)
     e = Engine(parameters.default_pod("twod"), n)
@@ -28,23 +36,21 @@ for label, inc, churn in (("static", True, False), ("incremental", True, True), 
     e.add_agents(s0, 5.0)
     e.set_dest_queue(np.arange(n), off, dq, reset=True)
     e.step(300, sync=True)
-    rng = np.random.default_rng(0)
-    k = int(frac * n)
-    nxt = 0
+    calls = 0.0
     t0 = time.perf_counter()
     for t in range(t_run):
-        if churn:
-            kill = np.sort(rng.choice(n, k, replace=False))
-            new = (np.arange(k) + nxt) % (8 * n)
-            nxt += k
-            e.remove_agents(kill)
-            e.add_agents(pool[new], 5.0)
-            e.set_dest_queue(np.arange(n - k, n), np.arange(k + 1) * 4, pdq[new].reshape(-1, 3), reset=True)
+        if churn and k:
+            c0 = time.perf_counter()
+            e.remove_agents(kills[t])
+            e.add_agents(new_s[t], 5.0)
+            e.set_dest_queue(tail, qoff, new_q[t], reset=True)
+            calls += time.perf_counter() - c0
         e.step(1)
     e.sync()
     dt = time.perf_counter() - t0
     healthy = bool(np.isfinite(e.state()).all() and (e.status() == 0).all())
-    out[label] = {"us_per_tick": dt / t_run * 1e6, "ticks": t_run, "healthy": healthy}
+    out[label] = {"us_per_tick": dt / t_run * 1e6, "host_us_in_population_calls": calls / t_run * 1e6, "ticks": t_run,
+                  "healthy": healthy}
     e.close()
 out["incremental_over_static"] = out["incremental"]["us_per_tick"] / out["static"]["us_per_tick"]
 print(json.dumps(out))
