@@ -334,3 +334,38 @@ def test_sumo_cosimulation_loop():
         last[m[1]] = (m[4], m[5])
     gone = [vid for vid in last if vid not in ins.get_road_user_ids()]
     assert len(gone) == 16 and all(np.hypot(last[vid][0] - entry[vid][0], last[vid][1] - entry[vid][1]) > 2.0 for vid in gone)
+
+
+def test_animated_demo_on_agg_canvas(tmp_path):
+    """the reference's demo with animate=True (demo/demoCSFstandalone.py:120-156) - drawings created on
+    the first tick, refreshed from the read-back of every tick, blitted by Scenario, histories plotted afterwards."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    fig, ax = plt.subplots(1, 1)
+    ax.set_xlim(0, 30); ax.set_ylim(-10, 20)
+    bikes = demo_bikes(TwoDBicycle)
+    ins = SocialForceIntersection(bikes, animate=True, axes=ax)
+    scn = Scenario(ins.step, t_r=0, verbose=False, animate=True, axes=ax)
+    scn.run(1.0)
+    assert all(v.drawing is not None and v.drawing.body.get_animated() for v in bikes)
+    for v in bikes:                                              # the artists follow the device state
+        assert np.allclose(v.drawing.trajectory.get_xdata()[-1], v.s[0]) and len(v.drawing.trajectory.get_xdata()) == 101
+        assert np.allclose(v.drawing.body.get_xy().mean(axis=0), v.s[:2], atol=1.0)
+    ins.set_animated(False)
+    assert not any(v.drawing.body.get_animated() for v in bikes)
+    axs = axf = None
+    for v in bikes:
+        axs = v.plot_states(t_end=1.0, axes=axs)
+        axf = v.plot_forces(t_end=1.0, axes=axf, components_to_plot=["magnitude", "direction"])
+    assert len(axs[0].lines) == 3 and len(axf[0].lines) == 3
+    fig.savefig(tmp_path / "scene.png")
+    late = TwoDBicycle((5.0, 5.0, 0.0, 4.0, 0.0), id="late")
+    late.setDestinations((40.0, 80.0), (5.0, 5.0))
+    ins.add_road_user(late)                                      # arrivals get an animated drawing (intersection.py:521-524)
+    assert late.drawing is not None and late.drawing.body.get_animated()
+    ins.step()
+    plt.close("all")
+    with pytest.raises(AssertionError):
+        SocialForceIntersection(demo_bikes(TwoDBicycle), animate=True)
