@@ -144,8 +144,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     rehearse = os.environ.get("CSF_BENCH_FORCE_DIST") == "1"  # 1-GPU rehearsal of the multi-rank code path
+    real_stdout = None
     if world > 1 or rehearse:
         import torch.distributed as dist
+
+        # RCCL prints a version banner on stdout when a communicator is created: everything but the one JSON line goes
+        # to stderr (the C-level descriptor is redirected, and restored right before the line is printed)
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -295,6 +302,9 @@ def main():
                                  "note": "CSF_FAR_EPS=0: no batch is skipped for distance"}
         if world == 1 and args.cpu_ticks > 0 and args.model == "twod" and road is None:
             out["cpu_baseline"] = cpu_baseline(n, box, args.cpu_ticks)
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

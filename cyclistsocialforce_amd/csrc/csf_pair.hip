@@ -41,6 +41,9 @@ constexpr int TILE = 1024;           // simple kernels: source records per LDS t
 #ifndef CSF_CULL_WAVES
 #define CSF_CULL_WAVES 7
 #endif
+#ifndef CSF_PREFETCH
+#define CSF_PREFETCH 0       // reach test: request the next two batches before the current two are tested (A/B knob)
+#endif
 constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 7 waves/SIMD (72 VGPRs, 12 B spilled) measured best (tools/sweep_cull.sh)
 constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
 constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
@@ -522,28 +525,69 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 // both are wholly inside); what it keeps is appended to the queue, first batch first.
                 // (A single loop over both kinds of batch pairs with the records of the next pair requested ahead of the
                 // queue append was tried: the compiler spilled 30 registers into the loops and the kernel ran at 180 us.)
-                auto sift2 = [&](int b1, int b2, bool two, auto fov) {
+                // test of the two batches whose records are in (sx, sy, sc, ss), append of what it keeps
+                auto sift2 = [&](int b1, int b2, bool two, auto fov, v2f sx, v2f sy, v2f sc, v2f ss) {
                     constexpr bool FOV = decltype(fov)::value;
-                    const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
                     bool k0, k1;
-                    keep_x2<FOV, P2R>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
-                                      lds_pair(ts, i0, i1), k0, k1);
+                    keep_x2<FOV, P2R>(k, ru, sx, sy, sc, ss, k0, k1);
                     k1 = k1 & two;
                     tests += two ? 2u * WAVE : (unsigned)WAVE;
                     const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
                     const int n0 = __builtin_popcountll(m0);
-                    if (k0) {
-                        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0));
-                        queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)(4 * i0);
+                    if (k0) {                       // slot = (head + length) + kept lanes below this one: v_mbcnt adds onto its operand
+                        const int at = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, (unsigned)(qhead + qlen)));
+                        queue[wave][at & (QCAP - 1)] = (unsigned short)(4 * ((b1 << 6) + lane));
                     }
                     if (k1) {
-                        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0));
-                        queue[wave][(qhead + qlen + n0 + pre) & (QCAP - 1)] = (unsigned short)(4 * i1);
+                        const int at = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, (unsigned)(qhead + qlen + n0)));
+                        queue[wave][at & (QCAP - 1)] = (unsigned short)(4 * ((b2 << 6) + lane));
                     }
                     qlen = __builtin_amdgcn_readfirstlane(qlen + n0 + __builtin_popcountll(m1));
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     while (qlen >= CHUNK) pop(u, std::true_type{});
+                };
+#if CSF_PREFETCH
+                // the records of the NEXT two batches are requested before the current two are tested, so that their LDS
+                // round trip runs beside the test instead of in front of it (the kernel waits on LDS, not on issue)
+                auto run = [&](unsigned m, auto fov) {
+                    if (!m) return;
+                    int b1 = __builtin_ctz(m);
+                    m &= m - 1u;
+                    bool two = m != 0u;
+                    int b2 = two ? __builtin_ctz(m) : b1;
+                    m &= m - 1u;
+                    int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
+                    v2f sx = lds_pair(tx, i0, i1), sy = lds_pair(ty, i0, i1), sc = lds_pair(tc, i0, i1), ss = lds_pair(ts, i0, i1);
+                    while (true) {
+                        const bool more = m != 0u;
+                        const int c1 = b1, c2 = b2;
+                        const bool ctwo = two;
+                        const v2f cx = sx, cy = sy, cc = sc, cs = ss;
+                        if (more) {
+                            b1 = __builtin_ctz(m);
+                            m &= m - 1u;
+                            two = m != 0u;
+                            b2 = two ? __builtin_ctz(m) : b1;
+                            m &= m - 1u;
+                            i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
+                            sx = lds_pair(tx, i0, i1), sy = lds_pair(ty, i0, i1), sc = lds_pair(tc, i0, i1), ss = lds_pair(ts, i0, i1);
+                        }
+                        sift2(c1, c2, ctwo, fov, cx, cy, cc, cs);
+                        if (!more) break;
+                    }
+                };
+                unsigned ins = inside, odd = 0u;
+                if (__builtin_popcount(ins) & 1) {               // an odd inside batch joins the partial ones: the exact test passes all of it
+                    odd = 1u << (31 - __builtin_clz(ins));
+                    ins &= ~odd;
+                }
+                run(ins, std::false_type{});
+                run((cand & ~inside) | odd, std::true_type{});
+#else
+                auto load2 = [&](int b1, int b2, bool two, auto fov) {
+                    const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
+                    sift2(b1, b2, two, fov, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1), lds_pair(ts, i0, i1));
                 };
                 unsigned ins = inside;
                 while (__builtin_popcount(ins) >= 2) {
@@ -551,7 +595,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     ins &= ins - 1u;
                     const int b2 = __builtin_ctz(ins);
                     ins &= ins - 1u;
-                    sift2(b1, b2, true, std::false_type{});
+                    load2(b1, b2, true, std::false_type{});
                 }
                 unsigned rest = (cand & ~inside) | ins;      // partial batches (+ an odd inside one: the exact test passes all of it)
                 while (rest) {
@@ -560,8 +604,9 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     const bool two = rest != 0u;
                     const int b2 = two ? __builtin_ctz(rest) : b1;
                     rest &= rest - 1u;                       // (0 & anything: stays 0)
-                    sift2(b1, b2, two, std::true_type{});
+                    load2(b1, b2, two, std::true_type{});
                 }
+#endif
                 cand = 0u;
             }
             // batches that are entirely inside the field of view need neither the test nor the queue: two at a

@@ -10,7 +10,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS --preroll 0 --cpu-ticks 0 --every-pair-steps 0 > $OUT/$name.log 2>&1
+  case "$ARGS" in *--preroll*) PRE="";; *) PRE="--preroll 0";; esac
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS $PRE --cpu-ticks 0 --every-pair-steps 0 > $OUT/$name.log 2>&1
   echo "pass $name done"
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
