@@ -43,6 +43,7 @@ struct Dev {
     int64_t cap;       // SoA stride
     int64_t lo, hi;    // receiver block integrated by this rank
     int64_t n_pad;     // n rounded up to a multiple of 64 (sentinel source records behind n)
+    int64_t n_src;     // places of the source order that can hold a road user (multiple of 64, <= n_pad): the pair kernel stops there
     int32_t ns;        // states per agent
     int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
     int32_t back;      // int(1 / t_s) — vehicle.py:1487

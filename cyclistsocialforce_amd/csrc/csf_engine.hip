@@ -86,7 +86,8 @@ struct DevBuf {
 struct csf_engine {
     Dev d{};
     int device = 0;
-    int64_t cap = 0;
+    int64_t cap = 0;        // slots: the caller's capacity + head room for arrivals between two re-binnings (csf_create)
+    int64_t cap_user = 0;   // road users the caller may have at once
     hipStream_t main = nullptr, comm = nullptr;
     hipEvent_t ev_integ = nullptr, ev_gather = nullptr;
     std::string err;
@@ -100,7 +101,15 @@ struct csf_engine {
     // The population: road user i of the caller's order lives in slot order[i].  Slots are what every device array is
     // indexed by.  csf_remove_agents on a live device copy only kills slots (they keep a sentinel record), csf_add_agents
     // reuses them; a full upload compacts the slots back into population order.
-    std::vector<int32_t> order, free_slots;
+    std::vector<int32_t> order;
+    // Dead slots.  `free_tail`: dead at the last re-binning, so their place in the binned order is in the tail of
+    // sentinels behind the real batches - a road user spawned into one of them (or into a fresh slot below n_pad) joins a
+    // tail batch of other newcomers and stretches no real batch's circle.  `free_recent`: retired since; their places are
+    // inside real batches, so they are handed out only when nothing else is left, and move to `free_tail` at the next
+    // re-binning.  `slack`: sentinel slots kept behind the population for arrivals (twice what the last period saw).
+    std::vector<int32_t> free_tail, free_recent;   // free_tail: descending, so that pop_back hands out ascending slots
+    int64_t live_at_rebin = 0, tail_used = 0;       // road users at the last re-binning; sentinel places handed out since
+    bool tail_tracked = false;                      // the places of the sentinel tail are known (binned single engine)
     std::vector<uint8_t> h_alive;
     bool order_dirty = true;               // the device copy of `order` is stale
     bool incremental = true;               // csf_set_incremental
@@ -500,12 +509,16 @@ int alloc_all(csf_engine *e) {
     return CSF_OK;
 }
 
+constexpr int64_t TAIL_SLOTS = 4096;   // sentinel slots kept behind a binned population (csf_create adds them to the capacity)
+void set_chunks(csf_engine *e);
+
 void set_shard(csf_engine *e) {
     Dev &d = e->d;
     if (e->world <= 1) {
         d.lo = 0;
         d.hi = d.n;
-        d.n_pad = (d.n + 63) / 64 * 64;
+        // (sentinel slots behind the population take the arrivals between two re-binnings, csf_add_agents)
+        d.n_pad = (std::min<int64_t>(e->cap, d.n + (e->loopback ? 0 : TAIL_SLOTS)) + 63) / 64 * 64;
     } else {
         int64_t shard = (d.n + e->world - 1) / e->world;
         shard = (shard + 63) / 64 * 64;
@@ -521,28 +534,39 @@ void set_shard(csf_engine *e) {
             d.hi = std::min<int64_t>(d.n, d.lo + shard);
         }
     }
+    d.n_src = d.n_pad;          // every place of the source order may hold a road user (rebin() knows better)
+    e->tail_tracked = false;
+    set_chunks(e);
+}
+
+// the source chunks of the pair kernel's grid, for the d.n_src places of the source order that can hold road users
+void set_chunks(csf_engine *e) {
+    Dev &d = e->d;
     int64_t nloc = d.hi - d.lo;
     int64_t blocks = (nloc + 15) / 16;
-    int64_t units = std::max<int64_t>(1, d.n_pad / 64);
+    int64_t units = std::max<int64_t>(1, d.n_src / 64);
     // Many more workgroups than the chip holds at once: receivers see very different numbers of sources (field
     // of view, position in the scene), so the hardware's dynamic workgroup dispatch is the load balancer.  Chunks
     // of one LDS tile (1024 sources) measured best for 1-, 2-, 4- and 8-way shards of N = 16 384.
     int64_t split;
-    if (d.n_pad >= 16384) {
+    if (d.n_src >= 16384) {
         split = blocks > 0 ? (16384 + blocks - 1) / blocks : 1;
-        split = std::min<int64_t>(split, d.n_pad / 1024);
+        split = std::min<int64_t>(split, d.n_src / 1024);
     } else {
         split = blocks > 0 ? (1024 + blocks - 1) / blocks : 1;
     }
     split = std::max<int64_t>(1, std::min<int64_t>({split, (int64_t)MAX_SPLIT, units}));
     // large populations run the far-tile-skipping variant (rebin: recv_binned): most tiles of a chunk are
     // skipped unloaded, and longer chunks amortise the workgroup's start-up (config 4: 7.3 ms at 64 chunks, 6.2 at 8-16)
-    if (d.n_pad >= 65536 && d.p.model != CSF_BICYCLE) split = std::min<int64_t>(split, 16);
+    if (d.n_src >= 65536 && d.p.model != CSF_BICYCLE) split = std::min<int64_t>(split, 16);
     if (const char *ov = getenv("CSF_NSPLIT")) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoi(ov), (int64_t)MAX_SPLIT, units}));
     // no empty chunk: with per = ceil(units / split) units per chunk only ceil(units / per) chunks hold sources (n = 1040:
     // 17 units, split 16 -> per 2 -> 9 chunks).  A workgroup of an empty chunk would leave its slot of d.part untouched,
     // and the combine phase would add whatever an earlier population layout left there.
-    const int64_t per = (units + split - 1) / split;
+    int64_t per = (units + split - 1) / split;
+    // a chunk just over one LDS tile (16 batches) would load a second, nearly empty tile in every workgroup: the few
+    // batches of arrivals behind a population that filled whole tiles get a chunk - and workgroups - of their own
+    if (per > 16 && per < 32 && (units + 15) / 16 <= MAX_SPLIT && !getenv("CSF_NSPLIT")) per = 16;
     split = (units + per - 1) / per;
     d.n_split = (int32_t)split;
     d.chunk_units = (int32_t)per;
@@ -560,6 +584,10 @@ constexpr int64_t BIN_MIN_AGENTS = 1024;
 // (re)build the spatially binned order of the records; decides whether batches are classified this tick
 int rebin(csf_engine *e) {
     Dev &d = e->d;
+    if (e->world <= 1 && !e->loopback && d.n_pad < e->cap && d.n + TAIL_SLOTS / 2 > d.n_pad) {   // fresh slots are running out
+        set_shard(e);
+        launch_records(d, e->main);     // sentinels in the new tail (the records of the road users are rewritten as they are)
+    }
     const bool binned = d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS;
     d.classify = binned;
     update_far_radius(e);
@@ -585,6 +613,24 @@ int rebin(csf_engine *e) {
             d.rlist = e->rlist.p;
         }
     }
+    // Where the sentinels went: the sort is stable and their key is the largest, so the road users fill the places
+    // [0, n_live) and the free slots follow in ascending slot order.  Handing the free slots out in that order
+    // (csf_add_agents) keeps the places that can hold a road user a prefix of the order, and the pair kernel's source
+    // chunks end there (d.n_src) instead of at n_pad.  Slots retired since the last re-binning are sentinels from now on.
+    e->tail_tracked = binned && e->world <= 1 && !e->loopback;
+    e->free_tail.insert(e->free_tail.end(), e->free_recent.begin(), e->free_recent.end());
+    e->free_recent.clear();
+    std::sort(e->free_tail.begin(), e->free_tail.end(), std::greater<int32_t>());
+    e->live_at_rebin = d.n_live;
+    e->tail_used = 0;
+    {
+        const int64_t n_src = e->tail_tracked ? std::max<int64_t>(64, (d.n_live + 63) / 64 * 64)
+                              : (e->world <= 1 && !e->loopback && !binned ? std::max<int64_t>(64, (d.n + 63) / 64 * 64) : d.n_pad);
+        if (n_src != d.n_src) {
+            d.n_src = std::min(n_src, d.n_pad);
+            set_chunks(e);
+        }
+    }
     e->ticks_since_rebin = 0;
     e->churn = 0;
     e->bounds_fresh = false;
@@ -594,12 +640,13 @@ int rebin(csf_engine *e) {
 // bounding circles for the pair launch that follows; afterwards the circles emitted by that launch become current
 int bounds_before_pair(csf_engine *e) {
     Dev &d = e->d;
-    // A new road user sits in the batch of the slot it took, among far-away neighbours, and stretches that batch's circle
-    // over the scene until the next re-binning; every stretched batch costs each receiver a per-lane test (measured:
-    // ~0.4 us per batch and tick at N = 16 384) against ~60 us for a re-binning: renew the order once a quarter of the
-    // batches holds a newcomer.  (Retired slots cost nothing: their sentinel records are left out of the circles.)
-    static const int64_t churn_div = getenv("CSF_REBIN_CHURN") ? std::max(1, atoi(getenv("CSF_REBIN_CHURN"))) : 256;
-    if (e->ticks_since_rebin >= REBIN_TICKS || churn_div * e->churn > d.n) {
+    // Road users that arrived since the last re-binning sit in the tail batches of the binned order, among each other
+    // and far from sorted: every receiver tests those batches lane by lane (measured ~1.3 us per batch and tick at
+    // N = 16 384), against ~35 us for the kernels of a re-binning.  With r arrivals per tick the cheapest period is about
+    // sqrt(2 * 35 * 64 / (1.3 r)) ticks, i.e. re-bin when ticks x arrivals since the last one reaches ~3500; 3000 to 6000
+    // measured alike (profiles/r2_churn_rate.txt; CSF_REBIN_CHURN overrides the constant).
+    static const int64_t churn_k = getenv("CSF_REBIN_CHURN") ? std::max(1, atoi(getenv("CSF_REBIN_CHURN"))) : 4000;
+    if (e->ticks_since_rebin >= REBIN_TICKS || e->ticks_since_rebin * e->churn >= churn_k) {
         int rc = rebin(e);
         if (rc) return rc;
     }
@@ -649,7 +696,7 @@ int download_all(csf_engine *e) {
 // slots -> population order on the host mirror (a full upload starts from a population without holes)
 void compact_host(csf_engine *e) {
     const int64_t n = (int64_t)e->order.size(), cap = e->cap, hl = e->d.hist_len;
-    bool identity = e->free_slots.empty() && n == e->d.n;
+    bool identity = e->free_tail.empty() && e->free_recent.empty() && n == e->d.n;
     for (int64_t i = 0; identity && i < n; i++) identity = e->order[(size_t)i] == i;
     if (!identity) {
         auto gather = [&](auto &vec, int64_t comps) {
@@ -665,7 +712,8 @@ void compact_host(csf_engine *e) {
         for (int64_t i = 0; i < n; i++) q[(size_t)i] = std::move(e->h_q[(size_t)e->order[(size_t)i]]);
         e->h_q.swap(q);
         for (int64_t i = 0; i < n; i++) e->order[(size_t)i] = (int32_t)i;
-        e->free_slots.clear();
+        e->free_tail.clear();
+        e->free_recent.clear();
     }
     std::fill(e->h_alive.begin(), e->h_alive.end(), (uint8_t)0);
     std::fill(e->h_alive.begin(), e->h_alive.begin() + n, (uint8_t)1);
@@ -674,35 +722,54 @@ void compact_host(csf_engine *e) {
     e->order_dirty = true;
 }
 
-int upload_all(csf_engine *e) {
-    if (!e->dirty) return flush_pending(e);
+// destination queues of the live slots -> one slab of rows, every queue contiguous, with room behind them for the queues
+// of road users that arrive and for queues that are replaced (those are appended, flush_pending), `extra` rows at least
+int upload_queues(csf_engine *e, int64_t extra) {
     Dev &d = e->d;
-    compact_host(e);
-    const int64_t n = d.n;
-    // destination queues -> one slab of rows, every queue contiguous, with room for queues that are replaced later
     std::vector<int64_t> beg((size_t)e->cap, 0);
     std::vector<int32_t> len((size_t)e->cap, 0);
     int64_t rows = 0;
-    for (int64_t a = 0; a < n; a++) {
+    for (int64_t a = 0; a < d.n; a++) {
+        if (!e->h_alive[(size_t)a]) continue;
         beg[(size_t)a] = rows;
         len[(size_t)a] = (int32_t)(e->h_q[(size_t)a].size() / 3);
         rows += len[(size_t)a];
     }
-    if ((size_t)(3 * rows) > e->q.n || e->q.n == 0) {
-        size_t want = (size_t)std::max<int64_t>(3 * rows * 2, 3 * 4096);
+    if ((size_t)(3 * (rows + extra)) > e->q.n || e->q.n == 0) {
+        size_t want = (size_t)std::max<int64_t>(3 * (rows + extra) * 2, 3 * 4096);
         HIPCHK(e, e->q.alloc(want));
     }
     d.q = e->q.p;
     d.qcap = (int64_t)(e->q.n / 3);
     e->q_top = rows;
     std::vector<double> flat((size_t)(3 * rows), 0.0);
-    for (int64_t a = 0; a < n; a++) {
+    for (int64_t a = 0; a < d.n; a++) {
+        if (!e->h_alive[(size_t)a]) continue;
         const std::vector<double> &qa = e->h_q[(size_t)a];
         std::copy(qa.begin(), qa.end(), flat.begin() + 3 * beg[(size_t)a]);
     }
     if (!flat.empty()) HIPCHK(e, hipMemcpy(e->q.p, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->qbeg.p, beg.data(), beg.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->qlen.p, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return CSF_OK;
+}
+
+// The slab is full of queues that were replaced or whose road users left: write the live queues afresh (the host holds
+// every queue as it was last set; the pointers into them live on the device and stay as they are).
+int compact_slab(csf_engine *e, int64_t extra) {
+    int rc = flush_pending(e);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->main));                  // ticks in flight read the old slab
+    return upload_queues(e, extra);
+}
+
+int upload_all(csf_engine *e) {
+    if (!e->dirty) return flush_pending(e);
+    Dev &d = e->d;
+    compact_host(e);
+    const int64_t n = d.n;
+    int qrc = upload_queues(e, 0);
+    if (qrc) return qrc;
     HIPCHK(e, hipMemcpy(e->alive.p, e->h_alive.data(), e->h_alive.size(), hipMemcpyHostToDevice));
     e->dev_alive = e->h_alive;
 #define H2D(vec, buf) HIPCHK(e, hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
@@ -887,7 +954,7 @@ int read_rows(csf_engine *e, const T *dev, int comps, T *out, bool row_major) {
 
 // entry points that index the device arrays by road user (replay, history, sharding) want slots == population order
 int ensure_compact(csf_engine *e) {
-    bool identity = e->free_slots.empty() && (int64_t)e->order.size() == e->d.n;
+    bool identity = e->free_tail.empty() && e->free_recent.empty() && (int64_t)e->order.size() == e->d.n;
     for (size_t i = 0; identity && i < e->order.size(); i++) identity = e->order[i] == (int32_t)i;
     if (identity) return CSF_OK;
     int rc = download_all(e);
@@ -1006,7 +1073,9 @@ csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t dev
     }
     csf_engine *e = new csf_engine();
     e->device = device;
-    e->cap = n_capacity;
+    e->cap_user = n_capacity;
+    // a binned population keeps up to 4096 sentinel slots behind its real batches for arrivals (rebin(), csf_add_agents)
+    e->cap = n_capacity + (n_capacity >= BIN_MIN_AGENTS ? std::min<int64_t>(TAIL_SLOTS, n_capacity / 4) : 0);
     e->d.p = *params;
     derive_consts(e);
     auto bail = [&](const char *what) {
@@ -1072,16 +1141,19 @@ int32_t csf_num_states(const csf_engine *e) { return e ? e->d.ns : 0; }
 int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired) {
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!s0 || !v_desired))) return fail(e, CSF_E_ARG, "csf_add_agents: bad arguments");
-    if ((int64_t)e->order.size() + n > e->cap) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap);
+    if ((int64_t)e->order.size() + n > e->cap_user) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap_user);
     if (e->world > 1 && e->nccl) return fail(e, CSF_E_STATE, "population is frozen once the shard communicator exists");
     if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
     Dev &d = e->d;
-    const int64_t reuse = std::min<int64_t>(n, (int64_t)e->free_slots.size());
+    const int64_t reuse = std::min<int64_t>(n, (int64_t)(e->free_tail.size() + e->free_recent.size()));
     // collected for the device when its copy is current, the new slots have a place in the binned order (slot < n_pad)
     // and the start rows fit behind the queues already in the slab
-    const bool patch = can_patch_device(e) && d.n + (n - reuse) <= d.n_pad &&
-                       e->q_top + (int64_t)(e->pend.rows.size() / 3) + n <= d.qcap;
+    bool patch = can_patch_device(e) && d.n + (n - reuse) <= d.n_pad;
+    if (patch && e->q_top + (int64_t)(e->pend.rows.size() / 3) + n > d.qcap) {
+        int rc = compact_slab(e, n);
+        if (rc) return rc;
+    }
     if (!patch) {
         int rc = prepare_mutation(e);
         if (rc) return rc;
@@ -1091,12 +1163,20 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     const csf_params &p = d.p;
     for (int64_t k = 0; k < n; k++) {
         int64_t a;
-        if (!e->free_slots.empty()) {
-            a = e->free_slots.back();
-            e->free_slots.pop_back();
+        bool tail = true;
+        if (!e->free_tail.empty()) {                             // the next place of the sentinel tail
+            a = e->free_tail.back();
+            e->free_tail.pop_back();
+        } else if (patch ? d.n < d.n_pad : e->free_recent.empty()) {   // a fresh slot: the tail continues there
+            a = d.n++;
+        } else if (!e->free_recent.empty()) {                    // (inside a real batch: only when nothing else is left)
+            a = e->free_recent.back();
+            e->free_recent.pop_back();
+            tail = false;
         } else {
             a = d.n++;
         }
+        if (tail) e->tail_used++;
         const double *s = s0 + k * ns;
         e->h_vdes[a] = v_desired[k];
         e->h_q[a].assign({s[0], s[1], 0.0});                     // vehicle.py:183-185
@@ -1143,7 +1223,15 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     }
     d.n_live = (int64_t)e->order.size();
     e->order_dirty = true;
-    if (!patch) set_shard(e);
+    if (!patch) {
+        set_shard(e);
+    } else {
+        const int64_t n_src = e->tail_tracked ? std::min(d.n_pad, (e->live_at_rebin + e->tail_used + 63) / 64 * 64) : d.n_pad;
+        if (n_src > d.n_src || !e->tail_tracked) {
+            d.n_src = std::max(n_src, d.n_src);
+            set_chunks(e);
+        }
+    }
     return CSF_OK;
 }
 
@@ -1174,7 +1262,7 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         }
         e->h_alive[(size_t)a] = 0;
         e->h_q[(size_t)a].clear();
-        e->free_slots.push_back(a);
+        e->free_recent.push_back(a);
         if (!patch) continue;
         if (e->pend_spawn_at[(size_t)a] >= 0) {                  // added and removed within one batch: never reaches the device
             const int32_t at = e->pend_spawn_at[(size_t)a];
@@ -1213,7 +1301,12 @@ int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int
     if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
     // on a current device copy the new queues are appended to the slab and the slots pointed at them
-    const bool patch = can_patch_device(e) && e->q_top + (int64_t)(e->pend.rows.size() / 3) + total <= e->d.qcap;
+    const bool patch = can_patch_device(e);
+    if (patch && e->q_top + (int64_t)(e->pend.rows.size() / 3) + total > e->d.qcap) {
+        // (the queues being replaced are still counted among the live ones: room for both)
+        int rc = compact_slab(e, total);
+        if (rc) return rc;
+    }
     if (!patch) {
         int rc = prepare_mutation(e);
         if (rc) return rc;

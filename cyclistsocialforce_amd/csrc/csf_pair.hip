@@ -270,7 +270,7 @@ __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_
     const int64_t per = d.chunk_units;  // blockIdx.y selects a chunk of sources, in units of 64 records
     ibeg = (int64_t)blockIdx.y * per * WAVE;
     iend = ibeg + per * WAVE;
-    if (iend > d.n_pad) iend = d.n_pad;
+    if (iend > d.n_src) iend = d.n_src;   // (the places behind hold sentinels only, csf_engine.hip: rebin)
 }
 
 // One LDS load per value: hipcc would otherwise merge the loads of (x, y) and (c, s) of ONE record into
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
     if (CLASSIFY && d.bnd_next != nullptr && blockIdx.y == 0) {
-        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_pad; b += (int64_t)gridDim.x * WPB)
+        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
 
@@ -385,6 +385,12 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     auto pop = [&](int u, auto full) {
         constexpr bool FULL = decltype(full)::value;
         const int n = FULL ? CHUNK : (qlen < CHUNK ? qlen : CHUNK);
+#ifdef CSF_NO_POP       // timing-only build (tools/): classification, tests and queue traffic without the field
+        ax[u] += (float)n;
+        qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
+        qlen = __builtin_amdgcn_readfirstlane(qlen - n);
+        return;
+#endif
         int i0 = queue[wave][(qhead + lane) & (QCAP - 1)];
         int i1 = queue[wave][(qhead + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
@@ -399,6 +405,12 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // the last (at most 64) queued sources of a receiver: one per lane through the unpacked field - about 60 % of the
     // instructions of a packed evaluation whose second half would be empty
     auto pop_tail = [&](int u) {
+#ifdef CSF_NO_POP
+        ax[u] += (float)qlen;
+        qhead = __builtin_amdgcn_readfirstlane((qhead + qlen) & (QCAP - 1));
+        qlen = 0;
+        return;
+#endif
         const bool v = lane < qlen;
         const int o = v ? (int)queue[wave][(qhead + lane) & (QCAP - 1)] : 0;
         const float4 q = make_float4(*(const float *)((const char *)tx + o), *(const float *)((const char *)ty + o),
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
     if (d.bnd_next != nullptr && blockIdx.y == 0) {   // the next tick's bounding circles (see pair_cull_kernel)
-        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_pad; b += (int64_t)gridDim.x * WPB)
+        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
     if (ibeg >= iend) return;
