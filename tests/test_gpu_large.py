@@ -459,10 +459,54 @@ def test_population_changes_on_the_device(amd, model):
     assert A.shape == B.shape and np.percentile(np.abs(A[:, :2] - B[:, :2]).max(axis=1), 99) < 2e-5
     pa, pb = engines[0].state(with_nav=True)[1], engines[1].state(with_nav=True)[1]
     assert np.array_equal(pa, pb)
-    # many replaced queues overflow the slab: the engine falls back to a rebuild and carries on
+    # many replaced queues overflow the slab: the incremental engine writes the live queues afresh (the pointers into
+    # them stay on the device) and carries on like the engine that rebuilds everything
+    m = engines[0].n
+    for e in engines:
+        for _ in range(12):
+            e.set_dest_queue(np.arange(m), np.arange(m + 1) * 4, dq3[:m].reshape(-1, 3), reset=2)
+            e.step(1)
+    (A, pa), (B, pb) = engines[0].state(with_nav=True)[:2], engines[1].state(with_nav=True)[:2]
+    assert np.array_equal(pa, pb)
+    assert np.percentile(np.abs(A[:, :2] - B[:, :2]).max(axis=1), 99) < 5e-5      # (another 12 ticks of amplification)
     e = engines[0]
-    m = e.n
-    for _ in range(12):
-        e.set_dest_queue(np.arange(m), np.arange(m + 1) * 4, dq3[:m].reshape(-1, 3), reset=2)
-        e.step(1)
     assert np.isfinite(e.state()).all() and e.n == m           # (the queues handed out here are other agents': no status check)
+
+
+def test_arrivals_in_the_sentinel_tail(amd):
+    """N = 16 384 with arrivals and departures EVERY tick: the arrivals take the places of the sentinel tail of the binned
+    order, which get source chunks of their own behind the sixteen full tiles, until the next re-binning sorts them in
+    (csf_engine.hip: rebin, set_chunks).  The repulsive sums of old and new road users against the oracle's on the
+    population as it is after 1, 5 and 14 such ticks."""
+    n, box = 16384, 200.0
+    s0, off, dq = population(n + 4096, box, seed=21)
+    dq3 = dq.reshape(-1, 4, 3)
+    p = orc.default_params("twod")
+    e = amd.Engine(amd.pod("twod"), n)
+    e.set_incremental(True)
+    e.add_agents(s0[:n, :5], 5.0)
+    e.set_dest_queue(np.arange(n), np.arange(n + 1) * 4, dq3[:n].reshape(-1, 3), reset=True)
+    e.step(40)                                                   # (past the first re-binning period)
+    rng = np.random.default_rng(5)
+    fresh, k = n, 160
+    for tick in range(14):
+        kill = np.sort(rng.choice(n, k, replace=False))
+        new = np.arange(fresh, fresh + k)
+        fresh += k
+        e.remove_agents(kill)
+        e.add_agents(s0[new, :5], 5.0)
+        e.set_dest_queue(np.arange(n - k, n), np.arange(k + 1) * 4, dq3[new].reshape(-1, 3), reset=True)
+        e.step(1)
+        if tick in (0, 4, 13):
+            assert e.n == n
+            e.calc_forces()                                      # of the state as it is now
+            fdx, fdy, frx, fry = e.force_parts()
+            st = e.state()
+            recv = np.concatenate([np.arange(0, n - k, 211), np.arange(n - k, n, 7)])    # old ones and this tick's arrivals
+            ox, oy = orc.column_sums(p, st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv)
+            cx, cy = clamped(ox, oy, fdx[recv], fdy[recv])
+            err = max(np.abs(frx[recv] - cx).max(), np.abs(fry[recv] - cy).max()) / max(np.hypot(cx, cy).max(), 1.0)
+            print(f"  tick {tick}: clamped repulsive sums vs oracle {err:.1e}")
+            assert err < 1e-4
+    assert (e.status() == 0).all() and np.isfinite(e.state()).all()
+    e.close()
