@@ -67,6 +67,11 @@ typedef struct csfo_params {
 
 typedef struct csfo {
     csfo_params p;
+    /* per-vehicle parameter sets (every reference vehicle owns a params object: vehicle.py:64-204): class table and the
+     * class of every agent; NULL = everyone uses p */
+    int n_classes;
+    csfo_params *ptab;
+    uint8_t *pcls;
     int n, ns;
     double *s;        /* [n][6] */
     double *vdes;     /* [n]  params.v_desired_default per agent (demoCSFstandalone.py:104-113) */
@@ -247,6 +252,7 @@ void csfo_road_forces(int64_t nv, const double *vx, const double *vy, const doub
 /* ----------------------------------------------- destination queue + nav state machine ---- */
 
 static inline double *S(csfo_t *o, int a) { return o->s + 6 * (size_t)a; }
+static inline const csfo_params *PA(const csfo_t *o, int a) { return o->pcls ? &o->ptab[o->pcls[a]] : &o->p; }
 static inline int qlen(csfo_t *o, int a) { return (int)(o->qoff[a + 1] - o->qoff[a]); }
 static inline double *qrow(csfo_t *o, int a, int k) { return o->dq + 3 * (o->qoff[a] + k); }
 static inline double *trj(csfo_t *o, int a, int row) {
@@ -268,7 +274,7 @@ static void update_destination(csfo_t *o, int a) {
     uint8_t *z = o->znav + 3 * a;
     if (z[1] || z[2]) return;                                      /* :567-568 */
     int K = qlen(o, a);
-    if (dnext <= o->p.d_arrived_inter) {                           /* :571-574 */
+    if (dnext <= PA(o, a)->d_arrived_inter) {                           /* :571-574 */
         int np1 = o->ptr[a] + 1;
         o->ptr[a] = np1 < K - 1 ? np1 : K - 1;
     }
@@ -281,7 +287,7 @@ static void update_destination(csfo_t *o, int a) {
 
 /* vehicle.py:354-457 */
 static void update_nav_state(csfo_t *o, int a, double *vd_out, double *ddest_out) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     uint8_t *zn = o->znav + 3 * a;
     double *zp = o->znavp + 4 * a, *s = S(o, a);
     int stop = qrow(o, a, o->ptr[a])[2] != 0.0;
@@ -463,7 +469,7 @@ int csfo_spline20(int m, const double *px, const double *py, double out[20][6]) 
 
 /* vehicle.py:1416-1558 */
 static void twod_dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     const int nSplV = 4, nSplpnts = 20, ipred = 3, ipredlast = 5;  /* :1444-1448 */
     double *s = S(o, a);
     update_destination(o, a);                                      /* :1451 */
@@ -563,7 +569,7 @@ static void dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
 
 /* vehicle.py:1218-1245 with dynamics.py:33-54 (ki = kd = 0) */
 static void bike_control(csfo_t *o, int a, double Fx, double Fy, double *acc, double *omega) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     double *s = S(o, a), *dest = qrow(o, a, o->ptr[a]);
     double theta = atan2(Fy, Fx);                                  /* :1223 */
     double v = sqrt(pow(Fx, 2) + pow(Fy, 2));                      /* :1224 */
@@ -578,7 +584,7 @@ static void bike_control(csfo_t *o, int a, double Fx, double Fy, double *acc, do
 
 /* vehicle.py:1247-1272 */
 static void bike_move(csfo_t *o, int a, double acc, double omega) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     double *s = S(o, a);
     acc = thresh(acc, p->a_max[0], p->a_max[1]);                   /* :1249 */
     double delta = csfo_limit_angle(s[4] + p->t_s * omega);        /* :1254 */
@@ -741,7 +747,7 @@ static void invpend_closed_loop(const csfo_params *p, double v, double A[25], do
  * constant input = the block matrix exponential [[A h, B h], [0, 0]]) */
 static void invpend_step_yaw(csfo_t *o, int a, double Fx, double Fy, double *psi, double *delta,
                              double *theta) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     double A[25], B[5], M[36], E[36];
     invpend_closed_loop(p, S(o, a)[3], A, B);                      /* :1829 (speed already updated) */
     double psi_d = atan2(Fy, Fx);                                  /* :1832 */
@@ -765,7 +771,7 @@ static void invpend_step_yaw(csfo_t *o, int a, double Fx, double Fy, double *psi
 
 /* vehicle.py:1932-1950 */
 static void invpend_update_riding_state(csfo_t *o, int a) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     double *s = S(o, a);
     uint8_t *zr = o->zrid + 2 * a;
     int cvwalk = s[3] < p->v_max_walk;                             /* :1939 */
@@ -784,7 +790,7 @@ static void invpend_update_riding_state(csfo_t *o, int a) {
 /* dynamics.py:996-1079; the implicit-midpoint system is solved in closed form (yaw equation linear,
  * position explicit given yaw) where the reference runs MINPACK lm to ~1.5e-8 */
 static void planarpoint_step(csfo_t *o, int a, double Fx, double Fy) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     double *s = S(o, a), *x = o->xdyn + 3 * a;
     double vd = sqrt(Fx * Fx + Fy * Fy);                           /* :1018 */
     double acc = thresh(p->k_p_v * (vd - o->vdyn[a]), p->a_max[0], p->a_max[1]); /* :1021-1022 */
@@ -845,7 +851,7 @@ void csfo_planarbike_gains(const csfo_params *p, double v, double Kx[2], double 
 
 /* PlanarTwoWheelerDynamics.step (dynamics.py:225-258) + PPointSpeedDynamics.step (dynamics.py:160-175) */
 static void planarbike_step(csfo_t *o, int a, double Fx, double Fy) {
-    const csfo_params *p = &o->p;
+    const csfo_params *p = PA(o, a);
     double *s = S(o, a), *x = o->xdyn + 3 * a;                      /* x = (delta, psi), unwrapped */
     double Kx[2], Ku;
     csfo_planarbike_gains(p, s[3], Kx, &Ku);                       /* :228: gains for the current speed */
@@ -880,14 +886,15 @@ void csfo_calc_forces_range(csfo_t *o, int lo, int hi) {
         double rx = 0, ry = 0;
         if (n > 1) {                                               /* :813, :825 */
             for (int i = 0; i < n; i++) {
-                if (csfo_untracked(p->hfov, p->priority_rule, i, j, o->sx[i], o->sy[i], o->sx[j],
+                const csfo_params *pi = PA(o, i);                  /* the field and the hfov of vehicle i: :733-735, 815 */
+                if (csfo_untracked(pi->hfov, p->priority_rule, i, j, o->sx[i], o->sy[i], o->sx[j],
                                    o->sy[j], o->spsi[j]))
                     continue;                                      /* :815-823 */
                 double gx, gy;
                 if (p->model == CSFO_BICYCLE)
-                    csfo_pair_bicycle(p, o->sx[i], o->sy[i], o->spsi[i], o->sv[i], o->sx[j], o->sy[j], &gx, &gy);
+                    csfo_pair_bicycle(pi, o->sx[i], o->sy[i], o->spsi[i], o->sv[i], o->sx[j], o->sy[j], &gx, &gy);
                 else
-                    csfo_pair_twod(p, o->sx[i], o->sy[i], o->spsi[i], o->sx[j], o->sy[j], o->spsi[j], &gx, &gy);
+                    csfo_pair_twod(pi, o->sx[i], o->sy[i], o->spsi[i], o->sx[j], o->sy[j], o->spsi[j], &gx, &gy);
                 rx += gx;                                          /* :842-843 column sum */
                 ry += gy;
             }
@@ -913,10 +920,10 @@ void csfo_calc_forces_range(csfo_t *o, int lo, int hi) {
 
 /* vehicle.*.step for agents [lo, hi) with the forces of csfo_calc_forces_range — intersection.py:891-892 */
 void csfo_integrate_range(csfo_t *o, int lo, int hi) {
-    const csfo_params *p = &o->p;
-    int L = p->traj_len;
+    int L = o->p.traj_len;
 #pragma omp parallel for schedule(static)
     for (int a = lo; a < hi; a++) {
+        const csfo_params *p = PA(o, a);
         double *s = S(o, a), Fx = o->Fx[a], Fy = o->Fy[a];
         double acc, om;
         switch (p->model) {
@@ -1115,7 +1122,24 @@ void csfo_destroy(csfo_t *o) {
     free(o->vdyn); free(o->sx); free(o->sy); free(o->spsi); free(o->sv); free(o->Fx); free(o->Fy);
     free(o->Fdx); free(o->Fdy); free(o->Frx); free(o->Fry); free(o->status);
     free(o->vx); free(o->vy); free(o->vF0); free(o->vsig);
+    free(o->ptab); free(o->pcls);
     free(o);
+}
+
+/* every reference vehicle owns its params object (vehicle.py:64-204): a table of parameter sets and the set of every
+ * agent.  Model, t_s and traj_len are those of the population (the sets of one Scenario share the clock). */
+void csfo_set_classes(csfo_t *o, int n_classes, const csfo_params *tab, const uint8_t *cls) {
+    free(o->ptab);
+    free(o->pcls);
+    o->ptab = NULL;
+    o->pcls = NULL;
+    o->n_classes = 0;
+    if (n_classes <= 0) return;
+    o->n_classes = n_classes;
+    o->ptab = (csfo_params *)malloc(sizeof(csfo_params) * (size_t)n_classes);
+    memcpy(o->ptab, tab, sizeof(csfo_params) * (size_t)n_classes);
+    o->pcls = (uint8_t *)malloc((size_t)(o->n > 0 ? o->n : 1));
+    memcpy(o->pcls, cls, (size_t)o->n);
 }
 
 /* edges as CSR over vertices with one (F0, sigma) per edge — intersection.py:222-224 */

@@ -133,6 +133,7 @@ def lib():
         L.csfo_create.restype = C.c_void_p
         L.csfo_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_destroy.argtypes = [C.c_void_p]
+        L.csfo_set_classes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.csfo_set_road.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_step.argtypes = [C.c_void_p, C.c_int]
         for f in ("csfo_calc_forces_range", "csfo_integrate_range", "csfo_update_snapshot_range"):
@@ -290,6 +291,13 @@ class Population:
                 self.h = None
         except Exception:
             pass
+
+    def set_classes(self, classes, cls):
+        """per-vehicle parameter sets: `classes` a list of Params, `cls[a]` the set of agent a"""
+        tab = (Params * len(classes))(*classes)
+        cls = np.ascontiguousarray(cls, dtype=np.uint8)
+        assert cls.shape == (self.n,) and (len(classes) == 0 or cls.max() < len(classes))
+        lib().csfo_set_classes(self.h, len(classes), tab, _p(cls))
 
     def set_road(self, off, verts, F0, sigma):
         off = np.ascontiguousarray(off, dtype=np.int64)

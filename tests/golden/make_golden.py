@@ -635,11 +635,68 @@ def gen_planarbike():
     save("planarbike", **out)
 
 
+# ----------------------------------------------------------------------------
+# (13) populations whose vehicles own DIFFERENT parameter sets — vehicle.py:64-204 (params per vehicle),
+#      vehicle.py:1592-1612 (the field of vehicle i with ITS parameters), intersection.py:733-735 (its hfov)
+# ----------------------------------------------------------------------------
+HETERO_RECIPES = {
+    "twod": [
+        {},
+        dict(hfov=1.1 * np.pi, f_0=10.0, sigma_0=0.6, sigma_1=5.5),
+        dict(hfov=1.0, e_0=0.9, e_1=0.4, sigma_2=0.25, sigma_3=4.0, d_arrived_inter=3.0, k_p_v=13.0),
+        dict(hfov=2 * np.pi, f_0=0.0, v_max_riding=[-1.0, 5.0], a_max=[-2.0, 0.8]),
+    ],
+    "bicycle": [
+        {},
+        dict(hfov=1.1 * np.pi, p_0=40.0, p_decay=4.0),
+        dict(hfov=1.0, p_decay=6.0, d_arrived_inter=3.0, k_p_v=13.0, l=1.2),
+        dict(v_max_riding=[-1.0, 5.0], k_p_delta=8.0, a_max=[-6.0, 6.0], delta_max=1.0),
+    ],
+    "invpend": [
+        {},
+        dict(hfov=1.1 * np.pi, f_0=10.0, h=1.1, m=80.0),
+        dict(hfov=1.0, e_0=0.9, k_p_v=12.0, v_max_walk=1.2, delta_max=1.2, d_arrived_inter=2.5),
+        dict(f_0=0.0, v_max_riding=[-1.0, 6.0], a_max=[-2.5, 0.8], l_1=0.55, l_2=0.5),
+    ],
+}
+HETERO_PARAMS = {"twod": rp.InvPendulumBicycleParameters, "bicycle": rp.BicycleParameters,
+                 "invpend": rp.InvPendulumBicycleParameters}
+
+
+def gen_hetero():
+    import json
+    rng = np.random.default_rng(1414)
+    out = {}
+    for model, n, box, ticks in (("twod", 16, 28.0, 250), ("bicycle", 12, 28.0, 200), ("invpend", 10, 24.0, 150)):
+        recipes = HETERO_RECIPES[model]
+        ns = NSTATES[model]
+        vs, cls = [], []
+        for k in range(n):
+            s0 = np.zeros(ns)
+            s0[0] = rng.uniform(0, box)
+            s0[1] = rng.uniform(0, box)
+            s0[2] = rng.uniform(-np.pi, np.pi)
+            s0[3] = rng.uniform(3, 4.8)
+            c = k % len(recipes)
+            v = make_vehicle(model, s0, vdes=rng.uniform(4, 4.9), id=str(k), params=HETERO_PARAMS[model](**recipes[c]))
+            d = np.array([15.0, 29.0, 30.0])
+            v.setDestinations(s0[0] + d * np.cos(s0[2]), s0[1] + d * np.sin(s0[2]))
+            vs.append(v)
+            cls.append(c)
+        s0, vdes, off, dq = pop_arrays(vs)
+        S, Ft = run_population(vs, ticks, every=10)
+        out.update({f"{model}_s0": s0, f"{model}_vdes": vdes, f"{model}_off": off, f"{model}_dq": dq,
+                    f"{model}_cls": np.array(cls), f"{model}_S": S, f"{model}_F": Ft,
+                    f"{model}_recipes": np.array(json.dumps(recipes))})
+    save("hetero", **out)
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike"]
+    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero"]
     gens = {"pair": gen_pair_fields, "masks": gen_masks_and_totals, "control": gen_control_move,
             "dest": gen_dest_force, "pp": gen_planarpoint_steps, "road": gen_road,
             "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep,
-            "planarbike": gen_planarbike}
+            "planarbike": gen_planarbike, "hetero": gen_hetero}
     for w in which:
         gens[w]()

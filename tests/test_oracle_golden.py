@@ -222,3 +222,28 @@ def test_planarbike_against_reference(golden):
             pop.step(10)
             np.testing.assert_allclose(pop.state(), S[k], rtol=0, atol=1e-9, err_msg=f"{tag} sample {k}")
         np.testing.assert_allclose(np.c_[pop.forces()], g[f"{tag}_F"][-1], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("model,tol", [("twod", 1e-9), ("bicycle", 1e-9), ("invpend", 1e-9)])
+def test_population_with_individual_parameter_sets(golden, model, tol):
+    """Every reference vehicle owns its params object (vehicle.py:64-204): the field of vehicle i is evaluated with ITS
+    f_0 / sigma / e (vehicle.py:1592-1612; p_0 / p_decay for the Bicycle field), masked with ITS hfov
+    (intersection.py:733-735), and it steers, accelerates and arrives with its own limits and gains.  Four parameter sets
+    dealt round-robin over 10-16 vehicles, trajectories captured from the literal reference (make_golden.py: gen_hetero)."""
+    from conftest import hetero_classes
+
+    g = golden("hetero")
+    pods, cls = hetero_classes(g, model)
+    classes = [orc.Params.from_buffer_copy(bytes(p)) for p in pods]
+    pop = orc.Population(classes[0], g[f"{model}_s0"], g[f"{model}_vdes"], g[f"{model}_off"], g[f"{model}_dq"])
+    pop.set_classes(classes, cls)
+    S, F = g[f"{model}_S"], g[f"{model}_F"]
+    for k in range(1, S.shape[0]):
+        pop.step(10)
+        np.testing.assert_allclose(pop.state(), S[k], rtol=tol, atol=tol * 10, err_msg=f"{model} sample {k}")
+        fx, fy = pop.forces()
+        np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=100 * tol, atol=100 * tol, err_msg=f"{model} forces {k}")
+    # and the uniform oracle on the same start does NOT follow it: the parameter sets matter
+    uni = orc.Population(classes[0], g[f"{model}_s0"], g[f"{model}_vdes"], g[f"{model}_off"], g[f"{model}_dq"])
+    uni.step(10 * (S.shape[0] - 1))
+    assert np.abs(uni.state()[:, :2] - S[-1][:, :2]).max() > 1e-2
