@@ -19,7 +19,7 @@ ST_SPLINE, ST_NAN, ST_NAVSTATE, ST_UNCONTROLLABLE = 1, 2, 4, 8
 # every symbol include/csf.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "csf_create", "csf_destroy", "csf_last_error", "csf_abi_version", "csf_add_agents", "csf_remove_agents",
-    "csf_set_dest_queue", "csf_set_road_vertices", "csf_set_params", "csf_set_v_desired",
+    "csf_set_dest_queue", "csf_set_road_vertices", "csf_set_params", "csf_set_param_classes", "csf_set_agent_class", "csf_set_v_desired",
     "csf_set_priority_rule", "csf_push_state", "csf_num_agents", "csf_num_states", "csf_step", "csf_sync",
     "csf_calc_forces", "csf_apply_forces", "csf_replay_forces", "csf_dest_force", "csf_get_state", "csf_get_forces",
     "csf_get_force_parts", "csf_status", "csf_enable_history", "csf_get_history", "csf_pair_force",
@@ -83,6 +83,8 @@ def load():
     L.csf_set_dest_queue.argtypes = [vp, i64, vp, vp, dp, i32]
     L.csf_set_road_vertices.argtypes = [vp, i32, vp, dp, dp, dp]
     L.csf_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.csf_set_param_classes.argtypes = [vp, i32, C.POINTER(Params)]
+    L.csf_set_agent_class.argtypes = [vp, i64, vp, vp]
     L.csf_set_v_desired.argtypes = [vp, i64, vp, dp]
     L.csf_set_priority_rule.argtypes = [vp, i32]
     L.csf_push_state.argtypes = [vp, i64, vp, dp]
@@ -122,7 +124,7 @@ def load():
     L.csf_update_nav_state.argtypes = [vp, i64, vp, vp, dp, dp]
     L.csf_set_dest_pointer.argtypes = [vp, i64, vp, vp]
     L.csf_set_incremental.argtypes = [vp, i32]
-    if L.csf_abi_version() != 2:
-        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 2")
+    if L.csf_abi_version() != 3:
+        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 3")
     _lib = L
     return L

@@ -50,7 +50,24 @@ struct Agent {
     uint32_t st;
     double cpsi, spsi;  // cos / sin of psi when the integrator has just computed them (cs_fresh), for the fp32 record
     bool cs_fresh;
+    // the parameter set of this road user (vehicle.py:64-204: every vehicle owns one): the engine's only one in the kernel
+    // arguments, or its row of the class table; pb: the PlanarBicycle step matrices that belong to it (Dev::pb)
+    const csf_params *p;
+    const double *pb;
 };
+
+// HET: the population holds more than one parameter set (csf_set_param_classes)
+template <bool HET>
+__device__ __forceinline__ void agent_params(const Dev &d, int64_t a, Agent &g) {
+    if (HET) {
+        const int c = d.cls[a];
+        g.p = d.ptab + c;
+        g.pb = d.pbtab + 7 * c;
+    } else {
+        g.p = &d.p;
+        g.pb = d.pb;
+    }
+}
 
 __device__ __forceinline__ double qx(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k)]; }
 __device__ __forceinline__ double qy(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k) + 1]; }
@@ -68,7 +85,7 @@ __device__ __forceinline__ double dest_dist(const Dev &d, const Agent &g) {
 __device__ void update_destination(const Dev &d, Agent &g) {
     if (g.zn != 0) return;                                    // :567-568
     double dnext = dest_dist(d, g);
-    if (dnext <= d.p.d_arrived_inter) g.ptr = min(g.ptr + 1, g.K - 1);   // :571-574
+    if (dnext <= g.p->d_arrived_inter) g.ptr = min(g.ptr + 1, g.K - 1);   // :571-574
     if (g.ptr < g.K - 1) {                                    // :577-583
         double ex = qx(d, g, g.ptr + 1) - g.x, ey = qy(d, g, g.ptr + 1) - g.y;
         if (sqrt(ex * ex + ey * ey) < dnext) g.ptr += 1;
@@ -77,7 +94,7 @@ __device__ void update_destination(const Dev &d, Agent &g) {
 
 // vehicle.py:354-457.  Returns the desired speed; ddest through the reference argument.
 __device__ double update_nav(const Dev &d, Agent &g, double &ddest) {
-    const csf_params &p = d.p;
+    const csf_params &p = *g.p;
     const double k = 1.5;                                     // :377
     double d0, d1;
     if (g.zn == 0) {                                          // :379-386
@@ -350,7 +367,7 @@ __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const doubl
         const double sp = sqrt(dX * dX + dY * dY);
         const double R = sp * sp * sp / fabs(dX * ddY - dY * ddX);  // :1532-1537
         const double thetacomf = 10 * (2 * PI / 360);         // :1541
-        double v = fmax(2.5, sqrt(thetacomf * d.p.g * R));    // :1542-1544
+        double v = fmax(2.5, sqrt(thetacomf * g.p->g * R));    // :1542-1544
         v = fmin(v, vd);                                      // :1545
         const double ex = X1 - X0, ey = Y1 - Y0;
         const double tmp = v / sqrt(ex * ex + ey * ey);       // :1548-1553
@@ -413,7 +430,7 @@ __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, d
 
 // vehicle.py:1218-1272 (Bicycle.control + Bicycle.move; PIDcontroller with ki = kd = 0, dynamics.py:33-54)
 __device__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) {
-    const csf_params &p = d.p;
+    const csf_params &p = *g.p;
     double theta = atan2(Fy, Fx);                             // :1223
     double vd = sqrt(Fx * Fx + Fy * Fy);                      // :1224
     double ddest = dest_dist(d, g);                           // :1226-1229
@@ -441,7 +458,7 @@ __device__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) 
 // constant input equals x+ = E11 x + E12 u with E = exp([[A h, B h],[0, 0]]).  E is formed by scaling and
 // squaring of a degree-12 Taylor polynomial (||M/2^s||_1 <= 1/2); only the 5 non-trivial rows are carried.
 __device__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, double Fy) {
-    const csf_params &p = d.p;
+    const csf_params &p = *g.p;
     const double v = g.v;
     const double iv = 1.0 / v, iv2 = iv * iv, iv3 = iv2 * iv;
     const double kx0 = 3.48203226e02 - 5.12057324e03 * iv + 1.58364873e04 * iv2 - 1.98073306e04 * iv3;
@@ -551,7 +568,7 @@ __device__ __forceinline__ int64_t a_idx(int c, int64_t cap, int64_t a) { return
 
 template <int MODEL>
 __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
-    const csf_params &p = d.p;
+    const csf_params &p = *g.p;
     const int64_t a = g.a, cap = d.cap;
     if (MODEL == CSF_BICYCLE) {                               // vehicle.py:1274-1289
         bike_control_move(d, g, Fx, Fy);
@@ -606,8 +623,8 @@ __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
         const double psi_d = atan2(Fy, Fx), v_d = sqrt(Fy * Fy + Fx * Fx);   // :231-232
         if (a > 0.0) {
             const double z0 = a * del, z1 = psu;
-            del = (d.pb_E[0] * z0 + d.pb_E[1] * z1 + d.pb_G[0] * psi_d) / a;   // :235-244
-            psu = d.pb_E[2] * z0 + d.pb_E[3] * z1 + d.pb_G[1] * psi_d;
+            del = (g.pb[0] * z0 + g.pb[1] * z1 + g.pb[4] * psi_d) / a;   // :235-244
+            psu = g.pb[2] * z0 + g.pb[3] * z1 + g.pb[5] * psi_d;
         } else {
             g.st |= CSF_ST_UNCONTROLLABLE;                    // dynamics.py:1212-1214 asserts; here the yaw loop holds still
         }
@@ -615,7 +632,7 @@ __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
         d.ppsi[g.a] = psu;
         g.psi = limit_angle(psu);                             // :246-247
         g.delta = limit_angle(del);
-        g.v = v_d + (g.v - v_d) * d.pb_ev;                    // PPointSpeedDynamics: dynamics.py:156, 175
+        g.v = v_d + (g.v - v_d) * g.pb[6];                    // PPointSpeedDynamics: dynamics.py:156, 175
         g.y += p.t_s * g.v * sin(g.psi);                      // :251-258
         g.x += p.t_s * g.v * cos(g.psi);
     } else {                                                  // PlanarPoint: dynamics.py:996-1079
@@ -647,22 +664,22 @@ __device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
 }
 
 // fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677
-__device__ __forceinline__ void write_record(const Dev &d, int64_t a, double x, double y, double psi, double v,
-                                             bool cs_fresh = false, double c = 0.0, double s = 0.0) {
+__device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, int64_t a, double x, double y, double psi,
+                                             double v, bool cs_fresh = false, double c = 0.0, double s = 0.0) {
     if (!cs_fresh) sincos(psi, &s, &c);
     const float4 q = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)c, (float)s);
     d.rec[a] = q;
     if (d.recs_valid) d.recs[d.pos[a]] = q;                   // the copy in binned order (csf_bin.hip)
     if (d.p.model == CSF_BICYCLE) {                           // vehicle.py:1062-1064 (v <= 0: e := 0)
         double e = 0.0;
-        if (v > 0.0) e = fmin(pow(v / d.p.v_max_riding[1], 0.1), 0.7);
+        if (v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
         const float2 q2 = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
         d.rec2[a] = q2;
         if (d.recs_valid) d.recs2[d.pos[a]] = q2;
     }
 }
 
-template <int MODEL>
+template <int MODEL, bool HET = false>
 __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
     const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= d.hi) return;
@@ -687,6 +704,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     g.ti = d.ti[a];
     g.st = d.status[a];
     g.cs_fresh = false;
+    agent_params<HET>(d, a, g);
 
     double fdx, fdy;
     if (phases & PH_DEST) {
@@ -755,7 +773,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         d.s[4 * cap + a] = g.delta;
         d.s[5 * cap + a] = g.theta;
         d.ti[a] = g.ti;
-        write_record(d, a, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi);
+        write_record(d, *g.p, a, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi);
         if (d.hist != nullptr) {
             int64_t t1 = d.tick + 1;
             if (t1 % d.hist_stride == 0) {
@@ -783,20 +801,24 @@ __global__ void records_kernel(const Dev d) {
         if (d.p.model == CSF_BICYCLE) d.rec2[a] = make_float2(0.0f, 1.0f);
         return;
     }
-    write_record(d, a, d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);
+    write_record(d, d.ptab[d.cls[a]], a, d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);
 }
 
 void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo) return;
     static const int bs = getenv("CSF_AGENT_BLOCK") ? atoi(getenv("CSF_AGENT_BLOCK")) : 64;   // 256 waves on 256 CUs: 0.6 us less than 64 workgroups of 4
     dim3 g((unsigned)((d.hi - d.lo + bs - 1) / bs)), b(bs);
+#define CSF_AGENT(MODEL)                                                                                             \
+    if (d.n_classes > 1) hipExtLaunchKernelGGL((agent_kernel<MODEL, true>), g, b, 0, st, t0, t1, 0, d, phases);           \
+    else hipExtLaunchKernelGGL((agent_kernel<MODEL, false>), g, b, 0, st, t0, t1, 0, d, phases)
     switch (d.p.model) {
-    case CSF_BICYCLE: hipExtLaunchKernelGGL(agent_kernel<CSF_BICYCLE>, g, b, 0, st, t0, t1, 0, d, phases); break;
-    case CSF_TWOD: hipExtLaunchKernelGGL(agent_kernel<CSF_TWOD>, g, b, 0, st, t0, t1, 0, d, phases); break;
-    case CSF_INVPEND: hipExtLaunchKernelGGL(agent_kernel<CSF_INVPEND>, g, b, 0, st, t0, t1, 0, d, phases); break;
-    case CSF_PLANARBIKE: hipExtLaunchKernelGGL(agent_kernel<CSF_PLANARBIKE>, g, b, 0, st, t0, t1, 0, d, phases); break;
-    default: hipExtLaunchKernelGGL(agent_kernel<CSF_PLANARPOINT>, g, b, 0, st, t0, t1, 0, d, phases); break;
+    case CSF_BICYCLE: CSF_AGENT(CSF_BICYCLE); break;
+    case CSF_TWOD: CSF_AGENT(CSF_TWOD); break;
+    case CSF_INVPEND: CSF_AGENT(CSF_INVPEND); break;
+    case CSF_PLANARBIKE: CSF_AGENT(CSF_PLANARBIKE); break;
+    default: CSF_AGENT(CSF_PLANARPOINT); break;
     }
+#undef CSF_AGENT
 }
 
 // Vehicle.updateDestination (vehicle.py:545-594) and Vehicle.updateNavState(stop) (vehicle.py:354-457) on their own, for
@@ -822,6 +844,7 @@ __global__ void nav_kat_kernel(const Dev d, const int32_t *idx, int64_t m, int w
     g.zd0 = d.znp[cap + a];
     g.zd1 = d.znp[2 * cap + a];
     g.st = d.status[a];
+    agent_params<true>(d, a, g);                             // (the class table is there for one parameter set as well)
     if (what & 1) {
         update_destination(d, g);
         d.ptr[a] = g.ptr;
@@ -941,7 +964,7 @@ __global__ void patch_kernel(const Dev d, const PatchHeader *hp) {
         for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
         d.status[a] = 0;
         d.alive[a] = 1;
-        write_record(d, a, s[0], s[1], s[2], s[3]);
+        write_record(d, d.p, a, s[0], s[1], s[2], s[3]);
         return;
     }
     k -= h.n_spawn;

@@ -36,8 +36,16 @@ struct Dev {
     csf_params p;
     PairConsts pc;
     // PlanarBicycle (csf_engine.hip: derive_planarbike): one exact step of z' = M z + (1/G, 0)^T u for z = (v delta / l, psi),
-    // M = [[p1 + p2, -p1 p2], [1, 0]]: z+ = pb_E z + pb_G u, the same for every speed; pb_ev = exp(-k_p_v t_s)
-    double pb_E[4], pb_G[2], pb_ev;
+    // M = [[p1 + p2, -p1 p2], [1, 0]]: z+ = E z + G u, the same for every speed.  pb = (E[4] row-major, G[2], exp(-k_p_v t_s))
+    double pb[7];
+    // Parameter sets (csf_set_param_classes; every reference vehicle owns its params object, vehicle.py:64-204): the table
+    // (n_classes >= 1 rows; row 0 == p), what derive_consts makes of each row, and the row of every slot.  With one row
+    // the kernels read p / pc / pb from their arguments; with more, the per-agent kernel and the pair kernel read the rows.
+    int32_t n_classes;
+    const csf_params *ptab;
+    const PairConsts *pctab;
+    const double *pbtab;     // [n_classes][7]
+    const uint8_t *cls;      // [cap]
     int64_t n;         // agent SLOTS in use (the highest one + 1); a slot may be dead after csf_remove_agents until it is reused
     int64_t n_live;    // road users (intersection.py n_bikes)
     int64_t cap;       // SoA stride

@@ -86,6 +86,14 @@ struct DevBuf {
 struct csf_engine {
     Dev d{};
     int device = 0;
+    // parameter sets (csf_set_param_classes): classes[0] is d.p; h_cls[slot] the set of a road user
+    std::vector<csf_params> classes;
+    std::vector<uint8_t> h_cls;
+    DevBuf<csf_params> ptab;
+    DevBuf<PairConsts> pctab;
+    DevBuf<double> pbtab;
+    DevBuf<uint8_t> cls;
+    bool classes_dirty = true;
     int64_t cap = 0;        // slots: the caller's capacity + head room for arrivals between two re-binnings (csf_create)
     int64_t cap_user = 0;   // road users the caller may have at once
     hipStream_t main = nullptr, comm = nullptr;
@@ -284,7 +292,7 @@ double far_eps() {
 void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
     const double eps = far_eps();
     PairConsts &k = e->d.pc;
-    k.rfar = (float)far_radius(e->far_kappa, e->d.n, eps);
+    k.rfar = e->classes.size() > 1 ? INFINITY : (float)far_radius(e->far_kappa, e->d.n, eps);   // (one bound per parameter set: not built)
     const csf_params &p = e->d.p;
     const bool on = std::isfinite(k.rfar) && p.model != CSF_BICYCLE && e->d.n >= 1 && p.sigma_2 < p.sigma_0 && p.sigma_3 < p.sigma_1 &&
                     !(getenv("CSF_REACH") && atoi(getenv("CSF_REACH")) == 0);
@@ -337,9 +345,7 @@ void expm_small(int n, const double *A, double *E) {
 // 0.01, input 0 for ten samples then 1, first-order hold) of the loop with K_u = 1: psi_sim = a G with G the same response
 // of z' = M z + (1, 0)^T u.  Hence a K_u = 1 / G and the controlled loop is z' = M z + (1 / G, 0)^T psi_d at EVERY speed:
 // one exact step z+ = E z + Gamma psi_d is derived here once; the kernel scales delta by a on the way in and out.
-void derive_planarbike(csf_engine *e) {
-    const csf_params &p = e->d.p;
-    Dev &d = e->d;
+void derive_planarbike(const csf_params &p, double pb[7]) {
     const double k1 = -(p.pb_poles[0] + p.pb_poles[2]), w2 = p.pb_poles[0] * p.pb_poles[2] - p.pb_poles[1] * p.pb_poles[3];
     auto step_matrices = [&](double dt, double Ad[4], double Bd0[2], double Bd1[2]) {   // first-order hold, input (1, 0)^T
         double Mx[16] = {0}, Ex[16];
@@ -362,16 +368,14 @@ void derive_planarbike(csf_engine *e) {
     }
     const double G = z1;
     step_matrices(p.t_s, Ad, Bd0, Bd1);                        // forced_response over [0, t_s], input psi_d at both ends
-    for (int i = 0; i < 4; i++) d.pb_E[i] = Ad[i];
-    d.pb_G[0] = (Bd0[0] + Bd1[0]) / G;
-    d.pb_G[1] = (Bd0[1] + Bd1[1]) / G;
-    d.pb_ev = std::exp(-p.k_p_v * p.t_s);                      // dynamics.py:156
+    for (int i = 0; i < 4; i++) pb[i] = Ad[i];
+    pb[4] = (Bd0[0] + Bd1[0]) / G;
+    pb[5] = (Bd0[1] + Bd1[1]) / G;
+    pb[6] = std::exp(-p.k_p_v * p.t_s);                        // dynamics.py:156
 }
 
-void derive_consts(csf_engine *e) {
-    const csf_params &p = e->d.p;
-    if (p.model == CSF_PLANARBIKE) derive_planarbike(e);
-    PairConsts &k = e->d.pc;
+// what the pair kernels need of one parameter set
+void derive_pair_consts(const csf_params &p, PairConsts &k) {
     k.sg0 = (float)p.sigma_0;
     k.sg1 = (float)p.sigma_1;
     k.sg2 = (float)p.sigma_2;
@@ -396,12 +400,27 @@ void derive_consts(csf_engine *e) {
     }
     k.full_circle = p.hfov >= 2 * PI_;
     k.fov_classify = 1;   // any field of view: csf_pair.hip guards the wide ones (set to 0 to fall back to exact tests)
+    k.rfar = INFINITY;
+    k.tA0 = k.tA1 = k.tB0 = k.tB1 = 0.f;
+    k.reach = 0;
+}
+
+void derive_consts(csf_engine *e) {
+    const csf_params &p = e->d.p;
+    if (p.model == CSF_PLANARBIKE) derive_planarbike(p, e->d.pb);
+    derive_pair_consts(p, e->d.pc);
     e->far_kappa = far_kappa(p);
     update_far_radius(e);
+    if (e->classes.empty()) e->classes.push_back(p);
+    e->classes[0] = p;
+    e->d.n_classes = (int32_t)e->classes.size();
+    e->classes_dirty = true;
     const char *variant = getenv("CSF_PAIR_VARIANT");
     e->d.pair_variant = variant ? atoi(variant) : 0;
     {   // no rider model moves faster than its speed clamp (vehicle.py:1258, 1876, 1905; dynamics.py:1025)
-        double vmax = std::max({std::fabs(p.v_max_riding[0]), std::fabs(p.v_max_riding[1]), std::fabs(p.v_max_walk)});
+        double vmax = 0;
+        for (const csf_params &c : e->classes)
+            vmax = std::max({vmax, std::fabs(c.v_max_riding[0]), std::fabs(c.v_max_riding[1]), std::fabs(c.v_max_walk)});
         e->d.bnd_margin = (float)(p.t_s * vmax * 1.01 + 1e-4);
     }
     e->d.back = (int32_t)(1.0 / p.t_s);
@@ -465,6 +484,8 @@ int alloc_all(csf_engine *e) {
     e->h_status.assign(cap, 0);
     e->h_q.assign(cap, {});
     e->h_alive.assign(cap, 0);
+    e->h_cls.assign(cap, 0);
+    HIPCHK(e, e->cls.alloc(cap));
     e->pend_spawn_at.assign(cap, -1);
     e->pend_requeue_at.assign(cap, -1);
     e->pend_retire_at.assign(cap, -1);
@@ -588,7 +609,7 @@ int rebin(csf_engine *e) {
         set_shard(e);
         launch_records(d, e->main);     // sentinels in the new tail (the records of the road users are rewritten as they are)
     }
-    const bool binned = d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS;
+    const bool binned = d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS && d.n_classes == 1;   // (several parameter sets: the plain kernel)
     d.classify = binned;
     update_far_radius(e);
     if (binned) {
@@ -707,7 +728,7 @@ void compact_host(csf_engine *e) {
         gather(e->h_s, 6); gather(e->h_F, 6); gather(e->h_znp, 3); gather(e->h_lti, 5);
         gather(e->h_hx, hl); gather(e->h_hy, hl);
         gather(e->h_vdes, 1); gather(e->h_ppsi, 1); gather(e->h_ptr, 1); gather(e->h_ti, 1); gather(e->h_dgood, 1);
-        gather(e->h_znav, 1); gather(e->h_zrid, 1); gather(e->h_status, 1);
+        gather(e->h_znav, 1); gather(e->h_zrid, 1); gather(e->h_status, 1); gather(e->h_cls, 1);
         std::vector<std::vector<double>> q((size_t)cap);
         for (int64_t i = 0; i < n; i++) q[(size_t)i] = std::move(e->h_q[(size_t)e->order[(size_t)i]]);
         e->h_q.swap(q);
@@ -763,10 +784,45 @@ int compact_slab(csf_engine *e, int64_t extra) {
     return upload_queues(e, extra);
 }
 
+// the table of parameter sets, what the kernels derive from each row, and the row of every slot
+int upload_classes(csf_engine *e) {
+    Dev &d = e->d;
+    const size_t K = e->classes.size();
+    if (e->ptab.n < K) {
+        HIPCHK(e, e->ptab.alloc(K));
+        HIPCHK(e, e->pctab.alloc(K));
+        HIPCHK(e, e->pbtab.alloc(7 * K));
+    }
+    std::vector<PairConsts> pc(K);
+    std::vector<double> pb(7 * K, 0.0);
+    for (size_t c = 0; c < K; c++) {
+        derive_pair_consts(e->classes[c], pc[c]);
+        pc[c].p2r = d.pc.p2r;                                    // (the rule belongs to the intersection: intersection.py:324)
+        if (e->classes[c].model == CSF_PLANARBIKE) derive_planarbike(e->classes[c], &pb[7 * c]);
+    }
+    HIPCHK(e, hipStreamSynchronize(e->main));                  // ticks in flight read the old rows
+    HIPCHK(e, hipMemcpy(e->ptab.p, e->classes.data(), K * sizeof(csf_params), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->pctab.p, pc.data(), K * sizeof(PairConsts), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->pbtab.p, pb.data(), pb.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->cls.p, e->h_cls.data(), e->h_cls.size(), hipMemcpyHostToDevice));
+    d.ptab = e->ptab.p;
+    d.pctab = e->pctab.p;
+    d.pbtab = e->pbtab.p;
+    d.cls = e->cls.p;
+    d.n_classes = (int32_t)K;
+    e->classes_dirty = false;
+    return CSF_OK;
+}
+
 int upload_all(csf_engine *e) {
+    if (e->classes_dirty) {
+        int rc = upload_classes(e);
+        if (rc) return rc;
+    }
     if (!e->dirty) return flush_pending(e);
     Dev &d = e->d;
     compact_host(e);
+    if (e->classes.size() > 1) HIPCHK(e, hipMemcpy(e->cls.p, e->h_cls.data(), e->h_cls.size(), hipMemcpyHostToDevice));   // (slots moved)
     const int64_t n = d.n;
     int qrc = upload_queues(e, 0);
     if (qrc) return qrc;
@@ -850,7 +906,8 @@ int prepare_mutation(csf_engine *e) {
 // history ring and CSF_INCREMENTAL=0 take the round trip through the host mirror (prepare_mutation / upload_all).
 bool can_patch_device(const csf_engine *e) {
     static const bool off = getenv("CSF_INCREMENTAL") && atoi(getenv("CSF_INCREMENTAL")) == 0;
-    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
+    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr &&
+           e->classes.size() == 1;   // (a spawn record carries no parameter set)
 }
 
 // a pinned, device-visible host buffer of `bytes` from the ring; waits only if the ring of four is exhausted
@@ -1181,6 +1238,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         e->h_vdes[a] = v_desired[k];
         e->h_q[a].assign({s[0], s[1], 0.0});                     // vehicle.py:183-185
         e->h_alive[a] = 1;
+        e->h_cls[a] = 0;
         e->order.push_back((int32_t)a);
         if (patch) {                                             // a record for the patch kernel, which writes the rest
             if (e->pend_retire_at[(size_t)a] >= 0) {             // the slot was freed in this batch: the spawn resets all of it
@@ -1382,6 +1440,46 @@ int csf_set_params(csf_engine *e, const csf_params *params) {
         return fail(e, CSF_E_ARG, "t_s is immutable (parameters.py:516-528)");
     e->d.p = *params;
     derive_consts(e);
+    return CSF_OK;
+}
+
+int csf_set_param_classes(csf_engine *e, int32_t n_classes, const csf_params *classes) {
+    if (!e) return CSF_E_ARG;
+    if (n_classes < 1 || n_classes > 256 || !classes) return fail(e, CSF_E_ARG, "csf_set_param_classes: 1 to 256 parameter sets");
+    for (int32_t c = 0; c < n_classes; c++) {
+        int rc = check_params(e, classes + c);
+        if (rc) return rc;
+        if (classes[c].model != e->d.p.model)
+            return fail(e, CSF_E_ARG, "parameter set %d is of another vehicle class (model %d, engine %d)", c, classes[c].model, e->d.p.model);
+        if (classes[c].t_s != e->d.p.t_s || classes[c].traj_len != e->d.p.traj_len)
+            return fail(e, CSF_E_ARG, "parameter set %d: the vehicles of one intersection share t_s (parameters.py:516-528)", c);
+    }
+    for (int32_t a : e->order)
+        if (e->h_cls[(size_t)a] >= n_classes)
+            return fail(e, CSF_E_ARG, "a road user still uses parameter set %d", (int)e->h_cls[(size_t)a]);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = flush_pending(e);                                 // (changes collected for the device assume one parameter set)
+    if (rc) return rc;
+    const int32_t rule = e->d.p.priority_rule;
+    e->classes.assign(classes, classes + n_classes);
+    for (csf_params &c : e->classes) c.priority_rule = rule;
+    e->d.p = e->classes[0];
+    derive_consts(e);
+    e->ticks_since_rebin = 1 << 20;                            // binned or not may have changed: decide again (rebin)
+    return CSF_OK;
+}
+
+int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *cls) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && (!idx || !cls))) return fail(e, CSF_E_ARG, "csf_set_agent_class: bad arguments");
+    const int64_t pop = (int64_t)e->order.size();
+    for (int64_t k = 0; k < n; k++) {
+        if (idx[k] < 0 || idx[k] >= pop) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+        if (cls[k] < 0 || cls[k] >= (int32_t)e->classes.size())
+            return fail(e, CSF_E_ARG, "parameter set %d of %d (csf_set_param_classes first)", cls[k], (int)e->classes.size());
+    }
+    for (int64_t k = 0; k < n; k++) e->h_cls[(size_t)e->order[(size_t)idx[k]]] = (uint8_t)cls[k];
+    e->classes_dirty = true;                                   // (the slots' rows are uploaded with the table)
     return CSF_OK;
 }
 

@@ -702,10 +702,22 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
 }
 
 // ---- simple kernel: every pair evaluated, masked afterwards (Bicycle field; also the TwoD field on request) --
-template <bool BICYCLE, bool P2R>
+// HET: the vehicles own different parameter sets (csf_set_param_classes).  The field of source i is evaluated with ITS
+// f_0 / sigma / e (vehicle.py:1592-1612; p_0 / p_decay: 1095-1101) and masked with ITS hfov (intersection.py:733-735):
+// the table of what derive_pair_consts makes of every set sits in LDS and each lane looks its source's row up.  No
+// cull (the far-field bound and the batch classification are per parameter set): this is the O(N^2) path of small,
+// mixed populations.
+constexpr int MAX_CLASSES = 256;
+template <bool BICYCLE, bool P2R, bool HET = false>
 __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
     __shared__ float4 tile[TILE];
     __shared__ float2 tile2[BICYCLE ? TILE : 1];
+    __shared__ PairConsts ctab[HET ? MAX_CLASSES : 1];
+    __shared__ uint8_t tcls[HET ? TILE : 1];
+    if (HET) {
+        const int words = d.n_classes * (int)(sizeof(PairConsts) / 4);
+        for (int w = threadIdx.x; w < words; w += BLOCK) ((uint32_t *)ctab)[w] = ((const uint32_t *)d.pctab)[w];
+    }
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
@@ -727,20 +739,22 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
             tile[t] = d.rec[base + t];
             if (BICYCLE) tile2[t] = d.rec2[base + t];
+            if (HET) tcls[t] = base + t < d.n ? d.cls[base + t] : (uint8_t)0;   // (padding records are sentinels of any set)
         }
         __syncthreads();
         for (int t = lane; t < cnt; t += WAVE) {
             float4 q = tile[t];
             float2 qb = BICYCLE ? tile2[t] : make_float2(0.f, 0.f);
+            const PairConsts &ks = HET ? ctab[tcls[t]] : k;   // the source's parameter set
 #pragma unroll
             for (int u = 0; u < RPW; u++) {
                 float dx = r[u].x - q.x, dy = r[u].y - q.y;  // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
-                bool in = tracked<P2R>(k.chs, r[u], dx, dy, r2);
+                bool in = tracked<P2R>(ks.chs, r[u], dx, dy, r2);
                 r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
-                if (BICYCLE) field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
-                else field_twod(k, r[u], q, dx, dy, r2, F, gx, gy);
+                if (BICYCLE) field_bicycle(ks, q, qb, dx, dy, r2, F, gx, gy);
+                else field_twod(ks, r[u], q, dx, dy, r2, F, gx, gy);
                 F = in ? F : 0.0f;
                 ax[u] += F * gx;
                 ay[u] += F * gy;
@@ -958,7 +972,8 @@ __global__ void untracked_kernel(const Dev d, uint8_t *out) {
     const float4 q = d.rec[d.order ? d.order[i] : i], rr = d.rec[d.order ? d.order[j] : j];
     const Recv r{rr.x, rr.y, rr.z, rr.w};
     const float dx = r.x - q.x, dy = r.y - q.y, r2 = dx * dx + dy * dy;
-    const bool in = (i != j) & (d.pc.p2r ? tracked<true>(d.pc.chs, r, dx, dy, r2) : tracked<false>(d.pc.chs, r, dx, dy, r2));
+    const float chs = d.pctab[d.cls[d.order ? d.order[i] : i]].chs;      // the hfov of the source's parameter set (:733-735)
+    const bool in = (i != j) & (d.pc.p2r ? tracked<true>(chs, r, dx, dy, r2) : tracked<false>(chs, r, dx, dy, r2));
     out[t] = in ? 0 : 1;
 }
 
@@ -1010,7 +1025,16 @@ void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo) return;
     const dim3 g = recv_grid(d, d.n_split);
     const bool p2r = d.pc.p2r != 0;
-    if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
+    if (d.n_classes > 1) {                         // several parameter sets: the source's own row for every pair
+        if (d.n_classes > MAX_CLASSES) return;     // (csf_set_param_classes refuses more)
+        if (d.p.model == CSF_BICYCLE) {
+            if (p2r) CSF_LAUNCH((pair_kernel<true, true, true>), g);
+            else CSF_LAUNCH((pair_kernel<true, false, true>), g);
+        } else {
+            if (p2r) CSF_LAUNCH((pair_kernel<false, true, true>), g);
+            else CSF_LAUNCH((pair_kernel<false, false, true>), g);
+        }
+    } else if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
         if (d.rpb == 32) {
             const dim3 g8 = recv_grid(d, d.n_split, 32);
             if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 8>), g8);
@@ -1032,6 +1056,7 @@ void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
 
 // which pair kernel launch_pair() takes for this engine (profiles and the bench line name it)
 const char *pair_kernel_name(const Dev &d) {
+    if (d.n_classes > 1) return "pair_kernel";
     if (d.p.model == CSF_BICYCLE) return (d.classify && d.recs_valid) ? "pair_bike_kernel" : "pair_kernel";
     if (d.pair_variant == 1) return "pair_kernel";
     return "pair_cull_kernel";

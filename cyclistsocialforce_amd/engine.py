@@ -98,6 +98,25 @@ class Engine:
         self._ck(self._lib.csf_set_params(self._h, C.byref(params)))
         self.params = params
 
+    def set_param_classes(self, classes, cls=None, idx=None):
+        """Parameter sets for a population whose vehicles own different params objects (vehicle.py:64-204): `classes` a
+        sequence of csf_params (set 0 replaces the engine's own), `cls[k]` the set of agent `idx[k]` (default: everyone)."""
+        classes = list(classes)
+        tab = (type(self.params) * len(classes))(*classes)
+        rows_first = cls is not None and len(classes) < getattr(self, "_n_classes", 1)    # no row may point beyond the table
+        if rows_first:
+            self.set_agent_class(np.arange(self.n) if idx is None else idx, cls)
+        self._ck(self._lib.csf_set_param_classes(self._h, len(classes), tab))
+        self.params = classes[0]
+        self._n_classes = len(classes)
+        if cls is not None and not rows_first:
+            self.set_agent_class(np.arange(self.n) if idx is None else idx, cls)
+
+    def set_agent_class(self, idx, cls):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        cls = np.ascontiguousarray(np.broadcast_to(np.asarray(cls, dtype=np.int32), idx.shape))
+        self._ck(self._lib.csf_set_agent_class(self._h, idx.size, _ptr(idx), _ptr(cls)))
+
     def set_v_desired(self, idx, v):
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         v = _f64(np.broadcast_to(np.asarray(v, dtype=np.float64), idx.shape))

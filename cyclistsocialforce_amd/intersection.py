@@ -172,6 +172,8 @@ class SocialForceIntersection:
         self._vd = None
         self._rule_on_device = None
         self._pod_bytes = None
+        self._class_table = None
+        self._cls = None
         self._road_sig = None
         self._pending = []        # vehicles waiting to be added to the engine
         # bulk mirror of the per-vehicle attributes the device produces (Vehicle properties read these): one
@@ -278,7 +280,6 @@ class SocialForceIntersection:
         if v.dest_force_func is not None or v.rep_force_func is not None:
             raise NotImplementedError(f"vehicle {v.id} carries a custom dest_force_func / rep_force_func: the population "
                                       "engine evaluates the class's own force functions for every agent")
-        self._check_uniform(v)
         if v._solo is not None:
             v._solo.close()
             v._solo = None
@@ -295,30 +296,53 @@ class SocialForceIntersection:
         self.vehicleY = np.vstack((self.vehicleY, [[v.s[1]]]))
         self.vehicleTheta = np.vstack((self.vehicleTheta, [[v.s[2]]]))
 
-    def _check_uniform(self, v=None):
-        """One engine holds ONE parameter set (csf_params); only `params.v_desired_default` is per vehicle.  The reference
-        evaluates every source with its own parameters (vehicle.py:1592-1612) and the mask with the source's hfov
-        (intersection.py:733-735): a vehicle whose parameters differ from vehicle 0's would silently get vehicle 0's
-        here, so it is refused.  v = None re-checks the whole population (after parameter objects were assigned to)."""
-        if not self.vehicles and v is not None:
-            return
-        first = self.vehicles[0] if self.vehicles else v
-        stamp = (id(first.params), parameters.mutation_count())
-        if getattr(self, "_uniform_ref", (None,))[0] != stamp:        # vehicle 0's parameters, flattened once per change
-            self._uniform_ref = (stamp, first._pod(0))
-        ref = self._uniform_ref[1]
-        for w in ([v] if v is not None else self.vehicles[1:]):
-            if w.params is first.params:
-                continue
-            pod = w._pod(0)
-            if bytes(pod) != bytes(ref):
-                a, b = bytes(pod), bytes(ref)
-                diff = [name for name, _ in pod._fields_
-                        if a[getattr(type(pod), name).offset:][:getattr(type(pod), name).size]
-                        != b[getattr(type(pod), name).offset:][:getattr(type(pod), name).size]]
-                raise NotImplementedError(
-                    f"vehicle {w.id!r} differs from vehicle {first.id!r} in {', '.join(diff)}: one intersection engine "
-                    "holds one parameter set; only params.v_desired_default may differ between its vehicles")
+    def _param_classes(self, vehicles=None):
+        """The parameter sets of the population.  Every reference vehicle owns its params object: the field vehicle i
+        exerts is evaluated with ITS f_0 / sigma / e (vehicle.py:1592-1612) and masked with ITS hfov
+        (intersection.py:733-735), and it moves with its own gains and limits.  The engine holds a table of up to 256
+        distinct csf_params and a row index per road user (csf_set_param_classes); `params.v_desired_default` is per
+        road user anyway.  Returns (list of PODs, vehicle 0's first; int32 row of every vehicle)."""
+        vehicles = self.vehicles if vehicles is None else vehicles
+        rule = PRIORITY_RULES.get(self.priority_rule, 0)
+        by_object, rows, pods = {}, {}, []
+        cls = np.zeros(len(vehicles), dtype=np.int32)
+        for k, v in enumerate(vehicles):
+            c = by_object.get(id(v.params))
+            if c is None:
+                pod = v._pod(rule)
+                key = bytes(pod)
+                c = rows.get(key)
+                if c is None:
+                    if pods and (pod.t_s != pods[0].t_s or pod.traj_len != pods[0].traj_len):
+                        raise NotImplementedError(f"vehicle {v.id!r}: t_s = {pod.t_s} but vehicle {vehicles[0].id!r} has "
+                                                  f"{pods[0].t_s}; the road users of one intersection share the clock")
+                    c = rows[key] = len(pods)
+                    pods.append(pod)
+                by_object[id(v.params)] = c
+            cls[k] = c
+        if len(pods) > 256:
+            raise NotImplementedError(f"{len(pods)} distinct parameter sets in one intersection; the engine's table holds 256")
+        return pods, cls
+
+    def _sync_param_classes(self):
+        """table and rows -> engine, when they changed (new road users, assignments to parameter attributes)"""
+        e = self._engine
+        n = len(self.vehicles)
+        pods, cls = self._param_classes()
+        table = tuple(bytes(p) for p in pods)
+        if table != self._class_table:
+            shrink = self._class_table is not None and len(table) < len(self._class_table)
+            if shrink:                                          # rows first: none may point beyond the new table
+                e.set_agent_class(np.arange(n), cls)
+            e.set_param_classes(pods)
+            if shrink:
+                self._cls[:n] = cls
+            self._class_table = table
+            self._pod_bytes = table[0]
+        ch = np.where(cls != self._cls[:n])[0]
+        if ch.size:
+            e.set_agent_class(ch, cls[ch])
+            self._cls[:n] = cls
 
     def add_road_user(self, user):
         """intersection.py:458-539"""
@@ -367,7 +391,7 @@ class SocialForceIntersection:
         self.vehicles = [self.vehicles[k] for k in keep]
         m = len(keep)
         if self._S is not None:
-            for a in (self._S, self._shadow, self._vd, self._ptr, self._zn, self._fx, self._fy, self._ti):
+            for a in (self._S, self._shadow, self._vd, self._ptr, self._zn, self._fx, self._fy, self._ti, self._cls):
                 a[:m] = a[keep]
         if self._traj is not None and m:
             self._traj[:, :m] = self._traj[:, keep]
@@ -420,6 +444,8 @@ class SocialForceIntersection:
             self._ti = np.zeros(cap, dtype=np.int64)
             self._rule_on_device = self.priority_rule
             self._pod_bytes = bytes(v0._pod(PRIORITY_RULES[self.priority_rule]))
+            self._class_table = (self._pod_bytes,)
+            self._cls = np.zeros(cap, dtype=np.int32)
         self._flush_pending()
         return self._engine
 
@@ -464,6 +490,8 @@ class SocialForceIntersection:
             self._bind(v)
             self._dirty_queues[v] = -1
         self._drawn_stale = True
+        self._cls[first:first + len(new)] = 0        # (the engine starts a road user in parameter set 0)
+        self._sync_param_classes()
 
     def _mark_queue_dirty(self, v, how=None):
         """how: None rows appended, -1 queue replaced (pointer rewinds), -2 rows edited in place (pointer kept)"""
@@ -517,11 +545,7 @@ class SocialForceIntersection:
                 if ch.size:
                     e.set_v_desired(ch, vd[ch])
                     self._vd[ch] = vd[ch]
-                self._check_uniform()
-                pod = self.vehicles[0]._pod(PRIORITY_RULES[self.priority_rule])
-                if bytes(pod) != self._pod_bytes:
-                    e.set_params(pod)
-                    self._pod_bytes = bytes(pod)
+                self._sync_param_classes()
         if self.priority_rule != self._rule_on_device:
             if self.priority_rule not in PRIORITY_RULES:
                 raise ValueError(f"priority_rule must be one of {tuple(PRIORITY_RULES)}")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSF_ABI_VERSION 2
+#define CSF_ABI_VERSION 3
 
 /* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
  * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle) */
@@ -50,7 +50,8 @@ enum csf_status_code {
 #define CSF_ST_UNCONTROLLABLE 8u /* dynamics.py:1212-1214: PlanarBicycle at v <= 0 ("System not controllable!") */
 
 /* POD mirror of the reference's parameter objects (parameters.py).  One set per engine = per vehicle
- * class; the only per-agent parameter is v_desired_default (csf_add_agents).  Field order is ABI. */
+ * class; v_desired_default is per agent (csf_add_agents), whole parameter sets per agent: csf_set_param_classes.
+ * Field order is ABI. */
 typedef struct csf_params {
     /* VehicleParameters — parameters.py:430-508 */
     double t_s, d_arrived_inter, d_arrived_stop, v_max_stop, v_max_harddecel, hfov;
@@ -113,6 +114,16 @@ int csf_set_road_vertices(csf_engine *e, int32_t n_edges, const int64_t *offsets
                           const double *F0, const double *sigma);
 
 int csf_set_params(csf_engine *e, const csf_params *params);           /* parameter mutation between ticks */
+
+/* Every reference vehicle owns its params object (vehicle.py:64-204): the field vehicle i exerts is evaluated with ITS
+ * f_0 / sigma_* / e_* (vehicle.py:1592-1612; p_0 / p_decay for the Bicycle field, :1095-1101) and masked with ITS hfov
+ * (intersection.py:733-735), and it steers, accelerates, brakes and arrives with its own gains and limits.
+ * csf_set_param_classes installs 1 to 256 parameter sets (same model, t_s and traj_len as the engine; set 0 replaces the
+ * engine's own, the priority rule stays the intersection's); csf_set_agent_class assigns sets to road users (new road
+ * users start in set 0).  With more than one set the engine runs the pair kernel without the far-field and field-of-view
+ * culls (O(N^2) per tick) and takes population changes through the host mirror. */
+int csf_set_param_classes(csf_engine *e, int32_t n_classes, const csf_params *classes);
+int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *cls);
 int csf_set_v_desired(csf_engine *e, int64_t n, const int32_t *idx, const double *v_desired);
 int csf_set_priority_rule(csf_engine *e, int32_t rule);                /* intersection.py:324 */
 

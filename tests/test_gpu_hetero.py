@@ -1,0 +1,161 @@
+"""Populations whose vehicles own DIFFERENT parameter sets (vehicle.py:64-204; vehicle.py:1592-1612 and
+intersection.py:733-735 for what the pair term takes from the source's set) on the HIP path: against trajectories
+captured from the literal reference (tests/golden/hetero.npz) and against the CPU oracle.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+from conftest import hetero_classes
+from oracle import csf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MODELS = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3, "planarbike": 4}
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from cyclistsocialforce_amd import engine, parameters
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.Engine = engine.Engine
+    ns.pod = parameters.default_pod
+    return ns
+
+
+def orc_params(pod):
+    return orc.Params.from_buffer_copy(bytes(pod))
+
+
+@pytest.mark.parametrize("model", ["twod", "bicycle", "invpend"])
+def test_individual_parameter_sets_golden(amd, golden, model):
+    """Four parameter sets dealt round-robin over 10-16 vehicles, 150-250 ticks, against the literal reference."""
+    g = golden("hetero")
+    pods, cls = hetero_classes(g, model)
+    s0 = g[f"{model}_s0"]
+    n = s0.shape[0]
+    e = amd.Engine(pods[0], n)
+    e.add_agents(s0, g[f"{model}_vdes"])
+    e.set_dest_queue(np.arange(n), g[f"{model}_off"], g[f"{model}_dq"], reset=True)
+    e.set_param_classes(pods, cls)
+    S, F = g[f"{model}_S"], g[f"{model}_F"]
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    worst = 0.0
+    for k in range(1, S.shape[0]):
+        e.step(10)
+        got = e.state()
+        worst = max(worst, np.abs(got[:, :2] - S[k][:, :2]).max() / extent)
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"{model} sample {k}")
+        np.testing.assert_allclose(got[:, 3], S[k][:, 3], rtol=0, atol=2e-3, err_msg=f"{model} speed sample {k}")
+        fx, fy = e.forces()
+        np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=0, atol=2e-3 * max(np.abs(F[k - 1]).max(), 1.0))
+    assert (e.status() == 0).all()
+    print(f"{model}: worst position deviation / extent = {worst:.3e}")
+    # the mask is the source's: row i of get_untracked_foes uses hfov of vehicle i's set (intersection.py:733-735)
+    U = e.untracked()
+    st = e.state()
+    p2 = [orc_params(p) for p in pods]
+    for i in range(n):
+        for j in range(n):
+            want = orc.lib().csfo_untracked(p2[cls[i]].hfov, 0, i, j, st[i, 0], st[i, 1], st[j, 0], st[j, 1], st[j, 2])
+            assert bool(U[i, j]) == bool(want) or _on_the_edge(p2[cls[i]].hfov, st, i, j), (i, j)
+    e.close()
+
+
+def _on_the_edge(hfov, st, i, j):
+    """fp32 records vs fp64 state: a bearing within 1e-5 rad of +-hfov/2 may fall either way"""
+    az = np.arctan2(st[i, 1] - st[j, 1], st[i, 0] - st[j, 0])
+    rel = (st[j, 2] - az + np.pi) % (2 * np.pi) - np.pi
+    return abs(abs(rel) - hfov / 2) < 1e-5
+
+
+@pytest.mark.parametrize("model,n,box,ticks", [("twod", 1500, 150.0, 60), ("bicycle", 700, 100.0, 60), ("invpend", 600, 100.0, 60),
+                                                ("planarpoint", 500, 100.0, 60), ("planarbike", 500, 100.0, 60)])
+def test_random_population_with_parameter_sets_vs_oracle(amd, model, n, box, ticks):
+    """Five parameter sets over a random population (beyond one LDS tile and the binning threshold for twod), against the
+    oracle with the same table; then the table shrinks back to one set and the engine returns to its culling kernel."""
+    rng = np.random.default_rng(77)
+    ns = orc.N_STATES[MODELS[model]]
+    s0 = np.zeros((n, ns))
+    s0[:, 0] = rng.uniform(0, box, n); s0[:, 1] = rng.uniform(0, box, n)
+    s0[:, 2] = rng.uniform(-np.pi, np.pi, n); s0[:, 3] = rng.uniform(3, 4.8, n)
+    d = np.array([40.0, 79.0, 80.0])
+    dq = np.zeros((n, 4, 3))
+    dq[:, 0, 0] = s0[:, 0]; dq[:, 0, 1] = s0[:, 1]
+    dq[:, 1:, 0] = s0[:, 0, None] + d[None, :] * np.cos(s0[:, 2])[:, None]
+    dq[:, 1:, 1] = s0[:, 1, None] + d[None, :] * np.sin(s0[:, 2])[:, None]
+    off = np.arange(n + 1) * 4
+    field = ([dict(), dict(hfov=1.2 * np.pi, p_0=40.0, p_decay=4.0), dict(hfov=1.0, p_decay=6.0, k_p_v=13.0),
+              dict(hfov=2 * np.pi, a_max=[-6.0, 6.0], delta_max=1.0), dict(hfov=0.5, d_arrived_inter=3.0)] if model == "bicycle" else
+             [dict(), dict(hfov=1.2 * np.pi, f_0=10.0, sigma_0=0.6, sigma_1=5.5), dict(hfov=1.0, e_0=0.9, e_1=0.4, sigma_2=0.25, sigma_3=4.0),
+              dict(hfov=2 * np.pi, f_0=0.0), dict(hfov=0.5, f_0=4.0, d_arrived_inter=3.0)])
+    if model == "planarpoint":
+        field[2]["poles"] = [-3.0 + 0j]
+        field[4]["poles"] = [-1.5 + 0j]
+    if model == "planarbike":
+        field[2]["poles"] = (-4.0 + 1.0j, -4.0 - 1.0j)
+        field[4]["poles"] = (-2.5, -6.0)
+    pods = [amd.pod(model, **kw) for kw in field]
+    cls = rng.integers(0, len(pods), n).astype(np.uint8)
+    e = amd.Engine(pods[0], n)
+    e.add_agents(s0, 4.5)
+    e.set_dest_queue(np.arange(n), off, dq.reshape(-1, 3), reset=True)
+    e.set_param_classes(pods, cls)
+    classes = [orc_params(p) for p in pods]
+    pop = orc.Population(classes[0], s0, 4.5, off, dq.reshape(-1, 3))
+    pop.set_classes(classes, cls)
+    # one tick's forces first: the pair term with the source's field and hfov, clamped and summed per receiver
+    e.calc_forces(); pop.calc_forces_range(0, n)
+    fx, fy = e.forces(); ox, oy = pop.forces()
+    scale = max(np.hypot(ox, oy).max(), 1.0)
+    err = max(np.abs(fx - ox).max(), np.abs(fy - oy).max()) / scale
+    assert err < 1e-4, err
+    e.step(ticks); pop.step(ticks)
+    got, ref = e.state(), pop.state()
+    devs = np.abs(got[:, :2] - ref[:, :2]).max(axis=1)
+    print(f"{model}: forces vs oracle {err:.1e}; after {ticks} ticks |dpos| max {devs.max():.1e} m, 99 % {np.percentile(devs, 99):.1e} m")
+    assert devs.max() < 1e-4 * box and (e.status() == 0).all()
+    assert e.count_pairs()[1] == "pair_kernel"
+    if model != "bicycle":
+        e.set_param_classes(pods[:1], np.zeros(n, dtype=np.uint8))
+        e.step(1)
+        assert e.count_pairs()[1] == "pair_cull_kernel"
+    e.close()
+
+
+def test_mirror_classes_with_individual_parameters(golden):
+    """The same through the drop-in classes: vehicles constructed with their own parameter objects, as the reference's
+    users do (params= keyword, vehicle.py:64-97), stepped by SocialForceIntersection.step()."""
+    import json
+
+    from cyclistsocialforce_amd import parameters as P
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import TwoDBicycle
+
+    g = golden("hetero")
+    recipes = json.loads(str(g["twod_recipes"]))
+    s0, vdes, off, dq, cls = g["twod_s0"], g["twod_vdes"], g["twod_off"], g["twod_dq"], g["twod_cls"]
+    bikes = []
+    for k in range(s0.shape[0]):
+        v = TwoDBicycle(tuple(s0[k]), id=str(k), params=P.InvPendulumBicycleParameters(**recipes[cls[k]]))
+        v.params.v_desired_default = float(vdes[k])
+        rows = dq[off[k] + 1:off[k + 1]]
+        v.setDestinations(rows[:, 0], rows[:, 1])
+        bikes.append(v)
+    ins = SocialForceIntersection(bikes)
+    S = g["twod_S"]
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    for k in range(1, 8):
+        for _ in range(10):
+            ins.step()
+        got = np.array([v.s for v in bikes])
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent)
+    # a parameter assigned between ticks moves the vehicle into a set of its own; the run no longer follows the golden one
+    bikes[3].params.f_0 = 25.0
+    for _ in range(30):
+        ins.step()
+    got = np.array([v.s for v in bikes])
+    assert np.abs(got[:, :2] - S[10][:, :2]).max() > 1e-3
+    assert len(ins._class_table) == 5

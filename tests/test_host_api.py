@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.csf_abi_version() == 2
+    assert lib.csf_abi_version() == 3
     assert ctypes.sizeof(_ffi.Params) == 328
 
 
@@ -192,35 +192,39 @@ def test_scenario_driver(capsys, monkeypatch):
         Scenario(None)
 
 
-def test_one_parameter_set_per_intersection():
-    """One engine = one csf_params: vehicles whose parameters differ from vehicle 0's (anything but v_desired_default)
-    are refused instead of silently receiving vehicle 0's values (vehicle.py:1592-1612, intersection.py:733-735)."""
+def test_parameter_sets_of_an_intersection():
+    """Every vehicle owns its params object (vehicle.py:64-204).  The mirror groups the population into distinct
+    csf_params (anything but v_desired_default, which is per road user anyway) for the engine's table
+    (csf_set_param_classes); what the engine cannot hold is refused: another clock, more than 256 sets, custom hooks."""
+    from cyclistsocialforce_amd import parameters as P
     from cyclistsocialforce_amd.intersection import SocialForceIntersection
     from cyclistsocialforce_amd.vehicle import TwoDBicycle
 
     a = TwoDBicycle((0, 0, 0, 5, 0), id="a")
     b = TwoDBicycle((0, 5, 0, 5, 0), id="b")
-    b.params.v_desired_default = 4.0                 # the per-vehicle parameter
-    ins = SocialForceIntersection((a, b))
+    b.params.v_desired_default = 4.0                 # the per-vehicle parameter: no set of its own
     c = TwoDBicycle((0, 9, 0, 5, 0), id="c")
     c.params.f_0 = 3.0
-    with pytest.raises(NotImplementedError, match="f_0"):
-        ins.add_road_user(c)
-    assert ins.n_bikes == 2 and c._owner is None
-    d = TwoDBicycle((0, 9, 0, 5, 0), id="d")
-    d.params.sigma_0 = 0.6
-    with pytest.raises(NotImplementedError, match="sigma_0"):
-        SocialForceIntersection((a2 := TwoDBicycle((1, 1, 0, 5, 0), id="a2"), d))
-    shared = TwoDBicycle((0, 12, 0, 5, 0), id="s", params=a.params)       # sharing vehicle 0's object is fine
-    ins.add_road_user(shared)
-    hooked = TwoDBicycle((0, 15, 0, 5, 0), id="h", dest_force_func=lambda v: (0.0, 0.0))
+    d = TwoDBicycle((0, 12, 0, 5, 0), id="d", params=P.InvPendulumBicycleParameters(f_0=3.0))     # equal to c's by value
+    s = TwoDBicycle((0, 15, 0, 5, 0), id="s", params=a.params)                                     # a's object
+    h = TwoDBicycle((0, 18, 0, 5, 0), id="h", params=P.InvPendulumBicycleParameters(hfov=1.0, sigma_0=0.6))
+    ins = SocialForceIntersection((a, b, c, d, s, h))
+    pods, cls = ins._param_classes()
+    assert cls.tolist() == [0, 0, 1, 1, 0, 2] and len(pods) == 3
+    assert pods[1].f_0 == 3.0 and pods[2].hfov == 1.0 and pods[2].sigma_0 == 0.6 and pods[0].f_0 == 7.0
+    b.params.e_1 = 0.6                               # a later assignment moves b into a set of its own
+    pods, cls = ins._param_classes()
+    assert cls.tolist() == [0, 1, 2, 2, 0, 3] and pods[1].e_1 == 0.6
+    slow = TwoDBicycle((0, 21, 0, 5, 0), id="slow", params=P.InvPendulumBicycleParameters(t_s=0.02))
+    with pytest.raises(NotImplementedError, match="share the clock"):
+        ins._param_classes(ins.vehicles + [slow])
+    many = [TwoDBicycle((k, 30, 0, 5, 0), id=f"m{k}", params=P.InvPendulumBicycleParameters(f_0=1.0 + 0.01 * k)) for k in range(257)]
+    with pytest.raises(NotImplementedError, match="256"):
+        ins._param_classes(many)
+    hooked = TwoDBicycle((0, 15, 0, 5, 0), id="h2", dest_force_func=lambda v: (0.0, 0.0))
     with pytest.raises(NotImplementedError, match="dest_force_func"):
         ins.add_road_user(hooked)
-    assert hooked.calcDestinationForce.__self__ is hooked and a2 is not None
-    # a later assignment on a member's parameters is caught by the re-check before the next tick
-    b.params.f_0 = 5.0
-    with pytest.raises(NotImplementedError, match="f_0"):
-        ins._check_uniform()
+    assert hooked.calcDestinationForce.__self__ is hooked and hooked._owner is None
 
 
 def test_shard_bounds_cover_the_population():
