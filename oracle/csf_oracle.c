@@ -551,7 +551,7 @@ static void twod_dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
 }
 
 static void dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
-    switch (o->p.model) {
+    switch (PA(o, a)->model) {
     case CSFO_BICYCLE:
         direct_approach(o, a, Fx, Fy);                             /* vehicle.py:1189-1194 */
         break;
@@ -891,7 +891,7 @@ void csfo_calc_forces_range(csfo_t *o, int lo, int hi) {
                                    o->sy[j], o->spsi[j]))
                     continue;                                      /* :815-823 */
                 double gx, gy;
-                if (p->model == CSFO_BICYCLE)
+                if (pi->model == CSFO_BICYCLE)                    /* the field of vehicle i's class */
                     csfo_pair_bicycle(pi, o->sx[i], o->sy[i], o->spsi[i], o->sv[i], o->sx[j], o->sy[j], &gx, &gy);
                 else
                     csfo_pair_twod(pi, o->sx[i], o->sy[i], o->spsi[i], o->sx[j], o->sy[j], o->spsi[j], &gx, &gy);
@@ -1011,13 +1011,44 @@ void csfo_step(csfo_t *o, int nticks) {
 
 /* ----------------------------------------------------------------- construction ---- */
 
-csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double *vdes,
-                    const int64_t *qoff, const double *dq) {
+static const int NS[5] = {5, 5, 6, 4, 5};
+
+/* what the constructors of the rider classes derive from the start state (vehicle.py:1728-1736; dynamics.py:195-197, 828,
+ * 987-993), by the class of agent a */
+static void init_side_state(csfo_t *o, int a) {
+    const csfo_params *p = PA(o, a);
+    double *s = S(o, a);
+    o->zrid[2 * a] = o->zrid[2 * a + 1] = 0;
+    if (p->model == CSFO_INVPEND) {                                /* vehicle.py:1728-1736 */
+        double *x = o->xlti + 5 * a;
+        x[0] = s[4];
+        x[1] = 0;
+        x[2] = s[5];
+        x[3] = 0;
+        x[4] = s[2];
+        if (s[3] < p->v_max_walk) o->zrid[2 * a + 1] = 1;
+        else o->zrid[2 * a] = 1;
+    }
+    if (p->model == CSFO_PLANARBIKE) {                             /* dynamics.py:195-197 */
+        o->xdyn[3 * a] = s[4];
+        o->xdyn[3 * a + 1] = s[2];
+    }
+    if (p->model == CSFO_PLANARPOINT) {                            /* dynamics.py:828, 987-993 */
+        o->xdyn[3 * a] = s[2];
+        o->xdyn[3 * a + 1] = s[0];
+        o->xdyn[3 * a + 2] = s[1];
+        o->vdyn[a] = s[3];
+    }
+}
+
+/* ns: columns of s0 / of csfo_get_state (a population of several vehicle classes - csfo_set_classes - uses 6, the unused
+ * states of a class stay 0) */
+csfo_t *csfo_create_ns(const csfo_params *p, int n, int ns, const double *s0, const double *vdes,
+                       const int64_t *qoff, const double *dq) {
     csfo_t *o = (csfo_t *)calloc(1, sizeof *o);
     o->p = *p;
     o->n = n;
-    static const int NS[5] = {5, 5, 6, 4, 5};
-    o->ns = NS[p->model];
+    o->ns = ns;
     size_t N = (size_t)(n > 0 ? n : 1), L = (size_t)p->traj_len;
     o->s = (double *)calloc(N * 6, sizeof(double));
     o->vdes = (double *)calloc(N, sizeof(double));
@@ -1055,27 +1086,15 @@ csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double 
         trj(o, a, 0)[0] = s[0];                                    /* vehicle.py:159-160 */
         trj(o, a, 1)[0] = s[1];
         trj(o, a, 2)[0] = s[4];
-        if (p->model == CSFO_INVPEND) {                            /* vehicle.py:1728-1736 */
-            double *x = o->xlti + 5 * a;
-            x[0] = s[4];
-            x[2] = s[5];
-            x[4] = s[2];
-            if (s[3] < p->v_max_walk) o->zrid[2 * a + 1] = 1;
-            else o->zrid[2 * a] = 1;
-        }
-        if (p->model == CSFO_PLANARBIKE) {                         /* dynamics.py:195-197 */
-            o->xdyn[3 * a] = s[4];
-            o->xdyn[3 * a + 1] = s[2];
-        }
-        if (p->model == CSFO_PLANARPOINT) {                        /* dynamics.py:828, 987-993 */
-            o->xdyn[3 * a] = s[2];
-            o->xdyn[3 * a + 1] = s[0];
-            o->xdyn[3 * a + 2] = s[1];
-            o->vdyn[a] = s[3];
-        }
+        init_side_state(o, a);
     }
     csfo_update_snapshot_range(o, 0, n);                           /* intersection.py:320 */
     return o;
+}
+
+csfo_t *csfo_create(const csfo_params *p, int n, const double *s0, const double *vdes,
+                    const int64_t *qoff, const double *dq) {
+    return csfo_create_ns(p, n, NS[p->model], s0, vdes, qoff, dq);
 }
 
 /* Test aid (no reference counterpart): re-anchor the oracle on a state produced elsewhere - what csf_push_state does for
@@ -1092,17 +1111,17 @@ void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const ui
         trj(o, a, 0)[i] = s[0];
         trj(o, a, 1)[i] = s[1];
         trj(o, a, 2)[i] = s[4];
-        if (o->p.model == CSFO_INVPEND) {
+        if (PA(o, a)->model == CSFO_INVPEND) {
             double *x = o->xlti + 5 * a;
             x[0] = s[4];
             x[2] = s[5];
             x[4] = s[2];
         }
-        if (o->p.model == CSFO_PLANARBIKE) {
+        if (PA(o, a)->model == CSFO_PLANARBIKE) {
             o->xdyn[3 * a] = s[4];
             o->xdyn[3 * a + 1] = s[2];
         }
-        if (o->p.model == CSFO_PLANARPOINT) {
+        if (PA(o, a)->model == CSFO_PLANARPOINT) {
             o->xdyn[3 * a] = s[2];
             o->xdyn[3 * a + 1] = s[0];
             o->xdyn[3 * a + 2] = s[1];
@@ -1126,8 +1145,9 @@ void csfo_destroy(csfo_t *o) {
     free(o);
 }
 
-/* every reference vehicle owns its params object (vehicle.py:64-204): a table of parameter sets and the set of every
- * agent.  Model, t_s and traj_len are those of the population (the sets of one Scenario share the clock). */
+/* every reference vehicle owns its params object (vehicle.py:64-204) and any vehicle classes may share an intersection
+ * (intersection.py:797-823 calls each vehicle's own methods): a table of parameter sets - each with its model - and the set
+ * of every agent.  t_s and traj_len are those of the population (the sets of one Scenario share the clock). */
 void csfo_set_classes(csfo_t *o, int n_classes, const csfo_params *tab, const uint8_t *cls) {
     free(o->ptab);
     free(o->pcls);
@@ -1140,6 +1160,7 @@ void csfo_set_classes(csfo_t *o, int n_classes, const csfo_params *tab, const ui
     memcpy(o->ptab, tab, sizeof(csfo_params) * (size_t)n_classes);
     o->pcls = (uint8_t *)malloc((size_t)(o->n > 0 ? o->n : 1));
     memcpy(o->pcls, cls, (size_t)o->n);
+    for (int a = 0; a < o->n; a++) init_side_state(o, a);         /* (the sets may be of other vehicle classes: before any tick) */
 }
 
 /* edges as CSR over vertices with one (F0, sigma) per edge — intersection.py:222-224 */

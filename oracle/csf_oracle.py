@@ -132,6 +132,8 @@ def lib():
         L.csfo_planarbike_gains.argtypes = [C.POINTER(Params), C.c_double, C.c_void_p, C.POINTER(C.c_double)]
         L.csfo_create.restype = C.c_void_p
         L.csfo_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_create_ns.restype = C.c_void_p
+        L.csfo_create_ns.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_destroy.argtypes = [C.c_void_p]
         L.csfo_set_classes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.csfo_set_road.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -273,16 +275,17 @@ def expm(A):
 class Population:
     """Population of one vehicle class stepped by the CPU oracle (SocialForceIntersection.step)."""
 
-    def __init__(self, params, s0, vdes, qoff, dq):
+    def __init__(self, params, s0, vdes, qoff, dq, ns=None):
+        """ns: state columns (default: those of params.model; 6 for a population of several vehicle classes, set_classes)"""
         self.params = params
-        self.ns = N_STATES[params.model]
+        self.ns = N_STATES[params.model] if ns is None else int(ns)
         s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.float64)[:, :self.ns])
         self.n = s0.shape[0]
         vdes = np.ascontiguousarray(np.broadcast_to(np.asarray(vdes, dtype=np.float64), (self.n,)))
         qoff = np.ascontiguousarray(qoff, dtype=np.int64)
         dq = np.ascontiguousarray(dq, dtype=np.float64).reshape(-1, 3)
         assert qoff.shape == (self.n + 1,) and qoff[-1] == dq.shape[0]
-        self.h = C.c_void_p(lib().csfo_create(C.byref(params), self.n, _p(s0), _p(vdes), _p(qoff), _p(dq)))
+        self.h = C.c_void_p(lib().csfo_create_ns(C.byref(params), self.n, self.ns, _p(s0), _p(vdes), _p(qoff), _p(dq)))
 
     def __del__(self):
         try:

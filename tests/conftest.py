@@ -33,3 +33,20 @@ def hetero_classes(g, model):
 
     recipes = json.loads(str(g[f"{model}_recipes"]))
     return [parameters.default_pod(model, **kw) for kw in recipes], g[f"{model}_cls"].astype("uint8")
+
+
+MIXED_OWN = {"twod": dict(hfov=1.0, f_0=10.0), "bicycle": dict(hfov=1.1 * 3.141592653589793, p_0=40.0, p_decay=4.0),
+             "invpend": dict(hfov=2.5, e_0=0.9, k_p_v=12.0), "planarpoint": dict(hfov=1.5, f_0=5.0, poles=[-3.0 + 0j]),
+             "planarbike": dict(hfov=2.8, sigma_0=0.6)}
+
+
+def mixed_classes(g):
+    """The parameter sets of tests/golden/mixed.npz (make_golden.py: gen_mixed): the defaults of each of the five vehicle
+    classes + the sets the last five vehicles own, as csf_params PODs, and the set of every vehicle."""
+    from cyclistsocialforce_amd import parameters
+
+    order = ["twod", "bicycle", "invpend", "planarpoint", "planarbike"]
+    pods = [parameters.default_pod(m) for m in order] + [parameters.default_pod(m, **MIXED_OWN[m]) for m in order]
+    cls = [order.index(str(m)) + (5 if own else 0) for m, own in zip(g["models"], g["own"])]
+    import numpy as np
+    return pods, np.array(cls, dtype="uint8")

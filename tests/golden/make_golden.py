@@ -692,11 +692,59 @@ def gen_hetero():
 
 
 
+# ----------------------------------------------------------------------------
+# (14) several vehicle CLASSES in one intersection — intersection.py:797-823 calls each vehicle's own
+#      calcDestinationForce / calcRepulsiveForce / step, so any mix of rider models may share it
+# ----------------------------------------------------------------------------
+def gen_mixed():
+    rng = np.random.default_rng(1515)
+    order = ["twod", "bicycle", "invpend", "planarpoint", "planarbike"]
+    n, box, ticks = 15, 28.0, 250
+    vs, models = [], []
+    for k in range(n):
+        m = order[k % len(order)]
+        s0 = np.zeros(NSTATES[m])
+        s0[0] = rng.uniform(0, box)
+        s0[1] = rng.uniform(0, box)
+        s0[2] = rng.uniform(-np.pi, np.pi)
+        s0[3] = rng.uniform(3, 4.8)
+        kw = {}
+        if k >= 10:                                   # the third vehicle of every class with parameters of its own
+            kw["params"] = {"twod": rp.InvPendulumBicycleParameters(hfov=1.0, f_0=10.0),
+                            "bicycle": rp.BicycleParameters(hfov=1.1 * np.pi, p_0=40.0, p_decay=4.0),
+                            "invpend": rp.InvPendulumBicycleParameters(hfov=2.5, e_0=0.9, k_p_v=12.0),
+                            "planarpoint": rp.PlanarPointBicycleParameters(hfov=1.5, f_0=5.0, poles=[-3.0 + 0j]),
+                            "planarbike": rp.PlanarBicycleParameters(hfov=2.8, sigma_0=0.6)}[m]
+        v = make_vehicle(m, s0, vdes=rng.uniform(4, 4.9), id=str(k), **kw)
+        d = np.array([15.0, 29.0, 30.0])
+        v.setDestinations(s0[0] + d * np.cos(s0[2]), s0[1] + d * np.sin(s0[2]))
+        vs.append(v)
+        models.append(m)
+    s6 = np.zeros((n, 6))
+    for k, v in enumerate(vs):
+        s6[k, : len(v.s)] = v.s
+    vdes = np.array([v.params.v_desired_default for v in vs])
+    off = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
+    dq = np.vstack([v.destqueue for v in vs])
+    ins = ri.SocialForceIntersection(vs)
+    S = np.zeros((ticks // 10 + 1, n, 6))
+    F = np.zeros((ticks // 10, n, 2))
+    S[0] = s6
+    for t in range(ticks):
+        ins.step()
+        if (t + 1) % 10 == 0:
+            for k, v in enumerate(vs):
+                S[(t + 1) // 10, k, : len(v.s)] = v.s
+                F[(t + 1) // 10 - 1, k] = v.force
+    save("mixed", s0=s6, vdes=vdes, off=off, dq=dq, models=np.array(models), own=np.arange(n) >= 10, S=S, F=F)
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero"]
+    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero", "mixed"]
     gens = {"pair": gen_pair_fields, "masks": gen_masks_and_totals, "control": gen_control_move,
             "dest": gen_dest_force, "pp": gen_planarpoint_steps, "road": gen_road,
             "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep,
-            "planarbike": gen_planarbike, "hetero": gen_hetero}
+            "planarbike": gen_planarbike, "hetero": gen_hetero, "mixed": gen_mixed}
     for w in which:
         gens[w]()

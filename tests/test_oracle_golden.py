@@ -247,3 +247,22 @@ def test_population_with_individual_parameter_sets(golden, model, tol):
     uni = orc.Population(classes[0], g[f"{model}_s0"], g[f"{model}_vdes"], g[f"{model}_off"], g[f"{model}_dq"])
     uni.step(10 * (S.shape[0] - 1))
     assert np.abs(uni.state()[:, :2] - S[-1][:, :2]).max() > 1e-2
+
+
+def test_population_of_several_vehicle_classes(golden):
+    """intersection.py:797-823 calls each vehicle's own calcDestinationForce / calcRepulsiveForce / step: Bicycle,
+    TwoDBicycle, InvPendulumBicycle, PlanarPointBicycle and PlanarBicycle in ONE intersection (three of each, the third with
+    parameters of its own), 250 ticks captured from the literal reference (make_golden.py: gen_mixed)."""
+    from conftest import mixed_classes
+
+    g = golden("mixed")
+    pods, cls = mixed_classes(g)
+    classes = [orc.Params.from_buffer_copy(bytes(p)) for p in pods]
+    pop = orc.Population(classes[0], g["s0"], g["vdes"], g["off"], g["dq"], ns=6)
+    pop.set_classes(classes, cls)
+    S, F = g["S"], g["F"]
+    for k in range(1, S.shape[0]):
+        pop.step(10)
+        np.testing.assert_allclose(pop.state(), S[k], rtol=1e-9, atol=1e-8, err_msg=f"sample {k}")
+        fx, fy = pop.forces()
+        np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=1e-7, atol=1e-7, err_msg=f"forces {k}")
