@@ -670,9 +670,9 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     const float4 q = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)c, (float)s);
     d.rec[a] = q;
     if (d.recs_valid) d.recs[d.pos[a]] = q;                   // the copy in binned order (csf_bin.hip)
-    if (d.p.model == CSF_BICYCLE) {                           // vehicle.py:1062-1064 (v <= 0: e := 0)
+    if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
         double e = 0.0;
-        if (v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
+        if (p.model == CSF_BICYCLE && v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
         const float2 q2 = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
         d.rec2[a] = q2;
         if (d.recs_valid) d.recs2[d.pos[a]] = q2;
@@ -705,6 +705,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     g.st = d.status[a];
     g.cs_fresh = false;
     agent_params<HET>(d, a, g);
+    if (HET && g.p->model != MODEL) return;                    // a mixed population: one launch per vehicle class
 
     double fdx, fdy;
     if (phases & PH_DEST) {
@@ -798,7 +799,7 @@ __global__ void records_kernel(const Dev d) {
     if (a >= d.n_pad) return;
     if (a >= d.n || !d.alive[a]) {  // sentinel: far away, contributes exactly 0 (exp2 underflow), never NaN
         d.rec[a] = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
-        if (d.p.model == CSF_BICYCLE) d.rec2[a] = make_float2(0.0f, 1.0f);
+        if (d.has_bike) d.rec2[a] = make_float2(0.0f, 1.0f);
         return;
     }
     write_record(d, d.ptab[d.cls[a]], a, d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);
@@ -811,12 +812,18 @@ void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0, hipEv
 #define CSF_AGENT(MODEL)                                                                                             \
     if (d.n_classes > 1) hipExtLaunchKernelGGL((agent_kernel<MODEL, true>), g, b, 0, st, t0, t1, 0, d, phases);           \
     else hipExtLaunchKernelGGL((agent_kernel<MODEL, false>), g, b, 0, st, t0, t1, 0, d, phases)
-    switch (d.p.model) {
-    case CSF_BICYCLE: CSF_AGENT(CSF_BICYCLE); break;
-    case CSF_TWOD: CSF_AGENT(CSF_TWOD); break;
-    case CSF_INVPEND: CSF_AGENT(CSF_INVPEND); break;
-    case CSF_PLANARBIKE: CSF_AGENT(CSF_PLANARBIKE); break;
-    default: CSF_AGENT(CSF_PLANARPOINT); break;
+    // every vehicle class of the population in turn (one, unless csf_set_param_classes installed sets of several classes;
+    // the launches touch disjoint agents).  The time stamps bracket the first launch.
+    for (int m = 0; m < 5; m++) {
+        if (!(d.model_mask >> m & 1)) continue;
+        switch (m) {
+        case CSF_BICYCLE: CSF_AGENT(CSF_BICYCLE); break;
+        case CSF_TWOD: CSF_AGENT(CSF_TWOD); break;
+        case CSF_INVPEND: CSF_AGENT(CSF_INVPEND); break;
+        case CSF_PLANARBIKE: CSF_AGENT(CSF_PLANARBIKE); break;
+        default: CSF_AGENT(CSF_PLANARPOINT); break;
+        }
+        t0 = t1 = nullptr;
     }
 #undef CSF_AGENT
 }
@@ -928,7 +935,7 @@ __global__ void patch_kernel(const Dev d, const PatchHeader *hp) {
         const float4 q = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
         d.rec[a] = q;
         if (d.recs_valid) d.recs[d.pos[a]] = q;
-        if (d.p.model == CSF_BICYCLE) {
+        if (d.has_bike) {
             d.rec2[a] = make_float2(0.0f, 1.0f);
             if (d.recs_valid) d.recs2[d.pos[a]] = make_float2(0.0f, 1.0f);
         }

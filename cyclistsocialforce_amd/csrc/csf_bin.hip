@@ -66,7 +66,7 @@ __global__ void sorted_copy_kernel(const Dev d) {
     const int32_t a = d.perm[p];
     d.pos[a] = (int32_t)p;
     d.recs[p] = d.rec[a];
-    if (d.p.model == CSF_BICYCLE) d.recs2[p] = d.rec2[a];
+    if (d.has_bike) d.recs2[p] = d.rec2[a];
 }
 
 __global__ __launch_bounds__(256) void bounds_kernel(const Dev d) {

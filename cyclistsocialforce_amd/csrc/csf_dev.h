@@ -42,6 +42,8 @@ struct Dev {
     // (n_classes >= 1 rows; row 0 == p), what derive_consts makes of each row, and the row of every slot.  With one row
     // the kernels read p / pc / pb from their arguments; with more, the per-agent kernel and the pair kernel read the rows.
     int32_t n_classes;
+    int32_t model_mask;      // bit m: some parameter set is of vehicle class m (enum csf_model); several bits: a mixed population
+    int32_t has_bike;        // ... bit CSF_BICYCLE: the second record (rec2: e, 1/sqrt(1-e^2) of the Bicycle field) is maintained
     const csf_params *ptab;
     const PairConsts *pctab;
     const double *pbtab;     // [n_classes][7]

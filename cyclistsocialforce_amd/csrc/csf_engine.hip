@@ -427,7 +427,13 @@ void derive_consts(csf_engine *e) {
     int hl = 4;
     while (hl < e->d.back + 2) hl *= 2;
     e->d.hist_len = hl;
-    e->d.ns = NS_OF[p.model];
+    e->d.ns = 0;
+    e->d.model_mask = 0;
+    for (const csf_params &c : e->classes) {
+        e->d.ns = std::max(e->d.ns, NS_OF[c.model]);            // (several vehicle classes: the widest state; unused ones stay 0)
+        e->d.model_mask |= 1 << c.model;
+    }
+    e->d.has_bike = e->d.model_mask & 1;
 }
 
 int alloc_all(csf_engine *e) {
@@ -1035,7 +1041,7 @@ int all_gather_records(csf_engine *e) {
     const bool second = comm_second_stream();
     hipStream_t cs = second ? e->comm : e->main;
     if (second) HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
-    const bool two = d.p.model == CSF_BICYCLE;
+    const bool two = d.has_bike != 0;
     if (two) NCCLCHK(e, g_rccl.GroupStart());
     NCCLCHK(e, g_rccl.AllGather(d.rec + (size_t)e->rank * shard, d.rec, shard * 4, ncclFloat32, e->nccl, cs));
     if (two) {
@@ -1449,8 +1455,6 @@ int csf_set_param_classes(csf_engine *e, int32_t n_classes, const csf_params *cl
     for (int32_t c = 0; c < n_classes; c++) {
         int rc = check_params(e, classes + c);
         if (rc) return rc;
-        if (classes[c].model != e->d.p.model)
-            return fail(e, CSF_E_ARG, "parameter set %d is of another vehicle class (model %d, engine %d)", c, classes[c].model, e->d.p.model);
         if (classes[c].t_s != e->d.p.t_s || classes[c].traj_len != e->d.p.traj_len)
             return fail(e, CSF_E_ARG, "parameter set %d: the vehicles of one intersection share t_s (parameters.py:516-528)", c);
     }
@@ -1478,7 +1482,21 @@ int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int3
         if (cls[k] < 0 || cls[k] >= (int32_t)e->classes.size())
             return fail(e, CSF_E_ARG, "parameter set %d of %d (csf_set_param_classes first)", cls[k], (int)e->classes.size());
     }
-    for (int64_t k = 0; k < n; k++) e->h_cls[(size_t)e->order[(size_t)idx[k]]] = (uint8_t)cls[k];
+    const int64_t cap = e->cap;
+    for (int64_t k = 0; k < n; k++) {
+        const size_t a = (size_t)e->order[(size_t)idx[k]];
+        e->h_cls[a] = (uint8_t)cls[k];
+        // A road user that has not moved yet is what its constructor made of it, with the limits of ITS set
+        // (vehicle.py:1728-1736).  (With the device ahead of the host mirror every road user has taken a tick: engines with
+        // several sets take arrivals through the mirror.)
+        if (!e->device_ahead && e->h_ti[a] == 0) {
+            const csf_params &p = e->classes[(size_t)cls[k]];
+            const double delta = e->h_s[4 * cap + a];
+            e->h_zrid[a] = e->h_s[3 * cap + a] < p.v_max_walk ? 0 : 1;
+            e->h_dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
+            e->dirty = true;
+        }
+    }
     e->classes_dirty = true;                                   // (the slots' rows are uploaded with the table)
     return CSF_OK;
 }
@@ -1520,7 +1538,7 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
         for (int c = 0; c < ns; c++) e->h_s[c * cap + a] = s[k * ns + c];
         // keep the model side-state consistent with the pushed vehicle.s
         e->h_ppsi[a] = e->h_s[2 * cap + a];
-        if (e->d.p.model == CSF_PLANARBIKE) e->h_lti[a] = e->h_s[4 * cap + a];   // dynamics.x[0] = delta
+        if (e->classes[e->h_cls[(size_t)a]].model == CSF_PLANARBIKE) e->h_lti[a] = e->h_s[4 * cap + a];   // dynamics.x[0] = delta
         const int slot = e->h_ti[a] & (e->d.hist_len - 1);
         e->h_hx[(size_t)slot * cap + a] = e->h_s[a];
         e->h_hy[(size_t)slot * cap + a] = e->h_s[cap + a];
@@ -1589,7 +1607,7 @@ static int loopback_exchange(csf_engine *const *g, int world) {
             if (p == r) continue;
             HIPCHK(g[p], hipMemcpyAsync(g[p]->rec.p + r * shard, src->rec.p + r * shard, shard * sizeof(float4),
                                         hipMemcpyDeviceToDevice, src->main));
-            if (src->d.p.model == CSF_BICYCLE)
+            if (src->d.has_bike)
                 HIPCHK(g[p], hipMemcpyAsync(g[p]->rec2.p + r * shard, src->rec2.p + r * shard, shard * sizeof(float2),
                                             hipMemcpyDeviceToDevice, src->main));
         }

@@ -707,9 +707,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
 // the table of what derive_pair_consts makes of every set sits in LDS and each lane looks its source's row up.  No
 // cull (the far-field bound and the batch classification are per parameter set): this is the O(N^2) path of small,
 // mixed populations.
+// FIELD: 0 the TwoD field (vehicle.py:1560-1648), 1 the Bicycle field (vehicle.py:1054-1147), 2 (HET only) a population of
+// several vehicle classes (intersection.py:797-823: each vehicle's own calcRepulsiveForce): the field of the source's class.
 constexpr int MAX_CLASSES = 256;
-template <bool BICYCLE, bool P2R, bool HET = false>
+template <int FIELD, bool P2R, bool HET = false>
 __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
+    static_assert(FIELD != 2 || HET, "the field per source class needs the table of parameter sets");
+    constexpr bool BICYCLE = FIELD != 0;              // the second record is read
     __shared__ float4 tile[TILE];
     __shared__ float2 tile2[BICYCLE ? TILE : 1];
     __shared__ PairConsts ctab[HET ? MAX_CLASSES : 1];
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
                 bool in = tracked<P2R>(ks.chs, r[u], dx, dy, r2);
                 r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
-                if (BICYCLE) field_bicycle(ks, q, qb, dx, dy, r2, F, gx, gy);
+                if (FIELD == 1 || (FIELD == 2 && ks.ipd != 0.0f)) field_bicycle(ks, q, qb, dx, dy, r2, F, gx, gy);   // (ipd: Bicycle sets only)
                 else field_twod(ks, r[u], q, dx, dy, r2, F, gx, gy);
                 F = in ? F : 0.0f;
                 ax[u] += F * gx;
@@ -1027,12 +1031,15 @@ void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     const bool p2r = d.pc.p2r != 0;
     if (d.n_classes > 1) {                         // several parameter sets: the source's own row for every pair
         if (d.n_classes > MAX_CLASSES) return;     // (csf_set_param_classes refuses more)
-        if (d.p.model == CSF_BICYCLE) {
-            if (p2r) CSF_LAUNCH((pair_kernel<true, true, true>), g);
-            else CSF_LAUNCH((pair_kernel<true, false, true>), g);
+        if (d.has_bike && (d.model_mask & ~1)) {   // Bicycle and other classes together: the field of the source's class
+            if (p2r) CSF_LAUNCH((pair_kernel<2, true, true>), g);
+            else CSF_LAUNCH((pair_kernel<2, false, true>), g);
+        } else if (d.has_bike) {
+            if (p2r) CSF_LAUNCH((pair_kernel<1, true, true>), g);
+            else CSF_LAUNCH((pair_kernel<1, false, true>), g);
         } else {
-            if (p2r) CSF_LAUNCH((pair_kernel<false, true, true>), g);
-            else CSF_LAUNCH((pair_kernel<false, false, true>), g);
+            if (p2r) CSF_LAUNCH((pair_kernel<0, true, true>), g);
+            else CSF_LAUNCH((pair_kernel<0, false, true>), g);
         }
     } else if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
         if (d.rpb == 32) {
@@ -1044,11 +1051,11 @@ void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
             else CSF_LAUNCH((pair_bike_kernel<false, 4>), g);
         }
     } else if (d.p.model == CSF_BICYCLE) {
-        if (p2r) CSF_LAUNCH((pair_kernel<true, true>), g);
-        else CSF_LAUNCH((pair_kernel<true, false>), g);
+        if (p2r) CSF_LAUNCH((pair_kernel<1, true>), g);
+        else CSF_LAUNCH((pair_kernel<1, false>), g);
     } else if (d.pair_variant == 1) {
-        if (p2r) CSF_LAUNCH((pair_kernel<false, true>), g);
-        else CSF_LAUNCH((pair_kernel<false, false>), g);
+        if (p2r) CSF_LAUNCH((pair_kernel<0, true>), g);
+        else CSF_LAUNCH((pair_kernel<0, false>), g);
     } else {
         launch_cull(d, st, t0, t1);
     }

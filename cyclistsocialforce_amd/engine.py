@@ -99,8 +99,10 @@ class Engine:
         self.params = params
 
     def set_param_classes(self, classes, cls=None, idx=None):
-        """Parameter sets for a population whose vehicles own different params objects (vehicle.py:64-204): `classes` a
-        sequence of csf_params (set 0 replaces the engine's own), `cls[k]` the set of agent `idx[k]` (default: everyone)."""
+        """Parameter sets for a population whose vehicles own different params objects (vehicle.py:64-204) or are of
+        different classes (intersection.py:797-823): `classes` a sequence of csf_params (set 0 replaces the engine's own),
+        `cls[k]` the set of agent `idx[k]` (default: everyone).  With sets of several vehicle classes the state arrays
+        take the widest layout (x, y, psi, v, delta, theta); install them before add_agents."""
         classes = list(classes)
         tab = (type(self.params) * len(classes))(*classes)
         rows_first = cls is not None and len(classes) < getattr(self, "_n_classes", 1)    # no row may point beyond the table
@@ -109,6 +111,7 @@ class Engine:
         self._ck(self._lib.csf_set_param_classes(self._h, len(classes), tab))
         self.params = classes[0]
         self._n_classes = len(classes)
+        self.ns = int(self._lib.csf_num_states(self._h))         # sets of several vehicle classes: the widest state
         if cls is not None and not rows_first:
             self.set_agent_class(np.arange(self.n) if idx is None else idx, cls)
 

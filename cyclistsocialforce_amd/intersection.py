@@ -275,8 +275,6 @@ class SocialForceIntersection:
             raise TypeError("road users must be cyclistsocialforce_amd.vehicle.Vehicle objects")
         if v._owner is not None and v._owner is not self:
             raise RuntimeError(f"vehicle {v.id} already belongs to another intersection")
-        if self.vehicles and type(v).MODEL != type(self.vehicles[0]).MODEL:
-            raise NotImplementedError("one intersection holds one vehicle class (one engine per rider model)")
         if v.dest_force_func is not None or v.rep_force_func is not None:
             raise NotImplementedError(f"vehicle {v.id} carries a custom dest_force_func / rep_force_func: the population "
                                       "engine evaluates the class's own force functions for every agent")
@@ -326,22 +324,26 @@ class SocialForceIntersection:
 
     def _sync_param_classes(self):
         """table and rows -> engine, when they changed (new road users, assignments to parameter attributes)"""
-        e = self._engine
-        n = len(self.vehicles)
         pods, cls = self._param_classes()
+        self._sync_param_table(pods, cls, len(self.vehicles))
+        self._sync_param_rows(cls)
+
+    def _sync_param_table(self, pods, cls, n_on_device):
+        e = self._engine
         table = tuple(bytes(p) for p in pods)
         if table != self._class_table:
-            shrink = self._class_table is not None and len(table) < len(self._class_table)
-            if shrink:                                          # rows first: none may point beyond the new table
-                e.set_agent_class(np.arange(n), cls)
+            if self._class_table is not None and len(table) < len(self._class_table) and n_on_device:
+                e.set_agent_class(np.arange(n_on_device), cls[:n_on_device])      # rows first: none may point beyond the new table
+                self._cls[:n_on_device] = cls[:n_on_device]
             e.set_param_classes(pods)
-            if shrink:
-                self._cls[:n] = cls
             self._class_table = table
             self._pod_bytes = table[0]
+
+    def _sync_param_rows(self, cls):
+        n = len(self.vehicles)
         ch = np.where(cls != self._cls[:n])[0]
         if ch.size:
-            e.set_agent_class(ch, cls[ch])
+            self._engine.set_agent_class(ch, cls[ch])
             self._cls[:n] = cls
 
     def add_road_user(self, user):
@@ -407,10 +409,10 @@ class SocialForceIntersection:
 
     def _bind(self, v):
         """vehicle attributes that are views of the bulk mirror"""
-        k = v._index
-        v.s = self._S[k]
+        k, w = v._index, type(v).N_STATES       # (a mixed population: the bulk rows are as wide as the widest class)
+        v.s = self._S[k, :w]
         v.znav = self._zn[k]
-        v.traj = self._traj[:, k, :].T
+        v.traj = self._traj[:, k, :w].T
 
     def _detach(self, v):
         """the vehicle leaves with private copies of everything it saw through the mirror"""
@@ -433,7 +435,7 @@ class SocialForceIntersection:
             cap = self._capacity or max(256, 4 * len(self.vehicles))
             self._engine = Engine(v0._pod(PRIORITY_RULES[self.priority_rule]), cap, device=self._device)
             self._capacity = cap
-            ns = type(v0).N_STATES
+            ns = max(type(v).N_STATES for v in self.vehicles)
             self._S = np.zeros((cap, ns))
             self._shadow = np.zeros((cap, ns))
             self._vd = np.zeros(cap)
@@ -457,12 +459,19 @@ class SocialForceIntersection:
             raise RuntimeError(f"intersection capacity {self._capacity} exceeded; pass capacity= at construction")
         new = self._pending
         self._pending = []
-        s0 = np.array([v.s for v in new], dtype=float)
+        pods, cls = self._param_classes()                      # of everyone, the arrivals included
+        ns = max(self._S.shape[1], max(type(v).N_STATES for v in new))
+        if ns > self._S.shape[1]:                              # a wider vehicle class joins: wider rows
+            self._widen(ns)
+        self._sync_param_table(pods, cls, len(self.vehicles) - len(new))   # first: it decides the engine's state layout
+        s0 = np.zeros((len(new), ns))
+        for k, v in enumerate(new):
+            s0[k, : v.s.size] = v.s
         vd = np.array([float(v.params.v_desired_default) for v in new])
         first = new[0]._index
-        e.add_agents(s0, vd)
+        e.add_agents(s0[:, : e.ns], vd)
         # vehicle.traj rows of the bulk history (grown geometrically; every vehicle of an engine shares t_s)
-        ns, T = new[0].traj.shape
+        T = new[0].traj.shape[1]
         n = len(self.vehicles)
         if self._traj is None or self._traj.shape[1] < n:
             grown = np.zeros((T, max(n, 2 * (0 if self._traj is None else self._traj.shape[1])), ns))
@@ -471,17 +480,21 @@ class SocialForceIntersection:
             self._traj = grown
             for v in self.vehicles:
                 if v._live:
-                    v.traj = self._traj[:, v._index, :].T
+                    v.traj = self._traj[:, v._index, : type(v).N_STATES].T
         for v in new:
-            if v.traj.shape != (ns, T):
-                raise NotImplementedError("all road users of one intersection share t_s (one engine per vehicle class)")
-        for c in range(0, len(new), 512):            # adopt the vehicles' own histories, a slab of rows at a time
-            blk = new[c:c + 512]
-            self._traj[:, first + c:first + c + len(blk), :] = np.stack([v.traj for v in blk]).transpose(2, 0, 1)
+            if v.traj.shape[1] != T:
+                raise NotImplementedError("all road users of one intersection share t_s (one engine per intersection)")
+        if all(type(v).N_STATES == ns for v in new):
+            for c in range(0, len(new), 512):        # adopt the vehicles' own histories, a slab of rows at a time
+                blk = new[c:c + 512]
+                self._traj[:, first + c:first + c + len(blk), :] = np.stack([v.traj for v in blk]).transpose(2, 0, 1)
+        else:
+            for k, v in enumerate(new):
+                self._traj[:, first + k, : type(v).N_STATES] = v.traj.T
         for k, v in enumerate(new):
             r = first + k
-            self._S[r] = v.s
-            self._shadow[r] = v.s
+            self._S[r] = s0[k]
+            self._shadow[r] = s0[k]
             self._vd[r] = vd[k]
             self._zn[r] = v.znav
             st = (v.i, v.destpointer, v.force)
@@ -491,7 +504,24 @@ class SocialForceIntersection:
             self._dirty_queues[v] = -1
         self._drawn_stale = True
         self._cls[first:first + len(new)] = 0        # (the engine starts a road user in parameter set 0)
-        self._sync_param_classes()
+        self._sync_param_rows(cls)
+
+    def _widen(self, ns):
+        """rows of the bulk mirror as wide as the widest vehicle class of the population"""
+        for name in ("_S", "_shadow"):
+            old = getattr(self, name)
+            new = np.zeros((old.shape[0], ns))
+            new[:, : old.shape[1]] = old
+            setattr(self, name, new)
+        if self._traj is not None:
+            grown = np.zeros(self._traj.shape[:2] + (ns,))
+            grown[:, :, : self._traj.shape[2]] = self._traj
+            self._traj = grown
+        for v in self.vehicles:
+            if v._live:
+                st = (v.i, v.destpointer, v.force)
+                self._bind(v)
+                v.i, v.destpointer, v.force = st
 
     def _mark_queue_dirty(self, v, how=None):
         """how: None rows appended, -1 queue replaced (pointer rewinds), -2 rows edited in place (pointer kept)"""
@@ -533,7 +563,7 @@ class SocialForceIntersection:
         # vehicle.s edited in place (calibration.py:455-460)
         changed = np.where(np.any(self._S[:n] != self._shadow[:n], axis=1))[0]
         if changed.size:
-            e.push_state(changed, self._S[changed])
+            e.push_state(changed, self._S[changed][:, : e.ns])
             self._shadow[changed] = self._S[changed]
         if self._track_params:
             # params.v_desired_default is the per-agent parameter (demoCSFstandalone.py:104-113); the population is
@@ -563,8 +593,8 @@ class SocialForceIntersection:
         e = self._engine
         n = len(self.vehicles)
         s, ptr, zn, fx, fy, _ = e.tick_snapshot(forces=forces)
-        self._S[:n] = s
-        self._shadow[:n] = s
+        self._S[:n, : s.shape[1]] = s
+        self._shadow[:n, : s.shape[1]] = s
         self._ptr[:n] = ptr
         self._zn[:n] = zn
         if forces:

@@ -118,10 +118,14 @@ int csf_set_params(csf_engine *e, const csf_params *params);           /* parame
 /* Every reference vehicle owns its params object (vehicle.py:64-204): the field vehicle i exerts is evaluated with ITS
  * f_0 / sigma_* / e_* (vehicle.py:1592-1612; p_0 / p_decay for the Bicycle field, :1095-1101) and masked with ITS hfov
  * (intersection.py:733-735), and it steers, accelerates, brakes and arrives with its own gains and limits.
- * csf_set_param_classes installs 1 to 256 parameter sets (same model, t_s and traj_len as the engine; set 0 replaces the
+ * csf_set_param_classes installs 1 to 256 parameter sets (same t_s and traj_len as the engine; set 0 replaces the
  * engine's own, the priority rule stays the intersection's); csf_set_agent_class assigns sets to road users (new road
- * users start in set 0).  With more than one set the engine runs the pair kernel without the far-field and field-of-view
- * culls (O(N^2) per tick) and takes population changes through the host mirror. */
+ * users start in set 0; a road user that has not taken a tick yet is re-initialised as the constructor of its set's
+ * class would, vehicle.py:1728-1736).  The sets may be of different vehicle CLASSES (intersection.py:797-823 calls each
+ * vehicle's own methods, so any mix may share an intersection): every row of s0 / csf_get_state then has the widest
+ * layout among them (csf_num_states; states a class does not have stay 0), so install the sets before csf_add_agents.
+ * With more than one set the engine runs the pair kernel without the far-field and field-of-view culls (O(N^2) per tick)
+ * and takes population changes through the host mirror. */
 int csf_set_param_classes(csf_engine *e, int32_t n_classes, const csf_params *classes);
 int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *cls);
 int csf_set_v_desired(csf_engine *e, int64_t n, const int32_t *idx, const double *v_desired);

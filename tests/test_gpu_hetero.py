@@ -159,3 +159,120 @@ def test_mirror_classes_with_individual_parameters(golden):
     got = np.array([v.s for v in bikes])
     assert np.abs(got[:, :2] - S[10][:, :2]).max() > 1e-3
     assert len(ins._class_table) == 5
+
+
+def test_several_vehicle_classes_golden(amd, golden):
+    """Bicycle, TwoDBicycle, InvPendulumBicycle, PlanarPointBicycle and PlanarBicycle in ONE intersection
+    (intersection.py:797-823 calls each vehicle's own methods), three of each, the third with parameters of its own:
+    250 ticks against the literal reference, and the same population against the oracle tick by tick."""
+    from conftest import mixed_classes
+
+    g = golden("mixed")
+    pods, cls = mixed_classes(g)
+    n = g["s0"].shape[0]
+    e = amd.Engine(pods[0], n)
+    e.set_param_classes(pods)                                   # before the road users: six states per row from here on
+    assert e.ns == 6
+    e.add_agents(g["s0"], g["vdes"])
+    e.set_dest_queue(np.arange(n), g["off"], g["dq"], reset=True)
+    e.set_agent_class(np.arange(n), cls)
+    S, F = g["S"], g["F"]
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    worst = 0.0
+    for k in range(1, S.shape[0]):
+        e.step(10)
+        got = e.state()
+        worst = max(worst, np.abs(got[:, :2] - S[k][:, :2]).max() / extent)
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"sample {k}")
+        np.testing.assert_allclose(got[:, 2:], S[k][:, 2:], rtol=0, atol=2e-3, err_msg=f"sample {k}")
+        fx, fy = e.forces()
+        np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=0, atol=2e-3 * max(np.abs(F[k - 1]).max(), 1.0))
+    assert (e.status() == 0).all()
+    print(f"mixed: worst position deviation / extent = {worst:.3e}")
+    e.close()
+
+
+def test_random_mixed_population_vs_oracle(amd):
+    """900 road users of five classes and ten parameter sets (beyond one LDS tile) against the oracle."""
+    rng = np.random.default_rng(99)
+    n, box, ticks = 900, 110.0, 50
+    order = ["twod", "bicycle", "invpend", "planarpoint", "planarbike"]
+    own = {"twod": dict(hfov=1.0, f_0=10.0), "bicycle": dict(hfov=3.4, p_0=40.0, p_decay=4.0), "invpend": dict(hfov=2.5, e_0=0.9, k_p_v=12.0, v_max_walk=3.5),
+           "planarpoint": dict(hfov=1.5, f_0=5.0, poles=[-3.0 + 0j]), "planarbike": dict(hfov=2.8, sigma_0=0.6)}
+    pods = [amd.pod(m) for m in order] + [amd.pod(m, **own[m]) for m in order]
+    cls = rng.integers(0, len(pods), n).astype(np.uint8)
+    s0 = np.zeros((n, 6))
+    s0[:, 0] = rng.uniform(0, box, n); s0[:, 1] = rng.uniform(0, box, n)
+    s0[:, 2] = rng.uniform(-np.pi, np.pi, n); s0[:, 3] = rng.uniform(3, 4.8, n)
+    d = np.array([40.0, 79.0, 80.0])
+    dq = np.zeros((n, 4, 3))
+    dq[:, 0, 0] = s0[:, 0]; dq[:, 0, 1] = s0[:, 1]
+    dq[:, 1:, 0] = s0[:, 0, None] + d[None, :] * np.cos(s0[:, 2])[:, None]
+    dq[:, 1:, 1] = s0[:, 1, None] + d[None, :] * np.sin(s0[:, 2])[:, None]
+    off = np.arange(n + 1) * 4
+    e = amd.Engine(pods[0], n)
+    e.set_param_classes(pods)
+    e.add_agents(s0, 4.5)
+    e.set_dest_queue(np.arange(n), off, dq.reshape(-1, 3), reset=True)
+    e.set_agent_class(np.arange(n), cls)
+    classes = [orc_params(p) for p in pods]
+    pop = orc.Population(classes[0], s0, 4.5, off, dq.reshape(-1, 3), ns=6)
+    pop.set_classes(classes, cls)
+    e.calc_forces(); pop.calc_forces_range(0, n)
+    fx, fy = e.forces(); ox, oy = pop.forces()
+    err = max(np.abs(fx - ox).max(), np.abs(fy - oy).max()) / max(np.hypot(ox, oy).max(), 1.0)
+    assert err < 1e-4, err
+    e.step(ticks); pop.step(ticks)
+    got, ref = e.state(), pop.state()
+    devs = np.abs(got[:, :2] - ref[:, :2]).max(axis=1)
+    print(f"mixed random: forces vs oracle {err:.1e}; after {ticks} ticks |dpos| max {devs.max():.1e} m, 99 % {np.percentile(devs, 99):.1e} m")
+    assert devs.max() < 1e-4 * box and (e.status() == 0).all()
+    # invpend road users slower than their set's v_max_walk start walking (vehicle.py:1732-1736 with THEIR limit)
+    slow = (cls == 7) & (s0[:, 3] < 3.5)
+    assert slow.any()
+    np.testing.assert_allclose(got[:, 2:], ref[:, 2:], rtol=0, atol=2e-3)
+    e.close()
+
+
+def test_mirror_classes_mixed_intersection(golden):
+    """The five rider classes of the mirror in ONE SocialForceIntersection, constructed as the reference's users would,
+    a sixth class member joining later through add_road_user; vehicle.s keeps each class's own length."""
+    from conftest import MIXED_OWN
+    from cyclistsocialforce_amd import parameters as P
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import Bicycle, InvPendulumBicycle, PlanarBicycle, PlanarPointBicycle, TwoDBicycle
+
+    g = golden("mixed")
+    cls_of = {"twod": TwoDBicycle, "bicycle": Bicycle, "invpend": InvPendulumBicycle, "planarpoint": PlanarPointBicycle,
+              "planarbike": PlanarBicycle}
+    par_of = {"twod": P.InvPendulumBicycleParameters, "bicycle": P.BicycleParameters, "invpend": P.InvPendulumBicycleParameters,
+              "planarpoint": P.PlanarPointBicycleParameters, "planarbike": P.PlanarBicycleParameters}
+    bikes = []
+    for k in range(g["s0"].shape[0]):
+        m = str(g["models"][k])
+        kw = dict(params=par_of[m](**MIXED_OWN[m])) if g["own"][k] else {}
+        v = cls_of[m](tuple(g["s0"][k][: cls_of[m].N_STATES]), id=str(k), **kw)
+        v.params.v_desired_default = float(g["vdes"][k])
+        rows = g["dq"][g["off"][k] + 1:g["off"][k + 1]]
+        v.setDestinations(rows[:, 0], rows[:, 1])
+        bikes.append(v)
+    # the first two classes only at first (rows five states wide); the others - among them the six-state class - join before
+    # the first tick through add_road_user, which widens the mirror
+    first = [v for v in bikes if int(v.id) % 5 < 2]
+    ins = SocialForceIntersection(first)
+    ins.calc_forces()                                           # (the engine exists now, with two vehicle classes)
+    for v in bikes:
+        if v not in first:
+            ins.add_road_user(v)
+    order = [int(v.id) for v in ins.vehicles]
+    S = g["S"]
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    for k in range(1, 9):
+        for _ in range(10):
+            ins.step()
+        for v in ins.vehicles:
+            w = type(v).N_STATES
+            assert v.s.shape == (w,) and v.traj.shape[0] == w
+            np.testing.assert_allclose(v.s[:2], S[k][int(v.id), :2], rtol=0, atol=1e-4 * extent)
+            np.testing.assert_allclose(v.s[2:], S[k][int(v.id), 2:w], rtol=0, atol=2e-3)
+    assert len(ins._class_table) == 10 and order[:6] == [0, 1, 5, 6, 10, 11]

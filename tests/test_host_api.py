@@ -121,8 +121,9 @@ def test_intersection_host_bookkeeping():
     assert ins.get_road_user_ids() == ["b"]
     with pytest.raises(ValueError):                      # co-simulation needs the net (tests: test_sumo_seam_host_side)
         SocialForceIntersection((), activate_sumo_cosimulation=True)
-    with pytest.raises(NotImplementedError):
-        SocialForceIntersection((b2 := Bicycle((0, 0, 0, 5, 0)), PlanarPointBicycle((0, 0, 0, 5))))
+    mixed = SocialForceIntersection((Bicycle((0, 0, 0, 5, 0)), PlanarPointBicycle((0, 0, 0, 5))))     # intersection.py:797-823:
+    pods, cls = mixed._param_classes()                                    # any vehicle classes may share an intersection
+    assert [p.model for p in pods] == [0, 3] and cls.tolist() == [0, 1]
     with pytest.raises(ValueError):
         SocialForceIntersection((), priority_rule="left")
     empty = SocialForceIntersection(())
