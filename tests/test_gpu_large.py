@@ -316,6 +316,44 @@ def test_loopback_first_tick_matches_unsharded_closely(amd):
         assert max(np.abs(mx[lo:hi] - rx[lo:hi]).max(), np.abs(my[lo:hi] - ry[lo:hi]).max()) < 2e-6 * scale
 
 
+def test_sharded_engine_with_parameter_sets(amd):
+    """a 2-way loopback group whose road users are of two vehicle classes and four parameter sets (csf_set_param_classes):
+    every rank holds the whole row array and reads the SOURCE's row for the records it gathered.  Against the unsharded
+    engine and the oracle."""
+    n, box, world = 1100, 70.0, 2
+    s0, off, dq = population(n, box, seed=12)
+    s = np.zeros((n, 6)); s[:, :4] = s0[:, :4]
+    pods = [amd.pod("twod"), amd.pod("invpend", hfov=1.0, f_0=10.0), amd.pod("twod", hfov=3.6, sigma_0=0.6), amd.pod("invpend")]
+    cls = np.random.default_rng(3).integers(0, 4, n).astype(np.uint8)
+
+    def build():
+        e = amd.Engine(pods[0], n)
+        e.set_param_classes(pods)
+        e.add_agents(s, 5.0)
+        e.set_dest_queue(np.arange(n), off, dq, reset=True)
+        e.set_agent_class(np.arange(n), cls)
+        return e
+
+    ref = build()
+    members = [build() for _ in range(world)]
+    amd.Engine.loopback_group(members)
+    classes = [orc.Params.from_buffer_copy(bytes(p)) for p in pods]
+    pop = orc.Population(classes[0], s, 5.0, off, dq, ns=6)
+    pop.set_classes(classes, cls)
+    for chunk in (1, 9, 30):
+        ref.step(chunk)
+        amd.Engine.step_group(members, chunk)
+        pop.step(chunk)
+        got, _ = gather_blocks(members)
+        dev = np.abs(got[:, :2] - ref.state()[:, :2]).max()
+        dor = np.abs(got[:, :2] - pop.state()[:, :2]).max()
+        print(f"  after {chunk:2d} more ticks: vs unsharded {dev:.1e} m, vs oracle {dor:.1e} m")
+        assert dev < (2e-6 if chunk < 30 else 1e-4 * box) and dor < 1e-4 * box
+    for m in members[::-1]:
+        m.close()
+    ref.close()
+
+
 # --------------------------------------------------------------------------- measurement plumbing
 
 def test_profiling_event_pool_is_bounded(amd):
