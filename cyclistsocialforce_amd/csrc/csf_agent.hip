@@ -924,9 +924,12 @@ void launch_records(const Dev &d, hipStream_t st) {
 // retire: remove_road_user (intersection.py:576-634): the slot is no longer integrated and its record becomes the
 //   sentinel that contributes exactly nothing as a source.
 // requeue: Vehicle.setDestinations (vehicle.py:606-647): the queue of a slot now lives at another place of the slab.
-__global__ void patch_kernel(const Dev d, const PatchHeader *hp) {
-    const PatchHeader h = *hp;
-    const char *base = (const char *)hp;
+// The batch header travels as a kernel argument (one round trip over PCIe less than reading it from the pinned buffer).
+// [b0, b1): the batches of the binned order that receive arrivals in this launch (the host knows the places of the
+// sentinel tail it hands out, csf_engine.hip: rebin): the workgroup that finishes last recomputes their bounding circles,
+// which saves the bounds_kernel launch in front of the next pair launch.
+__global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHeader h, const char *base, unsigned *ticket,
+                                                    int b0, int b1) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t cap = d.cap;
     if (k < h.n_retire) {
@@ -939,10 +942,7 @@ __global__ void patch_kernel(const Dev d, const PatchHeader *hp) {
             d.rec2[a] = make_float2(0.0f, 1.0f);
             if (d.recs_valid) d.recs2[d.pos[a]] = make_float2(0.0f, 1.0f);
         }
-        return;
-    }
-    k -= h.n_retire;
-    if (k < h.n_spawn) {
+    } else if ((k -= h.n_retire) < h.n_spawn) {
         const SpawnRec r = ((const SpawnRec *)(base + h.off_spawn))[k];
         const int64_t a = r.slot;
         const csf_params &p = d.p;
@@ -972,23 +972,31 @@ __global__ void patch_kernel(const Dev d, const PatchHeader *hp) {
         d.status[a] = 0;
         d.alive[a] = 1;
         write_record(d, d.p, a, s[0], s[1], s[2], s[3]);
-        return;
-    }
-    k -= h.n_spawn;
-    if (k < h.n_requeue) {
+    } else if ((k -= h.n_spawn) < h.n_requeue) {
         const QueueRec r = ((const QueueRec *)(base + h.off_requeue))[k];
         d.qbeg[r.slot] = r.qbeg;
         d.qlen[r.slot] = r.qlen;
         const int32_t ptr = r.mode == 1 ? 0 : d.ptr[r.slot];       // vehicle.py:642-645: reset rewinds the pointer
         d.ptr[r.slot] = ptr < r.qlen ? ptr : r.qlen - 1;
-        return;
+    } else if ((k -= h.n_requeue) < 3 * h.n_rows) {
+        d.q[3 * h.q_top + k] = ((const double *)(base + h.off_rows))[k];
     }
-    k -= h.n_requeue;
-    if (k < 3 * h.n_rows) d.q[3 * h.q_top + k] = ((const double *)(base + h.off_rows))[k];
+    if (b1 <= b0) return;                                          // (uniform) no circles to renew
+    __shared__ bool last;
+    __threadfence();                                               // this thread's records, before the ticket
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    for (int bb = b0 + (int)(threadIdx.x >> 6); bb < b1; bb += (int)(blockDim.x >> 6)) batch_circle(d, bb, threadIdx.x & 63, 0.0f, d.bnd);
+    if (threadIdx.x == 0) *ticket = 0;                             // for the next launch
 }
 
-void launch_patch(const Dev &d, const PatchHeader *h, int64_t items, hipStream_t st) {
-    if (items > 0) hipLaunchKernelGGL(patch_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, d, h);
+void launch_patch(const Dev &d, const PatchHeader &h, const void *records, unsigned *ticket, int b0, int b1, int64_t items,
+                  hipStream_t st) {
+    if (items > 0)
+        hipLaunchKernelGGL(patch_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, d, h, (const char *)records, ticket, b0, b1);
 }
 
 }  // namespace csf

@@ -155,7 +155,8 @@ struct PatchHeader {
     int64_t off_retire, off_spawn, off_requeue, off_rows;   // byte offsets from the header
     int64_t q_top;                                   // first row of the queue slab that the rows go to
 };
-void launch_patch(const Dev &d, const PatchHeader *h, int64_t items, hipStream_t st);
+void launch_patch(const Dev &d, const PatchHeader &h, const void *records, unsigned *ticket, int b0, int b1, int64_t items,
+                  hipStream_t st);
 void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st);   // get_untracked_foes as the reference's matrix
 void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const int32_t *stop, double *vd_out,
                     double *ddest_out, hipStream_t st);

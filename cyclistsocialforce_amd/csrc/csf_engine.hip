@@ -117,6 +117,9 @@ struct csf_engine {
     // re-binning.  `slack`: sentinel slots kept behind the population for arrivals (twice what the last period saw).
     std::vector<int32_t> free_tail, free_recent;   // free_tail: descending, so that pop_back hands out ascending slots
     int64_t live_at_rebin = 0, tail_used = 0;       // road users at the last re-binning; sentinel places handed out since
+    int64_t tail_flushed = 0;                       // ... of which the device has seen this many (flush_pending)
+    bool pend_inplace = false;                      // an arrival of the pending batch took a slot inside a real batch
+    DevBuf<unsigned> ticket;                        // patch_kernel: which workgroup finishes last
     bool tail_tracked = false;                      // the places of the sentinel tail are known (binned single engine)
     std::vector<uint8_t> h_alive;
     bool order_dirty = true;               // the device copy of `order` is stale
@@ -650,6 +653,7 @@ int rebin(csf_engine *e) {
     std::sort(e->free_tail.begin(), e->free_tail.end(), std::greater<int32_t>());
     e->live_at_rebin = d.n_live;
     e->tail_used = 0;
+    e->tail_flushed = 0;
     {
         const int64_t n_src = e->tail_tracked ? std::max<int64_t>(64, (d.n_live + 63) / 64 * 64)
                               : (e->world <= 1 && !e->loopback && !binned ? std::max<int64_t>(64, (d.n + 63) / 64 * 64) : d.n_pad);
@@ -967,7 +971,20 @@ int flush_pending(csf_engine *e) {
     if (b_sp) memcpy(base + h.off_spawn, pd.spawn.data(), b_sp);
     if (b_rq) memcpy(base + h.off_requeue, pd.requeue.data(), b_rq);
     if (b_rows) memcpy(base + h.off_rows, pd.rows.data(), b_rows);
-    launch_patch(d, (const PatchHeader *)pin->dev, h.n_retire + h.n_spawn + h.n_requeue + 3 * h.n_rows, e->main);
+    // The arrivals went to known places of the sentinel tail (rebin): the launch itself renews the circles of those few
+    // batches, and the circles the last pair launch emitted for this tick stay good for all others (a retirement only
+    // leaves a circle larger than necessary).  Otherwise every circle is recomputed before the next pair launch.
+    int b0 = 0, b1 = 0;
+    bool circles_here = e->bounds_fresh && e->tail_tracked && d.classify && !e->pend_inplace;
+    if (circles_here && h.n_spawn > 0) {
+        b0 = (int)((e->live_at_rebin + e->tail_flushed) / 64);
+        b1 = (int)((e->live_at_rebin + e->tail_used + 63) / 64);
+        if (b1 - b0 > 32 || (int64_t)b1 * 64 > d.n_src) circles_here = false, b0 = b1 = 0;
+    }
+    if (e->ticket.p == nullptr) HIPCHK(e, e->ticket.alloc(1));
+    launch_patch(d, h, pin->dev, e->ticket.p, b0, b1, h.n_retire + h.n_spawn + h.n_requeue + 3 * h.n_rows, e->main);
+    e->tail_flushed = e->tail_used;
+    e->pend_inplace = false;
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(pin->done, e->main));
     pin->busy = true;
@@ -980,7 +997,7 @@ int flush_pending(csf_engine *e) {
     pd.spawn.clear();
     pd.requeue.clear();
     pd.rows.clear();
-    e->bounds_fresh = false;
+    if (!circles_here) e->bounds_fresh = false;
     e->device_ahead = true;                                    // the host mirror of the patched slots was not kept up
     d.n_live = (int64_t)e->order.size();
     if (!getenv("CSF_FAKE_SHARD")) d.hi = d.n;                 // (unsharded: the receiver block is every slot)
@@ -1181,6 +1198,7 @@ int csf_destroy(csf_engine *e) {
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
+    e->ticket.release(); e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);
     for (auto &sl : e->pinned) {
@@ -1236,6 +1254,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             a = e->free_recent.back();
             e->free_recent.pop_back();
             tail = false;
+            e->pend_inplace = true;
         } else {
             a = d.n++;
         }
