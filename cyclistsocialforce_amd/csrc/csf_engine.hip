@@ -226,6 +226,7 @@ int fail(csf_engine *e, int code, const char *fmt, ...) {
     } while (0)
 
 const int NS_OF[5] = {5, 5, 6, 4, 5};
+int32_t pair_variant_for(int64_t n);   // (with rebin, below)
 
 double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, vehicle.py:154-155)
     const double PI = 3.141592653589793238462643383279502884;
@@ -418,8 +419,7 @@ void derive_consts(csf_engine *e) {
     e->classes[0] = p;
     e->d.n_classes = (int32_t)e->classes.size();
     e->classes_dirty = true;
-    const char *variant = getenv("CSF_PAIR_VARIANT");
-    e->d.pair_variant = variant ? atoi(variant) : 0;
+    e->d.pair_variant = pair_variant_for(e->d.n_live);
     {   // no rider model moves faster than its speed clamp (vehicle.py:1258, 1876, 1905; dynamics.py:1025)
         double vmax = 0;
         for (const csf_params &c : e->classes)
@@ -611,6 +611,17 @@ void set_chunks(csf_engine *e) {
 constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long
 constexpr int64_t BIN_MIN_AGENTS = 1024;
 
+// Which pair kernel (csf_pair.hip: launch_pair): 0 the cull-first kernel (binned records from BIN_MIN_AGENTS road users),
+// 1 the plain all-pairs kernel, 2 cull-first without binning.  Below ~3 000 road users the plain kernel is the faster
+// one - no classification, no queue, no re-binning launches: 14.1 against 20.7 us per tick at 1 024 TwoDBicycle, 11.1
+// against 13.2 at 64, level at ~3 000, 41 against 32 at 4 096 (tools/variant_by_n.py; the Bicycle field crosses over at
+// the same size) - and small populations are what the reference itself runs.  CSF_PAIR_VARIANT overrides.
+constexpr int64_t PLAIN_BELOW = 3072;
+int32_t pair_variant_for(int64_t n) {
+    const char *ov = getenv("CSF_PAIR_VARIANT");
+    return ov ? atoi(ov) : (n < PLAIN_BELOW ? 1 : 0);
+}
+
 // (re)build the spatially binned order of the records; decides whether batches are classified this tick
 int rebin(csf_engine *e) {
     Dev &d = e->d;
@@ -618,6 +629,7 @@ int rebin(csf_engine *e) {
         set_shard(e);
         launch_records(d, e->main);     // sentinels in the new tail (the records of the road users are rewritten as they are)
     }
+    d.pair_variant = pair_variant_for(d.n_live);
     const bool binned = d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS && d.n_classes == 1;   // (several parameter sets: the plain kernel)
     d.classify = binned;
     update_far_radius(e);

@@ -12,6 +12,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "auto_variant: the engine chooses its pair kernel by population size")
+
+
+@pytest.fixture(autouse=True)
+def _cull_kernel_at_every_size(request, monkeypatch):
+    """The engine picks the plain all-pairs kernel below ~3 000 road users and the cull-first kernel above
+    (csf_engine.hip: pair_variant_for).  Most parity cases are small and exist to exercise the cull-first kernel - its
+    classification, queue and far-field cull - so the suite pins that kernel; tests marked `auto_variant` (and every test
+    that sets CSF_PAIR_VARIANT itself) run with the engine's own choice."""
+    if "auto_variant" not in request.keywords and "CSF_PAIR_VARIANT" not in os.environ:
+        monkeypatch.setenv("CSF_PAIR_VARIANT", "0")
 
 
 @pytest.fixture(scope="session")

@@ -207,6 +207,46 @@ def test_population_trajectories_golden(amd, golden, prefix, model, rule):
     print(f"{prefix}: worst position deviation / extent = {worst:.3e}")
 
 
+@pytest.mark.auto_variant
+@pytest.mark.parametrize("prefix,model,rule", TRAJ)
+def test_population_trajectories_golden_plain_kernel(amd, golden, prefix, model, rule):
+    """The same runs with the engine's own choice of pair kernel: below ~3 000 road users the plain all-pairs kernel
+    (csf_engine.hip: pair_variant_for), which is what a drop-in user of these population sizes gets."""
+    g = golden("trajectories")
+    e = make_engine(amd, model, g[f"{prefix}_s0"], g[f"{prefix}_vdes"], g[f"{prefix}_off"], g[f"{prefix}_dq"], rule)
+    if f"{prefix}_verts" in g.files:
+        e.set_road(g[f"{prefix}_roff"], g[f"{prefix}_verts"], g[f"{prefix}_F0"], g[f"{prefix}_sigma"])
+    S = g[f"{prefix}_S"]
+    every = {"lap_twod": 50}.get(prefix, 10)
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    for k in range(1, S.shape[0]):
+        e.step(every)
+        got = e.state()
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"{prefix} sample {k}")
+        np.testing.assert_allclose(got[:, 3], S[k][:, 3], rtol=0, atol=2e-3, err_msg=f"{prefix} speed sample {k}")
+    assert (e.status() == 0).all() and e.count_pairs()[1] == "pair_kernel"
+
+
+@pytest.mark.auto_variant
+@pytest.mark.parametrize("model,n,kernel", [("twod", 1024, "pair_kernel"), ("twod", 2900, "pair_kernel"), ("twod", 3100, "pair_cull_kernel"),
+                                             ("bicycle", 2900, "pair_kernel"), ("bicycle", 3100, "pair_bike_kernel")])
+def test_pair_kernel_chosen_by_population_size(amd, model, n, kernel):
+    """plain below 3 072 road users, cull-first (binned) from there - and either against the oracle"""
+    box = float(np.sqrt(n / 0.2))
+    x, y, psi, v, off, dq = synthetic_population(n, box, seed=4)
+    s0 = np.zeros((n, 5)); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
+    e = make_engine(amd, model, s0, 5.0, off, dq)
+    pop = orc.Population(orc.default_params(model), s0, 5.0, off, dq)
+    e.step(40); pop.step(40)
+    assert e.count_pairs()[1] == kernel
+    assert np.abs(e.state()[:, :2] - pop.state()[:, :2]).max() < 1e-4 * box and (e.status() == 0).all()
+    # a population that shrinks below the threshold changes kernel at the next re-binning
+    if n == 3100:
+        e.remove_agents(np.arange(0, 400))
+        e.step(40)
+        assert e.count_pairs()[1] == "pair_kernel" and np.isfinite(e.state()).all()
+
+
 def synthetic_population(n, box, seed=0):
     """SURVEY.md §8(d) synthetic inputs."""
     rng = np.random.default_rng(seed)
