@@ -82,7 +82,7 @@ __device__ __forceinline__ double dest_dist(const Dev &d, const Agent &g) {
 }
 
 // vehicle.py:545-594
-__device__ void update_destination(const Dev &d, Agent &g) {
+__device__ __forceinline__ void update_destination(const Dev &d, Agent &g) {
     if (g.zn != 0) return;                                    // :567-568
     double dnext = dest_dist(d, g);
     if (dnext <= g.p->d_arrived_inter) g.ptr = min(g.ptr + 1, g.K - 1);   // :571-574
@@ -93,7 +93,7 @@ __device__ void update_destination(const Dev &d, Agent &g) {
 }
 
 // vehicle.py:354-457.  Returns the desired speed; ddest through the reference argument.
-__device__ double update_nav(const Dev &d, Agent &g, double &ddest) {
+__device__ __forceinline__ double update_nav(const Dev &d, Agent &g, double &ddest) {
     const csf_params &p = *g.p;
     const double k = 1.5;                                     // :377
     double d0, d1;
@@ -127,7 +127,7 @@ __device__ double update_nav(const Dev &d, Agent &g, double &ddest) {
 }
 
 // vehicle.py:1150-1194 / 2078-2108
-__device__ void direct_approach(const Dev &d, Agent &g, double &fx, double &fy) {
+__device__ __forceinline__ void direct_approach(const Dev &d, Agent &g, double &fx, double &fy) {
     update_destination(d, g);
     double ddest, vd = update_nav(d, g, ddest);
     if (ddest > 0) {
@@ -379,7 +379,7 @@ __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const doubl
 }
 
 // vehicle.py:1416-1558
-__device__ void twod_dest(const Dev &d, Agent &g, double &fx, double &fy) {
+__device__ __forceinline__ void twod_dest(const Dev &d, Agent &g, double &fx, double &fy) {
     update_destination(d, g);                                 // :1451
     double ddest, vd = update_nav(d, g, ddest);               // :1452
     if (g.ti == 0) {                                          // :1455-1458
@@ -429,7 +429,7 @@ __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, d
 }
 
 // vehicle.py:1218-1272 (Bicycle.control + Bicycle.move; PIDcontroller with ki = kd = 0, dynamics.py:33-54)
-__device__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) {
+__device__ __forceinline__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) {
     const csf_params &p = *g.p;
     double theta = atan2(Fy, Fx);                             // :1223
     double vd = sqrt(Fx * Fx + Fy * Fy);                      // :1224
@@ -457,7 +457,7 @@ __device__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) 
 // vehicle.py:1738-1786, 1810-1848; parameters.py:1832-1892.  control.forced_response over [0, t_s] with
 // constant input equals x+ = E11 x + E12 u with E = exp([[A h, B h],[0, 0]]).  E is formed by scaling and
 // squaring of a degree-12 Taylor polynomial (||M/2^s||_1 <= 1/2); only the 5 non-trivial rows are carried.
-__device__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, double Fy) {
+__device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, double Fy) {
     const csf_params &p = *g.p;
     const double v = g.v;
     const double iv = 1.0 / v, iv2 = iv * iv, iv3 = iv2 * iv;
@@ -567,7 +567,7 @@ __device__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, 
 __device__ __forceinline__ int64_t a_idx(int c, int64_t cap, int64_t a) { return (int64_t)c * cap + a; }
 
 template <int MODEL>
-__device__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
+__device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
     const csf_params &p = *g.p;
     const int64_t a = g.a, cap = d.cap;
     if (MODEL == CSF_BICYCLE) {                               // vehicle.py:1274-1289
