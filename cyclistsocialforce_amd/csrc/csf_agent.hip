@@ -945,7 +945,8 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
     } else if ((k -= h.n_retire) < h.n_spawn) {
         const SpawnRec r = ((const SpawnRec *)(base + h.off_spawn))[k];
         const int64_t a = r.slot;
-        const csf_params &p = d.p;
+        const csf_params &p = d.ptab[r.cls];
+        d.cls[a] = (uint8_t)r.cls;
         double s[6];
         for (int c = 0; c < 6; c++) s[c] = c < d.ns ? r.s[c] : 0.0;
         s[2] = limit_angle(s[2]);                                  // vehicle.py:154-155
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
         d.status[a] = 0;
         d.alive[a] = 1;
-        write_record(d, d.p, a, s[0], s[1], s[2], s[3]);
+        write_record(d, p, a, s[0], s[1], s[2], s[3]);
     } else if ((k -= h.n_spawn) < h.n_requeue) {
         const QueueRec r = ((const QueueRec *)(base + h.off_requeue))[k];
         d.qbeg[r.slot] = r.qbeg;

@@ -47,7 +47,7 @@ struct Dev {
     const csf_params *ptab;
     const PairConsts *pctab;
     const double *pbtab;     // [n_classes][7]
-    const uint8_t *cls;      // [cap]
+    uint8_t *cls;            // [cap]
     int64_t n;         // agent SLOTS in use (the highest one + 1); a slot may be dead after csf_remove_agents until it is reused
     int64_t n_live;    // road users (intersection.py n_bikes)
     int64_t cap;       // SoA stride
@@ -143,6 +143,7 @@ struct SpawnRec {      // one new road user (Vehicle.__init__, vehicle.py:64-204
     int32_t slot, qlen;
     int64_t qbeg;
     double s[6], vdes;
+    int32_t cls, pad;  // its parameter set (csf_set_agent_class before the batch reaches the device)
 };
 struct QueueRec {      // one replaced destination queue (Vehicle.setDestinations, vehicle.py:606-647)
     int32_t slot, qlen;

@@ -928,8 +928,7 @@ int prepare_mutation(csf_engine *e) {
 // history ring and CSF_INCREMENTAL=0 take the round trip through the host mirror (prepare_mutation / upload_all).
 bool can_patch_device(const csf_engine *e) {
     static const bool off = getenv("CSF_INCREMENTAL") && atoi(getenv("CSF_INCREMENTAL")) == 0;
-    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr &&
-           e->classes.size() == 1;   // (a spawn record carries no parameter set)
+    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
 }
 
 // a pinned, device-visible host buffer of `bytes` from the ring; waits only if the ring of four is exhausted
@@ -1291,6 +1290,8 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             r.qbeg = (int64_t)(e->pend.rows.size() / 3);
             for (int c = 0; c < 6; c++) r.s[c] = c < ns ? s[c] : 0.0;
             r.vdes = v_desired[k];
+            r.cls = 0;
+            r.pad = 0;
             e->pend.rows.insert(e->pend.rows.end(), {s[0], s[1], 0.0});
             e->pend_spawn_at[(size_t)a] = (int32_t)e->pend.spawn.size();
             e->pend.spawn.push_back(r);
@@ -1321,7 +1322,9 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     if (!patch) {
         set_shard(e);
     } else {
-        const int64_t n_src = e->tail_tracked ? std::min(d.n_pad, (e->live_at_rebin + e->tail_used + 63) / 64 * 64) : d.n_pad;
+        // (without the binned order a slot is its own place: the sources end with the last slot in use)
+        const int64_t n_src = e->tail_tracked ? std::min(d.n_pad, (e->live_at_rebin + e->tail_used + 63) / 64 * 64)
+                              : (d.classify ? d.n_pad : std::min(d.n_pad, (d.n + 63) / 64 * 64));
         if (n_src > d.n_src || !e->tail_tracked) {
             d.n_src = std::max(n_src, d.n_src);
             set_chunks(e);
@@ -1514,8 +1517,14 @@ int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int3
             return fail(e, CSF_E_ARG, "parameter set %d of %d (csf_set_param_classes first)", cls[k], (int)e->classes.size());
     }
     const int64_t cap = e->cap;
+    bool device_rows_stale = false;
     for (int64_t k = 0; k < n; k++) {
         const size_t a = (size_t)e->order[(size_t)idx[k]];
+        if (e->pend_spawn_at[a] >= 0) {                          // an arrival still on its way to the device: its spawn record
+            e->pend.spawn[(size_t)e->pend_spawn_at[a]].cls = cls[k];   // carries the set, and the patch kernel writes the row
+        } else if (e->h_cls[a] != (uint8_t)cls[k]) {
+            device_rows_stale = true;
+        }
         e->h_cls[a] = (uint8_t)cls[k];
         // A road user that has not moved yet is what its constructor made of it, with the limits of ITS set
         // (vehicle.py:1728-1736).  (With the device ahead of the host mirror every road user has taken a tick: engines with
@@ -1528,7 +1537,7 @@ int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int3
             e->dirty = true;
         }
     }
-    e->classes_dirty = true;                                   // (the slots' rows are uploaded with the table)
+    if (device_rows_stale) e->classes_dirty = true;            // (the slots' rows are uploaded with the table)
     return CSF_OK;
 }
 

@@ -242,6 +242,28 @@ void csfo_column_sums(const csfo_params *p, int64_t n, const double *x, const do
     }
 }
 
+/* the same for a population whose vehicles own different parameter sets / are of different classes (csfo_set_classes):
+ * source i with the field, the hfov and the class of ITS set tab[cls[i]] */
+void csfo_column_sums_classes(const csfo_params *tab, const uint8_t *cls, int rule, int64_t n, const double *x, const double *y,
+                              const double *psi, const double *v, int64_t m, const int64_t *recv, double *rx, double *ry) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t k = 0; k < m; k++) {
+        const int64_t j = recv[k];
+        double sx = 0, sy = 0;
+        for (int64_t i = 0; i < n; i++) {
+            const csfo_params *p = &tab[cls[i]];
+            if (csfo_untracked(p->hfov, rule, i == j ? 0 : 1, 0, x[i], y[i], x[j], y[j], psi[j])) continue;
+            double gx, gy;
+            if (p->model == CSFO_BICYCLE) csfo_pair_bicycle(p, x[i], y[i], psi[i], v[i], x[j], y[j], &gx, &gy);
+            else csfo_pair_twod(p, x[i], y[i], psi[i], x[j], y[j], psi[j], &gx, &gy);
+            sx += gx;
+            sy += gy;
+        }
+        rx[k] = sx;
+        ry[k] = sy;
+    }
+}
+
 /* intersection.py:226-242, 854-857 for m receivers (OpenMP over the receivers) */
 void csfo_road_forces(int64_t nv, const double *vx, const double *vy, const double *vF0, const double *vsig,
                       int64_t m, const double *x, const double *y, double *fx, double *fy) {

@@ -123,6 +123,7 @@ def lib():
         L.csfo_road_force.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_double, C.c_double, dp, dp]
         L.csfo_column_sums.argtypes = [C.POINTER(Params), C.c_int64] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
+        L.csfo_column_sums_classes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
         L.csfo_road_forces.argtypes = [C.c_int64] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 4
         L.csfo_spline20.restype = C.c_int
         L.csfo_spline20.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -222,11 +223,17 @@ def road_force(verts, off, F0, sigma, x, y):
     return fx, fy
 
 
-def column_sums(params, x, y, psi, v, recv):
-    """unclamped repulsive column sums (intersection.py:814-843) of the receivers `recv` over all sources"""
+def column_sums(params, x, y, psi, v, recv, cls=None, rule=0):
+    """unclamped repulsive column sums (intersection.py:814-843) of the receivers `recv` over all sources; with `cls`,
+    `params` is a list of parameter sets and cls[i] the set of source i"""
     x, y, psi, v = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, psi, v))
     recv = np.ascontiguousarray(recv, dtype=np.int64)
     rx = np.zeros(recv.size); ry = np.zeros(recv.size)
+    if cls is not None:
+        tab = (Params * len(params))(*params)
+        cls = np.ascontiguousarray(cls, dtype=np.uint8)
+        lib().csfo_column_sums_classes(tab, _p(cls), int(rule), x.size, _p(x), _p(y), _p(psi), _p(v), recv.size, _p(recv), _p(rx), _p(ry))
+        return rx, ry
     lib().csfo_column_sums(C.byref(params), x.size, _p(x), _p(y), _p(psi), _p(v), recv.size, _p(recv), _p(rx), _p(ry))
     return rx, ry
 

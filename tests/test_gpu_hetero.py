@@ -276,3 +276,69 @@ def test_mirror_classes_mixed_intersection(golden):
             np.testing.assert_allclose(v.s[:2], S[k][int(v.id), :2], rtol=0, atol=1e-4 * extent)
             np.testing.assert_allclose(v.s[2:], S[k][int(v.id), 2:w], rtol=0, atol=2e-3)
     assert len(ins._class_table) == 10 and order[:6] == [0, 1, 5, 6, 10, 11]
+
+
+def test_arrivals_and_departures_with_parameter_sets(amd):
+    """SUMO-style traffic (road users arrive and leave every few ticks) in a population of two vehicle classes and four
+    parameter sets: through the device-side path (the spawn record carries the arrival's set) against the same sequence
+    through the host mirror, and at the end against the oracle on the population as it is."""
+    rng = np.random.default_rng(21)
+    n0, cap, box = 1200, 2048, 90.0
+    pods = [amd.pod("twod"), amd.pod("invpend", hfov=1.0, f_0=10.0, v_max_walk=3.6), amd.pod("twod", hfov=3.6, sigma_0=0.6), amd.pod("invpend")]
+    pool = cap + 2500
+    s = np.zeros((pool, 6))
+    s[:, 0] = rng.uniform(0, box, pool); s[:, 1] = rng.uniform(0, box, pool)
+    s[:, 2] = rng.uniform(-np.pi, np.pi, pool); s[:, 3] = rng.uniform(3, 4.8, pool)
+    d = np.array([40.0, 79.0, 80.0])
+    dq = np.zeros((pool, 4, 3))
+    dq[:, 0, 0] = s[:, 0]; dq[:, 0, 1] = s[:, 1]
+    dq[:, 1:, 0] = s[:, 0, None] + d[None, :] * np.cos(s[:, 2])[:, None]
+    dq[:, 1:, 1] = s[:, 1, None] + d[None, :] * np.sin(s[:, 2])[:, None]
+    cls_of = rng.integers(0, 4, pool).astype(np.int32)
+    engines = []
+    for inc in (True, False):
+        e = amd.Engine(pods[0], cap)
+        e.set_incremental(inc)
+        e.set_param_classes(pods)
+        e.add_agents(s[:n0], 4.5)
+        e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, dq[:n0].reshape(-1, 3), reset=True)
+        e.set_agent_class(np.arange(n0), cls_of[:n0])
+        engines.append(e)
+    ids = list(range(n0))
+    fresh = n0
+    for rnd in range(14):
+        for e in engines:
+            e.step(3)
+        k = int(rng.integers(40, 90))
+        kill = np.sort(rng.choice(len(ids), k, replace=False))
+        grow = k + int(rng.integers(-15, 25))
+        new = list(range(fresh, fresh + grow))
+        fresh += grow
+        for e in engines:
+            e.remove_agents(kill)
+            e.add_agents(s[new], 4.5)
+            m = len(ids) - k
+            e.set_dest_queue(np.arange(m, m + grow), np.arange(grow + 1) * 4, dq[new].reshape(-1, 3), reset=True)
+            e.set_agent_class(np.arange(m, m + grow), cls_of[new])
+        gone = set(kill.tolist())
+        ids = [a for i, a in enumerate(ids) if i not in gone] + new
+        A, B = engines[0].state(), engines[1].state()
+        assert A.shape == (len(ids), 6)
+        devs = np.abs(A[:, :2] - B[:, :2]).max(axis=1)
+        assert np.percentile(devs, 99) < 2e-5 and devs.max() < 1e-4 * box, (rnd, devs.max())
+        np.testing.assert_allclose(A[:, 2:], B[:, 2:], rtol=0, atol=2e-3)      # incl. walking / riding of the arrivals' own sets
+    e = engines[0]
+    cls = cls_of[ids].astype(np.uint8)
+    e.calc_forces()
+    fdx, fdy, frx, fry = e.force_parts()
+    st = e.state()
+    recv = np.arange(0, len(ids), 13)
+    ox, oy = orc.column_sums([orc_params(p) for p in pods], st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv, cls=cls)
+    lim, mag = np.hypot(fdx[recv], fdy[recv]), np.hypot(ox, oy)                 # utils.py:79-84 with the engine's own F_dest
+    scale = np.where(mag > lim, lim / np.maximum(mag, 1e-300), 1.0)
+    cx, cy = ox * scale, oy * scale
+    err = max(np.abs(frx[recv] - cx).max(), np.abs(fry[recv] - cy).max()) / max(np.hypot(cx, cy).max(), 1.0)
+    print(f"  {len(ids)} road users after 14 rounds: clamped repulsive sums vs oracle {err:.1e}")
+    assert err < 1e-4 and (e.status() == 0).all()
+    for eng in engines:
+        eng.close()
