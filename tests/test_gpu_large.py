@@ -548,3 +548,101 @@ def test_arrivals_in_the_sentinel_tail(amd):
             assert err < 1e-4
     assert (e.status() == 0).all() and np.isfinite(e.state()).all()
     e.close()
+
+
+@pytest.mark.parametrize("seed,n0,box,sets", [(1, 1300, 420.0, 1), (2, 3300, 700.0, 1), (3, 1100, 400.0, 3)])
+def test_random_population_calls_device_path_vs_host_mirror(amd, seed, n0, box, sets):
+    """A random sequence of the population calls SUMO co-simulation makes - arrivals, departures, queues replaced / edited
+    / extended, desired speeds, now and then a state pushed from the host, a few ticks in between - through the
+    device-side path (pending lists, sentinel tail, slot reuse, slab rewrites, re-binning) and through the host mirror
+    (csf_set_incremental(0)); sets = 3: three parameter sets, every arrival with a set of its own choice (the spawn record
+    carries it).  A sparse population (few pairs interact: differences stay at rounding level), so the two
+    engines are compared tightly after every call: positions, pointers, navigation states, status."""
+    rng = np.random.default_rng(seed)
+    cap = n0 + 900
+    pool, _, pdq = population(cap + 6000, box, seed=seed + 50)
+    pdq = pdq.reshape(-1, 4, 3)
+    pods = [amd.pod("twod"), amd.pod("twod", hfov=1.0, f_0=10.0), amd.pod("twod", hfov=3.6, sigma_0=0.6, k_p_v=12.0)][:sets]
+    cls_of = rng.integers(0, sets, pool.shape[0])
+    engines = []
+    for inc in (True, False):
+        e = amd.Engine(pods[0], cap)
+        e.set_incremental(inc)
+        if sets > 1:
+            e.set_param_classes(pods)
+        e.add_agents(pool[:n0], 5.0)
+        e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, pdq[:n0].reshape(-1, 3), reset=True)
+        if sets > 1:
+            e.set_agent_class(np.arange(n0), cls_of[:n0])
+        e.step(2)
+        engines.append(e)
+    fresh, n = n0, n0
+    counts = dict.fromkeys(("step", "remove", "add", "replace", "edit", "extend", "vdes", "push"), 0)
+    history = []
+    for it in range(160):
+        op = rng.choice(["step", "step", "remove", "add", "add", "replace", "edit", "extend", "vdes", "push"],
+                        p=[0.22, 0.1, 0.14, 0.12, 0.08, 0.1, 0.08, 0.08, 0.05, 0.03])
+        counts[str(op)] += 1
+        if op == "step":
+            k = int(rng.integers(1, 4))
+            for e in engines:
+                e.step(k)
+        elif op == "remove" and n > 200:
+            idx = np.sort(rng.choice(n, int(rng.integers(1, 40)), replace=False))
+            for e in engines:
+                e.remove_agents(idx)
+            n -= idx.size
+        elif op == "add" and n + 60 < cap:
+            k = int(rng.integers(1, 60))
+            new = np.arange(fresh, fresh + k)
+            fresh += k
+            for e in engines:
+                e.add_agents(pool[new], 5.0)
+                e.set_dest_queue(np.arange(n, n + k), np.arange(k + 1) * 4, pdq[new].reshape(-1, 3), reset=True)
+                if sets > 1:
+                    e.set_agent_class(np.arange(n, n + k), cls_of[new])
+            n += k
+        elif op in ("replace", "edit", "extend"):
+            k = int(rng.integers(1, 30))
+            idx = np.sort(rng.choice(n, k, replace=False))
+            src = rng.integers(0, pdq.shape[0], k)
+            if op == "replace":
+                rows, off, mode = pdq[src].reshape(-1, 3), np.arange(k + 1) * 4, 1
+            elif op == "edit":                                  # the same rows with another stop flag, pointer kept
+                rows = pdq[src].reshape(-1, 3).copy(); rows[:, 2] = 0.0
+                off, mode = np.arange(k + 1) * 4, 2
+            else:
+                rows, off, mode = pdq[src][:, 2:].reshape(-1, 3), np.arange(k + 1) * 2, 0
+            for e in engines:
+                e.set_dest_queue(idx, off, rows, reset=mode)
+        elif op == "vdes":
+            idx = np.sort(rng.choice(n, 20, replace=False))
+            v = rng.uniform(3.5, 5.5, 20)
+            for e in engines:
+                e.set_v_desired(idx, v)
+        elif op == "push":
+            idx = np.sort(rng.choice(n, 5, replace=False))
+            st = engines[0].state()[idx]
+            st[:, 0] += 0.25
+            for e in engines:
+                e.push_state(idx, st)
+        (A, pa, za, _), (B, pb, zb, _) = engines[0].state(with_nav=True), engines[1].state(with_nav=True)
+        assert A.shape == B.shape == (n, 5), (it, op)
+        assert np.array_equal(pa, pb) and np.array_equal(za, zb), (it, op)
+        # The two engines centre their fp32 records on different origins (the host-mirror path re-centres at every upload):
+        # positions are quantised differently by up to ~2e-5 m in a box this large, which a pair at arm's length turns into
+        # a steering difference of ~1e-5 rad per tick - rounding level for this design, far below any bookkeeping error
+        # (a missed or doubled source changes a force by percents, a wrong slot moves a road user by metres).
+        history.append(str(op))
+        dpos, dang, dv = np.abs(A[:, :2] - B[:, :2]).max(), np.abs(A[:, [2, 4]] - B[:, [2, 4]]).max(), np.abs(A[:, 3] - B[:, 3]).max()
+        if dpos >= 2e-4 or dang >= 2e-3 or dv >= 2e-4:
+            r, c = np.unravel_index(np.abs(A - B).argmax(), A.shape)
+            raise AssertionError(f"call {it} ({op}): |A - B| = {dpos:.1e} m, {dang:.1e} rad, {dv:.1e} m/s; worst: road user {r} of "
+                                 f"{n}, state {c}: {A[r]} vs {B[r]}; calls so far: {history}")
+    print(f"  after the last call: |A - B| = {dpos:.1e} m, {dang:.1e} rad, {dv:.1e} m/s")
+    for e in engines:
+        assert np.isfinite(e.state()).all()
+        assert ((e.status() & ~np.uint32(1024)) == 0).all()      # (random queues may end a spline: CSF_ST_SPLINE only)
+        e.close()
+    print(f"  calls: {counts}; {n} road users at the end")
+    assert min(counts.values()) > 0
