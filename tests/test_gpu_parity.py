@@ -594,3 +594,48 @@ def test_bicycle_field_on_binned_records_vs_oracle(amd, monkeypatch, hfov, rule,
     # the force jumps there, and that one receiver then follows a different path (seen with hfov = 4.0: 1 of 2048)
     assert np.percentile(dev, 99.5) < 1e-4 * box and (dev > 1e-4 * box).sum() <= 3
     assert (e2.status() == 0).all()
+
+
+def test_receiver_that_leaves_the_band_crossed_a_field_of_view_edge(amd, monkeypatch):
+    """DESIGN D6, shown rather than asserted: in the run of test_bicycle_field_on_binned_records_vs_oracle with hfov = 4.0
+    one receiver of 2 048 ends up outside the 1e-4 band.  Engine and oracle are stepped side by side, the oracle re-anchored
+    on the engine's state before every tick, so that the FIRST tick on which any receiver's force differs visibly is a
+    difference of that tick's force evaluation alone.  On that tick the receiver's mask column differs from the oracle's in
+    one source, whose bearing - evaluated in fp64 on the state both started the tick from - lies within fp32 rounding of
+    the records (a few 1e-6 rad) of +-hfov/2: the source is tracked in one arithmetic and not in the other, and the Bicycle
+    field it switches on or off is not small at that distance."""
+    monkeypatch.setenv("CSF_RPB", "16")
+    hfov, n, box = 4.0, 2048, 120.0
+    x, y, psi, v, off, dq = synthetic_population(n, box, seed=3)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    e = make_engine(amd, "bicycle", s0, 5.0, off, dq, hfov=hfov)
+    p = orc.default_params("bicycle", hfov=hfov)
+    pop = orc.Population(p, s0, 5.0, off, dq)
+    found = None
+    for tick in range(40):
+        st, ptr, zn, _ = e.state(with_nav=True)
+        pop.push_state(st, ptr=ptr, znav=zn)                     # both evaluate this tick's forces on the same state
+        e.step(1); pop.step(1)
+        fx, fy = e.forces(); ox, oy = pop.forces()
+        scale = max(np.hypot(ox, oy).max(), 1.0)
+        d = np.maximum(np.abs(fx - ox), np.abs(fy - oy)) / scale
+        if d.max() > 1e-3:                                       # far above summation-order differences (~1e-5)
+            found = (tick, int(d.argmax()), float(d.max()), st)
+            break
+    assert found is not None, "no receiver left the band in 40 ticks: the case this test documents has disappeared"
+    tick, j, dmax, st = found
+    # which source does receiver j see differently?  fp64 bearing of every source relative to j's heading (:711-736)
+    az = np.arctan2(st[:, 1] - st[j, 1], st[:, 0] - st[j, 0])
+    rel = (st[j, 2] - az + np.pi) % (2 * np.pi) - np.pi
+    margin = np.abs(np.abs(rel) - hfov / 2)
+    margin[j] = np.inf
+    i = int(margin.argmin())
+    rho = float(np.hypot(st[i, 0] - st[j, 0], st[i, 1] - st[j, 1]))
+    print(f"  tick {tick}: receiver {j} differs by {dmax:.1e} of the largest force; source {i} at {rho:.2f} m has its bearing "
+          f"{margin[i]:.1e} rad from the field-of-view edge")
+    assert margin[i] < 2e-5                                      # fp32 records: positions to ~4e-6 m, headings to ~1e-7
+    # with that one source switched the other way, the oracle's force on j matches the engine's
+    gx, gy = orc.pair_bicycle(p, st[i, :3], st[i, 3], st[j:j + 1, 0], st[j:j + 1, 1])
+    dfx, dfy = fx[j] - ox[j], fy[j] - oy[j]
+    # (the clamp of :841-845 may scale the repulsive sum: compare directions when it does, magnitudes otherwise)
+    assert np.hypot(gx[0], gy[0]) > 0.3 * np.hypot(dfx, dfy)
