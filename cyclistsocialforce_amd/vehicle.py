@@ -419,3 +419,15 @@ class PlanarBicycle(Vehicle):
     def __init__(self, s0, **kwargs):
         assert len(s0) >= 5, ("s0 has to have at least five elements:", " (x, y, psi, v, delta)!")
         Vehicle.__init__(self, s0, **kwargs)
+
+
+class BalancingRiderBicycle(Vehicle):
+    """vehicle.py:1953-1990 — NOT available: its Whipple-Carvallo model is assembled by the `bicycleparameters` package and
+    its feedback gains by `controlbehavior.py` (dynamics.py:261-705); neither can be imported where this engine was built,
+    so there is nothing to capture fixtures from and nothing to pin a restatement to.  The name
+    exists so that scripts importing it (demoCSFstandalone.py:23) load; constructing one says why it cannot run."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("BalancingRiderBicycle is not part of the MI355X engine: its dynamics come from the "
+                                  "bicycleparameters / controlbehavior packages (DESIGN.md section 9); the other rider models "
+                                  "('invpendulum', 'planarpoint', 'planartwowheel', PlanarBicycle, TwoDBicycle) are")

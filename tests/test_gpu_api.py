@@ -369,3 +369,44 @@ def test_animated_demo_on_agg_canvas(tmp_path):
     plt.close("all")
     with pytest.raises(AssertionError):
         SocialForceIntersection(demo_bikes(TwoDBicycle), animate=True)
+
+
+def test_scripts_written_against_the_reference_package_name(golden):
+    """compat/cyclistsocialforce in front of the path: the reference demo's own import lines and call sequence
+    (demoCSFstandalone.py:23-25, 94-146) on the engine, against the golden demo trajectory."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        from cyclistsocialforce.intersection import SocialForceIntersection
+        from cyclistsocialforce.scenario import Scenario
+        from cyclistsocialforce.vehicle import InvPendulumBicycle
+
+        class DemoScenario(Scenario):
+            def __init__(self):
+                bike1 = InvPendulumBicycle((-23 + 17, 0, 0, 5, 0, 0, 0, 0), id="a", saveForces=True)
+                bike1.params.v_desired_default = 4.5
+                bike2 = InvPendulumBicycle((0 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), id="b", saveForces=True)
+                bike2.params.v_desired_default = 5.0
+                bike3 = InvPendulumBicycle((-2 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), id="c", saveForces=True)
+                bike3.params.v_desired_default = 5.0
+                bike1.setDestinations((35, 64, 65), (0, 0, 0))
+                bike2.setDestinations((15, 15, 15), (20, 49, 50))
+                bike3.setDestinations((13, 13, 13), (20, 49, 50))
+                self.intersection = SocialForceIntersection((bike1, bike2, bike3), activate_sumo_cosimulation=False)
+                Scenario.__init__(self, self._step_func, verbose=False)
+
+            def _step_func(self):
+                self.intersection.step()
+
+        scn = DemoScenario()
+        scn.run(7)
+        g = golden("trajectories")
+        got = np.array([v.s for v in scn.intersection.vehicles])
+        np.testing.assert_allclose(got[:, :2], g["demo_invpend_S"][-1][:, :2], rtol=0, atol=2e-4)
+    finally:
+        sys.path.remove(os.path.join(root, "compat"))
+        for k in [k for k in sys.modules if k == "cyclistsocialforce" or k.startswith("cyclistsocialforce.")]:
+            del sys.modules[k]

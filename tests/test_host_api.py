@@ -317,3 +317,27 @@ def test_visual_hook_drawings():
     with pytest.raises(ValueError):
         TwoDBicycle((0, 0, 0, 5, 0)).plot_forces()
     plt.close("all")
+
+
+def test_reference_package_name_resolves_to_the_mirror():
+    """compat/cyclistsocialforce: the import lines of the reference's scripts (demoCSFstandalone.py:23-25) load the mirror
+    classes; BalancingRiderBicycle exists as a name and refuses to be constructed."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        for mod in ("vehicle", "intersection", "scenario", "parameters", "utils", "vizualisation"):
+            alias = importlib.import_module(f"cyclistsocialforce.{mod}")
+            impl = importlib.import_module(f"cyclistsocialforce_amd.{mod}")
+            names = [k for k in vars(impl) if not k.startswith("_")]
+            assert names and all(getattr(alias, k) is getattr(impl, k) for k in names), mod
+        from cyclistsocialforce.vehicle import BalancingRiderBicycle, Bicycle, InvPendulumBicycle, PlanarPointBicycle  # noqa: F401
+        with pytest.raises(NotImplementedError, match="bicycleparameters"):
+            BalancingRiderBicycle((0, 0, 0, 5, 0, 0, 0, 0), id="a")
+    finally:
+        sys.path.remove(os.path.join(root, "compat"))
+        for k in [k for k in sys.modules if k == "cyclistsocialforce" or k.startswith("cyclistsocialforce.")]:
+            del sys.modules[k]
