@@ -95,9 +95,11 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
 
 /* How csf_add_agents / csf_remove_agents / csf_set_dest_queue reach the device once ticks have run (the per-tick arrivals
  * and departures of SUMO co-simulation, intersection.py:429-453, 458-634; scenario.py:376-466).  on != 0 (default): the
- * change is written straight into the device arrays by small kernels - a removed road user leaves a dead slot with a
- * sentinel record, a new one takes a free slot, a replaced queue is appended to the queue slab; no download, no upload,
- * the binned order is renewed once a sixteenth of the slots has changed.  on == 0: every change goes through the host
+ * calls only record what to do, and the next device call applies the batch with one small launch - a removed road user
+ * leaves a dead slot with a sentinel record, a new one takes a free slot whose place in the binned order lies in the tail
+ * of sentinels behind the sorted batches, a replaced queue is appended to the queue slab (rewritten from the host's copy of
+ * the queues when full); no download, no upload; the binned order is renewed when ticks x arrivals since the last renewal
+ * reaches a few thousand.  The capacity holds up to 4096 extra slots for this.  on == 0: every change goes through the host
  * mirror (download, edit, upload, re-sort), which is also what sharded engines and engines with the history ring do.
  * The population order seen by every other entry point is the same either way. */
 int csf_set_incremental(csf_engine *e, int32_t on);
