@@ -919,8 +919,8 @@ void launch_records(const Dev &d, hipStream_t st) {
 //
 // spawn: Vehicle.__init__ (vehicle.py:64-204, 1728-1736; dynamics.py:828) for a new road user placed into a free slot:
 //   what csf_add_agents writes into the host mirror on the upload path, plus the fp32 record.  The slot keeps the
-//   position of the binned order it had (pos[]): until the next re-binning the new record sits in a batch of far-away
-//   neighbours, whose bounding circle the engine recomputes before the next pair launch.
+//   position of the binned order it had (pos[]) - the host picks slots whose place is in the tail of sentinels behind
+//   the sorted batches (csf_engine.hip: rebin), so until the next re-binning the arrivals share a few tail batches.
 // retire: remove_road_user (intersection.py:576-634): the slot is no longer integrated and its record becomes the
 //   sentinel that contributes exactly nothing as a source.
 // requeue: Vehicle.setDestinations (vehicle.py:606-647): the queue of a slot now lives at another place of the slab.

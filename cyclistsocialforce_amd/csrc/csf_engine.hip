@@ -951,9 +951,9 @@ int stage_acquire(csf_engine *e, size_t bytes, csf_engine::PinnedSlot **out) {
     return CSF_OK;
 }
 
-// The collected retirements, spawns and queue replacements -> one patch_kernel launch (csf_agent.hip).  Afterwards the
-// circles of the batches the changed slots sit in are stale, and once a sixteenth of the slots has changed the binned
-// order is renewed at the next tick instead of after REBIN_TICKS.
+// The collected retirements, spawns and queue replacements -> one patch_kernel launch (csf_agent.hip), which also renews
+// the circles of the tail batches the arrivals went to; the binned order is renewed when ticks x arrivals since the last
+// re-binning says so (bounds_before_pair).
 int flush_pending(csf_engine *e) {
     csf_engine::Pending &pd = e->pend;
     if (pd.empty()) return CSF_OK;
