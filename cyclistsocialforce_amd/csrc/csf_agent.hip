@@ -706,6 +706,14 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     g.cs_fresh = false;
     agent_params<HET>(d, a, g);
     if (HET && g.p->model != MODEL) return;                    // a mixed population: one launch per vehicle class
+    // The partial sums of the pair kernel (the first 16 chunks: the usual split) and the road term are requested here, with
+    // the agent's own scalars, so that their round trip runs beside the destination-force phase.  Unconditional loads from
+    // clamped addresses: a guarded load is a branch with its own wait.
+    constexpr int PRE = 16;
+    float2 pp[PRE];
+#pragma unroll
+    for (int c = 0; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
+    const float2 froad = d.froad[a];
 
     double fdx, fdy;
     if (phases & PH_DEST) {
@@ -727,12 +735,15 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         Fx = fdx;
         Fy = fdy;
         if (d.n_live > 1) {                                   // intersection.py:813, 825, 849-851
-            int c = 0;                                        // fixed order: reproducible
-            for (; c + 4 <= d.n_split; c += 4) {              // four independent loads in flight
-                const float2 p0 = d.part[(int64_t)c * cap + a], p1 = d.part[(int64_t)(c + 1) * cap + a];
-                const float2 p2 = d.part[(int64_t)(c + 2) * cap + a], p3 = d.part[(int64_t)(c + 3) * cap + a];
-                rx = (((rx + (double)p0.x) + (double)p1.x) + (double)p2.x) + (double)p3.x;
-                ry = (((ry + (double)p0.y) + (double)p1.y) + (double)p2.y) + (double)p3.y;
+            // the first 16 chunks (the usual split) requested together: one round trip, not one per group of four.  Added
+            // in chunk order: reproducible
+            int c = 0;
+#pragma unroll
+            for (; c < PRE; c++) {
+                if (c < d.n_split) {
+                    rx += (double)pp[c].x;
+                    ry += (double)pp[c].y;
+                }
             }
             for (; c < d.n_split; c++) {
                 const float2 pr = d.part[(int64_t)c * cap + a];
@@ -748,9 +759,8 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
             Fy = ry + fdy;
         }
         if (d.nv > 0) {                                       // :854-857
-            float2 fr = d.froad[a];
-            Fx += (double)fr.x;
-            Fy += (double)fr.y;
+            Fx += (double)froad.x;
+            Fy += (double)froad.y;
         }
         d.F[a] = Fx;                                          // :860-861
         d.F[cap + a] = Fy;
