@@ -945,6 +945,7 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
     if (k < h.n_retire) {
         const int64_t a = ((const int32_t *)(base + h.off_retire))[k];
         d.alive[a] = 0;
+        d.cls[a] = 0;                                              // (its sentinel record is looked up in set 0 from now on)
         const float4 q = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
         d.rec[a] = q;
         if (d.recs_valid) d.recs[d.pos[a]] = q;

@@ -760,6 +760,7 @@ void compact_host(csf_engine *e) {
     }
     std::fill(e->h_alive.begin(), e->h_alive.end(), (uint8_t)0);
     std::fill(e->h_alive.begin(), e->h_alive.begin() + n, (uint8_t)1);
+    std::fill(e->h_cls.begin() + n, e->h_cls.end(), (uint8_t)0);
     e->d.n = n;
     e->d.n_live = n;
     e->order_dirty = true;
@@ -1359,6 +1360,7 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
             continue;
         }
         e->h_alive[(size_t)a] = 0;
+        e->h_cls[(size_t)a] = 0;                                // (a dead slot's sentinel record is looked up in set 0: the table may shrink)
         e->h_q[(size_t)a].clear();
         e->free_recent.push_back(a);
         if (!patch) continue;

@@ -342,3 +342,74 @@ def test_arrivals_and_departures_with_parameter_sets(amd):
     assert err < 1e-4 and (e.status() == 0).all()
     for eng in engines:
         eng.close()
+
+
+def test_parameter_sets_with_priority_rule_road_and_table_changes(amd):
+    """The remaining combinations around the table of parameter sets: priority to the right (the rule stays the
+    intersection's, intersection.py:324), a road (its force knows no parameter set), sets replaced and the table grown and
+    shrunk while ticks run, road users removed - after every change one force evaluation against the oracle on the
+    population as it is: repulsive sums with the source's set and the rule, road term, and their sum."""
+    import bench
+
+    rng = np.random.default_rng(31)
+    n, box = 700, 80.0
+    s = np.zeros((n, 5))
+    s[:, 0] = rng.uniform(5, box, n); s[:, 1] = rng.uniform(5, box, n)
+    s[:, 2] = rng.uniform(-np.pi, np.pi, n); s[:, 3] = rng.uniform(3, 4.8, n)
+    d = np.array([40.0, 79.0, 80.0])
+    dq = np.zeros((n, 4, 3))
+    dq[:, 0, 0] = s[:, 0]; dq[:, 0, 1] = s[:, 1]
+    dq[:, 1:, 0] = s[:, 0, None] + d[None, :] * np.cos(s[:, 2])[:, None]
+    dq[:, 1:, 1] = s[:, 1, None] + d[None, :] * np.sin(s[:, 2])[:, None]
+    recipes = [dict(), dict(hfov=1.2 * np.pi, f_0=10.0, sigma_0=0.6, sigma_1=5.5), dict(hfov=1.0, e_0=0.9, e_1=0.4),
+               dict(hfov=2.5, f_0=4.0, k_p_v=12.0), dict(hfov=0.7, f_0=12.0)]
+    pods = [amd.pod("twod", priority_rule=1, **kw) for kw in recipes]
+    road = bench.tiled_curve_road(box, pitch=40.0)
+    e = amd.Engine(pods[0], n)
+    e.add_agents(s, 4.5)
+    e.set_dest_queue(np.arange(n), np.arange(n + 1) * 4, dq.reshape(-1, 3), reset=True)
+    e.set_road(*road)
+    cls = rng.integers(0, 3, n).astype(np.int32)
+    e.set_param_classes(pods[:3], cls)
+    ids = np.arange(n)
+
+    def check(label):
+        e.calc_forces()
+        fx, fy = e.forces()
+        fdx, fdy, frx, fry = e.force_parts()
+        st = e.state()
+        tab = [orc_params(p) for p in pods[:e._n_classes]]
+        ox, oy = orc.column_sums(tab, st[:, 0], st[:, 1], st[:, 2], st[:, 3], np.arange(len(ids)), cls=cls.astype(np.uint8), rule=1)
+        lim, mag = np.hypot(fdx, fdy), np.hypot(ox, oy)
+        sc = np.where(mag > lim, lim / np.maximum(mag, 1e-300), 1.0)
+        cx, cy = ox * sc, oy * sc
+        scale = max(np.hypot(cx, cy).max(), 1.0)
+        e_rep = max(np.abs(frx - cx).max(), np.abs(fry - cy).max()) / scale
+        off, verts, F0, sg = road
+        rx, ry = orc.road_forces(verts, off, F0, sg, st[:, 0], st[:, 1])
+        e_road = max(np.abs(fx - fdx - frx - rx).max(), np.abs(fy - fdy - fry - ry).max()) / max(np.hypot(rx, ry).max(), 1.0)
+        print(f"  {label}: {len(ids)} road users, {e._n_classes} sets: repulsive {e_rep:.1e}, road {e_road:.1e}")
+        assert e_rep < 1e-4 and e_road < 1e-4, label
+
+    check("three sets, p2r, road")
+    e.step(5)
+    e.set_param_classes(pods, cls)                              # the table grows; rows unchanged
+    cls[::7] = 4
+    e.set_agent_class(np.arange(n), cls)
+    check("five sets")
+    e.step(5)
+    kill = np.sort(rng.choice(n, 120, replace=False))           # everybody of set 4 among them or not: as it comes
+    e.remove_agents(kill)
+    ids = np.delete(ids, kill); cls = np.delete(cls, kill)
+    check("after departures")
+    e.step(5)
+    cls[cls >= 2] = 1
+    e.set_param_classes(pods[:2], cls)                          # the table shrinks (rows first, engine.py)
+    check("two sets")
+    pods2 = [pods[0], amd.pod("twod", priority_rule=1, hfov=2.0, f_0=9.0)]
+    e.set_param_classes(pods2, cls)                             # a set replaced in place
+    pods[1] = pods2[1]
+    check("a set replaced")
+    e.step(5)
+    assert (e.status() == 0).all() and np.isfinite(e.state()).all()
+    e.close()
