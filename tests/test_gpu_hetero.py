@@ -413,3 +413,69 @@ def test_parameter_sets_with_priority_rule_road_and_table_changes(amd):
     e.step(5)
     assert (e.status() == 0).all() and np.isfinite(e.state()).all()
     e.close()
+
+
+def test_mirror_bookkeeping_of_parameter_sets_under_population_changes():
+    """SocialForceIntersection with vehicles of three classes and individual parameters: road users leave (by id and by
+    index), others join (one of a class that was not there before, one sharing a parameter object), a parameter is
+    assigned to.  After every change the engine's rows must still belong to the right vehicles: its repulsive sums
+    against the oracle's, computed from the vehicles' own states and the mirror's own grouping of their parameters."""
+    from cyclistsocialforce_amd import parameters as P
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import InvPendulumBicycle, PlanarPointBicycle, TwoDBicycle
+
+    rng = np.random.default_rng(41)
+
+    def make(k, kind):
+        x, y, psi, v = rng.uniform(0, 30), rng.uniform(0, 30), rng.uniform(-np.pi, np.pi), rng.uniform(3, 4.8)
+        if kind == "twod":
+            b = TwoDBicycle((x, y, psi, v, 0), id=f"t{k}", params=P.InvPendulumBicycleParameters(hfov=rng.uniform(1.0, 4.0), f_0=rng.uniform(4, 11)))
+        elif kind == "invpend":
+            b = InvPendulumBicycle((x, y, psi, v, 0, 0), id=f"i{k}", params=P.InvPendulumBicycleParameters(hfov=rng.uniform(1.0, 4.0), sigma_0=rng.uniform(0.4, 0.7)))
+        else:
+            b = PlanarPointBicycle((x, y, psi, v), id=f"p{k}", params=P.PlanarPointBicycleParameters(hfov=rng.uniform(1.0, 4.0), f_0=rng.uniform(4, 11)))
+        d = np.array([15.0, 29.0, 30.0])
+        b.setDestinations(x + d * np.cos(psi), y + d * np.sin(psi))
+        return b
+
+    bikes = [make(k, "twod" if k % 2 == 0 else "invpend") for k in range(24)]
+    ins = SocialForceIntersection(bikes)
+
+    def check(label):
+        ins.calc_forces()
+        e = ins._engine
+        fdx, fdy, frx, fry = e.force_parts()
+        pods, cls = ins._param_classes()
+        n = len(ins.vehicles)
+        st = np.zeros((n, 4))
+        for k, v in enumerate(ins.vehicles):
+            st[k] = v.s[:4]
+        ox, oy = orc.column_sums([orc_params(p) for p in pods], st[:, 0], st[:, 1], st[:, 2], st[:, 3], np.arange(n), cls=cls.astype(np.uint8))
+        lim, mag = np.hypot(fdx, fdy), np.hypot(ox, oy)
+        sc = np.where(mag > lim, lim / np.maximum(mag, 1e-300), 1.0)
+        err = max(np.abs(frx - ox * sc).max(), np.abs(fry - oy * sc).max()) / max(np.hypot(ox * sc, oy * sc).max(), 1.0)
+        print(f"  {label}: {n} road users, {len(pods)} sets, repulsive sums vs oracle {err:.1e}")
+        assert err < 1e-4, label
+        assert all(v.s.shape == (type(v).N_STATES,) for v in ins.vehicles)
+
+    check("start")
+    for _ in range(5):
+        ins.step()
+    ins.remove_road_users_by_id(["t4", "i7", "t10"])
+    check("three left")
+    ins.add_road_user(make(100, "planarpoint"))                  # a class that was not there: four states, its own set
+    shared = TwoDBicycle((12.0, 12.0, 0.3, 4.0, 0), id="shared", params=ins.vehicles[0].params)
+    shared.setDestinations((40.0, 60.0), (14.0, 14.0))
+    ins.add_road_user(shared)                                    # shares vehicle 0's object: no new set
+    check("two joined")
+    for _ in range(5):
+        ins.step()
+    ins.vehicles[3].params.f_0 = 2.5                              # an assignment between ticks
+    ins.vehicles[0].params.e_1 = 0.5                              # ... and one that two vehicles share
+    check("parameters assigned")
+    ins.remove_road_user(0)
+    ins.remove_road_user(len(ins.vehicles) - 2)                  # the PlanarPoint one
+    for _ in range(5):
+        ins.step()
+    check("two more left")
+    assert all(np.isfinite(v.s).all() for v in ins.vehicles)
