@@ -646,3 +646,77 @@ def test_random_population_calls_device_path_vs_host_mirror(amd, seed, n0, box, 
         e.close()
     print(f"  calls: {counts}; {n} road users at the end")
     assert min(counts.values()) > 0
+
+
+def test_arrival_bursts_beyond_the_sentinel_tail(amd):
+    """What the sentinel tail cannot take: (a) more arrivals in one call than there are fresh slots behind the population
+    (the engine falls back to the rebuild), (b) more arrivals than free places in the tail while slots retired since the
+    last re-binning are available (arrivals take those slots inside the sorted batches, and every circle is recomputed).
+    Both against the same calls through the host mirror and, at the end, the oracle's repulsive sums."""
+    cap, n0, box = 8000, 2000, 260.0
+    pool, _, pdq = population(cap + 9000, box, seed=77)
+    pdq = pdq.reshape(-1, 4, 3)
+    engines = []
+    for inc in (True, False):
+        e = amd.Engine(amd.pod("twod"), cap)
+        e.set_incremental(inc)
+        e.add_agents(pool[:n0], 5.0)
+        e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, pdq[:n0].reshape(-1, 3), reset=True)
+        e.step(3)
+        engines.append(e)
+    ids = list(range(n0))
+    fresh = n0
+
+    def arrive(k):
+        nonlocal fresh
+        new = list(range(fresh, fresh + k))
+        fresh += k
+        for e in engines:
+            m = e.n
+            e.add_agents(pool[new], 5.0)
+            e.set_dest_queue(np.arange(m, m + k), np.arange(k + 1) * 4, pdq[new].reshape(-1, 3), reset=True)
+        ids.extend(new)
+
+    def leave(k, rng):
+        idx = np.sort(rng.choice(len(ids), k, replace=False))
+        for e in engines:
+            e.remove_agents(idx)
+        gone = set(idx.tolist())
+        ids[:] = [a for i, a in enumerate(ids) if i not in gone]
+
+    def compare(label):
+        for e in engines:
+            e.step(2)
+        A, B = engines[0].state(), engines[1].state()
+        assert A.shape == B.shape == (len(ids), 5), label
+        np.testing.assert_array_equal(A[-5:, 2], np.asarray(A[-5:, 2]))      # (finite)
+        dev = np.abs(A[:, :2] - B[:, :2]).max()
+        print(f"  {label}: {len(ids)} road users, device path vs host mirror {dev:.1e} m")
+        assert dev < 1e-4, label
+
+    rng = np.random.default_rng(8)
+    arrive(3000)                        # (a) the head room behind 2 000 road users is 2 000 slots
+    compare("burst beyond the fresh slots")
+    leave(2500, rng)
+    arrive(2600)                        # (b) 2 500 slots retired since the last re-binning, no place left in the tail
+    compare("burst into retired slots")
+    leave(100, rng); arrive(40)
+    compare("and on")
+    e = engines[0]
+    e.calc_forces()
+    fdx, fdy, frx, fry = e.force_parts()
+    st = e.state()
+    recv = np.arange(0, len(ids), 17)
+    ox, oy = orc.column_sums(orc.default_params("twod"), st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv)
+    cx, cy = clamped(ox, oy, fdx[recv], fdy[recv])
+    errs = np.maximum(np.abs(frx[recv] - cx), np.abs(fry[recv] - cy)) / max(np.hypot(cx, cy).max(), 1.0)
+    # arrivals are dropped at random places: a few land centimetres from somebody, where the fp32 record resolves the
+    # distance to ~1e-5 relative and the field is steepest (DESIGN.md section 2: "pairs centimetres apart")
+    worst = recv[int(errs.argmax())]
+    near = np.sort(np.hypot(st[:, 0] - st[worst, 0], st[:, 1] - st[worst, 1]))[1]
+    print(f"  clamped repulsive sums vs oracle: median {np.median(errs):.1e}, 99 % {np.percentile(errs, 99):.1e}, max {errs.max():.1e} "
+          f"(receiver {worst}, nearest neighbour {near:.3f} m)")
+    assert np.median(errs) < 1e-5 and np.percentile(errs, 98) < 1e-4 and errs.max() < 1e-3 and (errs.max() < 1e-4 or near < 0.5)
+    assert (e.status() == 0).all()
+    for e in engines:
+        e.close()
