@@ -49,6 +49,10 @@ __global__ void keys_kernel(const Dev d, uint32_t *keys, int32_t *vals) {
         xi = xi < 0 ? 0 : (xi > 65535 ? 65535 : xi);
         yi = yi < 0 ? 0 : (yi > 65535 ? 65535 : yi);
         key = hilbert16((uint32_t)xi, (uint32_t)yi);
+        // several parameter sets (at most 16 in this mode): the set leads the key, so that every set is one run of the
+        // sorted order - a launch of the culling kernel per run, each with its set's constants (csf_engine.hip); the
+        // curve index loses its four lowest bits (cells of 2 m instead of 0.5 m)
+        if (d.seg_keys) key = ((uint32_t)d.cls[a] << 28) | (key >> 4);
         if (key == 0xFFFFFFFFu) key = 0xFFFFFFFEu;
     }
     keys[a] = key;
@@ -99,6 +103,26 @@ int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void 
     if (m <= 0) return 0;
     hipLaunchKernelGGL(receiver_keys_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, keys);
     return (int)hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, keys, (uint32_t *)rlist_out, (int)m, 0, 32, st);
+}
+
+// the sorted slots -> perm with every set's run starting at a multiple of 64 places, sentinel slot in between and behind
+__global__ void segment_fill_kernel(const Dev d, int32_t sent_slot) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < d.n_pad) d.perm[p] = sent_slot;
+}
+__global__ void segment_perm_kernel(const Dev d, const int32_t *sorted_slots, const SegTable tab) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= tab.sorted_beg[tab.n]) return;
+    int c = 0;
+    while (c + 1 < tab.n && p >= tab.sorted_beg[c + 1]) c++;
+    d.perm[tab.place_beg[c] + (p - tab.sorted_beg[c])] = sorted_slots[p];
+}
+
+void launch_segment_perm(const Dev &d, const int32_t *sorted_slots, const SegTable &tab, hipStream_t st) {
+    if (d.n_pad <= 0) return;
+    hipLaunchKernelGGL(segment_fill_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d, tab.sent_slot);
+    const int64_t m = tab.sorted_beg[tab.n];
+    if (m > 0) hipLaunchKernelGGL(segment_perm_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, sorted_slots, tab);
 }
 
 void launch_identity_perm(const Dev &d, hipStream_t st) {

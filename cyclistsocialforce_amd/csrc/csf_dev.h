@@ -54,6 +54,9 @@ struct Dev {
     int64_t lo, hi;    // receiver block integrated by this rank
     int64_t n_pad;     // n rounded up to a multiple of 64 (sentinel source records behind n)
     int64_t n_src;     // places of the source order that can hold a road user (multiple of 64, <= n_pad): the pair kernel stops there
+    int64_t src_beg;   // ... and starts here (0, or the first place of a class segment: csf_engine.hip launch_pair_segments)
+    int32_t part_base; // first slot of d.part this launch writes (its source chunks follow: one launch per class segment)
+    int32_t seg_keys;  // re-binning: the parameter set leads the sort key (csf_bin.hip), so that every set is a run of places
     int32_t ns;        // states per agent
     int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
     int32_t back;      // int(1 / t_s) — vehicle.py:1487
@@ -129,6 +132,14 @@ void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from
 void launch_snapshot(const Dev &d, double *out, hipStream_t st);
 // csf_bin.hip: spatial binning of the source records (Hilbert order) and per-batch bounding circles
 size_t bin_temp_bytes(int64_t n_pad);
+// class-segmented order: the runs of equal parameter set in the sorted order moved to batch-aligned places (csf_bin.hip)
+struct SegTable {
+    int32_t n;                 // parameter sets
+    int32_t sent_slot;         // a slot whose record is a sentinel for ever (fills the padding)
+    int64_t sorted_beg[17];    // first sorted position of set c (sets in ascending order; [n] = road users)
+    int64_t place_beg[16];     // first place of set c in the padded order (multiple of 64)
+};
+void launch_segment_perm(const Dev &d, const int32_t *sorted_slots, const SegTable &tab, hipStream_t st);
 int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,
                  hipStream_t st);
 void launch_identity_perm(const Dev &d, hipStream_t st);

@@ -88,6 +88,17 @@ struct csf_engine {
     int device = 0;
     // parameter sets (csf_set_param_classes): classes[0] is d.p; h_cls[slot] the set of a road user
     std::vector<csf_params> classes;
+    std::vector<double> class_kappa;     // far_kappa of every set (the grid search is done once per table)
+    // Class-segmented order (several parameter sets, binned): every set is a run of places starting at a multiple of 64,
+    // and the pair term is one launch of the culling kernel per run with that set's constants (rebin, launch_pair_all).
+    struct Segment {
+        int32_t cls;
+        int64_t beg, end;                 // places
+        int32_t chunk_units, n_split, part_base;
+        PairConsts pc;
+    };
+    std::vector<Segment> segs;
+    int32_t sent_slot = 0;               // index of a record that is a sentinel for ever
     std::vector<uint8_t> h_cls;
     DevBuf<csf_params> ptab;
     DevBuf<PairConsts> pctab;
@@ -293,16 +304,15 @@ double far_eps() {
 //     rho^2 - e^2 X^2 > T^2 (sigma_a - sigma_b / 2 + (sigma_b / 2) X / rho)^2   implies   x > T.
 // The kernel evaluates this with one rsq per pair (csf_pair.hip: keep_x2); T carries a 0.2 % margin against the fp32
 // rounding of the two sides.  At N = 16 384 in 200 m the test removes three of four pairs that pass the field of view.
-void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
+// far-field radius and reach-test constants of one parameter set in a population of n road users
+void set_far_consts(const csf_params &p, double kappa, int64_t n, PairConsts &k) {
     const double eps = far_eps();
-    PairConsts &k = e->d.pc;
-    k.rfar = e->classes.size() > 1 ? INFINITY : (float)far_radius(e->far_kappa, e->d.n, eps);   // (one bound per parameter set: not built)
-    const csf_params &p = e->d.p;
-    const bool on = std::isfinite(k.rfar) && p.model != CSF_BICYCLE && e->d.n >= 1 && p.sigma_2 < p.sigma_0 && p.sigma_3 < p.sigma_1 &&
+    k.rfar = (float)far_radius(kappa, n, eps);
+    const bool on = std::isfinite(k.rfar) && p.model != CSF_BICYCLE && n >= 1 && p.sigma_2 < p.sigma_0 && p.sigma_3 < p.sigma_1 &&
                     !(getenv("CSF_REACH") && atoi(getenv("CSF_REACH")) == 0);
     k.reach = on;
     if (on) {
-        const double T = std::log((double)e->d.n / eps) * 1.002;
+        const double T = std::log((double)n / eps) * 1.002;
         k.tA0 = (float)(T * (p.sigma_0 - 0.5 * p.sigma_2));
         k.tA1 = (float)(T * (p.sigma_1 - 0.5 * p.sigma_3));
         k.tB0 = (float)(T * 0.5 * p.sigma_2);
@@ -310,6 +320,17 @@ void update_far_radius(csf_engine *e) {   // depends on the parameters and on th
     } else {
         k.tA0 = k.tA1 = k.tB0 = k.tB1 = 0.f;
     }
+}
+
+void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
+    PairConsts &k = e->d.pc;
+    if (e->classes.size() > 1) {          // several parameter sets: the plain kernel, or one launch per set with its own
+        k.rfar = INFINITY;                // constants (Segment::pc)
+        k.reach = 0;
+        k.tA0 = k.tA1 = k.tB0 = k.tB1 = 0.f;
+        return;
+    }
+    set_far_consts(e->d.p, e->far_kappa, e->d.n, k);
 }
 
 // exp(A) of a small dense matrix (n <= 4, row major): scaling and squaring of a degree-18 Taylor polynomial
@@ -466,6 +487,13 @@ int alloc_all(csf_engine *e) {
     size_t nrec = (cap + 64 * 64 + 63) / 64 * 64;
     HIPCHK(e, e->rec.alloc(nrec));
     HIPCHK(e, e->rec2.alloc(nrec));
+    {   // the last record of the arrays is no slot's: a sentinel for ever (padding of the class-segmented order)
+        const float4 sent = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
+        const float2 sent2 = make_float2(0.0f, 1.0f);
+        HIPCHK(e, hipMemcpy(e->rec.p + nrec - 1, &sent, sizeof sent, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->rec2.p + nrec - 1, &sent2, sizeof sent2, hipMemcpyHostToDevice));
+        e->sent_slot = (int32_t)(nrec - 1);
+    }
     HIPCHK(e, e->recs2.alloc(nrec));
     HIPCHK(e, e->perm.alloc(nrec));
     HIPCHK(e, e->pos.alloc(nrec));
@@ -630,10 +658,77 @@ int rebin(csf_engine *e) {
         launch_records(d, e->main);     // sentinels in the new tail (the records of the road users are rewritten as they are)
     }
     d.pair_variant = pair_variant_for(d.n_live);
-    const bool binned = d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS && d.n_classes == 1;   // (several parameter sets: the plain kernel)
+    // Several parameter sets: up to 16 of them on an unsharded engine get the class-segmented order - the set leads the
+    // sort key, every set becomes a run of places that starts at a multiple of 64, and the pair term is one launch of the
+    // culling kernel per run with that set's constants, far-field radius and field (launch_pair_all).  Otherwise the
+    // plain kernel looks every source's set up (csf_pair.hip: HET).
+    e->segs.clear();
+    d.seg_keys = 0;
+    d.src_beg = 0;
+    d.part_base = 0;
+    // It pays from ~2 048 road users per set (a launch per set has its own start-up): four sets at N = 16 384 199 us per
+    // tick against 387 us, at 8 192 104 against 119, at 4 096 68 against 41 (tools/hetero_rate.py; CSF_SEGMENTS=1 forces
+    // it from 1 024 road users, 0 switches it off).
+    const char *seg_env = getenv("CSF_SEGMENTS");
+    bool seg = d.n_classes > 1 && d.n_classes <= 16 && d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS && e->world <= 1 && !e->loopback &&
+               !e->nccl && e->class_kappa.size() == e->classes.size() &&
+               (seg_env ? atoi(seg_env) != 0 : d.n_live >= 2048 * (int64_t)d.n_classes);
+    SegTable tab{};
+    if (seg) {
+        std::vector<int64_t> count((size_t)d.n_classes, 0);
+        for (int32_t a : e->order) count[e->h_cls[(size_t)a]]++;
+        int64_t sorted = 0, place = 0, units_total = 0;
+        tab.n = d.n_classes;
+        tab.sent_slot = e->sent_slot;
+        for (int c = 0; c < d.n_classes; c++) {
+            tab.sorted_beg[c] = sorted;
+            tab.place_beg[c] = place;
+            sorted += count[(size_t)c];
+            place += (count[(size_t)c] + 63) / 64 * 64;
+        }
+        tab.sorted_beg[d.n_classes] = sorted;
+        units_total = place / 64;
+        if (place > d.n_pad || sorted != d.n_live) seg = false;      // (no room for the padding: the plain kernel)
+        if (seg) {
+            const int64_t per_min = std::max<int64_t>(16, (units_total + (MAX_SPLIT - d.n_classes) - 1) / std::max(1, MAX_SPLIT - d.n_classes));
+            int32_t slots = 0;
+            for (int c = 0; c < d.n_classes; c++) {
+                const int64_t units = (count[(size_t)c] + 63) / 64;
+                PairConsts pc;
+                derive_pair_consts(e->classes[(size_t)c], pc);
+                pc.p2r = d.pc.p2r;
+                set_far_consts(e->classes[(size_t)c], e->class_kappa[(size_t)c], d.n, pc);
+                if (units == 0 || pc.f0_zero) continue;              // nobody of this set, or a set whose field is zero
+                const int64_t chunks = (units + per_min - 1) / per_min;
+                csf_engine::Segment sg;
+                sg.cls = c;
+                sg.beg = tab.place_beg[c];
+                sg.end = sg.beg + units * 64;
+                sg.chunk_units = (int32_t)((units + chunks - 1) / chunks);
+                sg.n_split = (int32_t)((units + sg.chunk_units - 1) / sg.chunk_units);
+                sg.part_base = slots;
+                sg.pc = pc;
+                slots += sg.n_split;
+                e->segs.push_back(sg);
+            }
+            if (slots > MAX_SPLIT) seg = false, e->segs.clear();
+            else {
+                d.seg_keys = 1;
+                d.n_split = std::max(1, slots);                       // what the per-agent kernel sums
+                d.n_src = place;
+            }
+        }
+    }
+    const bool binned = d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS && (d.n_classes == 1 || seg);
     d.classify = binned;
     update_far_radius(e);
-    if (binned) {
+    if (seg) {
+        Dev ds = d;
+        ds.perm = e->rlist.p;                                        // the sorted slots, before the runs are moved apart
+        int rc = launch_rebin(ds, e->sort_keys.p, e->sort_keys_out.p, e->sort_vals.p, e->sort_tmp.p, e->sort_tmp.n, e->main);
+        if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the record bins failed (%d)", rc);
+        launch_segment_perm(d, e->rlist.p, tab, e->main);
+    } else if (binned) {
         int rc = launch_rebin(d, e->sort_keys.p, e->sort_keys_out.p, e->sort_vals.p, e->sort_tmp.p, e->sort_tmp.n, e->main);
         if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the record bins failed (%d)", rc);
     } else {
@@ -659,20 +754,18 @@ int rebin(csf_engine *e) {
     // [0, n_live) and the free slots follow in ascending slot order.  Handing the free slots out in that order
     // (csf_add_agents) keeps the places that can hold a road user a prefix of the order, and the pair kernel's source
     // chunks end there (d.n_src) instead of at n_pad.  Slots retired since the last re-binning are sentinels from now on.
-    e->tail_tracked = binned && e->world <= 1 && !e->loopback;
+    e->tail_tracked = binned && !seg && e->world <= 1 && !e->loopback;
     e->free_tail.insert(e->free_tail.end(), e->free_recent.begin(), e->free_recent.end());
     e->free_recent.clear();
     std::sort(e->free_tail.begin(), e->free_tail.end(), std::greater<int32_t>());
     e->live_at_rebin = d.n_live;
     e->tail_used = 0;
     e->tail_flushed = 0;
-    {
+    if (!seg) {
         const int64_t n_src = e->tail_tracked ? std::max<int64_t>(64, (d.n_live + 63) / 64 * 64)
                               : (e->world <= 1 && !e->loopback && !binned ? std::max<int64_t>(64, (d.n + 63) / 64 * 64) : d.n_pad);
-        if (n_src != d.n_src) {
-            d.n_src = std::min(n_src, d.n_pad);
-            set_chunks(e);
-        }
+        d.n_src = std::min(n_src, d.n_pad);
+        set_chunks(e);                                               // (also after a segmented period: n_split was the segments')
     }
     e->ticks_since_rebin = 0;
     e->churn = 0;
@@ -818,8 +911,10 @@ int upload_classes(csf_engine *e) {
     }
     std::vector<PairConsts> pc(K);
     std::vector<double> pb(7 * K, 0.0);
+    e->class_kappa.assign(K, 0.0);
     for (size_t c = 0; c < K; c++) {
         derive_pair_consts(e->classes[c], pc[c]);
+        if (K > 1 && K <= 16) e->class_kappa[c] = far_kappa(e->classes[c]);   // (for the launches per set: rebin)
         pc[c].p2r = d.pc.p2r;                                    // (the rule belongs to the intersection: intersection.py:324)
         if (e->classes[c].model == CSF_PLANARBIKE) derive_planarbike(e->classes[c], &pb[7 * c]);
     }
@@ -929,7 +1024,8 @@ int prepare_mutation(csf_engine *e) {
 // history ring and CSF_INCREMENTAL=0 take the round trip through the host mirror (prepare_mutation / upload_all).
 bool can_patch_device(const csf_engine *e) {
     static const bool off = getenv("CSF_INCREMENTAL") && atoi(getenv("CSF_INCREMENTAL")) == 0;
-    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
+    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr &&
+           e->segs.empty();   // (the class-segmented order has no tail for arrivals: they go through the host mirror)
 }
 
 // a pinned, device-visible host buffer of `bytes` from the ring; waits only if the ring of four is exhausted
@@ -1593,6 +1689,31 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
 //   main:  bounds - pair - road - agent(DEST|COMBINE|INTEGRATE) - [all-gather(records)]       (world > 1: RCCL)
 // CSF_COMM_STREAM=second moves the collective to a second stream and issues the destination-force phase of the
 // next tick (it needs only the agent's own state) before the wait on it:
+// The pair term of a tick: one launch, or - class-segmented order, several parameter sets - one launch of the culling kernel
+// per set's run of places, with that set's constants, field (vehicle class) and far-field radius; `base` carries what the
+// caller wants of every launch (counters, next tick's circles or not).  The optional time stamps bracket the first launch.
+static void launch_pair_all(csf_engine *e, const Dev &base, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+    if (e->segs.empty()) {
+        launch_pair(base, e->main, t0, t1);
+        return;
+    }
+    for (const csf_engine::Segment &sg : e->segs) {
+        Dev dd = base;
+        dd.p = e->classes[(size_t)sg.cls];
+        dd.p.priority_rule = base.p.priority_rule;
+        dd.pc = sg.pc;
+        dd.n_classes = 1;
+        dd.src_beg = sg.beg;
+        dd.n_src = sg.end;
+        dd.chunk_units = sg.chunk_units;
+        dd.n_split = sg.n_split;
+        dd.part_base = sg.part_base;
+        dd.recv_binned = 0;
+        launch_pair(dd, e->main, t0, t1);
+        t0 = t1 = nullptr;
+    }
+}
+
 //   main:  agent(DEST) - wait(ev_gather) - bounds - pair - road - agent(COMBINE|INTEGRATE) - record(ev_integ)
 //   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)
 static int enqueue_tick(csf_engine *e) {
@@ -1614,7 +1735,7 @@ static int enqueue_tick(csf_engine *e) {
     // pair kernel 5 - 7 us at every shard size, the copy costs ~3 us
     if (sharded && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
     if (d.n_live > 1 && d.hi > d.lo) {
-        launch_pair(d, e->main, ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr);
+        launch_pair_all(e, d, ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr);
         if (ps) ps->pair = true;
     }
     bounds_after_pair(e, true);
@@ -1700,7 +1821,7 @@ int csf_calc_forces(csf_engine *e) {
     rc = bounds_before_pair(e);
     if (rc) return rc;
     if ((e->world > 1 || e->nccl != nullptr || e->loopback) && e->d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(e->d, e->main);
-    if (e->d.n_live > 1) launch_pair(e->d, e->main);
+    if (e->d.n_live > 1) launch_pair_all(e, e->d);
     bounds_after_pair(e, false);                     // the records do not move: recompute next time
     launch_road(e->d, e->main);
     launch_agent(e->d, PH_DEST | PH_COMBINE, e->main);
@@ -2214,9 +2335,16 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     int rc = upload_all(e);
     if (rc) return rc;
     Dev &d = e->d;
-    if (kernel_name) *kernel_name = pair_kernel_name(d);
+    const char *name = pair_kernel_name(d);
+    if (!e->segs.empty()) {                                      // one launch per parameter set: the kernel of the first
+        Dev d0 = d;
+        d0.p = e->classes[(size_t)e->segs[0].cls];
+        d0.n_classes = 1;
+        name = pair_kernel_name(d0);
+    }
+    if (kernel_name) *kernel_name = name;
     for (int k = 0; k < 4; k++) counts[k] = -1;
-    if (std::string(pair_kernel_name(d)) != "pair_cull_kernel") return CSF_OK;   // only the cull-first kernel counts
+    if (std::string(name) != "pair_cull_kernel") return CSF_OK;   // only the cull-first kernel counts
     for (int k = 0; k < 4; k++) counts[k] = 0;
     if (d.n_live <= 1 || d.hi <= d.lo) return CSF_OK;
     if ((rc = wait_gather(e))) return rc;
@@ -2228,7 +2356,7 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     Dev dd = d;                 // this tick's records and circles; the circles of the next tick are not touched
     dd.pair_count = cnt.p;
     dd.bnd_next = nullptr;
-    launch_pair(dd, e->main);
+    launch_pair_all(e, dd);                                      // (the Bicycle-field launches of a mixed population do not count)
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
     unsigned long long h[4] = {0, 0, 0, 0};

@@ -261,14 +261,14 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
     // agent_of (BINR): agent index of each of the wave's receivers, -1 for none (LDS); else the receivers are j0 + u
     const int64_t a = agent_of ? (int64_t)agent_of[u] : (j0 + u < d.hi ? j0 + u : -1);
     if ((lane & 7) == 0 && a >= 0) {
-        float *dst = (float *)&d.part[(int64_t)blockIdx.y * d.cap + a];
+        float *dst = (float *)&d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a];
         dst[idx & 1] = z;
     }
 }
 
 __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend) {
     const int64_t per = d.chunk_units;  // blockIdx.y selects a chunk of sources, in units of 64 records
-    ibeg = (int64_t)blockIdx.y * per * WAVE;
+    ibeg = d.src_beg + (int64_t)blockIdx.y * per * WAVE;
     iend = ibeg + per * WAVE;
     if (iend > d.n_src) iend = d.n_src;   // (the places behind hold sentinels only, csf_engine.hip: rebin)
 }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
     if (CLASSIFY && d.bnd_next != nullptr && blockIdx.y == 0) {
-        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
+        for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
 
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
         if (threadIdx.x < RPB && j < d.hi) {
             const int64_t a = BINR ? (int64_t)ragent[threadIdx.x] : j;
-            d.part[(int64_t)blockIdx.y * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
+            d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
         }
     } else {
         reduce_store(d, j0, lane, ax, ay, BINR ? &ragent[wave * RPW] : nullptr);
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
     if (d.bnd_next != nullptr && blockIdx.y == 0) {   // the next tick's bounding circles (see pair_cull_kernel)
-        for (int64_t b = (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
+        for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
     if (ibeg >= iend) return;

@@ -126,7 +126,9 @@ int csf_set_params(csf_engine *e, const csf_params *params);           /* parame
  * class would, vehicle.py:1728-1736).  The sets may be of different vehicle CLASSES (intersection.py:797-823 calls each
  * vehicle's own methods, so any mix may share an intersection): every row of s0 / csf_get_state then has the widest
  * layout among them (csf_num_states; states a class does not have stay 0), so install the sets before csf_add_agents.
- * With more than one set the engine runs the pair kernel without the far-field and field-of-view culls (O(N^2) per tick).
+ * With more than one set the engine evaluates the pair term either with a plain O(N^2) kernel that looks every source's
+ * set up, or - from about 2048 road users per set, up to 16 sets, unsharded - with one launch of its culling kernel per
+ * set over that set's run of the binned order.
  * An arrival whose set is assigned before the next device call (csf_add_agents, then csf_set_agent_class) takes it along in
  * its spawn record. */
 int csf_set_param_classes(csf_engine *e, int32_t n_classes, const csf_params *classes);
