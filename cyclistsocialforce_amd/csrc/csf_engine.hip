@@ -1619,15 +1619,16 @@ int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int3
     for (int64_t k = 0; k < n; k++) {
         const size_t a = (size_t)e->order[(size_t)idx[k]];
         if (e->pend_spawn_at[a] >= 0) {                          // an arrival still on its way to the device: its spawn record
-            e->pend.spawn[(size_t)e->pend_spawn_at[a]].cls = cls[k];   // carries the set, and the patch kernel writes the row
-        } else if (e->h_cls[a] != (uint8_t)cls[k]) {
-            device_rows_stale = true;
+            e->pend.spawn[(size_t)e->pend_spawn_at[a]].cls = cls[k];   // carries the set, the patch kernel writes the row and
+            e->h_cls[a] = (uint8_t)cls[k];                       // derives the start state with the set's limits
+            continue;
         }
+        if (e->h_cls[a] != (uint8_t)cls[k]) device_rows_stale = true;
         e->h_cls[a] = (uint8_t)cls[k];
         // A road user that has not moved yet is what its constructor made of it, with the limits of ITS set
-        // (vehicle.py:1728-1736).  (With the device ahead of the host mirror every road user has taken a tick: engines with
-        // several sets take arrivals through the mirror.)
-        if (!e->device_ahead && e->h_ti[a] == 0) {
+        // (vehicle.py:1728-1736).  Only where the host mirror is the state of record: nothing collected for the device
+        // (the mirror does not hold what a pending batch will write) and no tick since the last upload.
+        if (!e->device_ahead && e->pend.empty() && e->h_ti[a] == 0) {
             const csf_params &p = e->classes[(size_t)cls[k]];
             const double delta = e->h_s[4 * cap + a];
             e->h_zrid[a] = e->h_s[3 * cap + a] < p.v_max_walk ? 0 : 1;
