@@ -494,3 +494,84 @@ def test_mirror_bookkeeping_of_parameter_sets_under_population_changes():
         ins.step()
     check("two more left")
     assert all(np.isfinite(v.s).all() for v in ins.vehicles)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_mirror_calls_keep_rows_and_vehicles_together(seed):
+    """Random calls on a SocialForceIntersection of four vehicle classes with individual parameters - road users join and
+    leave (by index, by id), parameters are assigned to, destinations replaced, ticks taken.  After EVERY call the engine's
+    repulsive sums are checked against the oracle's, computed from the vehicles' own states and the mirror's own grouping
+    of their parameter objects: a row that belongs to another vehicle, a stale set, a lost arrival would all show."""
+    from cyclistsocialforce_amd import parameters as P
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import Bicycle, InvPendulumBicycle, PlanarPointBicycle, TwoDBicycle
+
+    rng = np.random.default_rng(seed)
+    counter = [0]
+
+    def make():
+        kind = rng.choice(["twod", "invpend", "planarpoint", "bicycle"])
+        k = counter[0] = counter[0] + 1
+        x, y, psi, v = rng.uniform(0, 35), rng.uniform(0, 35), rng.uniform(-np.pi, np.pi), rng.uniform(3, 4.8)
+        own = rng.random() < 0.6
+        if kind == "twod":
+            kw = dict(hfov=float(rng.uniform(1.0, 4.0)), f_0=float(rng.uniform(4, 11))) if own else {}
+            b = TwoDBicycle((x, y, psi, v, 0), id=f"t{k}", params=P.InvPendulumBicycleParameters(**kw))
+        elif kind == "invpend":
+            kw = dict(hfov=float(rng.uniform(1.0, 4.0)), sigma_0=float(rng.uniform(0.4, 0.7))) if own else {}
+            b = InvPendulumBicycle((x, y, psi, v, 0, 0), id=f"i{k}", params=P.InvPendulumBicycleParameters(**kw))
+        elif kind == "planarpoint":
+            kw = dict(hfov=float(rng.uniform(1.0, 4.0)), f_0=float(rng.uniform(4, 11))) if own else {}
+            b = PlanarPointBicycle((x, y, psi, v), id=f"p{k}", params=P.PlanarPointBicycleParameters(**kw))
+        else:
+            kw = dict(hfov=float(rng.uniform(1.0, 4.0)), p_0=float(rng.uniform(20, 40))) if own else {}
+            b = Bicycle((x, y, psi, v, 0), id=f"b{k}", params=P.BicycleParameters(**kw))
+        d = np.array([15.0, 29.0, 30.0])
+        b.setDestinations(x + d * np.cos(psi), y + d * np.sin(psi))
+        return b
+
+    ins = SocialForceIntersection([make() for _ in range(12)])
+    history = []
+
+    def check():
+        ins.calc_forces()
+        fdx, fdy, frx, fry = ins._engine.force_parts()
+        pods, cls = ins._param_classes()
+        n = len(ins.vehicles)
+        st = np.array([v.s[:4] for v in ins.vehicles])
+        ox, oy = orc.column_sums([orc_params(p) for p in pods], st[:, 0], st[:, 1], st[:, 2], st[:, 3], np.arange(n), cls=cls.astype(np.uint8))
+        lim, mag = np.hypot(fdx, fdy), np.hypot(ox, oy)
+        sc = np.where(mag > lim, lim / np.maximum(mag, 1e-300), 1.0)
+        err = max(np.abs(frx - ox * sc).max(), np.abs(fry - oy * sc).max()) / max(np.hypot(ox * sc, oy * sc).max(), 1.0)
+        assert err < 2e-4, (err, history)
+        assert all(v.s.shape == (type(v).N_STATES,) and np.isfinite(v.s).all() for v in ins.vehicles), history
+        return err
+
+    worst = check()
+    for it in range(70):
+        op = str(rng.choice(["step", "step", "join", "join", "leave_index", "leave_id", "assign", "route"]))
+        n = len(ins.vehicles)
+        if op == "step":
+            for _ in range(int(rng.integers(1, 4))):
+                ins.step()
+        elif op == "join" and n < 40:
+            ins.add_road_user(make())
+        elif op == "leave_index" and n > 4:
+            ins.remove_road_user(int(rng.integers(0, n)))
+        elif op == "leave_id" and n > 5:
+            ids = [ins.vehicles[int(i)].id for i in rng.choice(n, 2, replace=False)]
+            ins.remove_road_users_by_id(ids)
+        elif op == "assign":
+            v = ins.vehicles[int(rng.integers(0, n))]
+            if type(v).__name__ != "Bicycle":
+                v.params.f_0 = float(rng.uniform(2, 12))
+            else:
+                v.params.d_arrived_inter = float(rng.uniform(1.5, 3.0))     # (p_0 / p_decay are immutable in the reference)
+        elif op == "route":
+            v = ins.vehicles[int(rng.integers(0, n))]
+            d = np.array([20.0, 40.0])
+            a = rng.uniform(-np.pi, np.pi)
+            v.setDestinations(v.s[0] + d * np.cos(a), v.s[1] + d * np.sin(a), reset=True)
+        history.append(op)
+        worst = max(worst, check())
+    print(f"  seed {seed}: {len(ins.vehicles)} road users at the end, worst repulsive-sum error {worst:.1e}")
