@@ -549,7 +549,7 @@ def test_random_mirror_calls_keep_rows_and_vehicles_together(seed):
 
     worst = check()
     for it in range(70):
-        op = str(rng.choice(["step", "step", "join", "join", "leave_index", "leave_id", "assign", "route"]))
+        op = str(rng.choice(["step", "step", "join", "join", "join", "join", "leave_index", "leave_id", "assign", "route"]))
         n = len(ins.vehicles)
         if op == "step":
             for _ in range(int(rng.integers(1, 4))):
