@@ -1593,6 +1593,12 @@ int csf_set_param_classes(csf_engine *e, int32_t n_classes, const csf_params *cl
     for (int32_t a : e->order)
         if (e->h_cls[(size_t)a] >= n_classes)
             return fail(e, CSF_E_ARG, "a road user still uses parameter set %d", (int)e->h_cls[(size_t)a]);
+    if (e->d.hist != nullptr) {                                // the history ring was sized for the present state layout
+        int ns = 0;
+        for (int32_t c = 0; c < n_classes; c++) ns = std::max(ns, NS_OF[classes[c].model]);
+        if (ns != e->d.ns)
+            return fail(e, CSF_E_STATE, "parameter sets of a wider vehicle class after csf_enable_history: install the sets first");
+    }
     HIPCHK(e, hipSetDevice(e->device));
     int rc = flush_pending(e);                                 // (changes collected for the device assume one parameter set)
     if (rc) return rc;

@@ -575,3 +575,28 @@ def test_random_mirror_calls_keep_rows_and_vehicles_together(seed):
         history.append(op)
         worst = max(worst, check())
     print(f"  seed {seed}: {len(ins.vehicles)} road users at the end, worst repulsive-sum error {worst:.1e}")
+
+
+def test_history_ring_with_several_vehicle_classes(amd):
+    """csf_enable_history records the widest state layout of the table; sets of a wider class afterwards are refused (the ring
+    was sized before), sets of the same width are not."""
+    pods = [amd.pod("twod"), amd.pod("invpend", hfov=1.5)]
+    n = 8
+    s0 = np.zeros((n, 6)); s0[:, 0] = np.arange(n) * 3.0; s0[:, 3] = 4.0
+    e = amd.Engine(pods[0], n)
+    e.set_param_classes(pods)
+    e.add_agents(s0, 4.5)
+    e.set_dest_queue(np.arange(n), np.arange(n + 1) * 2, np.c_[np.repeat(s0[:, 0], 2) + np.tile([30.0, 60.0], n), np.zeros(2 * n), np.zeros(2 * n)], reset=True)
+    e.set_agent_class(np.arange(n), np.arange(n) % 2)
+    e.enable_history(stride=1, capacity=16)
+    e.step(10)
+    H = e.history(0, 10)
+    assert H.shape == (10, n, 6) and np.allclose(H[-1], e.state()) and np.isfinite(H).all()
+    e.set_param_classes([pods[0], amd.pod("invpend", hfov=2.0)])            # the same widths: fine
+    e.close()
+    e = amd.Engine(pods[0], n)
+    e.add_agents(s0[:, :5], 4.5)
+    e.enable_history(stride=1, capacity=16)
+    with pytest.raises(Exception, match="csf_enable_history"):
+        e.set_param_classes(pods)                                           # six states where the ring holds five
+    e.close()
