@@ -1024,8 +1024,7 @@ int prepare_mutation(csf_engine *e) {
 // history ring and CSF_INCREMENTAL=0 take the round trip through the host mirror (prepare_mutation / upload_all).
 bool can_patch_device(const csf_engine *e) {
     static const bool off = getenv("CSF_INCREMENTAL") && atoi(getenv("CSF_INCREMENTAL")) == 0;
-    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr &&
-           e->segs.empty();   // (the class-segmented order has no tail for arrivals: they go through the host mirror)
+    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
 }
 
 // a pinned, device-visible host buffer of `bytes` from the ring; waits only if the ring of four is exhausted
@@ -1093,6 +1092,10 @@ int flush_pending(csf_engine *e) {
     launch_patch(d, h, pin->dev, e->ticket.p, b0, b1, h.n_retire + h.n_spawn + h.n_requeue + 3 * h.n_rows, e->main);
     e->tail_flushed = e->tail_used;
     e->pend_inplace = false;
+    // The class-segmented order has no tail for arrivals: an arrival belongs into its set's run, which only a re-binning
+    // can give it (the sort reads every slot's record and set) - so the order is renewed before the next pair launch
+    // (~50 us, against 5 ms for the way through the host mirror).  Departures leave sentinel records in their runs.
+    if (!e->segs.empty() && h.n_spawn > 0) e->ticks_since_rebin = std::max<int64_t>(e->ticks_since_rebin, REBIN_TICKS);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(pin->done, e->main));
     pin->busy = true;
@@ -1422,7 +1425,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         // (without the binned order a slot is its own place: the sources end with the last slot in use)
         const int64_t n_src = e->tail_tracked ? std::min(d.n_pad, (e->live_at_rebin + e->tail_used + 63) / 64 * 64)
                               : (d.classify ? d.n_pad : std::min(d.n_pad, (d.n + 63) / 64 * 64));
-        if (n_src > d.n_src || !e->tail_tracked) {
+        if (e->segs.empty() && (n_src > d.n_src || !e->tail_tracked)) {     // (segments: the chunks are the runs', until the re-binning)
             d.n_src = std::max(n_src, d.n_src);
             set_chunks(e);
         }
@@ -2355,6 +2358,7 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     for (int k = 0; k < 4; k++) counts[k] = 0;
     if (d.n_live <= 1 || d.hi <= d.lo) return CSF_OK;
     if ((rc = wait_gather(e))) return rc;
+    if (!e->segs.empty() && e->ticks_since_rebin >= REBIN_TICKS && (rc = rebin(e))) return rc;   // (arrivals since: flush_pending)
     if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
     if ((e->world > 1 || e->nccl != nullptr || e->loopback) && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
     DevBuf<unsigned long long> cnt;

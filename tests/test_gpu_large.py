@@ -551,14 +551,17 @@ def test_arrivals_in_the_sentinel_tail(amd):
 
 
 @pytest.mark.parametrize("seed,n0,box,sets", [(1, 1300, 420.0, 1), (2, 3300, 700.0, 1), (3, 1100, 400.0, 3), (18, 1100, 400.0, 3),
-                                              (17, 3300, 700.0, 1), (30, 1100, 400.0, 3), (5, 1200, 420.0, -3), (6, 1200, 420.0, -3)])
-def test_random_population_calls_device_path_vs_host_mirror(amd, seed, n0, box, sets):
+                                              (17, 3300, 700.0, 1), (30, 1100, 400.0, 3), (5, 1200, 420.0, -3), (6, 1200, 420.0, -3),
+                                              (101, 1400, 420.0, 3), (102, 2600, 600.0, -3)])
+def test_random_population_calls_device_path_vs_host_mirror(amd, monkeypatch, seed, n0, box, sets):
     """A random sequence of the population calls SUMO co-simulation makes - arrivals, departures, queues replaced / edited
     / extended, desired speeds, now and then a state pushed from the host, a few ticks in between - through the
     device-side path (pending lists, sentinel tail, slot reuse, slab rewrites, re-binning) and through the host mirror
     (csf_set_incremental(0)); sets = 3: three parameter sets, every arrival with a set of its own choice (the spawn record
     carries it).  A sparse population (few pairs interact: differences stay at rounding level), so the two
     engines are compared tightly after every call: positions, pointers, navigation states, status."""
+    if seed > 100:                                             # the class-segmented order from 1 024 road users: an arrival
+        monkeypatch.setenv("CSF_SEGMENTS", "1")                # belongs into its set's run, which the next re-binning gives it
     rng = np.random.default_rng(seed)
     cap = n0 + 900
     pool, _, pdq = population(cap + 6000, box, seed=seed + 50)
