@@ -10,8 +10,6 @@
 //                 dynamics.py:996-1079), ring-buffer bookkeeping, and the refreshed (x, y, psi) snapshot
 //                 (intersection.py:660-677) written as the fp32 source record of the next tick.
 // The O(N) work is done in fp64 so that the only fp32 rounding in a tick is the pair sum.
-#include <cstdlib>
-
 #include "csf_dev.h"
 
 namespace csf {
@@ -663,11 +661,12 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
     }
 }
 
-// fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677
-__device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, int64_t a, double x, double y, double psi,
-                                             double v, bool cs_fresh = false, double c = 0.0, double s = 0.0) {
+// fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677.  The position is stored as
+// an offset from `o`, the road user's own origin (csf_dev.h: rorg), formed in fp64: one rounding, of a few metres.
+__device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, int64_t a, const float2 o, double x, double y,
+                                             double psi, double v, bool cs_fresh = false, double c = 0.0, double s = 0.0) {
     if (!cs_fresh) sincos(psi, &s, &c);
-    const float4 q = make_float4((float)(x - d.ox), (float)(y - d.oy), (float)c, (float)s);
+    const float4 q = make_float4((float)((x - d.ox) - (double)o.x), (float)((y - d.oy) - (double)o.y), (float)c, (float)s);
     d.rec[a] = q;
     if (d.recs_valid) d.recs[d.pos[a]] = q;                   // the copy in binned order (csf_bin.hip)
     if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
@@ -714,6 +713,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
 #pragma unroll
     for (int c = 0; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
     const float2 froad = d.froad[a];
+    const float2 rorg = d.rorg[a];                             // (for the record written at the end)
 
     double fdx, fdy;
     if (phases & PH_DEST) {
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         d.s[4 * cap + a] = g.delta;
         d.s[5 * cap + a] = g.theta;
         d.ti[a] = g.ti;
-        write_record(d, *g.p, a, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi);
+        write_record(d, *g.p, a, rorg, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi);
         if (d.hist != nullptr) {
             int64_t t1 = d.tick + 1;
             if (t1 % d.hist_stride == 0) {
@@ -812,12 +812,12 @@ __global__ void records_kernel(const Dev d) {
         if (d.has_bike) d.rec2[a] = make_float2(0.0f, 1.0f);
         return;
     }
-    write_record(d, d.ptab[d.cls[a]], a, d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);
+    write_record(d, d.ptab[d.cls[a]], a, d.rorg[a], d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);
 }
 
 void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo) return;
-    static const int bs = getenv("CSF_AGENT_BLOCK") ? atoi(getenv("CSF_AGENT_BLOCK")) : 64;   // 256 waves on 256 CUs: 0.6 us less than 64 workgroups of 4
+    constexpr int bs = 64;   // one-wave workgroups: 256 waves on 256 CUs measured 0.6 us faster than 64 workgroups of 4
     dim3 g((unsigned)((d.hi - d.lo + bs - 1) / bs)), b(bs);
 #define CSF_AGENT(MODEL)                                                                                             \
     if (d.n_classes > 1) hipExtLaunchKernelGGL((agent_kernel<MODEL, true>), g, b, 0, st, t0, t1, 0, d, phases);           \
@@ -983,7 +983,13 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
         d.status[a] = 0;
         d.alive[a] = 1;
-        write_record(d, p, a, s[0], s[1], s[2], s[3]);
+        // its own origin: where it starts, rounded to 1/4 m (unbinned populations: the scene origin); the slot keeps its
+        // place of the binned order
+        float2 o = make_float2(0.f, 0.f);
+        if (d.classify) o = make_float2((float)(0.25 * rint(4.0 * (s[0] - d.ox))), (float)(0.25 * rint(4.0 * (s[1] - d.oy))));
+        d.rorg[a] = o;
+        if (d.recs_valid) d.orgs[d.pos[a]] = o;
+        write_record(d, p, a, o, s[0], s[1], s[2], s[3]);
     } else if ((k -= h.n_spawn) < h.n_requeue) {
         const QueueRec r = ((const QueueRec *)(base + h.off_requeue))[k];
         d.qbeg[r.slot] = r.qbeg;

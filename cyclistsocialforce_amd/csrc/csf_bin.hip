@@ -5,7 +5,9 @@
 // circle alone (csf_pair.hip): entirely outside -> skipped, entirely inside -> queued without per-lane tests.
 // This file provides the order and the circles:
 //   * every REBIN ticks: Hilbert index of each record's cell (0.5 m) -> stable radix sort (hipCUB) -> perm[];
-//   * bounding circle of each batch of 64 records in perm order: right after a re-sort by bounds_kernel, otherwise
+//   * every record's own origin (where the road user is now, rounded to 1/4 m), which its fp32 position is an offset
+//     from until the next re-binning (rebase_kernel): a position resolves to 2^-24 of a few metres, not of the scene;
+//   * bounding circle of each batch of 64 records in perm order: right after a re-sort by rebase_kernel, otherwise
 //     by the pair kernel itself, which emits the circles of the NEXT tick from this tick's records grown by the
 //     largest possible displacement of one tick (positions move every tick, the order only drifts, so
 //     correctness never depends on how fresh perm is).
@@ -44,8 +46,9 @@ __global__ void keys_kernel(const Dev d, uint32_t *keys, int32_t *vals) {
     const float4 q = d.rec[a];
     uint32_t key = 0xFFFFFFFFu;  // sentinels (padding, shard holes) sort to the end
     if (fabsf(q.x) < 1e9f && fabsf(q.y) < 1e9f) {
-        const float cell = 2.0f;  // cells of 0.5 m, +-16 km around the origin of the records
-        int xi = (int)floorf(q.x * cell) + 32768, yi = (int)floorf(q.y * cell) + 32768;
+        const float2 o = d.rorg[a];  // the record is an offset from the origin of the batch it was binned into last time
+        const float cell = 2.0f;  // cells of 0.5 m, +-16 km around the origin of the scene
+        int xi = (int)floorf((q.x + o.x) * cell) + 32768, yi = (int)floorf((q.y + o.y) * cell) + 32768;
         xi = xi < 0 ? 0 : (xi > 65535 ? 65535 : xi);
         yi = yi < 0 ? 0 : (yi > 65535 ? 65535 : yi);
         key = hilbert16((uint32_t)xi, (uint32_t)yi);
@@ -71,6 +74,60 @@ __global__ void sorted_copy_kernel(const Dev d) {
     d.pos[a] = (int32_t)p;
     d.recs[p] = d.rec[a];
     if (d.has_bike) d.recs2[p] = d.rec2[a];
+}
+
+// After a re-sort (perm is new, pos / recs / org / bnd are not yet), one wave per batch of 64 places:
+//   * every record's new origin: its scene coordinates rounded to 1/4 m (with_origins; else 0: unbinned populations keep
+//     offsets from the scene origin), and the record re-expressed as an offset from it - recomputed from the fp64 state
+//     where this device holds it for every slot (a single device; any rank right after an upload), else from the old
+//     record and the old origin (the foreign blocks of a rank: (old origin - new origin) is exact, the sum rounds once);
+//   * pos[], the copies of records and origins in binned order, and the batch's bounding circle (scene coordinates).
+// Sentinel records stay as they are (the padding slot of the class-segmented order sits in many places at once); their
+// places get the origin of the batch's first road user, so that a workgroup of the pair kernel whose first receiver
+// place is empty still works relative to an origin near its receivers.
+__global__ __launch_bounds__(256) void rebase_kernel(const Dev d, const int with_origins) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b * 64 >= d.n_pad) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t p = b * 64 + lane;
+    const int32_t a = d.perm[p];
+    float4 q = d.rec[a];
+    const bool real = rec_is_real(q);
+    const float2 o = real ? d.rorg[a] : make_float2(0.f, 0.f);
+    const float x = q.x + o.x, y = q.y + o.y;                  // scene coordinates, rounded: good enough for the box
+    float x0 = real ? x : 3e38f, x1 = real ? x : -3e38f, y0 = real ? y : 3e38f, y1 = real ? y : -3e38f;
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o2, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o2, 64));
+        y0 = fminf(y0, __shfl_xor(y0, o2, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, o2, 64));
+    }
+    float2 on = make_float2(0.f, 0.f);
+    if (with_origins && real) on = make_float2(0.25f * rintf(4.0f * x), 0.25f * rintf(4.0f * y));
+    if (real) {
+        if (d.rebase_from_state) {
+            q.x = (float)((d.s[a] - d.ox) - (double)on.x);
+            q.y = (float)((d.s[d.cap + a] - d.oy) - (double)on.y);
+        } else {
+            q.x = (o.x - on.x) + q.x;
+            q.y = (o.y - on.y) + q.y;
+        }
+        d.rec[a] = q;
+        d.rorg[a] = on;
+        d.pos[a] = (int32_t)p;
+    } else if (a < d.n_pad) {
+        d.pos[a] = (int32_t)p;                                 // (a free slot's place: where an arrival spawned into it will sit)
+    }
+    d.recs[p] = q;
+    {   // origin of an empty place: that of the first road user of the batch (0 if there is none)
+        const unsigned long long m = __ballot(real);
+        const int first = m ? __builtin_ctzll(m) : 0;
+        const float fx = __shfl(on.x, first, 64), fy = __shfl(on.y, first, 64);
+        d.orgs[p] = real ? on : make_float2(fx, fy);
+    }
+    if (d.has_bike) d.recs2[p] = d.rec2[a];
+    if (lane == 0) d.bnd[b] = box_circle(x0, x1, y0, y1, 0.0f);
 }
 
 __global__ __launch_bounds__(256) void bounds_kernel(const Dev d) {
@@ -133,6 +190,12 @@ void launch_identity_perm(const Dev &d, hipStream_t st) {
 void launch_sorted_copy(const Dev &d, hipStream_t st) {
     if (d.n_pad <= 0) return;
     hipLaunchKernelGGL(sorted_copy_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+}
+
+void launch_rebase(const Dev &d, int with_origins, hipStream_t st) {
+    if (d.n_pad <= 0) return;
+    const int64_t batches = d.n_pad / 64;
+    hipLaunchKernelGGL(rebase_kernel, dim3((unsigned)((batches + 3) / 4)), dim3(256), 0, st, d, with_origins);
 }
 
 void launch_bounds(const Dev &d, hipStream_t st) {

@@ -54,6 +54,8 @@ struct Dev {
     int64_t lo, hi;    // receiver block integrated by this rank
     int64_t n_pad;     // n rounded up to a multiple of 64 (sentinel source records behind n)
     int64_t n_src;     // places of the source order that can hold a road user (multiple of 64, <= n_pad): the pair kernel stops there
+    int64_t n_places;  // the same for the whole order (n_src is narrowed to one run of places by a class-segment launch): with
+                       // binned records the receivers of the pair kernel are the places [0, n_places) (or rlist)
     int64_t src_beg;   // ... and starts here (0, or the first place of a class segment: csf_engine.hip launch_pair_segments)
     int32_t part_base; // first slot of d.part this launch writes (its source chunks follow: one launch per class segment)
     int32_t seg_keys;  // re-binning: the parameter set leads the sort key (csf_bin.hip), so that every set is a run of places
@@ -66,7 +68,7 @@ struct Dev {
     int32_t rpb;       // ... and receivers per workgroup then: 16 or 32
     int32_t pair_variant;  // 0: cull-first kernel on binned records (default), 1: evaluate-then-mask, 2: cull-first, unbinned
     int32_t classify;      // the records are binned and every batch of 64 carries a bounding circle
-    double ox, oy;     // origin of the fp32 source records
+    double ox, oy;     // origin of the scene: what the batch origins (org) and the bounding circles (bnd) are relative to
     int64_t tick;
 
     double *s;         // [6][cap]  x, y, psi, v, delta, theta
@@ -87,7 +89,14 @@ struct Dev {
     int32_t *dgood;    // consecutive ring samples with |delta| < delta_max_walk (vehicle.py:1943-1947)
     double *ppsi;      // PlanarPoint unwrapped yaw (dynamics.py:943-966)
 
-    float4 *rec;       // [n_pad] (x-ox, y-oy, cos psi, sin psi) fp32 source records
+    // fp32 source records (x - ox - rorg.x, y - oy - rorg.y, cos psi, sin psi): the position is an offset from the road
+    // user's OWN origin - where it was at the last re-binning, rounded to 1/4 m (exact in fp32, and so is the difference
+    // of two origins) - not from the scene origin.  The offset stays below a few metres (0.07 m per tick, 32 ticks), so
+    // a position resolves to ~2e-7 m whatever the extent of the scene.  Unbinned populations: every origin is 0.
+    float4 *rec;       // [n_pad] by slot
+    float2 *rorg;      // [n_pad] by slot: the origin its record is relative to, itself relative to (ox, oy)
+    float2 *orgs;      // [n_pad] the same by place of the binned order (beside recs); a place without a road user: an origin nearby
+    int32_t rebase_from_state;   // re-binning: every live slot's fp64 state is current on this device (else: re-express the old record)
     float2 *rec2;      // [n_pad] Bicycle field only: (e, 1/sqrt(1-e^2))
     int32_t *perm;     // [n_pad] spatially binned order of the source records (position -> record index)
     int32_t *pos;      // [n_pad] inverse of perm (record index -> position)
@@ -95,8 +104,8 @@ struct Dev {
                        // rec, so that the pair kernel's tile fill is one coalesced load instead of perm -> rec)
     float2 *recs2;     // [n_pad] Bicycle field: rec2 in binned order
     int32_t recs_valid;
-    int32_t recv_binned;   // the pair kernel takes its receivers in binned order too and skips far tiles (large populations)
-    const int32_t *rlist;  // recv_binned on a shard: binned positions of this rank's receivers, ascending (NULL: all of them)
+    int32_t recv_binned;   // the pair kernel skips tiles of sources beyond the far-field radius of a whole receiver group unloaded (large populations)
+    const int32_t *rlist;  // binned records on a shard: places of this rank's receivers, ascending (NULL: the places [0, n_places))
     float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
     float4 *bnd_next;  // written by the pair kernel for the next tick (from this tick's records + bnd_margin)
     float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
@@ -144,6 +153,9 @@ int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals
                  hipStream_t st);
 void launch_identity_perm(const Dev &d, hipStream_t st);
 void launch_sorted_copy(const Dev &d, hipStream_t st);  // pos[] and recs[] from perm[] and rec[]
+// after a re-sort: every record re-expressed relative to its new origin (from the fp64 state where
+// d.rebase_from_state), pos[] / recs[] / orgs[] and the bounding circles - one launch
+void launch_rebase(const Dev &d, int with_origins, hipStream_t st);
 void launch_bounds(const Dev &d, hipStream_t st);
 // binned positions of the receivers [lo, hi) of this rank in ascending order (the rank's receivers as neighbours in space)
 int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st);
@@ -175,30 +187,44 @@ void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
                      int apply_fov, float2 *out, hipStream_t st);
 
-// bounding circle of batch b (64 records in perm order), computed by one wave: centre and radius of the bounding
-// box's circumcircle, grown by `margin`
+// a + b as an unevaluated sum hi + lo (Knuth's TwoSum: no ordering of |a|, |b| assumed)
+__device__ __forceinline__ void two_sum(float a, float b, float &hi, float &lo) {
+    hi = a + b;
+    const float bb = hi - a;
+    lo = (a - (hi - bb)) + (b - bb);
+}
+
+// sentinel records (padding, holes of a shard, slots left by csf_remove_agents) sit at 1e15 m: they contribute exactly
+// nothing as sources (exp2 underflow) and take no part in origins, circles and sort keys
+__device__ __forceinline__ bool rec_is_real(const float4 q) { return fabsf(q.x) < 1e14f; }
+
+// circumcircle of a bounding box (scene coordinates), rounded up: it must contain every record of the batch, whose scene
+// coordinates are themselves rounded sums origin + offset (2^-24 relative)
+__device__ __forceinline__ float4 box_circle(float x0, float x1, float y0, float y1, float margin) {
+    if (x1 < x0) return make_float4(1e15f, 1e15f, 0.0f, 0.0f);   // nothing but sentinels: a circle beyond every far-field radius
+    const float w = x1 - x0, h = y1 - y0;
+    const float cx = 0.5f * (x0 + x1), cy = 0.5f * (y0 + y1);
+    const float rad = 0.5f * sqrtf(w * w + h * h) * 1.0001f + 1e-4f + margin + 2.4e-7f * (fabsf(cx) + fabsf(cy) + w + h);
+    return make_float4(cx, cy, rad, 0.0f);
+}
+
+// bounding circle of batch b (64 records in perm order), computed by one wave: centre (scene coordinates) and radius of
+// the bounding box's circumcircle, grown by `margin`
 __device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, float margin, float4 *out) {
-    const float4 q = d.rec[d.perm[b * 64 + lane]];
-    // sentinel records (padding, holes of a shard, slots left by csf_remove_agents) take no part: they contribute nothing
-    // as sources, and one of them inside a batch would blow its circle up to the whole plane
-    const bool real = fabsf(q.x) < 1e14f;
-    float x0 = real ? q.x : 3e38f, x1 = real ? q.x : -3e38f, y0 = real ? q.y : 3e38f, y1 = real ? q.y : -3e38f;
+    const int32_t a = d.perm[b * 64 + lane];
+    const float4 q = d.rec[a];
+    const bool real = rec_is_real(q);
+    const float2 o = real ? d.rorg[a] : make_float2(0.f, 0.f);
+    const float x = q.x + o.x, y = q.y + o.y;
+    float x0 = real ? x : 3e38f, x1 = real ? x : -3e38f, y0 = real ? y : 3e38f, y1 = real ? y : -3e38f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        x0 = fminf(x0, __shfl_xor(x0, o, 64));
-        x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
-        y0 = fminf(y0, __shfl_xor(y0, o, 64));
-        y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o2, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o2, 64));
+        y0 = fminf(y0, __shfl_xor(y0, o2, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, o2, 64));
     }
-    if (lane == 0) {
-        if (x1 < x0) {                       // nothing but sentinels: a circle beyond every far-field radius
-            out[b] = make_float4(1e15f, 1e15f, 0.0f, 0.0f);
-            return;
-        }
-        const float w = x1 - x0, h = y1 - y0;
-        const float rad = 0.5f * sqrtf(w * w + h * h) * 1.0001f + 1e-4f + margin;  // rounded up: must contain
-        out[b] = make_float4(0.5f * (x0 + x1), 0.5f * (y0 + y1), rad, 0.0f);
-    }
+    if (lane == 0) out[b] = box_circle(x0, x1, y0, y1, margin);
 }
 
 

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "csf_dev.h"
@@ -71,9 +72,13 @@ struct DevBuf {
         n = count;
         if (count == 0) return hipSuccess;
         hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        // the clear runs on the NULL stream, which the engine's non-blocking streams do not wait for: finish it here
         if (e == hipSuccess) e = hipMemset(p, 0, count * sizeof(T));
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         return e;
     }
+    // grow-only scratch: contents undefined
+    hipError_t reserve(size_t count) { return count <= n ? hipSuccess : alloc(count); }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -81,10 +86,52 @@ struct DevBuf {
     }
 };
 
+// Measurement and test knobs.  Read from the environment ONCE per engine, in csf_create: nothing on the tick path or in
+// a re-binning calls getenv.
+struct Knobs {
+    double far_eps = 5.9604644775390625e-8;   // CSF_FAR_EPS: bound of the far-field / reach cull (2^-24; 0: off)
+    bool reach = true;                        // CSF_REACH=0: no per-pair reach test
+    std::string trace_blocks;                 // CSF_TRACE_BLOCKS=<file>: per-wave timeline of the last pair launch
+    int fake_rank = 0, fake_world = 1;        // CSF_FAKE_SHARD=r/w: only rank r's receiver block of w (timing aid)
+    int nsplit = 0;                           // CSF_NSPLIT: source chunks of the pair grid (0: the engine's choice)
+    int dyn_recv = -1, rpb = 0;               // CSF_DYN_RECV, CSF_RPB
+    int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
+    int segments = -1;                        // CSF_SEGMENTS
+    int recv_binned = -1;                     // CSF_RECV_BINNED
+    int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
+    bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
+    bool comm_second = false;                 // CSF_COMM_STREAM=second
+    int fused = -1;                           // CSF_FUSED: the one-launch tick of small populations (-1: the engine's choice)
+    void read() {
+        auto geti = [](const char *name, int dflt) {
+            const char *v = getenv(name);
+            return v ? atoi(v) : dflt;
+        };
+        if (const char *v = getenv("CSF_FAR_EPS")) far_eps = atof(v);
+        reach = geti("CSF_REACH", 1) != 0;
+        if (const char *v = getenv("CSF_TRACE_BLOCKS")) trace_blocks = v;
+        if (const char *v = getenv("CSF_FAKE_SHARD")) {
+            int fr = 0, fw = 1;
+            if (sscanf(v, "%d/%d", &fr, &fw) == 2 && fw > 1 && fr >= 0 && fr < fw) fake_rank = fr, fake_world = fw;
+        }
+        nsplit = geti("CSF_NSPLIT", 0);
+        dyn_recv = geti("CSF_DYN_RECV", -1);
+        rpb = geti("CSF_RPB", 0);
+        pair_variant = geti("CSF_PAIR_VARIANT", -1);
+        segments = geti("CSF_SEGMENTS", -1);
+        recv_binned = geti("CSF_RECV_BINNED", -1);
+        rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
+        incremental = geti("CSF_INCREMENTAL", 1) != 0;
+        if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second";
+        fused = geti("CSF_FUSED", -1);
+    }
+};
+
 }  // namespace
 
 struct csf_engine {
     Dev d{};
+    Knobs knobs;
     int device = 0;
     // parameter sets (csf_set_param_classes): classes[0] is d.p; h_cls[slot] the set of a road user
     std::vector<csf_params> classes;
@@ -131,6 +178,12 @@ struct csf_engine {
     int64_t tail_flushed = 0;                       // ... of which the device has seen this many (flush_pending)
     bool pend_inplace = false;                      // an arrival of the pending batch took a slot inside a real batch
     DevBuf<unsigned> ticket;                        // patch_kernel: which workgroup finishes last
+    // grow-only device scratch of the single-piece entry points (csf_untracked, csf_update_*, csf_count_pairs): no
+    // hipMalloc / hipFree per call
+    DevBuf<uint8_t> scratch_u8;
+    DevBuf<int32_t> scratch_i32;
+    DevBuf<double> scratch_f64;
+    DevBuf<unsigned long long> scratch_cnt;
     bool tail_tracked = false;                      // the places of the sentinel tail are known (binned single engine)
     std::vector<uint8_t> h_alive;
     bool order_dirty = true;               // the device copy of `order` is stale
@@ -174,6 +227,8 @@ struct csf_engine {
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, recs2, part, froad, kat2;
+    DevBuf<float2> orgs, rorg;   // the origin every record is relative to: by place of the binned order, by slot
+    bool state_all_current = true;   // every live slot's fp64 state on this device is current (false once a rank has ticked)
     double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
     double last_gather_ms = 0.0;  // all-gather time accumulated by the last csf_profile_read
     bool ev_gather_recorded = false;
@@ -237,7 +292,7 @@ int fail(csf_engine *e, int code, const char *fmt, ...) {
     } while (0)
 
 const int NS_OF[5] = {5, 5, 6, 4, 5};
-int32_t pair_variant_for(int64_t n);   // (with rebin, below)
+int32_t pair_variant_for(const csf_engine *e, int64_t n);   // (with rebin, below)
 
 double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, vehicle.py:154-155)
     const double PI = 3.141592653589793238462643383279502884;
@@ -292,11 +347,6 @@ double far_radius(double kappa, int64_t n, double far_eps) {
     return std::log((double)n / far_eps) / kappa;
 }
 
-double far_eps() {
-    const char *fe = getenv("CSF_FAR_EPS");
-    return fe ? atof(fe) : 5.9604644775390625e-8;   // 2^-24
-}
-
 // Per-pair form of the same bound.  A pair adds f_0 exp(-x), x = rho q / sigma (vehicle.py:1628), and may be left out
 // when x > T = ln(n / far_eps): then it is below far_eps f_0 / n like every source beyond the far-field radius.  With
 // X = rho cos(phi) (the receiver along the source's heading), rho^2 q^2 = rho^2 - e^2 X^2 exactly, and
@@ -305,11 +355,13 @@ double far_eps() {
 // The kernel evaluates this with one rsq per pair (csf_pair.hip: keep_x2); T carries a 0.2 % margin against the fp32
 // rounding of the two sides.  At N = 16 384 in 200 m the test removes three of four pairs that pass the field of view.
 // far-field radius and reach-test constants of one parameter set in a population of n road users
-void set_far_consts(const csf_params &p, double kappa, int64_t n, PairConsts &k) {
-    const double eps = far_eps();
+void set_far_consts(const Knobs &kn, const csf_params &p, double kappa, int64_t n, PairConsts &k) {
+    const double eps = kn.far_eps;
     k.rfar = (float)far_radius(kappa, n, eps);
+    // (sigma_b >= 0 is what the bound sigma <= sigma_a - sigma_b (1 - cos phi) / 2 rests on; the reference's setters enforce
+    // it, the C ABI does not: a set with a negative sigma_2 / sigma_3 keeps the radius-only cull)
     const bool on = std::isfinite(k.rfar) && p.model != CSF_BICYCLE && n >= 1 && p.sigma_2 < p.sigma_0 && p.sigma_3 < p.sigma_1 &&
-                    !(getenv("CSF_REACH") && atoi(getenv("CSF_REACH")) == 0);
+                    p.sigma_2 >= 0 && p.sigma_3 >= 0 && p.sigma_2 + p.sigma_3 >= 0 && kn.reach;
     k.reach = on;
     if (on) {
         const double T = std::log((double)n / eps) * 1.002;
@@ -330,7 +382,7 @@ void update_far_radius(csf_engine *e) {   // depends on the parameters and on th
         k.tA0 = k.tA1 = k.tB0 = k.tB1 = 0.f;
         return;
     }
-    set_far_consts(e->d.p, e->far_kappa, e->d.n, k);
+    set_far_consts(e->knobs, e->d.p, e->far_kappa, e->d.n, k);
 }
 
 // exp(A) of a small dense matrix (n <= 4, row major): scaling and squaring of a degree-18 Taylor polynomial
@@ -440,7 +492,7 @@ void derive_consts(csf_engine *e) {
     e->classes[0] = p;
     e->d.n_classes = (int32_t)e->classes.size();
     e->classes_dirty = true;
-    e->d.pair_variant = pair_variant_for(e->d.n_live);
+    e->d.pair_variant = pair_variant_for(e, e->d.n_live);
     {   // no rider model moves faster than its speed clamp (vehicle.py:1258, 1876, 1905; dynamics.py:1025)
         double vmax = 0;
         for (const csf_params &c : e->classes)
@@ -500,6 +552,8 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->recs.alloc(nrec));
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
+    HIPCHK(e, e->orgs.alloc(nrec));
+    HIPCHK(e, e->rorg.alloc(nrec));
     HIPCHK(e, e->sort_vals.alloc(nrec));
     HIPCHK(e, e->rlist.alloc(nrec));
     HIPCHK(e, e->sort_keys.alloc(nrec));
@@ -523,6 +577,7 @@ int alloc_all(csf_engine *e) {
     e->h_alive.assign(cap, 0);
     e->h_cls.assign(cap, 0);
     HIPCHK(e, e->cls.alloc(cap));
+    HIPCHK(e, e->ticket.alloc(1));
     e->pend_spawn_at.assign(cap, -1);
     e->pend_requeue_at.assign(cap, -1);
     e->pend_retire_at.assign(cap, -1);
@@ -557,8 +612,10 @@ int alloc_all(csf_engine *e) {
     d.recs = e->recs.p;
     d.bnd = e->bnd.p;
     d.bnd_next = e->bnd2.p;
+    d.orgs = e->orgs.p;
+    d.rorg = e->rorg.p;
     d.trace = nullptr;
-    if (getenv("CSF_TRACE_BLOCKS")) {  // 3 words per wave: the grid is at most (cap/16) x MAX_SPLIT workgroups of 4 waves
+    if (!e->knobs.trace_blocks.empty()) {  // 3 words per wave: the grid is at most (cap/16) x MAX_SPLIT workgroups of 4 waves
         e->trace_words = 3 * 4 * ((size_t)cap / 16 + 1) * MAX_SPLIT;
         HIPCHK(e, e->trace.alloc(e->trace_words));
         HIPCHK(e, hipMemset(e->trace.p, 0, e->trace_words * sizeof(uint64_t)));
@@ -584,13 +641,11 @@ void set_shard(csf_engine *e) {
         d.hi = std::min<int64_t>(d.n, d.lo + shard);
         d.n_pad = shard * e->world;
     }
-    if (const char *fake = getenv("CSF_FAKE_SHARD")) {  // timing aid: "r/w" computes only rank r's receiver block of w
-        int fr = 0, fw = 1;                               // (no communicator, other blocks' records go stale)
-        if (sscanf(fake, "%d/%d", &fr, &fw) == 2 && fw > 1 && fr >= 0 && fr < fw) {
-            int64_t shard = ((d.n + fw - 1) / fw + 63) / 64 * 64;
-            d.lo = std::min<int64_t>(d.n, (int64_t)fr * shard);
-            d.hi = std::min<int64_t>(d.n, d.lo + shard);
-        }
+    if (e->knobs.fake_world > 1) {  // timing aid (CSF_FAKE_SHARD=r/w): only rank r's receiver block of w is computed
+        const int fr = e->knobs.fake_rank, fw = e->knobs.fake_world;   // (no communicator, other blocks' records go stale)
+        int64_t shard = ((d.n + fw - 1) / fw + 63) / 64 * 64;
+        d.lo = std::min<int64_t>(d.n, (int64_t)fr * shard);
+        d.hi = std::min<int64_t>(d.n, d.lo + shard);
     }
     d.n_src = d.n_pad;          // every place of the source order may hold a road user (rebin() knows better)
     e->tail_tracked = false;
@@ -600,6 +655,7 @@ void set_shard(csf_engine *e) {
 // the source chunks of the pair kernel's grid, for the d.n_src places of the source order that can hold road users
 void set_chunks(csf_engine *e) {
     Dev &d = e->d;
+    d.n_places = d.n_src;
     int64_t nloc = d.hi - d.lo;
     int64_t blocks = (nloc + 15) / 16;
     int64_t units = std::max<int64_t>(1, d.n_src / 64);
@@ -617,23 +673,23 @@ void set_chunks(csf_engine *e) {
     // large populations run the far-tile-skipping variant (rebin: recv_binned): most tiles of a chunk are
     // skipped unloaded, and longer chunks amortise the workgroup's start-up (config 4: 7.3 ms at 64 chunks, 6.2 at 8-16)
     if (d.n_src >= 65536 && d.p.model != CSF_BICYCLE) split = std::min<int64_t>(split, 16);
-    if (const char *ov = getenv("CSF_NSPLIT")) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoi(ov), (int64_t)MAX_SPLIT, units}));
+    if (e->knobs.nsplit > 0) split = std::max<int64_t>(1, std::min<int64_t>({(int64_t)e->knobs.nsplit, (int64_t)MAX_SPLIT, units}));
     // no empty chunk: with per = ceil(units / split) units per chunk only ceil(units / per) chunks hold sources (n = 1040:
     // 17 units, split 16 -> per 2 -> 9 chunks).  A workgroup of an empty chunk would leave its slot of d.part untouched,
     // and the combine phase would add whatever an earlier population layout left there.
     int64_t per = (units + split - 1) / split;
     // a chunk just over one LDS tile (16 batches) would load a second, nearly empty tile in every workgroup: the few
     // batches of arrivals behind a population that filled whole tiles get a chunk - and workgroups - of their own
-    if (per > 16 && per < 32 && (units + 15) / 16 <= MAX_SPLIT && !getenv("CSF_NSPLIT")) per = 16;
+    if (per > 16 && per < 32 && (units + 15) / 16 <= MAX_SPLIT && e->knobs.nsplit <= 0) per = 16;
     split = (units + per - 1) / per;
     d.n_split = (int32_t)split;
     d.chunk_units = (int32_t)per;
     d.dyn_recv = 1;   // receivers handed to the waves of a workgroup one at a time (csf_pair.hip, DYN; 0: four per wave)
-    if (const char *ov = getenv("CSF_DYN_RECV")) d.dyn_recv = atoi(ov) != 0;
+    if (e->knobs.dyn_recv >= 0) d.dyn_recv = e->knobs.dyn_recv != 0;
     // 32 receivers per workgroup where that still leaves thousands of workgroups (N = 16 384 unsharded: 8192): measured
     // better from 8192 receivers up, worse for the few workgroups of small populations and 4-way shards
     d.rpb = nloc >= 8192 ? 32 : 16;
-    if (const char *ov = getenv("CSF_RPB")) d.rpb = atoi(ov) == 32 ? 32 : 16;
+    if (e->knobs.rpb > 0) d.rpb = e->knobs.rpb == 32 ? 32 : 16;
 }
 
 constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long
@@ -645,9 +701,8 @@ constexpr int64_t BIN_MIN_AGENTS = 1024;
 // against 13.2 at 64, level at ~3 000, 41 against 32 at 4 096 (tools/variant_by_n.py; the Bicycle field crosses over at
 // the same size) - and small populations are what the reference itself runs.  CSF_PAIR_VARIANT overrides.
 constexpr int64_t PLAIN_BELOW = 3072;
-int32_t pair_variant_for(int64_t n) {
-    const char *ov = getenv("CSF_PAIR_VARIANT");
-    return ov ? atoi(ov) : (n < PLAIN_BELOW ? 1 : 0);
+int32_t pair_variant_for(const csf_engine *e, int64_t n) {
+    return e->knobs.pair_variant >= 0 ? e->knobs.pair_variant : (n < PLAIN_BELOW ? 1 : 0);
 }
 
 // (re)build the spatially binned order of the records; decides whether batches are classified this tick
@@ -657,7 +712,7 @@ int rebin(csf_engine *e) {
         set_shard(e);
         launch_records(d, e->main);     // sentinels in the new tail (the records of the road users are rewritten as they are)
     }
-    d.pair_variant = pair_variant_for(d.n_live);
+    d.pair_variant = pair_variant_for(e, d.n_live);
     // Several parameter sets: up to 16 of them on an unsharded engine get the class-segmented order - the set leads the
     // sort key, every set becomes a run of places that starts at a multiple of 64, and the pair term is one launch of the
     // culling kernel per run with that set's constants, far-field radius and field (launch_pair_all).  Otherwise the
@@ -669,10 +724,10 @@ int rebin(csf_engine *e) {
     // It pays from ~2 048 road users per set (a launch per set has its own start-up): four sets at N = 16 384 199 us per
     // tick against 387 us, at 8 192 104 against 119, at 4 096 68 against 41 (tools/hetero_rate.py; CSF_SEGMENTS=1 forces
     // it from 1 024 road users, 0 switches it off).
-    const char *seg_env = getenv("CSF_SEGMENTS");
+    const int seg_env = e->knobs.segments;
     bool seg = d.n_classes > 1 && d.n_classes <= 16 && d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS && e->world <= 1 && !e->loopback &&
                !e->nccl && e->class_kappa.size() == e->classes.size() &&
-               (seg_env ? atoi(seg_env) != 0 : d.n_live >= 2048 * (int64_t)d.n_classes);
+               (seg_env >= 0 ? seg_env != 0 : d.n_live >= 2048 * (int64_t)d.n_classes);
     SegTable tab{};
     if (seg) {
         std::vector<int64_t> count((size_t)d.n_classes, 0);
@@ -697,7 +752,7 @@ int rebin(csf_engine *e) {
                 PairConsts pc;
                 derive_pair_consts(e->classes[(size_t)c], pc);
                 pc.p2r = d.pc.p2r;
-                set_far_consts(e->classes[(size_t)c], e->class_kappa[(size_t)c], d.n, pc);
+                set_far_consts(e->knobs, e->classes[(size_t)c], e->class_kappa[(size_t)c], d.n, pc);
                 if (units == 0 || pc.f0_zero) continue;              // nobody of this set, or a set whose field is zero
                 const int64_t chunks = (units + per_min - 1) / per_min;
                 csf_engine::Segment sg;
@@ -716,6 +771,7 @@ int rebin(csf_engine *e) {
                 d.seg_keys = 1;
                 d.n_split = std::max(1, slots);                       // what the per-agent kernel sums
                 d.n_src = place;
+                d.n_places = place;
             }
         }
     }
@@ -734,17 +790,20 @@ int rebin(csf_engine *e) {
     } else {
         launch_identity_perm(d, e->main);
     }
-    // the binned copy of the records: maintained by the agent kernel where every record is local, rebuilt from the
-    // gathered records before every pair launch of a sharded run (enqueue_tick)
+    // Every record gets a new origin - where it is now (unbinned: the scene's) - and is re-expressed relative to it;
+    // pos[], the binned copies of records and origins and the circles (csf_bin.hip: rebase_kernel).  The binned copy is maintained
+    // by the agent kernel where every record is local, rebuilt from the gathered records before every pair launch of a
+    // sharded run (enqueue_tick).
     d.recs_valid = binned;
-    if (d.recs_valid) launch_sorted_copy(d, e->main);
-    {   // receivers in binned order + far-tile skipping, where there are enough tiles for it to pay.  A rank that owns
-        // an index block [lo, hi) takes ITS receivers in binned order: their positions, sorted
-        const char *ov = getenv("CSF_RECV_BINNED");
+    d.rebase_from_state = e->state_all_current;
+    launch_rebase(d, binned, e->main);
+    {   // The kernels on binned records take their receivers by place (csf_pair.hip: recv_count): a rank that owns an
+        // index block [lo, hi) takes ITS receivers' places, sorted.  Large populations also skip far tiles unloaded.
+        const int ov = e->knobs.recv_binned;
         const bool whole = d.lo == 0 && d.hi == d.n;
-        d.recv_binned = binned && d.recs_valid && std::isfinite(d.pc.rfar) && (ov ? atoi(ov) != 0 : d.n_pad >= 65536);
+        d.recv_binned = binned && d.recs_valid && std::isfinite(d.pc.rfar) && (ov >= 0 ? ov != 0 : d.n_pad >= 65536);
         d.rlist = nullptr;
-        if (d.recv_binned && !whole) {
+        if (binned && !whole) {
             int rc = launch_receiver_list(d, e->sort_keys.p, e->rlist.p, e->sort_tmp.p, e->sort_tmp.n, e->main);
             if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the receiver positions failed (%d)", rc);
             d.rlist = e->rlist.p;
@@ -769,7 +828,7 @@ int rebin(csf_engine *e) {
     }
     e->ticks_since_rebin = 0;
     e->churn = 0;
-    e->bounds_fresh = false;
+    e->bounds_fresh = binned;                                        // (rebase_kernel wrote the circles of the records as they are)
     return CSF_OK;
 }
 
@@ -781,7 +840,7 @@ int bounds_before_pair(csf_engine *e) {
     // N = 16 384), against ~35 us for the kernels of a re-binning.  With r arrivals per tick the cheapest period is about
     // sqrt(2 * 35 * 64 / (1.3 r)) ticks, i.e. re-bin when ticks x arrivals since the last one reaches ~3500; 3000 to 6000
     // measured alike (profiles/r2_churn_rate.txt; CSF_REBIN_CHURN overrides the constant).
-    static const int64_t churn_k = getenv("CSF_REBIN_CHURN") ? std::max(1, atoi(getenv("CSF_REBIN_CHURN"))) : 4000;
+    const int64_t churn_k = e->knobs.rebin_churn;
     if (e->ticks_since_rebin >= REBIN_TICKS || e->ticks_since_rebin * e->churn >= churn_k) {
         int rc = rebin(e);
         if (rc) return rc;
@@ -998,6 +1057,11 @@ int upload_all(csf_engine *e) {
     set_shard(e);
     if ((size_t)d.n_pad > e->rec.n) return fail(e, CSF_E_CAPACITY, "record buffer too small for this shard layout");
     HIPCHK(e, hipMemsetAsync(e->part.p, 0, e->part.n * sizeof(float2), e->main));   // a new layout starts from clean partial sums
+    // records as offsets from the scene origin first (what the sort keys are made of); the re-binning then gives every
+    // record its own origin and rewrites it from the fp64 state just uploaded
+    HIPCHK(e, hipMemsetAsync(e->orgs.p, 0, e->orgs.n * sizeof(float2), e->main));
+    HIPCHK(e, hipMemsetAsync(e->rorg.p, 0, e->rorg.n * sizeof(float2), e->main));
+    e->state_all_current = true;
     launch_records(d, e->main);
     int rrc = rebin(e);
     if (rrc) return rrc;
@@ -1023,8 +1087,7 @@ int prepare_mutation(csf_engine *e) {
 // when the device copy is current: no download, no upload, no re-sort.  Sharded engines, engines with the opt-in
 // history ring and CSF_INCREMENTAL=0 take the round trip through the host mirror (prepare_mutation / upload_all).
 bool can_patch_device(const csf_engine *e) {
-    static const bool off = getenv("CSF_INCREMENTAL") && atoi(getenv("CSF_INCREMENTAL")) == 0;
-    return !off && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
+    return e->knobs.incremental && e->incremental && !e->dirty && e->world == 1 && !e->nccl && !e->loopback && e->d.hist == nullptr;
 }
 
 // a pinned, device-visible host buffer of `bytes` from the ring; waits only if the ring of four is exhausted
@@ -1088,7 +1151,6 @@ int flush_pending(csf_engine *e) {
         b1 = (int)((e->live_at_rebin + e->tail_used + 63) / 64);
         if (b1 - b0 > 32 || (int64_t)b1 * 64 > d.n_src) circles_here = false, b0 = b1 = 0;
     }
-    if (e->ticket.p == nullptr) HIPCHK(e, e->ticket.alloc(1));
     launch_patch(d, h, pin->dev, e->ticket.p, b0, b1, h.n_retire + h.n_spawn + h.n_requeue + 3 * h.n_rows, e->main);
     e->tail_flushed = e->tail_used;
     e->pend_inplace = false;
@@ -1111,9 +1173,20 @@ int flush_pending(csf_engine *e) {
     if (!circles_here) e->bounds_fresh = false;
     e->device_ahead = true;                                    // the host mirror of the patched slots was not kept up
     d.n_live = (int64_t)e->order.size();
-    if (!getenv("CSF_FAKE_SHARD")) d.hi = d.n;                 // (unsharded: the receiver block is every slot)
+    if (e->knobs.fake_world <= 1) d.hi = d.n;                 // (unsharded: the receiver block is every slot)
     update_far_radius(e);
     return CSF_OK;
+}
+
+// the queue replacement collected for slot a, if any, is void (the slot is retired or spawned into anew)
+void drop_pending_requeue(csf_engine *e, size_t a) {
+    const int32_t at = e->pend_requeue_at[a];
+    if (at < 0) return;
+    const QueueRec last = e->pend.requeue.back();
+    e->pend.requeue[(size_t)at] = last;
+    e->pend_requeue_at[(size_t)last.slot] = at;
+    e->pend.requeue.pop_back();
+    e->pend_requeue_at[a] = -1;
 }
 
 int sync_order(csf_engine *e) {                         // the device copy of the population order (read-back kernels)
@@ -1158,15 +1231,12 @@ int ensure_compact(csf_engine *e) {
 // next tick (launched before the wait) overlaps it.  Measured with a 1-rank communicator the two cross-stream
 // event waits per tick and the extra launch cost 26 us against 8 us in stream order, more than the ~6 us of
 // destination-force work they can hide, so the default keeps the collective in stream order on the main stream.
-bool comm_second_stream() {
-    static const bool second = getenv("CSF_COMM_STREAM") && std::string(getenv("CSF_COMM_STREAM")) == "second";
-    return second;
-}
+bool comm_second_stream(const csf_engine *e) { return e->knobs.comm_second; }
 
 int all_gather_records(csf_engine *e) {
     Dev &d = e->d;
     size_t shard = (size_t)(d.n_pad / e->world);
-    const bool second = comm_second_stream();
+    const bool second = comm_second_stream(e);
     hipStream_t cs = second ? e->comm : e->main;
     if (second) HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
     const bool two = d.has_bike != 0;
@@ -1267,6 +1337,10 @@ csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t dev
     e->cap_user = n_capacity;
     // a binned population keeps up to 4096 sentinel slots behind its real batches for arrivals (rebin(), csf_add_agents)
     e->cap = n_capacity + (n_capacity >= BIN_MIN_AGENTS ? std::min<int64_t>(TAIL_SLOTS, n_capacity / 4) : 0);
+    // whole batches of 64 slots: n_pad (set_shard) is rounded up to a multiple of 64 and must stay <= cap, the stride of
+    // every SoA array - fresh slots are handed out up to n_pad (csf_add_agents)
+    e->cap = (e->cap + 63) / 64 * 64;
+    e->knobs.read();
     e->d.p = *params;
     derive_consts(e);
     auto bail = [&](const char *what) {
@@ -1291,7 +1365,7 @@ int csf_destroy(csf_engine *e) {
     if (e->trace.p) {  // CSF_TRACE_BLOCKS=<file>: workgroup timeline of the last pair-kernel launch
         std::vector<uint64_t> h(e->trace_words);
         if (hipMemcpy(h.data(), e->trace.p, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *f = fopen(getenv("CSF_TRACE_BLOCKS"), "wb")) {
+            if (FILE *f = fopen(e->knobs.trace_blocks.c_str(), "wb")) {
                 fwrite(h.data(), sizeof(uint64_t), h.size(), f);
                 fclose(f);
             }
@@ -1308,8 +1382,9 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->perm.release(); e->pos.release(); e->recs.release();
-    e->ticket.release(); e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->orgs.release(); e->rorg.release(); e->perm.release(); e->pos.release(); e->recs.release();
+    e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
+    e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);
     for (auto &sl : e->pinned) {
@@ -1384,6 +1459,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
                 e->pend.retire.pop_back();
                 e->pend_retire_at[(size_t)a] = -1;
             }
+            drop_pending_requeue(e, (size_t)a);                  // (defensive: a retirement has dropped it already)
             SpawnRec r;
             r.slot = (int32_t)a;
             r.qlen = 1;
@@ -1463,6 +1539,7 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         e->h_q[(size_t)a].clear();
         e->free_recent.push_back(a);
         if (!patch) continue;
+        drop_pending_requeue(e, (size_t)a);                      // a queue collected for the road user that leaves
         if (e->pend_spawn_at[(size_t)a] >= 0) {                  // added and removed within one batch: never reaches the device
             const int32_t at = e->pend_spawn_at[(size_t)a];
             const SpawnRec last = e->pend.spawn.back();
@@ -1490,12 +1567,21 @@ int csf_set_dest_queue(csf_engine *e, int64_t n, const int32_t *agent, const int
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!agent || !offsets || !xyz_stop))) return fail(e, CSF_E_ARG, "csf_set_dest_queue: bad arguments");
     const int64_t pop = (int64_t)e->order.size();
-    int64_t total = 0;                                           // rows of the queues as they will be
+    // rows the slab must take: every listed queue is written out whole, as it will be after ITS entry of the call (a
+    // road user listed twice in an appending call has the rows of its first entry copied again by the second)
+    int64_t total = 0;
+    std::unordered_map<int32_t, int64_t> grown;                  // appending call: rows of a road user after its last entry
     for (int64_t k = 0; k < n; k++) {
         if (agent[k] < 0 || agent[k] >= pop) return fail(e, CSF_E_ARG, "agent index %d out of range", agent[k]);
         if (offsets[k + 1] < offsets[k]) return fail(e, CSF_E_ARG, "offsets must be non-decreasing");
         if (reset && offsets[k + 1] == offsets[k]) return fail(e, CSF_E_ARG, "reset with an empty queue");
-        total += offsets[k + 1] - offsets[k] + (reset ? 0 : (int64_t)e->h_q[(size_t)e->order[(size_t)agent[k]]].size() / 3);
+        int64_t rows = offsets[k + 1] - offsets[k];
+        if (!reset) {
+            auto it = n > 1 ? grown.find(agent[k]) : grown.end();
+            rows += it != grown.end() ? it->second : (int64_t)e->h_q[(size_t)e->order[(size_t)agent[k]]].size() / 3;
+            if (n > 1) grown[agent[k]] = rows;
+        }
+        total += rows;
     }
     if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
@@ -1663,7 +1749,13 @@ int csf_set_v_desired(csf_engine *e, int64_t n, const int32_t *idx, const double
     for (int64_t k = 0; k < n; k++)
         if (idx[k] < 0 || idx[k] >= (int64_t)e->order.size()) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
     HIPCHK(e, hipSetDevice(e->device));
-    for (int64_t k = 0; k < n; k++) e->h_vdes[(size_t)e->order[(size_t)idx[k]]] = v_desired[k];
+    for (int64_t k = 0; k < n; k++) {
+        const size_t a = (size_t)e->order[(size_t)idx[k]];
+        e->h_vdes[a] = v_desired[k];
+        // an arrival still on its way to the device: its spawn record carries the desired speed (the patch kernel writes
+        // d.vdes[a] from it AFTER the copy below)
+        if (e->pend_spawn_at[a] >= 0) e->pend.spawn[(size_t)e->pend_spawn_at[a]].vdes = v_desired[k];
+    }
     if (!e->dirty) {  // device copy is current: patch it in place
         HIPCHK(e, hipStreamSynchronize(e->main));
         HIPCHK(e, hipMemcpy(e->vdes.p, e->h_vdes.data(), (size_t)e->d.n * sizeof(double), hipMemcpyHostToDevice));
@@ -1735,7 +1827,7 @@ static int enqueue_tick(csf_engine *e) {
     // time stamps cost a few microseconds of launch gap per kernel: the pair kernel (what the roofline is computed from)
     // takes them on every sampled tick, the other kernels on every 8th of those
     csf_engine::ProfSlot *po = (ps && (e->prof_ticks++ % 8 == 0)) ? ps : nullptr;
-    const bool overlap = sharded && !e->loopback && comm_second_stream();
+    const bool overlap = sharded && !e->loopback && comm_second_stream(e);
     if (overlap) {
         launch_agent(d, PH_DEST, e->main);
         if ((rc = wait_gather(e))) return rc;
@@ -1755,6 +1847,7 @@ static int enqueue_tick(csf_engine *e) {
     }
     launch_agent(d, overlap ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main,
                  po ? po->ev[4] : nullptr, po ? po->ev[5] : nullptr);
+    if (sharded) e->state_all_current = false;      // a rank integrates its own block only: the others' fp64 state is stale now
     if (po) po->agent = true;
     HIPCHK(e, hipGetLastError());
     d.tick++;
@@ -2115,13 +2208,11 @@ int csf_untracked(csf_engine *e, uint8_t *out) {
     if (n > 46340) return fail(e, CSF_E_ARG, "csf_untracked: the n x n matrix is limited to n <= 46340");
     if ((rc = wait_gather(e))) return rc;
     if ((rc = sync_order(e))) return rc;
-    DevBuf<uint8_t> buf;
-    HIPCHK(e, buf.alloc((size_t)(n * n)));
-    launch_untracked(e->d, buf.p, e->main);
+    HIPCHK(e, e->scratch_u8.reserve((size_t)(n * n)));         // (every byte of the matrix is written by the kernel)
+    launch_untracked(e->d, e->scratch_u8.p, e->main);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
-    HIPCHK(e, hipMemcpy(out, buf.p, (size_t)(n * n), hipMemcpyDeviceToHost));
-    buf.release();
+    HIPCHK(e, hipMemcpy(out, e->scratch_u8.p, (size_t)(n * n), hipMemcpyDeviceToHost));
     return CSF_OK;
 }
 
@@ -2133,26 +2224,21 @@ static int nav_kat(csf_engine *e, int64_t n, const int32_t *idx, int what, const
     int rc = upload_all(e);
     if (rc) return rc;
     if (n == 0) return CSF_OK;
-    DevBuf<int32_t> di, ds;
-    DevBuf<double> out;
-    HIPCHK(e, di.alloc((size_t)n));
-    HIPCHK(e, out.alloc((size_t)(2 * n)));
+    HIPCHK(e, hipStreamSynchronize(e->main));                  // (the scratch buffers may still be read by an earlier call)
+    HIPCHK(e, e->scratch_i32.reserve((size_t)(2 * n)));
+    HIPCHK(e, e->scratch_f64.reserve((size_t)(2 * n)));
+    int32_t *di = e->scratch_i32.p, *ds = e->scratch_i32.p + n;
+    double *out = e->scratch_f64.p;
     std::vector<int32_t> slots((size_t)n);
     for (int64_t k = 0; k < n; k++) slots[(size_t)k] = e->order[(size_t)idx[k]];
-    HIPCHK(e, hipMemcpy(di.p, slots.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (stop) {
-        HIPCHK(e, ds.alloc((size_t)n));
-        HIPCHK(e, hipMemcpy(ds.p, stop, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-    launch_nav_kat(e->d, di.p, n, what, stop ? ds.p : nullptr, out.p, out.p + n, e->main);
+    HIPCHK(e, hipMemcpy(di, slots.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (stop) HIPCHK(e, hipMemcpy(ds, stop, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    launch_nav_kat(e->d, di, n, what, stop ? ds : nullptr, out, out + n, e->main);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
     e->device_ahead = true;
-    if (vd) HIPCHK(e, hipMemcpy(vd, out.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (ddest) HIPCHK(e, hipMemcpy(ddest, out.p + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    di.release();
-    ds.release();
-    out.release();
+    if (vd) HIPCHK(e, hipMemcpy(vd, out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (ddest) HIPCHK(e, hipMemcpy(ddest, out + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return CSF_OK;
 }
 
@@ -2285,7 +2371,7 @@ int csf_far_radius(const csf_engine *e, double *radius_m) {
     if (!e || !radius_m) return CSF_E_ARG;
     const bool binned = e->d.pair_variant == 0 && e->d.p.model != CSF_BICYCLE && e->d.n >= BIN_MIN_AGENTS;
     // (computed here rather than read back: the kernel's copy is refreshed with the next upload of the population)
-    *radius_m = binned ? (double)(float)far_radius(e->far_kappa, e->d.n, far_eps()) : (double)INFINITY;  // no circles, no cull
+    *radius_m = binned ? (double)(float)far_radius(e->far_kappa, e->d.n, e->knobs.far_eps) : (double)INFINITY;  // no circles, no cull
     return CSF_OK;
 }
 
@@ -2361,9 +2447,9 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     if (!e->segs.empty() && e->ticks_since_rebin >= REBIN_TICKS && (rc = rebin(e))) return rc;   // (arrivals since: flush_pending)
     if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
     if ((e->world > 1 || e->nccl != nullptr || e->loopback) && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
-    DevBuf<unsigned long long> cnt;
-    HIPCHK(e, cnt.alloc(4));
-    HIPCHK(e, hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned long long), e->main));   // alloc() clears on the NULL stream, which this stream does not wait for
+    DevBuf<unsigned long long> &cnt = e->scratch_cnt;
+    HIPCHK(e, cnt.reserve(4));
+    HIPCHK(e, hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned long long), e->main));
     Dev dd = d;                 // this tick's records and circles; the circles of the next tick are not touched
     dd.pair_count = cnt.p;
     dd.bnd_next = nullptr;
@@ -2372,7 +2458,6 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     HIPCHK(e, hipStreamSynchronize(e->main));
     unsigned long long h[4] = {0, 0, 0, 0};
     HIPCHK(e, hipMemcpy(h, cnt.p, sizeof h, hipMemcpyDeviceToHost));
-    cnt.release();
     for (int k = 0; k < 4; k++) counts[k] = (int64_t)h[k];
     return CSF_OK;
 }

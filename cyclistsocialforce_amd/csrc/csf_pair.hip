@@ -41,9 +41,6 @@ constexpr int TILE = 1024;           // simple kernels: source records per LDS t
 #ifndef CSF_CULL_WAVES
 #define CSF_CULL_WAVES 7
 #endif
-#ifndef CSF_PREFETCH
-#define CSF_PREFETCH 0       // reach test: request the next two batches before the current two are tested (A/B knob)
-#endif
 constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 7 waves/SIMD (72 VGPRs, 12 B spilled) measured best (tools/sweep_cull.sh)
 constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
 constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
@@ -121,11 +118,6 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
                                               const v2f qc, const v2f qs, bool valid0, bool valid1, float &ax,
                                               float &ay) {
     v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
-#ifdef CSF_SKIP_FIELD   // timing-only build (tools/): everything but the field arithmetic
-    ax += dx.x + dx.y + qc.x + qs.y;
-    ay += dy.x + dy.y + qc.y + qs.x;
-    return;
-#endif
     v2f r2 = dx * dx + dy * dy;
     if (!FULL) r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};
     v2f inv = rsq2(r2), rho = r2 * inv;
@@ -213,8 +205,9 @@ __device__ __forceinline__ void load_receivers(const Dev &d, int64_t j0, Recv (&
     for (int u = 0; u < RPW; u++) {
         int64_t j = j0 + u < d.hi ? j0 + u : d.hi - 1;  // clamp: results of the duplicates are not stored
         float4 q = d.rec[j];
-        r[u].x = q.x;
-        r[u].y = q.y;
+        const float2 o = d.rorg[j];                     // (0 for unbinned populations: the plain kernel's only case)
+        r[u].x = q.x + o.x;
+        r[u].y = q.y + o.y;
         r[u].c = q.z;
         r[u].s = q.w;
         asm volatile("" : "+v"(r[u].x), "+v"(r[u].y), "+v"(r[u].c), "+v"(r[u].s));  // stay in VGPRs
@@ -258,12 +251,26 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
     // every lane of a group of 8 holds value index 4*bit5 + 2*bit4 + bit3 of the lane number
     const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     const int u = idx >> 1;
-    // agent_of (BINR): agent index of each of the wave's receivers, -1 for none (LDS); else the receivers are j0 + u
+    // agent_of (receivers taken by place): slot of each of the wave's receivers, -1 for none (LDS); else the receivers are j0 + u
     const int64_t a = agent_of ? (int64_t)agent_of[u] : (j0 + u < d.hi ? j0 + u : -1);
     if ((lane & 7) == 0 && a >= 0) {
         float *dst = (float *)&d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a];
         dst[idx & 1] = z;
     }
+}
+
+// Receivers of the kernels that work on binned records (pair_cull_kernel, pair_bike_kernel).  They are taken by PLACE of
+// the binned order, so that the receivers of a workgroup are neighbours in space: everything the workgroup touches is
+// then expressed relative to ONE origin near its receivers (the origin of the first receiver's place) - the sources that
+// matter (the near ones) and the receivers themselves are small numbers there, and an fp32 difference receiver - source
+// keeps 2^-24 of (pair distance + group extent) instead of 2^-24 of the scene extent (vehicle.py:1615-1617 forms it in
+// fp64).  A whole population: the places [0, n_places); a rank's block: its receivers' places in
+// ascending order (rlist); an unbinned population: place == slot, every origin 0.
+__device__ __forceinline__ int64_t recv_count(const Dev &d) {
+    return d.rlist ? d.hi - d.lo : (d.classify ? d.n_places : d.hi - d.lo);
+}
+__device__ __forceinline__ int64_t recv_place(const Dev &d, int64_t j) {
+    return d.rlist ? (int64_t)d.rlist[j] : (d.classify ? j : d.lo + j);
 }
 
 __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend) {
@@ -330,9 +337,10 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // decides every borderline source: these two leave the results identical with and without CLASSIFY.
 // A batch is also skipped when all of it lies beyond the far-field radius k.rfar (csf_engine.hip: far_radius),
 // where the contributions are below the resolution of the fp32 column sum.
-// BINR (large unsharded populations): the RECEIVERS of a workgroup are 16 consecutive positions of the binned order as
-// well, i.e. neighbours in space, so a whole tile of 1024 sources that lies beyond the far-field radius of the
-// group's bounding circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).
+// The RECEIVERS of a workgroup are consecutive places of the binned order (recv_place), i.e. neighbours in space; tile
+// and receivers are held relative to the origin of the group's first batch (see recv_count).
+// SKIP (large populations): a whole tile of 1024 sources that lies beyond the far-field radius of the group's bounding
+// circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).
 // DYN (small receiver blocks, i.e. shards of a small population: launch_pair): the 16 receivers of the workgroup are
 // handed to its waves one at a time through an LDS counter instead of four per wave.  With few workgroups the kernel
 // ends with its longest single wave (a lone wave issues one dependent instruction every ~8 cycles); sharing the
@@ -341,7 +349,7 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // workgroup of twice the receivers shares one tile fill and one start-up between them: 146 -> 141 us at N = 16 384)
 // REACH (with the far-field cull on): every candidate batch goes through the packed reach test keep_x2, two batches at a
 // time, and only the sources it keeps are queued for the field.
-template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false>
+template <bool P2R, bool CLASSIFY, bool SKIP, bool DYN, int RPB = WPB * RPW, bool REACH = false>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     static_assert(RPB == WPB * RPW || (DYN && RPB % (WPB * RPW) == 0 && RPB <= WAVE), "wider workgroups need the dynamic hand-out");
     static_assert(!REACH || (CLASSIFY && DYN), "the reach test is built into the classified, dynamically handed-out variant");
@@ -350,16 +358,19 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave, drained after each receiver; holds BYTE offsets
                                                  // into the tile arrays (4 x index <= 4092)
     __shared__ float4 rrec[RPB];
-    __shared__ int ragent[BINR ? RPB : 1];   // BINR: agent index of every receiver of the workgroup (-1: none)
+    __shared__ int ragent[RPB];              // slot of every receiver of the workgroup (-1: none)
     __shared__ unsigned bmask[DYN ? RPB : 1];   // DYN: candidate | inside << 16 batch masks of every receiver
     __shared__ float racc[2][DYN ? RPB : 1];    // DYN: column sums of the workgroup's receivers
     __shared__ int next_recv;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
     const uint64_t t_start = d.trace ? wall_clock64() : 0;
+    // origin of the workgroup: that of its first receiver's place (uniform: scalar loads)
+    const int64_t nrecv = recv_count(d);
+    const int64_t jg = (int64_t)blockIdx.x * RPB;
+    const float2 og = d.orgs[recv_place(d, jg)];
 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
@@ -385,12 +396,6 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     auto pop = [&](int u, auto full) {
         constexpr bool FULL = decltype(full)::value;
         const int n = FULL ? CHUNK : (qlen < CHUNK ? qlen : CHUNK);
-#ifdef CSF_NO_POP       // timing-only build (tools/): classification, tests and queue traffic without the field
-        ax[u] += (float)n;
-        qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
-        qlen = __builtin_amdgcn_readfirstlane(qlen - n);
-        return;
-#endif
         int i0 = queue[wave][(qhead + lane) & (QCAP - 1)];
         int i1 = queue[wave][(qhead + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
@@ -405,12 +410,6 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // the last (at most 64) queued sources of a receiver: one per lane through the unpacked field - about 60 % of the
     // instructions of a packed evaluation whose second half would be empty
     auto pop_tail = [&](int u) {
-#ifdef CSF_NO_POP
-        ax[u] += (float)qlen;
-        qhead = __builtin_amdgcn_readfirstlane((qhead + qlen) & (QCAP - 1));
-        qlen = 0;
-        return;
-#endif
         const bool v = lane < qlen;
         const int o = v ? (int)queue[wave][(qhead + lane) & (QCAP - 1)] : 0;
         const float4 q = make_float4(*(const float *)((const char *)tx + o), *(const float *)((const char *)ty + o),
@@ -427,35 +426,39 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         qlen = 0;
     };
 
+    // a tile: the records of 1024 places, re-expressed relative to the workgroup's origin (the difference of two origins
+    // is exact; the sum rounds to 2^-24 of the distance from the group, i.e. finely where it matters)
     auto fill_tile = [&](int64_t base, int cnt) {
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
             const float4 q = d.recs_valid ? d.recs[base + t] : d.rec[d.perm[base + t]];
-            tx[t] = q.x;
-            ty[t] = q.y;
+            const float2 o = d.orgs[base + t];
+            tx[t] = q.x + (o.x - og.x);
+            ty[t] = q.y + (o.y - og.y);
             tc[t] = q.z;
             ts[t] = q.w;
         }
-        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
+        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) {
+            const float4 bb = d.bnd[(base >> 6) + threadIdx.x];   // (scene coordinates)
+            tbnd[threadIdx.x] = make_float4(bb.x - og.x, bb.y - og.y, bb.z, 0.0f);
+        }
         if (DYN && threadIdx.x == BLOCK - 1) next_recv = 0;
     };
-    // first tile and the workgroup's 16 receiver records travel together: one global round trip, not two
+    // first tile and the workgroup's receiver records travel together: one global round trip, not two
     if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
-    if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
+    if (!SKIP) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
     if (threadIdx.x < RPB) {
-        const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
-        const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
-        if (BINR) {  // receiver slot jc - lo of this rank -> position of the binned order -> agent
-            const int64_t p = d.rlist ? (int64_t)d.rlist[jc - d.lo] : jc;
-            rrec[threadIdx.x] = d.recs[p];
-            ragent[threadIdx.x] = j < d.hi ? d.perm[p] : -1;
-        } else {
-            rrec[threadIdx.x] = d.rec[jc];
-        }
+        const int64_t j = jg + threadIdx.x;
+        const int64_t p = recv_place(d, j < nrecv ? j : nrecv - 1);   // clamp: results of the duplicates are not stored
+        const int32_t a = d.perm[p];
+        const float4 q = d.recs_valid ? d.recs[p] : d.rec[a];
+        const float2 o = d.orgs[p];
+        rrec[threadIdx.x] = make_float4(q.x + (o.x - og.x), q.y + (o.y - og.y), q.z, q.w);
+        ragent[threadIdx.x] = (j < nrecv && a < d.n) ? a : -1;   // (a place of padding holds no slot)
         if (DYN) racc[0][threadIdx.x] = racc[1][threadIdx.x] = 0.0f;
     }
     __syncthreads();
-    float gx = 0.f, gy = 0.f, gr = 0.f;   // BINR: bounding circle of the workgroup's receivers (the same in every wave)
-    if (BINR) {
+    float gx = 0.f, gy = 0.f, gr = 0.f;   // SKIP: bounding circle of the workgroup's receivers (the same in every wave)
+    if (SKIP) {
         const float4 q = rrec[lane & (RPB - 1)];
         float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
 #pragma unroll
@@ -473,15 +476,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     for (int64_t base = ibeg; base < iend; base += TILE2) {
         const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
         const int nb = cnt >> 6;
-#ifdef CSF_SKIP_LOOP    // timing-only build (tools/): start-up, tile fill and reduction alone
-        ax[0] += tx[lane] + rrec[wave * RPW].x;
-        continue;
-#endif
-        if (BINR) {
+        if (SKIP) {
             // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
             // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
             const float4 bb = d.bnd[(base >> 6) + ((lane & 15) < nb ? (lane & 15) : 0)];
-            const float ex = bb.x - gx, ey = bb.y - gy;
+            const float ex = (bb.x - og.x) - gx, ey = (bb.y - og.y) - gy;
             const float reach = k.rfar + bb.z + gr;
             if (__ballot(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
             if (filled) __syncthreads();
@@ -559,44 +558,6 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     __builtin_amdgcn_wave_barrier();
                     while (qlen >= CHUNK) pop(u, std::true_type{});
                 };
-#if CSF_PREFETCH
-                // the records of the NEXT two batches are requested before the current two are tested, so that their LDS
-                // round trip runs beside the test instead of in front of it (the kernel waits on LDS, not on issue)
-                auto run = [&](unsigned m, auto fov) {
-                    if (!m) return;
-                    int b1 = __builtin_ctz(m);
-                    m &= m - 1u;
-                    bool two = m != 0u;
-                    int b2 = two ? __builtin_ctz(m) : b1;
-                    m &= m - 1u;
-                    int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
-                    v2f sx = lds_pair(tx, i0, i1), sy = lds_pair(ty, i0, i1), sc = lds_pair(tc, i0, i1), ss = lds_pair(ts, i0, i1);
-                    while (true) {
-                        const bool more = m != 0u;
-                        const int c1 = b1, c2 = b2;
-                        const bool ctwo = two;
-                        const v2f cx = sx, cy = sy, cc = sc, cs = ss;
-                        if (more) {
-                            b1 = __builtin_ctz(m);
-                            m &= m - 1u;
-                            two = m != 0u;
-                            b2 = two ? __builtin_ctz(m) : b1;
-                            m &= m - 1u;
-                            i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
-                            sx = lds_pair(tx, i0, i1), sy = lds_pair(ty, i0, i1), sc = lds_pair(tc, i0, i1), ss = lds_pair(ts, i0, i1);
-                        }
-                        sift2(c1, c2, ctwo, fov, cx, cy, cc, cs);
-                        if (!more) break;
-                    }
-                };
-                unsigned ins = inside, odd = 0u;
-                if (__builtin_popcount(ins) & 1) {               // an odd inside batch joins the partial ones: the exact test passes all of it
-                    odd = 1u << (31 - __builtin_clz(ins));
-                    ins &= ~odd;
-                }
-                run(ins, std::false_type{});
-                run((cand & ~inside) | odd, std::true_type{});
-#else
                 auto load2 = [&](int b1, int b2, bool two, auto fov) {
                     const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
                     sift2(b1, b2, two, fov, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1), lds_pair(ts, i0, i1));
@@ -618,7 +579,6 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     rest &= rest - 1u;                       // (0 & anything: stays 0)
                     load2(b1, b2, two, std::true_type{});
                 }
-#endif
                 cand = 0u;
             }
             // batches that are entirely inside the field of view need neither the test nor the queue: two at a
@@ -678,13 +638,12 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     }
     if (DYN) {
         __syncthreads();
-        const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
-        if (threadIdx.x < RPB && j < d.hi) {
-            const int64_t a = BINR ? (int64_t)ragent[threadIdx.x] : j;
-            d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
+        if (threadIdx.x < RPB) {
+            const int64_t a = ragent[threadIdx.x];
+            if (a >= 0) d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
         }
     } else {
-        reduce_store(d, j0, lane, ax, ay, BINR ? &ragent[wave * RPW] : nullptr);
+        reduce_store(d, 0, lane, ax, ay, &ragent[wave * RPW]);
     }
     if (d.pair_count != nullptr && lane == 0) {
         atomicAdd(d.pair_count, (unsigned long long)evals);
@@ -781,19 +740,28 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     __shared__ float2 tile2[TILE];
     __shared__ float4 tbnd[TILE / WAVE];
     __shared__ float4 rrec[WPB * RW];
+    __shared__ int ragent[WPB * RW];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RW;
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
+    // receivers by place of the binned order, everything relative to the origin of the first one's place (recv_count)
+    const int64_t nrecv = recv_count(d);
+    const int64_t jg = (int64_t)blockIdx.x * WPB * RW;
+    const float2 og = d.orgs[recv_place(d, jg)];
     if (d.bnd_next != nullptr && blockIdx.y == 0) {   // the next tick's bounding circles (see pair_cull_kernel)
         for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
     if (ibeg >= iend) return;
     if (threadIdx.x < WPB * RW) {
-        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RW + threadIdx.x;
-        rrec[threadIdx.x] = d.rec[j < d.hi ? j : d.hi - 1];  // clamp: results of the duplicates are not stored
+        const int64_t j = jg + threadIdx.x;
+        const int64_t p = recv_place(d, j < nrecv ? j : nrecv - 1);   // clamp: results of the duplicates are not stored
+        const int32_t a = d.perm[p];
+        const float4 q = d.recs[p];
+        const float2 o = d.orgs[p];
+        rrec[threadIdx.x] = make_float4(q.x + (o.x - og.x), q.y + (o.y - og.y), q.z, q.w);
+        ragent[threadIdx.x] = (j < nrecv && a < d.n) ? a : -1;
     }
     float ax[RW], ay[RW];
 #pragma unroll
@@ -806,10 +774,15 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
         const int nb = cnt >> 6;
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
-            tile[t] = d.recs[base + t];
+            const float4 q = d.recs[base + t];
+            const float2 o = d.orgs[base + t];
+            tile[t] = make_float4(q.x + (o.x - og.x), q.y + (o.y - og.y), q.z, q.w);
             tile2[t] = d.recs2[base + t];
         }
-        if ((int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
+        if ((int)threadIdx.x < nb) {
+            const float4 bb = d.bnd[(base >> 6) + threadIdx.x];       // (scene coordinates)
+            tbnd[threadIdx.x] = make_float4(bb.x - og.x, bb.y - og.y, bb.z, 0.0f);
+        }
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < RW / 4; ps++) {
@@ -859,7 +832,7 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     for (int h = 0; h < RW / 4; h++) {
         const float bx4[4] = {ax[4 * h], ax[4 * h + 1], ax[4 * h + 2], ax[4 * h + 3]};
         const float by4[4] = {ay[4 * h], ay[4 * h + 1], ay[4 * h + 2], ay[4 * h + 3]};
-        reduce_store(d, j0 + 4 * h, lane, bx4, by4);
+        reduce_store(d, 0, lane, bx4, by4, &ragent[wave * RW + 4 * h]);
     }
 }
 
@@ -973,9 +946,11 @@ __global__ void untracked_kernel(const Dev d, uint8_t *out) {
     const int64_t n = d.n_live;
     if (t >= n * n) return;
     const int64_t i = t / n, j = t - i * n;
-    const float4 q = d.rec[d.order ? d.order[i] : i], rr = d.rec[d.order ? d.order[j] : j];
+    const int64_t ai = d.order ? d.order[i] : i, aj = d.order ? d.order[j] : j;
+    const float4 q = d.rec[ai], rr = d.rec[aj];
+    const float2 qo = d.rorg[ai], ro = d.rorg[aj];             // the records are offsets from their batches' origins
     const Recv r{rr.x, rr.y, rr.z, rr.w};
-    const float dx = r.x - q.x, dy = r.y - q.y, r2 = dx * dx + dy * dy;
+    const float dx = (r.x - q.x) + (ro.x - qo.x), dy = (r.y - q.y) + (ro.y - qo.y), r2 = dx * dx + dy * dy;
     const float chs = d.pctab[d.cls[d.order ? d.order[i] : i]].chs;      // the hfov of the source's parameter set (:733-735)
     const bool in = (i != j) & (d.pc.p2r ? tracked<true>(chs, r, dx, dy, r2) : tracked<false>(chs, r, dx, dy, r2));
     out[t] = in ? 0 : 1;
@@ -988,7 +963,8 @@ void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st) {
 }
 
 static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
-    int64_t nloc = d.hi - d.lo;
+    // (the kernels on binned records take their receivers by place: recv_count)
+    int64_t nloc = d.rlist ? d.hi - d.lo : (d.classify ? d.n_places : d.hi - d.lo);
     int64_t per_block = per_block_recv;
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
@@ -996,19 +972,19 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
 // every launch of this file: optional events take the kernel's own start / end time stamps (csf_dev.h)
 #define CSF_LAUNCH(kernel, grid) hipExtLaunchKernelGGL(kernel, grid, dim3(BLOCK), 0, st, t0, t1, 0, d)
 
-template <bool P2R, bool CLASSIFY, bool BINR>
+template <bool P2R, bool CLASSIFY, bool SKIP>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
-        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
-        else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
+        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
+        else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
         return;
     }
     if (d.dyn_recv && d.rpb == 32) {
-        CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32>), recv_grid(d, d.n_split, 32));
+        CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32>), recv_grid(d, d.n_split, 32));
         return;
     }
-    if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), recv_grid(d, d.n_split));
-    else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), recv_grid(d, d.n_split));
+    if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true>), recv_grid(d, d.n_split));
+    else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, false>), recv_grid(d, d.n_split));
 }
 
 static void launch_cull(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {

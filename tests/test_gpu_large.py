@@ -24,6 +24,7 @@ def amd():
 
     ns = NS()
     ns.Engine = engine.Engine
+    ns.EngineError = engine.EngineError
     ns.pod = parameters.default_pod
     return ns
 
@@ -728,13 +729,102 @@ def test_arrival_bursts_beyond_the_sentinel_tail(amd):
     ox, oy = orc.column_sums(orc.default_params("twod"), st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv)
     cx, cy = clamped(ox, oy, fdx[recv], fdy[recv])
     errs = np.maximum(np.abs(frx[recv] - cx), np.abs(fry[recv] - cy)) / max(np.hypot(cx, cy).max(), 1.0)
-    # arrivals are dropped at random places: a few land centimetres from somebody, where the fp32 record resolves the
-    # distance to ~1e-5 relative and the field is steepest ("pairs centimetres apart")
+    # arrivals are dropped at random places: a few land centimetres from somebody, where the field is steepest - every
+    # record is an offset from an origin of its own (an arrival's: where it starts), so the pair distance holds there too
     worst = recv[int(errs.argmax())]
     near = np.sort(np.hypot(st[:, 0] - st[worst, 0], st[:, 1] - st[worst, 1]))[1]
     print(f"  clamped repulsive sums vs oracle: median {np.median(errs):.1e}, 99 % {np.percentile(errs, 99):.1e}, max {errs.max():.1e} "
           f"(receiver {worst}, nearest neighbour {near:.3f} m)")
-    assert np.median(errs) < 1e-5 and np.percentile(errs, 98) < 1e-4 and errs.max() < 1e-3 and (errs.max() < 1e-4 or near < 0.5)
+    assert np.median(errs) < 1e-5 and errs.max() < 1e-4
     assert (e.status() == 0).all()
     for e in engines:
+        e.close()
+
+
+# --------------------------------------------------------------------------- pending-batch bookkeeping (review findings)
+
+@pytest.mark.parametrize("cap,n0", [(1000, 1000), (200, 200), (1500, 1500)])
+def test_full_engine_whose_capacity_is_no_multiple_of_64(amd, cap, n0):
+    """A capacity that is not a multiple of 64, filled to the brim: remove k, add k again WITHOUT a tick in between (the
+    arrivals take fresh slots behind the population before they reuse the freed ones: those must exist in every SoA
+    array), both below and above the size from which the records are binned."""
+    box = 120.0
+    s0, off, dq = population(cap + 300, box, seed=4)
+    dq3 = dq.reshape(-1, 4, 3)
+    engines = []
+    for inc in (True, False):
+        e = amd.Engine(amd.pod("twod"), cap)
+        e.set_incremental(inc)
+        e.add_agents(s0[:n0, :5], 5.0)
+        e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, dq3[:n0].reshape(-1, 3), reset=True)
+        e.step(2)
+        engines.append(e)
+    rng = np.random.default_rng(1)
+    fresh = n0
+    for rnd in range(4):
+        k = 90
+        kill = np.sort(rng.choice(n0, k, replace=False))
+        new = np.arange(fresh, fresh + k)
+        fresh += k
+        for e in engines:
+            e.remove_agents(kill)
+            e.add_agents(s0[new, :5], 5.0)                      # back to capacity, no tick since the removal
+            assert e.n == cap
+            e.set_dest_queue(np.arange(n0 - k, n0), np.arange(k + 1) * 4, dq3[new].reshape(-1, 3), reset=True)
+            with pytest.raises(amd.EngineError):
+                e.add_agents(s0[:1, :5], 5.0)                   # one more than the capacity
+            e.step(3)
+        A, B = engines[0].state(), engines[1].state()
+        assert A.shape == B.shape == (cap, 5) and np.isfinite(A).all()
+        np.testing.assert_allclose(A[:, :2], B[:, :2], atol=1e-4)
+    for e in engines:
+        assert (e.status() == 0).all()
+        e.close()
+
+
+def test_calls_that_meet_in_one_pending_batch(amd):
+    """Several population calls without a read-back or a tick in between (they are collected and applied by ONE launch):
+    a desired speed set on an arrival that has not reached the device yet; a queue collected for a road user that is then
+    removed and whose slot is spawned into again; a road user listed twice in one appending queue call.  Against the
+    same calls through the host mirror."""
+    n0, box = 1400, 90.0
+    s0, off, dq = population(n0 + 200, box, seed=12)
+    dq3 = dq.reshape(-1, 4, 3)
+    engines = []
+    for inc in (True, False):
+        e = amd.Engine(amd.pod("twod"), 2048)
+        e.set_incremental(inc)
+        e.add_agents(s0[:n0, :5], 5.0)
+        e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, dq3[:n0].reshape(-1, 3), reset=True)
+        e.step(2)
+        engines.append(e)
+    new = np.arange(n0, n0 + 8)
+    far = np.array([[300.0, 300.0, 0.0], [400.0, 400.0, 0.0]])
+    for e in engines:
+        # (1) v_desired on pending arrivals
+        e.add_agents(s0[new[:4], :5], 5.0)
+        e.set_v_desired(np.arange(n0, n0 + 4), [0.5, 0.7, 0.9, 1.1])
+        e.set_dest_queue(np.arange(n0, n0 + 4), np.arange(5) * 4, dq3[new[:4]].reshape(-1, 3), reset=True)
+        # (2) a queue for road user 5, who then leaves; its slot is the first to be reused by free_recent only after the
+        # tail is exhausted - force reuse by filling the engine: here the queue record must simply not outlive the road user
+        e.set_dest_queue([5], [0, 2], far, reset=True)
+        e.remove_agents([5])
+        e.add_agents(s0[new[4:8], :5], 6.0)
+        m = e.n
+        e.set_dest_queue(np.arange(m - 4, m), np.arange(5) * 4, dq3[new[4:8]].reshape(-1, 3), reset=True)
+        # (3) one road user twice in one appending call: three rows, then two more
+        e.set_dest_queue([7, 7], [0, 3, 5], np.r_[dq3[7][1:4] + 1.0, far], reset=False)
+        e.step(4)
+    (A, pa, za, _), (B, pb, zb, _) = engines[0].state(with_nav=True), engines[1].state(with_nav=True)
+    assert A.shape == B.shape == (n0 + 7, 5)
+    assert np.array_equal(pa, pb) and np.array_equal(za, zb)
+    np.testing.assert_allclose(A[:, :2], B[:, :2], atol=2e-5)
+    # the arrivals brake towards THEIR desired speeds (|F| <= 2 v_desired < 3 m/s <= v: the speed can only fall; with the
+    # default 5 m/s it would not)
+    v = A[n0 - 1:n0 + 3, 3]
+    v0 = s0[new[:4], 3]
+    assert (v < v0 - 0.05).all(), (v, v0)
+    np.testing.assert_allclose(A[:, 3], B[:, 3], atol=1e-6)
+    for e in engines:
+        assert (e.status() == 0).all()
         e.close()

@@ -529,15 +529,17 @@ def test_full_size_ticks_vs_oracle(amd, model):
     df = np.abs(np.c_[fx - ox, fy - oy]).max(axis=1)
     print(f"   force error / max force: median {np.median(df) / scale:.2e}, 99.9 % {np.percentile(df, 99.9) / scale:.2e}, "
           f"max {df.max() / scale:.2e}")
-    # a few of the 2.7e8 pairs are centimetres apart, where the 4e-6 m resolution of the fp32 records shows
-    assert np.median(df) < 2e-6 * scale and np.percentile(df, 99.9) < 1e-4 * scale and df.max() < 5e-4 * scale
+    # (a few of the 2.7e8 pairs are centimetres apart: the records are offsets from origins of their own and the pair
+    # kernel works relative to an origin beside its receivers, so the fp32 pair distance holds there as well)
+    assert np.median(df) < 2e-6 * scale and np.percentile(df, 99.9) < 2e-5 * scale and df.max() < 1e-4 * scale
     assert (e.status() == 0).all()
 
 
 def test_binned_receivers_and_far_tile_skip_are_exact(amd, monkeypatch):
-    """Large populations take their receivers in binned order and skip tiles of sources that lie beyond the far-field
-    radius of a whole receiver group without loading them (csf_pair.hip, BINR); a rank of a sharded run does the same
-    with the binned order of ITS receivers.  Neither changes which terms enter a column sum."""
+    """The cull-first kernel takes its receivers by place of the binned order; large populations (CSF_RECV_BINNED=1
+    forces it here) also skip tiles of sources that lie beyond the far-field radius of a whole receiver group without
+    loading them (csf_pair.hip, SKIP); a rank of a sharded run does the same with the places of ITS receivers.  The skip
+    does not change which terms enter a column sum."""
     n, box = 8192, 700.0
     x, y, psi, v, off, dq = synthetic_population(n, box)
     s0 = np.c_[x, y, psi, v, np.zeros(n)]
