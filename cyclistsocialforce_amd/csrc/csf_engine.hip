@@ -102,6 +102,7 @@ struct Knobs {
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
     bool comm_second = false;                 // CSF_COMM_STREAM=second
     int fused = -1;                           // CSF_FUSED: the one-launch tick of small populations (-1: the engine's choice)
+    bool recv_by_slot = false;                // CSF_RECV_ORDER=slot: receivers in slot order (A/B aid: spatial coherence of a workgroup's receivers off)
     void read() {
         auto geti = [](const char *name, int dflt) {
             const char *v = getenv(name);
@@ -124,6 +125,7 @@ struct Knobs {
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second";
         fused = geti("CSF_FUSED", -1);
+        if (const char *v = getenv("CSF_RECV_ORDER")) recv_by_slot = std::string(v) == "slot";
     }
 };
 
@@ -808,6 +810,7 @@ int rebin(csf_engine *e) {
             if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the receiver positions failed (%d)", rc);
             d.rlist = e->rlist.p;
         }
+        if (binned && whole && e->knobs.recv_by_slot) d.rlist = d.pos;   // (measurement aid: the place of every slot, in slot order)
     }
     // Where the sentinels went: the sort is stable and their key is the largest, so the road users fill the places
     // [0, n_live) and the free slots follow in ascending slot order.  Handing the free slots out in that order

@@ -235,7 +235,8 @@ __device__ __forceinline__ float dpp(float x) {
 constexpr int DPP_ROW_ROR8 = 0x128, DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141;
 
 __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane, const float (&ax)[RPW],
-                                             const float (&ay)[RPW], const int *agent_of = nullptr) {
+                                             const float (&ay)[RPW], const int *agent_of = nullptr, int chunk = -1) {
+    if (chunk < 0) chunk = blockIdx.y;
     static_assert(RPW == 4, "the reduction below is written for eight values");
     const float v[8] = {ax[0], ay[0], ax[1], ay[1], ax[2], ay[2], ax[3], ay[3]};
     float w[4], y[2];
@@ -254,7 +255,7 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
     // agent_of (receivers taken by place): slot of each of the wave's receivers, -1 for none (LDS); else the receivers are j0 + u
     const int64_t a = agent_of ? (int64_t)agent_of[u] : (j0 + u < d.hi ? j0 + u : -1);
     if ((lane & 7) == 0 && a >= 0) {
-        float *dst = (float *)&d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a];
+        float *dst = (float *)&d.part[(int64_t)(d.part_base + chunk) * d.cap + a];
         dst[idx & 1] = z;
     }
 }
@@ -273,9 +274,24 @@ __device__ __forceinline__ int64_t recv_place(const Dev &d, int64_t j) {
     return d.rlist ? (int64_t)d.rlist[j] : (d.classify ? j : d.lo + j);
 }
 
-__device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend) {
-    const int64_t per = d.chunk_units;  // blockIdx.y selects a chunk of sources, in units of 64 records
-    ibeg = d.src_beg + (int64_t)blockIdx.y * per * WAVE;
+// Which source chunk a workgroup of the kernels on binned records takes.  Its receivers are neighbours in space and a
+// chunk is a compact run of the binned order, so a (receiver group, chunk) pair is either heavy - the chunk lies in front
+// of the receivers: up to 32 x 1024 pair evaluations - or nearly empty.  Workgroups are dispatched with blockIdx.x
+// fastest: blockIdx.y = 0 takes the chunk that holds the group's own receivers (the heaviest), 1 and 2 its neighbours in
+// the binned order, and so on outwards - heavy workgroups first, the kernel ends with light ones.
+__device__ __forceinline__ int chunk_near_first(const Dev &d, int64_t first_place) {
+    const int n = (int)gridDim.y;
+    int64_t own = (first_place - d.src_beg) / ((int64_t)d.chunk_units * WAVE);
+    own = own < 0 ? 0 : (own >= n ? n - 1 : own);
+    const int y = (int)blockIdx.y, L = (int)own, R = n - 1 - (int)own, m = L < R ? L : R;
+    if (y <= 2 * m) return (int)own + ((y & 1) ? ((y + 1) >> 1) : -((y + 1) >> 1));
+    return R > L ? (int)own + (y - L) : (int)own - (y - R);   // one side is used up: the rest of the other, still outwards
+}
+
+__device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend, int chunk = -1) {
+    if (chunk < 0) chunk = blockIdx.y;
+    const int64_t per = d.chunk_units;  // a chunk of sources, in units of 64 records
+    ibeg = d.src_beg + (int64_t)chunk * per * WAVE;
     iend = ibeg + per * WAVE;
     if (iend > d.n_src) iend = d.n_src;   // (the places behind hold sentinels only, csf_engine.hip: rebin)
 }
@@ -364,13 +380,15 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     __shared__ int next_recv;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int64_t ibeg, iend;
-    source_chunk(d, ibeg, iend);
     const uint64_t t_start = d.trace ? wall_clock64() : 0;
     // origin of the workgroup: that of its first receiver's place (uniform: scalar loads)
     const int64_t nrecv = recv_count(d);
     const int64_t jg = (int64_t)blockIdx.x * RPB;
-    const float2 og = d.orgs[recv_place(d, jg)];
+    const int64_t pg = recv_place(d, jg);
+    const float2 og = d.orgs[pg];
+    const int chunk = chunk_near_first(d, pg);
+    int64_t ibeg, iend;
+    source_chunk(d, ibeg, iend, chunk);
 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
@@ -640,10 +658,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         __syncthreads();
         if (threadIdx.x < RPB) {
             const int64_t a = ragent[threadIdx.x];
-            if (a >= 0) d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
+            if (a >= 0) d.part[(int64_t)(d.part_base + chunk) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
         }
     } else {
-        reduce_store(d, 0, lane, ax, ay, &ragent[wave * RPW]);
+        reduce_store(d, 0, lane, ax, ay, &ragent[wave * RPW], chunk);
     }
     if (d.pair_count != nullptr && lane == 0) {
         atomicAdd(d.pair_count, (unsigned long long)evals);
@@ -743,12 +761,14 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     __shared__ int ragent[WPB * RW];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int64_t ibeg, iend;
-    source_chunk(d, ibeg, iend);
     // receivers by place of the binned order, everything relative to the origin of the first one's place (recv_count)
     const int64_t nrecv = recv_count(d);
     const int64_t jg = (int64_t)blockIdx.x * WPB * RW;
-    const float2 og = d.orgs[recv_place(d, jg)];
+    const int64_t pg = recv_place(d, jg);
+    const float2 og = d.orgs[pg];
+    const int chunk = chunk_near_first(d, pg);
+    int64_t ibeg, iend;
+    source_chunk(d, ibeg, iend, chunk);
     if (d.bnd_next != nullptr && blockIdx.y == 0) {   // the next tick's bounding circles (see pair_cull_kernel)
         for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
@@ -832,7 +852,7 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     for (int h = 0; h < RW / 4; h++) {
         const float bx4[4] = {ax[4 * h], ax[4 * h + 1], ax[4 * h + 2], ax[4 * h + 3]};
         const float by4[4] = {ay[4 * h], ay[4 * h + 1], ay[4 * h + 2], ay[4 * h + 3]};
-        reduce_store(d, 0, lane, bx4, by4, &ragent[wave * RW + 4 * h]);
+        reduce_store(d, 0, lane, bx4, by4, &ragent[wave * RW + 4 * h], chunk);
     }
 }
 
@@ -962,9 +982,9 @@ void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st) {
     hipLaunchKernelGGL(untracked_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, out);
 }
 
-static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
-    // (the kernels on binned records take their receivers by place: recv_count)
-    int64_t nloc = d.rlist ? d.hi - d.lo : (d.classify ? d.n_places : d.hi - d.lo);
+// by_place: the kernels on binned records take their receivers by place (recv_count); the others by slot [lo, hi)
+static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW, bool by_place = false) {
+    int64_t nloc = (by_place && !d.rlist && d.classify) ? d.n_places : d.hi - d.lo;
     int64_t per_block = per_block_recv;
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
@@ -975,16 +995,16 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
 template <bool P2R, bool CLASSIFY, bool SKIP>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
-        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
-        else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
+        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32, true));
+        else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split, WPB * RPW, true));
         return;
     }
     if (d.dyn_recv && d.rpb == 32) {
-        CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32>), recv_grid(d, d.n_split, 32));
+        CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32>), recv_grid(d, d.n_split, 32, true));
         return;
     }
-    if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true>), recv_grid(d, d.n_split));
-    else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, false>), recv_grid(d, d.n_split));
+    if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true>), recv_grid(d, d.n_split, WPB * RPW, true));
+    else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, false>), recv_grid(d, d.n_split, WPB * RPW, true));
 }
 
 static void launch_cull(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
@@ -1019,12 +1039,13 @@ void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
         }
     } else if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
         if (d.rpb == 32) {
-            const dim3 g8 = recv_grid(d, d.n_split, 32);
+            const dim3 g8 = recv_grid(d, d.n_split, 32, true);
             if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 8>), g8);
             else CSF_LAUNCH((pair_bike_kernel<false, 8>), g8);
         } else {
-            if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 4>), g);
-            else CSF_LAUNCH((pair_bike_kernel<false, 4>), g);
+            const dim3 g4 = recv_grid(d, d.n_split, WPB * RPW, true);
+            if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 4>), g4);
+            else CSF_LAUNCH((pair_bike_kernel<false, 4>), g4);
         }
     } else if (d.p.model == CSF_BICYCLE) {
         if (p2r) CSF_LAUNCH((pair_kernel<1, true>), g);

@@ -300,8 +300,10 @@ def test_sharded_engine_loopback(amd, monkeypatch, model, world, n, binned):
 
 
 def test_loopback_first_tick_matches_unsharded_closely(amd):
-    """one calc_forces() on a 4-way loopback group against the unsharded engine: the same terms, another fp32 summation
-    order (2e-6 of the largest force)"""
+    """one calc_forces() on a 4-way loopback group against the unsharded engine: the same terms in another fp32 summation
+    order, each formed relative to another origin - a workgroup of the pair kernel works relative to the origin of its
+    first receiver, and the 32 receivers of a rank's workgroup are spread over 4 x 32 places of the binned order (~20 m:
+    positions resolve to ~1e-6 m there, against ~2e-7 m unsharded)"""
     n, box, world = 5000, 150.0, 4
     s0, off, dq = population(n, box, seed=2)
     ref = make_engine(amd, "twod", s0, 1e6, off, dq)
@@ -314,7 +316,8 @@ def test_loopback_first_tick_matches_unsharded_closely(amd):
         m.calc_forces()
         lo, hi = m.shard_range()
         _, _, mx, my = m.force_parts()
-        assert max(np.abs(mx[lo:hi] - rx[lo:hi]).max(), np.abs(my[lo:hi] - ry[lo:hi]).max()) < 2e-6 * scale
+        dev = np.maximum(np.abs(mx[lo:hi] - rx[lo:hi]), np.abs(my[lo:hi] - ry[lo:hi]))
+        assert np.median(dev) < 5e-7 * scale and dev.max() < 2e-5 * scale
 
 
 def test_sharded_engine_with_parameter_sets(amd):
