@@ -668,7 +668,12 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     if (!cs_fresh) sincos(psi, &s, &c);
     const float4 q = make_float4((float)((x - d.ox) - (double)o.x), (float)((y - d.oy) - (double)o.y), (float)c, (float)s);
     d.rec[a] = q;
-    if (d.recs_valid) d.recs[d.pos[a]] = q;                   // the copy in binned order (csf_bin.hip)
+    // scene coordinates = offset + origin, in fp32 (the same sum a rank forms from the records it has gathered, so that
+    // every path sees the same numbers): by slot (the receivers), and the copy in binned order (csf_bin.hip) that the
+    // pair kernel's tiles are filled with
+    const float4 g = make_float4(q.x + o.x, q.y + o.y, q.z, q.w);
+    d.recg[a] = g;
+    if (d.recs_valid) d.recs[d.pos[a]] = g;
     if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
         double e = 0.0;
         if (p.model == CSF_BICYCLE && v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
@@ -809,6 +814,7 @@ __global__ void records_kernel(const Dev d) {
     if (a >= d.n_pad) return;
     if (a >= d.n || !d.alive[a]) {  // sentinel: far away, contributes exactly 0 (exp2 underflow), never NaN
         d.rec[a] = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
+        if (a < d.cap) d.recg[a] = d.rec[a];
         if (d.has_bike) d.rec2[a] = make_float2(0.0f, 1.0f);
         return;
     }
@@ -948,6 +954,7 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         d.cls[a] = 0;                                              // (its sentinel record is looked up in set 0 from now on)
         const float4 q = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
         d.rec[a] = q;
+        d.recg[a] = q;
         if (d.recs_valid) d.recs[d.pos[a]] = q;
         if (d.has_bike) {
             d.rec2[a] = make_float2(0.0f, 1.0f);
@@ -983,12 +990,9 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
         d.status[a] = 0;
         d.alive[a] = 1;
-        // its own origin: where it starts, rounded to 1/4 m (unbinned populations: the scene origin); the slot keeps its
-        // place of the binned order
-        float2 o = make_float2(0.f, 0.f);
-        if (d.classify) o = make_float2((float)(0.25 * rint(4.0 * (s[0] - d.ox))), (float)(0.25 * rint(4.0 * (s[1] - d.oy))));
+        // its own origin: where it starts, rounded to 1/4 m; the slot keeps its place of the binned order
+        const float2 o = make_float2((float)(0.25 * rint(4.0 * (s[0] - d.ox))), (float)(0.25 * rint(4.0 * (s[1] - d.oy))));
         d.rorg[a] = o;
-        if (d.recs_valid) d.orgs[d.pos[a]] = o;
         write_record(d, p, a, o, s[0], s[1], s[2], s[3]);
     } else if ((k -= h.n_spawn) < h.n_requeue) {
         const QueueRec r = ((const QueueRec *)(base + h.off_requeue))[k];

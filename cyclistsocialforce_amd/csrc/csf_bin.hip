@@ -71,21 +71,25 @@ __global__ void sorted_copy_kernel(const Dev d) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n_pad) return;
     const int32_t a = d.perm[p];
-    d.pos[a] = (int32_t)p;
-    d.recs[p] = d.rec[a];
+    if (a < d.n_pad) d.pos[a] = (int32_t)p;
+    float4 q = d.rec[a];
+    if (rec_is_real(q)) {                                     // scene coordinates: offset + the slot's origin
+        const float2 o = d.rorg[a];
+        q.x += o.x, q.y += o.y;
+        d.recg[a] = q;                                        // (a receiver must coincide with itself as a source)
+    }
+    d.recs[p] = q;
     if (d.has_bike) d.recs2[p] = d.rec2[a];
 }
 
 // After a re-sort (perm is new, pos / recs / org / bnd are not yet), one wave per batch of 64 places:
-//   * every record's new origin: its scene coordinates rounded to 1/4 m (with_origins; else 0: unbinned populations keep
-//     offsets from the scene origin), and the record re-expressed as an offset from it - recomputed from the fp64 state
-//     where this device holds it for every slot (a single device; any rank right after an upload), else from the old
-//     record and the old origin (the foreign blocks of a rank: (old origin - new origin) is exact, the sum rounds once);
-//   * pos[], the copies of records and origins in binned order, and the batch's bounding circle (scene coordinates).
-// Sentinel records stay as they are (the padding slot of the class-segmented order sits in many places at once); their
-// places get the origin of the batch's first road user, so that a workgroup of the pair kernel whose first receiver
-// place is empty still works relative to an origin near its receivers.
-__global__ __launch_bounds__(256) void rebase_kernel(const Dev d, const int with_origins) {
+//   * every record's new origin: its scene coordinates rounded to 1/4 m, and the record re-expressed as an offset from
+//     it - recomputed from the fp64 state where this device holds it for every slot (a single device; any rank right
+//     after an upload), else from the old record and the old origin (the foreign blocks of a rank: (old origin - new
+//     origin) is exact, the sum rounds once);
+//   * pos[], the copy of the records in binned order and scene coordinates, the batch's bounding circle.
+// Sentinel records stay as they are (the padding slot of the class-segmented order sits in many places at once).
+__global__ __launch_bounds__(256) void rebase_kernel(const Dev d) {
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b * 64 >= d.n_pad) return;
     const int lane = threadIdx.x & 63;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void rebase_kernel(const Dev d, const int with
         y1 = fmaxf(y1, __shfl_xor(y1, o2, 64));
     }
     float2 on = make_float2(0.f, 0.f);
-    if (with_origins && real) on = make_float2(0.25f * rintf(4.0f * x), 0.25f * rintf(4.0f * y));
+    if (real) on = make_float2(0.25f * rintf(4.0f * x), 0.25f * rintf(4.0f * y));
     if (real) {
         if (d.rebase_from_state) {
             q.x = (float)((d.s[a] - d.ox) - (double)on.x);
@@ -119,13 +123,10 @@ __global__ __launch_bounds__(256) void rebase_kernel(const Dev d, const int with
     } else if (a < d.n_pad) {
         d.pos[a] = (int32_t)p;                                 // (a free slot's place: where an arrival spawned into it will sit)
     }
+    // the binned copy holds scene coordinates, offset + origin (what the tiles of the pair kernels are filled with)
+    if (real) q.x += on.x, q.y += on.y;
     d.recs[p] = q;
-    {   // origin of an empty place: that of the first road user of the batch (0 if there is none)
-        const unsigned long long m = __ballot(real);
-        const int first = m ? __builtin_ctzll(m) : 0;
-        const float fx = __shfl(on.x, first, 64), fy = __shfl(on.y, first, 64);
-        d.orgs[p] = real ? on : make_float2(fx, fy);
-    }
+    if (real) d.recg[a] = q;
     if (d.has_bike) d.recs2[p] = d.rec2[a];
     if (lane == 0) d.bnd[b] = box_circle(x0, x1, y0, y1, 0.0f);
 }
@@ -192,10 +193,10 @@ void launch_sorted_copy(const Dev &d, hipStream_t st) {
     hipLaunchKernelGGL(sorted_copy_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
 }
 
-void launch_rebase(const Dev &d, int with_origins, hipStream_t st) {
+void launch_rebase(const Dev &d, hipStream_t st) {
     if (d.n_pad <= 0) return;
     const int64_t batches = d.n_pad / 64;
-    hipLaunchKernelGGL(rebase_kernel, dim3((unsigned)((batches + 3) / 4)), dim3(256), 0, st, d, with_origins);
+    hipLaunchKernelGGL(rebase_kernel, dim3((unsigned)((batches + 3) / 4)), dim3(256), 0, st, d);
 }
 
 void launch_bounds(const Dev &d, hipStream_t st) {

@@ -29,6 +29,9 @@ struct PairConsts {
     // polynomials in s2 = sin^2(psi0 - psi), T = ln(n / far_eps) with a margin for fp32 rounding
     float tA0, tA1, tB0, tB1;
     int32_t reach;                     // the reach test is on (far-field cull enabled)
+    // pairs closer than rnear are evaluated from the precise records (csf_pair.hip: precise_delta); rnear2 = rnear^2,
+    // rn2big = 1e20 rnear^2 (what makes the fast path drop such a pair without a branch)
+    float rnear, rnear2, rn2big;
 };
 
 // All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
@@ -54,8 +57,6 @@ struct Dev {
     int64_t lo, hi;    // receiver block integrated by this rank
     int64_t n_pad;     // n rounded up to a multiple of 64 (sentinel source records behind n)
     int64_t n_src;     // places of the source order that can hold a road user (multiple of 64, <= n_pad): the pair kernel stops there
-    int64_t n_places;  // the same for the whole order (n_src is narrowed to one run of places by a class-segment launch): with
-                       // binned records the receivers of the pair kernel are the places [0, n_places) (or rlist)
     int64_t src_beg;   // ... and starts here (0, or the first place of a class segment: csf_engine.hip launch_pair_segments)
     int32_t part_base; // first slot of d.part this launch writes (its source chunks follow: one launch per class segment)
     int32_t seg_keys;  // re-binning: the parameter set leads the sort key (csf_bin.hip), so that every set is a run of places
@@ -89,23 +90,27 @@ struct Dev {
     int32_t *dgood;    // consecutive ring samples with |delta| < delta_max_walk (vehicle.py:1943-1947)
     double *ppsi;      // PlanarPoint unwrapped yaw (dynamics.py:943-966)
 
-    // fp32 source records (x - ox - rorg.x, y - oy - rorg.y, cos psi, sin psi): the position is an offset from the road
-    // user's OWN origin - where it was at the last re-binning, rounded to 1/4 m (exact in fp32, and so is the difference
-    // of two origins) - not from the scene origin.  The offset stays below a few metres (0.07 m per tick, 32 ticks), so
-    // a position resolves to ~2e-7 m whatever the extent of the scene.  Unbinned populations: every origin is 0.
+    // The PRECISE fp32 source records (x - ox - rorg.x, y - oy - rorg.y, cos psi, sin psi): the position is an offset from
+    // the road user's OWN origin - where it was at the last re-binning, rounded to 1/4 m (exact in fp32, and so is the
+    // difference of two origins) - not from the scene origin.  The offset stays below a few metres (0.07 m per tick, 32
+    // ticks), so a position resolves to ~2e-7 m whatever the extent of the scene.  This is what is all-gathered, what
+    // the re-binning reads, and what near pairs are evaluated from (csf_pair.hip: precise_delta); the tiles of the pair
+    // kernels hold scene coordinates (recs, or offset + origin), 2^-24 of the scene extent.
     float4 *rec;       // [n_pad] by slot
     float2 *rorg;      // [n_pad] by slot: the origin its record is relative to, itself relative to (ox, oy)
-    float2 *orgs;      // [n_pad] the same by place of the binned order (beside recs); a place without a road user: an origin nearby
+    float4 *recg;      // [cap] by slot: the record in scene coordinates, bit for bit what recs holds at the slot's place (the
+                       // receivers of the kernels on binned records: a receiver must coincide with itself as a source)
     int32_t rebase_from_state;   // re-binning: every live slot's fp64 state is current on this device (else: re-express the old record)
     float2 *rec2;      // [n_pad] Bicycle field only: (e, 1/sqrt(1-e^2))
     int32_t *perm;     // [n_pad] spatially binned order of the source records (position -> record index)
     int32_t *pos;      // [n_pad] inverse of perm (record index -> position)
-    float4 *recs;      // [n_pad] the records in binned order (single device: written by the agent kernel beside
-                       // rec, so that the pair kernel's tile fill is one coalesced load instead of perm -> rec)
+    float4 *recs;      // [n_pad] the records in binned order AND scene coordinates (x - ox, y - oy, cos psi, sin psi)
+                       // (single device: written by the agent kernel beside rec, so that the pair kernel's tile
+                       // fill is one coalesced load instead of perm -> rec, rorg)
     float2 *recs2;     // [n_pad] Bicycle field: rec2 in binned order
     int32_t recs_valid;
-    int32_t recv_binned;   // the pair kernel skips tiles of sources beyond the far-field radius of a whole receiver group unloaded (large populations)
-    const int32_t *rlist;  // binned records on a shard: places of this rank's receivers, ascending (NULL: the places [0, n_places))
+    int32_t recv_binned;   // the pair kernel takes its receivers in binned order too and skips far tiles (large populations)
+    const int32_t *rlist;  // recv_binned on a shard: binned positions of this rank's receivers, ascending (NULL: all of them)
     float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
     float4 *bnd_next;  // written by the pair kernel for the next tick (from this tick's records + bnd_margin)
     float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
@@ -154,8 +159,8 @@ int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals
 void launch_identity_perm(const Dev &d, hipStream_t st);
 void launch_sorted_copy(const Dev &d, hipStream_t st);  // pos[] and recs[] from perm[] and rec[]
 // after a re-sort: every record re-expressed relative to its new origin (from the fp64 state where
-// d.rebase_from_state), pos[] / recs[] / orgs[] and the bounding circles - one launch
-void launch_rebase(const Dev &d, int with_origins, hipStream_t st);
+// d.rebase_from_state), pos[] / recs[] and the bounding circles - one launch
+void launch_rebase(const Dev &d, hipStream_t st);
 void launch_bounds(const Dev &d, hipStream_t st);
 // binned positions of the receivers [lo, hi) of this rank in ascending order (the rank's receivers as neighbours in space)
 int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st);
@@ -211,11 +216,17 @@ __device__ __forceinline__ float4 box_circle(float x0, float x1, float y0, float
 // bounding circle of batch b (64 records in perm order), computed by one wave: centre (scene coordinates) and radius of
 // the bounding box's circumcircle, grown by `margin`
 __device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, float margin, float4 *out) {
-    const int32_t a = d.perm[b * 64 + lane];
-    const float4 q = d.rec[a];
+    // scene coordinates of the batch's records: the binned copy, or (without it) offset + origin of the slot
+    float4 q;
+    if (d.recs_valid) {
+        q = d.recs[b * 64 + lane];
+    } else {
+        const int32_t a = d.perm[b * 64 + lane];
+        q = d.rec[a];
+        if (rec_is_real(q)) q.x += d.rorg[a].x, q.y += d.rorg[a].y;
+    }
     const bool real = rec_is_real(q);
-    const float2 o = real ? d.rorg[a] : make_float2(0.f, 0.f);
-    const float x = q.x + o.x, y = q.y + o.y;
+    const float x = q.x, y = q.y;
     float x0 = real ? x : 3e38f, x1 = real ? x : -3e38f, y0 = real ? y : 3e38f, y1 = real ? y : -3e38f;
 #pragma unroll
     for (int o2 = 32; o2 > 0; o2 >>= 1) {

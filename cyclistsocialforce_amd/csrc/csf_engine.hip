@@ -102,7 +102,7 @@ struct Knobs {
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
     bool comm_second = false;                 // CSF_COMM_STREAM=second
     int fused = -1;                           // CSF_FUSED: the one-launch tick of small populations (-1: the engine's choice)
-    bool recv_by_slot = false;                // CSF_RECV_ORDER=slot: receivers in slot order (A/B aid: spatial coherence of a workgroup's receivers off)
+    double rnear = 1.0;                       // CSF_RNEAR: pairs closer than this (m) are evaluated from the precise records (0: none)
     void read() {
         auto geti = [](const char *name, int dflt) {
             const char *v = getenv(name);
@@ -125,7 +125,7 @@ struct Knobs {
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second";
         fused = geti("CSF_FUSED", -1);
-        if (const char *v = getenv("CSF_RECV_ORDER")) recv_by_slot = std::string(v) == "slot";
+        if (const char *v = getenv("CSF_RNEAR")) rnear = atof(v);
     }
 };
 
@@ -221,7 +221,7 @@ struct csf_engine {
     PinnedSlot pinned[4];
     int pinned_next = 0;
     DevBuf<uint32_t> status;
-    DevBuf<float4> rec, recs, rv, kat4, bnd, bnd2;
+    DevBuf<float4> rec, recs, recg, rv, kat4, bnd, bnd2;
     DevBuf<int32_t> pos;
     bool bounds_fresh = false;   // d.bnd describes the current records (else: recompute before the pair kernel)
     DevBuf<int32_t> perm, sort_vals, rlist;
@@ -229,7 +229,7 @@ struct csf_engine {
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, recs2, part, froad, kat2;
-    DevBuf<float2> orgs, rorg;   // the origin every record is relative to: by place of the binned order, by slot
+    DevBuf<float2> rorg;         // the origin every precise record is relative to, by slot
     bool state_all_current = true;   // every live slot's fp64 state on this device is current (false once a rank has ticked)
     double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
     double last_gather_ms = 0.0;  // all-gather time accumulated by the last csf_profile_read
@@ -454,7 +454,7 @@ void derive_planarbike(const csf_params &p, double pb[7]) {
 }
 
 // what the pair kernels need of one parameter set
-void derive_pair_consts(const csf_params &p, PairConsts &k) {
+void derive_pair_consts(const csf_params &p, PairConsts &k, double rnear) {
     k.sg0 = (float)p.sigma_0;
     k.sg1 = (float)p.sigma_1;
     k.sg2 = (float)p.sigma_2;
@@ -482,12 +482,15 @@ void derive_pair_consts(const csf_params &p, PairConsts &k) {
     k.rfar = INFINITY;
     k.tA0 = k.tA1 = k.tB0 = k.tB1 = 0.f;
     k.reach = 0;
+    k.rnear = (float)std::max(0.0, rnear);
+    k.rnear2 = k.rnear * k.rnear;
+    k.rn2big = 1e20f * k.rnear2;
 }
 
 void derive_consts(csf_engine *e) {
     const csf_params &p = e->d.p;
     if (p.model == CSF_PLANARBIKE) derive_planarbike(p, e->d.pb);
-    derive_pair_consts(p, e->d.pc);
+    derive_pair_consts(p, e->d.pc, e->knobs.rnear);
     e->far_kappa = far_kappa(p);
     update_far_radius(e);
     if (e->classes.empty()) e->classes.push_back(p);
@@ -552,9 +555,9 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->perm.alloc(nrec));
     HIPCHK(e, e->pos.alloc(nrec));
     HIPCHK(e, e->recs.alloc(nrec));
+    HIPCHK(e, e->recg.alloc(nrec));
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
-    HIPCHK(e, e->orgs.alloc(nrec));
     HIPCHK(e, e->rorg.alloc(nrec));
     HIPCHK(e, e->sort_vals.alloc(nrec));
     HIPCHK(e, e->rlist.alloc(nrec));
@@ -612,9 +615,9 @@ int alloc_all(csf_engine *e) {
     d.perm = e->perm.p;
     d.pos = e->pos.p;
     d.recs = e->recs.p;
+    d.recg = e->recg.p;
     d.bnd = e->bnd.p;
     d.bnd_next = e->bnd2.p;
-    d.orgs = e->orgs.p;
     d.rorg = e->rorg.p;
     d.trace = nullptr;
     if (!e->knobs.trace_blocks.empty()) {  // 3 words per wave: the grid is at most (cap/16) x MAX_SPLIT workgroups of 4 waves
@@ -657,7 +660,6 @@ void set_shard(csf_engine *e) {
 // the source chunks of the pair kernel's grid, for the d.n_src places of the source order that can hold road users
 void set_chunks(csf_engine *e) {
     Dev &d = e->d;
-    d.n_places = d.n_src;
     int64_t nloc = d.hi - d.lo;
     int64_t blocks = (nloc + 15) / 16;
     int64_t units = std::max<int64_t>(1, d.n_src / 64);
@@ -752,7 +754,7 @@ int rebin(csf_engine *e) {
             for (int c = 0; c < d.n_classes; c++) {
                 const int64_t units = (count[(size_t)c] + 63) / 64;
                 PairConsts pc;
-                derive_pair_consts(e->classes[(size_t)c], pc);
+                derive_pair_consts(e->classes[(size_t)c], pc, e->knobs.rnear);
                 pc.p2r = d.pc.p2r;
                 set_far_consts(e->knobs, e->classes[(size_t)c], e->class_kappa[(size_t)c], d.n, pc);
                 if (units == 0 || pc.f0_zero) continue;              // nobody of this set, or a set whose field is zero
@@ -773,7 +775,6 @@ int rebin(csf_engine *e) {
                 d.seg_keys = 1;
                 d.n_split = std::max(1, slots);                       // what the per-agent kernel sums
                 d.n_src = place;
-                d.n_places = place;
             }
         }
     }
@@ -792,25 +793,24 @@ int rebin(csf_engine *e) {
     } else {
         launch_identity_perm(d, e->main);
     }
-    // Every record gets a new origin - where it is now (unbinned: the scene's) - and is re-expressed relative to it;
-    // pos[], the binned copies of records and origins and the circles (csf_bin.hip: rebase_kernel).  The binned copy is maintained
-    // by the agent kernel where every record is local, rebuilt from the gathered records before every pair launch of a
-    // sharded run (enqueue_tick).
+    // Every precise record gets a new origin - where the road user is now - and is re-expressed relative to it; pos[],
+    // the binned copy of the records in scene coordinates and the circles (csf_bin.hip: rebase_kernel).  The binned
+    // copy is maintained by the agent kernel where every record is local, rebuilt from the gathered records before every
+    // pair launch of a sharded run (enqueue_tick).
     d.recs_valid = binned;
     d.rebase_from_state = e->state_all_current;
-    launch_rebase(d, binned, e->main);
-    {   // The kernels on binned records take their receivers by place (csf_pair.hip: recv_count): a rank that owns an
-        // index block [lo, hi) takes ITS receivers' places, sorted.  Large populations also skip far tiles unloaded.
+    launch_rebase(d, e->main);
+    {   // receivers in binned order + far-tile skipping, where there are enough tiles for it to pay.  A rank that owns
+        // an index block [lo, hi) takes ITS receivers in binned order: their positions, sorted
         const int ov = e->knobs.recv_binned;
         const bool whole = d.lo == 0 && d.hi == d.n;
         d.recv_binned = binned && d.recs_valid && std::isfinite(d.pc.rfar) && (ov >= 0 ? ov != 0 : d.n_pad >= 65536);
         d.rlist = nullptr;
-        if (binned && !whole) {
+        if (d.recv_binned && !whole) {
             int rc = launch_receiver_list(d, e->sort_keys.p, e->rlist.p, e->sort_tmp.p, e->sort_tmp.n, e->main);
             if (rc != 0) return fail(e, CSF_E_DEVICE, "radix sort of the receiver positions failed (%d)", rc);
             d.rlist = e->rlist.p;
         }
-        if (binned && whole && e->knobs.recv_by_slot) d.rlist = d.pos;   // (measurement aid: the place of every slot, in slot order)
     }
     // Where the sentinels went: the sort is stable and their key is the largest, so the road users fill the places
     // [0, n_live) and the free slots follow in ascending slot order.  Handing the free slots out in that order
@@ -831,7 +831,7 @@ int rebin(csf_engine *e) {
     }
     e->ticks_since_rebin = 0;
     e->churn = 0;
-    e->bounds_fresh = binned;                                        // (rebase_kernel wrote the circles of the records as they are)
+    e->bounds_fresh = true;                                          // (rebase_kernel wrote the circles of the records as they are)
     return CSF_OK;
 }
 
@@ -975,7 +975,7 @@ int upload_classes(csf_engine *e) {
     std::vector<double> pb(7 * K, 0.0);
     e->class_kappa.assign(K, 0.0);
     for (size_t c = 0; c < K; c++) {
-        derive_pair_consts(e->classes[c], pc[c]);
+        derive_pair_consts(e->classes[c], pc[c], e->knobs.rnear);
         if (K > 1 && K <= 16) e->class_kappa[c] = far_kappa(e->classes[c]);   // (for the launches per set: rebin)
         pc[c].p2r = d.pc.p2r;                                    // (the rule belongs to the intersection: intersection.py:324)
         if (e->classes[c].model == CSF_PLANARBIKE) derive_planarbike(e->classes[c], &pb[7 * c]);
@@ -1062,7 +1062,6 @@ int upload_all(csf_engine *e) {
     HIPCHK(e, hipMemsetAsync(e->part.p, 0, e->part.n * sizeof(float2), e->main));   // a new layout starts from clean partial sums
     // records as offsets from the scene origin first (what the sort keys are made of); the re-binning then gives every
     // record its own origin and rewrites it from the fp64 state just uploaded
-    HIPCHK(e, hipMemsetAsync(e->orgs.p, 0, e->orgs.n * sizeof(float2), e->main));
     HIPCHK(e, hipMemsetAsync(e->rorg.p, 0, e->rorg.n * sizeof(float2), e->main));
     e->state_all_current = true;
     launch_records(d, e->main);
@@ -1385,7 +1384,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->orgs.release(); e->rorg.release(); e->perm.release(); e->pos.release(); e->recs.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -1850,7 +1849,8 @@ static int enqueue_tick(csf_engine *e) {
     }
     launch_agent(d, overlap ? (PH_COMBINE | PH_INTEGRATE) : (PH_DEST | PH_COMBINE | PH_INTEGRATE), e->main,
                  po ? po->ev[4] : nullptr, po ? po->ev[5] : nullptr);
-    if (sharded) e->state_all_current = false;      // a rank integrates its own block only: the others' fp64 state is stale now
+    // a rank integrates its own block only: the others' fp64 state is stale from now on (a 1-rank communicator owns every block)
+    if (e->world > 1 || e->loopback) e->state_all_current = false;
     if (po) po->agent = true;
     HIPCHK(e, hipGetLastError());
     d.tick++;

@@ -113,12 +113,17 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
 // The same field for TWO sources per lane (components .x / .y), float2 arithmetic -> v_pk_* instructions.
 // FULL: both sources of every lane are real, tracked pairs (rho > 0); otherwise valid0 / valid1 mask the lanes
 // of a partial batch, whose dummy record may coincide with the receiver.  Accumulates into (ax, ay).
-template <bool FULL>
+// NEARFLAG: near0 / near1 report the pairs closer than k.rnear (pair_cull_kernel corrects them from the precise records).
+template <bool FULL, bool NEARFLAG = false>
 __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r, const v2f qx, const v2f qy,
                                               const v2f qc, const v2f qs, bool valid0, bool valid1, float &ax,
-                                              float &ay) {
+                                              float &ay, bool *near0 = nullptr, bool *near1 = nullptr) {
     v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
     v2f r2 = dx * dx + dy * dy;
+    if (NEARFLAG) {
+        *near0 = valid0 & (r2.x < k.rnear2);
+        *near1 = valid1 & (r2.y < k.rnear2);
+    }
     if (!FULL) r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};
     v2f inv = rsq2(r2), rho = r2 * inv;
     v2f srel = qs * r.c - qc * r.s;                   // sin(psi0 - psi)            :1595
@@ -235,8 +240,7 @@ __device__ __forceinline__ float dpp(float x) {
 constexpr int DPP_ROW_ROR8 = 0x128, DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141;
 
 __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane, const float (&ax)[RPW],
-                                             const float (&ay)[RPW], const int *agent_of = nullptr, int chunk = -1) {
-    if (chunk < 0) chunk = blockIdx.y;
+                                             const float (&ay)[RPW], const int *agent_of = nullptr) {
     static_assert(RPW == 4, "the reduction below is written for eight values");
     const float v[8] = {ax[0], ay[0], ax[1], ay[1], ax[2], ay[2], ax[3], ay[3]};
     float w[4], y[2];
@@ -252,48 +256,39 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
     // every lane of a group of 8 holds value index 4*bit5 + 2*bit4 + bit3 of the lane number
     const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
     const int u = idx >> 1;
-    // agent_of (receivers taken by place): slot of each of the wave's receivers, -1 for none (LDS); else the receivers are j0 + u
+    // agent_of: slot of each of the wave's receivers, -1 for none (LDS); else the receivers are the slots j0 + u
     const int64_t a = agent_of ? (int64_t)agent_of[u] : (j0 + u < d.hi ? j0 + u : -1);
     if ((lane & 7) == 0 && a >= 0) {
-        float *dst = (float *)&d.part[(int64_t)(d.part_base + chunk) * d.cap + a];
+        float *dst = (float *)&d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a];
         dst[idx & 1] = z;
     }
 }
 
-// Receivers of the kernels that work on binned records (pair_cull_kernel, pair_bike_kernel).  They are taken by PLACE of
-// the binned order, so that the receivers of a workgroup are neighbours in space: everything the workgroup touches is
-// then expressed relative to ONE origin near its receivers (the origin of the first receiver's place) - the sources that
-// matter (the near ones) and the receivers themselves are small numbers there, and an fp32 difference receiver - source
-// keeps 2^-24 of (pair distance + group extent) instead of 2^-24 of the scene extent (vehicle.py:1615-1617 forms it in
-// fp64).  A whole population: the places [0, n_places); a rank's block: its receivers' places in
-// ascending order (rlist); an unbinned population: place == slot, every origin 0.
-__device__ __forceinline__ int64_t recv_count(const Dev &d) {
-    return d.rlist ? d.hi - d.lo : (d.classify ? d.n_places : d.hi - d.lo);
-}
-__device__ __forceinline__ int64_t recv_place(const Dev &d, int64_t j) {
-    return d.rlist ? (int64_t)d.rlist[j] : (d.classify ? j : d.lo + j);
-}
-
-// Which source chunk a workgroup of the kernels on binned records takes.  Its receivers are neighbours in space and a
-// chunk is a compact run of the binned order, so a (receiver group, chunk) pair is either heavy - the chunk lies in front
-// of the receivers: up to 32 x 1024 pair evaluations - or nearly empty.  Workgroups are dispatched with blockIdx.x
-// fastest: blockIdx.y = 0 takes the chunk that holds the group's own receivers (the heaviest), 1 and 2 its neighbours in
-// the binned order, and so on outwards - heavy workgroups first, the kernel ends with light ones.
-__device__ __forceinline__ int chunk_near_first(const Dev &d, int64_t first_place) {
-    const int n = (int)gridDim.y;
-    int64_t own = (first_place - d.src_beg) / ((int64_t)d.chunk_units * WAVE);
-    own = own < 0 ? 0 : (own >= n ? n - 1 : own);
-    const int y = (int)blockIdx.y, L = (int)own, R = n - 1 - (int)own, m = L < R ? L : R;
-    if (y <= 2 * m) return (int)own + ((y & 1) ? ((y + 1) >> 1) : -((y + 1) >> 1));
-    return R > L ? (int)own + (y - L) : (int)own - (y - R);   // one side is used up: the rest of the other, still outwards
-}
-
-__device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend, int chunk = -1) {
-    if (chunk < 0) chunk = blockIdx.y;
-    const int64_t per = d.chunk_units;  // a chunk of sources, in units of 64 records
-    ibeg = d.src_beg + (int64_t)chunk * per * WAVE;
+__device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend) {
+    const int64_t per = d.chunk_units;  // blockIdx.y selects a chunk of sources, in units of 64 records
+    ibeg = d.src_beg + (int64_t)blockIdx.y * per * WAVE;
     iend = ibeg + per * WAVE;
     if (iend > d.n_src) iend = d.n_src;   // (the places behind hold sentinels only, csf_engine.hip: rebin)
+}
+
+// ---- near pairs ---------------------------------------------------------------------------------------------------
+// The kernels work on fp32 positions relative to the scene origin (what the tile holds: 2^-24 of the scene extent, 8e-6 m
+// at 130 m).  The field's direction turns by (position error / distance) and its decay length is as short as 0.2 m, so
+// for the rare pairs closer than PairConsts::rnear (1 m) that is not enough - the reference forms x - x0 in fp64
+// (vehicle.py:1615-1617).  Such a pair is CORRECTED from the precise records: every record in HBM is an offset (a few
+// metres at most) from an origin of its own (a multiple of 1/4 m; csf_dev.h: rec, rorg), so
+// dx = (off_r - off_s) + (org_r - org_s)  carries ~2e-7 m whatever the extent of the scene.  pair_cull_kernel: the field
+// evaluation notes the near pairs it meets (two compares and a rarely taken branch per 128 pairs), and once per wave and
+// tile the noted pairs are evaluated twice, one per lane - from the precise records (field of view included) and as the
+// fast path saw them - and the difference is added; a list that is full leaves the rest uncorrected.  The other
+// kernels evaluate every pair in one place and swap the precise (dx, dy) in.
+__device__ __forceinline__ void precise_delta(const Dev &d, int32_t a_recv, int32_t a_src, float &dx, float &dy, float4 &qs) {
+    const float4 qr = d.rec[a_recv];
+    const float2 orr = d.rorg[a_recv];
+    qs = d.rec[a_src];
+    const float2 os = d.rorg[a_src];
+    dx = (qr.x - qs.x) + (orr.x - os.x);
+    dy = (qr.y - qs.y) + (orr.y - os.y);
 }
 
 // One LDS load per value: hipcc would otherwise merge the loads of (x, y) and (c, s) of ONE record into
@@ -353,10 +348,11 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // decides every borderline source: these two leave the results identical with and without CLASSIFY.
 // A batch is also skipped when all of it lies beyond the far-field radius k.rfar (csf_engine.hip: far_radius),
 // where the contributions are below the resolution of the fp32 column sum.
-// The RECEIVERS of a workgroup are consecutive places of the binned order (recv_place), i.e. neighbours in space; tile
-// and receivers are held relative to the origin of the group's first batch (see recv_count).
-// SKIP (large populations): a whole tile of 1024 sources that lies beyond the far-field radius of the group's bounding
-// circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).
+// BINR (large populations): the RECEIVERS of a workgroup are consecutive places of the binned order as well, i.e.
+// neighbours in space, so a whole tile of 1024 sources that lies beyond the far-field radius of the group's bounding
+// circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).  (Smaller populations take their
+// receivers in slot order: a workgroup then holds a random sample of receivers and every workgroup carries the same
+// load - with neighbours the few workgroups whose tile lies in front of ALL their receivers end the kernel 10 % later.)
 // DYN (small receiver blocks, i.e. shards of a small population: launch_pair): the 16 receivers of the workgroup are
 // handed to its waves one at a time through an LDS counter instead of four per wave.  With few workgroups the kernel
 // ends with its longest single wave (a lone wave issues one dependent instruction every ~8 cycles); sharing the
@@ -365,7 +361,7 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // workgroup of twice the receivers shares one tile fill and one start-up between them: 146 -> 141 us at N = 16 384)
 // REACH (with the far-field cull on): every candidate batch goes through the packed reach test keep_x2, two batches at a
 // time, and only the sources it keeps are queued for the field.
-template <bool P2R, bool CLASSIFY, bool SKIP, bool DYN, int RPB = WPB * RPW, bool REACH = false>
+template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     static_assert(RPB == WPB * RPW || (DYN && RPB % (WPB * RPW) == 0 && RPB <= WAVE), "wider workgroups need the dynamic hand-out");
     static_assert(!REACH || (CLASSIFY && DYN), "the reach test is built into the classified, dynamically handed-out variant");
@@ -376,19 +372,16 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     __shared__ float4 rrec[RPB];
     __shared__ int ragent[RPB];              // slot of every receiver of the workgroup (-1: none)
     __shared__ unsigned bmask[DYN ? RPB : 1];   // DYN: candidate | inside << 16 batch masks of every receiver
+    constexpr int NCAP = WAVE;                         // near pairs noted by one wave: receiver << 16 | tile index
+    __shared__ unsigned nlist[WPB][NCAP];
     __shared__ float racc[2][DYN ? RPB : 1];    // DYN: column sums of the workgroup's receivers
     __shared__ int next_recv;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t t_start = d.trace ? wall_clock64() : 0;
-    // origin of the workgroup: that of its first receiver's place (uniform: scalar loads)
-    const int64_t nrecv = recv_count(d);
-    const int64_t jg = (int64_t)blockIdx.x * RPB;
-    const int64_t pg = recv_place(d, jg);
-    const float2 og = d.orgs[pg];
-    const int chunk = chunk_near_first(d, pg);
+    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
     int64_t ibeg, iend;
-    source_chunk(d, ibeg, iend, chunk);
+    source_chunk(d, ibeg, iend);
+    const uint64_t t_start = d.trace ? wall_clock64() : 0;
 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
@@ -410,6 +403,18 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                  "+v"(k.kexp), "+v"(k.chs));
     if (REACH) asm volatile("" : "+v"(k.tA0), "+v"(k.tA1), "+v"(k.tB0), "+v"(k.tB1));
 
+    // Near pairs (precise_delta): what the field evaluation meets closer than k.rnear is noted here - receiver << 16 |
+    // tile index - and corrected once per wave and tile (near_drain, in the tile loop).
+    int nlen = 0, cur_recv = 0;         // (wave-uniform) entries of the wave's list; the receiver being worked on
+    auto near_note = [&](bool nr, int tile_index) {
+        const unsigned long long m = __ballot(nr);
+        if (nr) {
+            const int at = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nlen));
+            if (at < NCAP) nlist[wave][at] = ((unsigned)cur_recv << 16) | (unsigned)tile_index;   // (full: left uncorrected)
+        }
+        const int nn = nlen + __builtin_popcountll(m);
+        nlen = __builtin_amdgcn_readfirstlane(nn < NCAP ? nn : NCAP);
+    };
     // pop CHUNK (or, when draining, whatever is left) queued sources of receiver u; the field takes two per lane
     auto pop = [&](int u, auto full) {
         constexpr bool FULL = decltype(full)::value;
@@ -418,8 +423,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         int i1 = queue[wave][(qhead + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
         if (!FULL) i0 = v0 ? i0 : 0, i1 = v1 ? i1 : 0;
-        field_twod_x2<FULL>(k, ru, lds_pair_b(tx, i0, i1), lds_pair_b(ty, i0, i1), lds_pair_b(tc, i0, i1),
-                            lds_pair_b(ts, i0, i1), v0, v1, ax[u], ay[u]);
+        bool n0, n1;
+        field_twod_x2<FULL, true>(k, ru, lds_pair_b(tx, i0, i1), lds_pair_b(ty, i0, i1), lds_pair_b(tc, i0, i1),
+                                  lds_pair_b(ts, i0, i1), v0, v1, ax[u], ay[u], &n0, &n1);
+        if (__ballot(n0 | n1) != 0ull) {        // rare: a near pair among the 128 (the queue still holds their offsets)
+            near_note(n0, (int)queue[wave][(qhead + lane) & (QCAP - 1)] >> 2);
+            near_note(n1, (int)queue[wave][(qhead + WAVE + lane) & (QCAP - 1)] >> 2);
+        }
         qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
         qlen = __builtin_amdgcn_readfirstlane(qlen - n);
         evals += (unsigned)n;
@@ -432,9 +442,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         const int o = v ? (int)queue[wave][(qhead + lane) & (QCAP - 1)] : 0;
         const float4 q = make_float4(*(const float *)((const char *)tx + o), *(const float *)((const char *)ty + o),
                                      *(const float *)((const char *)tc + o), *(const float *)((const char *)ts + o));
-        const float dx = ru.x - q.x, dy = ru.y - q.y;
+        const float dx = ru.x - q.x, dy = ru.y - q.y, r2 = dx * dx + dy * dy;
         float F, gx, gy;
-        field_twod(k, ru, q, dx, dy, fmaxf(dx * dx + dy * dy, 1e-30f), F, gx, gy);
+        field_twod(k, ru, q, dx, dy, fmaxf(r2, 1e-30f), F, gx, gy);
+        if (__ballot(v & (r2 < k.rnear2)) != 0ull) near_note(v & (r2 < k.rnear2), o >> 2);
         F = v ? F : 0.0f;
         ax[u] += F * gx;
         ay[u] += F * gy;
@@ -444,39 +455,53 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         qlen = 0;
     };
 
-    // a tile: the records of 1024 places, re-expressed relative to the workgroup's origin (the difference of two origins
-    // is exact; the sum rounds to 2^-24 of the distance from the group, i.e. finely where it matters)
+    // a tile: 1024 places of the binned order in scene coordinates (recs: the copy the per-agent kernel maintains beside
+    // the precise records; without it - unbinned - offset + origin of the slot)
     auto fill_tile = [&](int64_t base, int cnt) {
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
-            const float4 q = d.recs_valid ? d.recs[base + t] : d.rec[d.perm[base + t]];
-            const float2 o = d.orgs[base + t];
-            tx[t] = q.x + (o.x - og.x);
-            ty[t] = q.y + (o.y - og.y);
+            float4 q;
+            if (d.recs_valid) {
+                q = d.recs[base + t];
+            } else {
+                const int32_t a = d.perm[base + t];
+                const float2 o = d.rorg[a];
+                q = d.rec[a];
+                q.x += o.x, q.y += o.y;
+            }
+            tx[t] = q.x;
+            ty[t] = q.y;
             tc[t] = q.z;
             ts[t] = q.w;
         }
-        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) {
-            const float4 bb = d.bnd[(base >> 6) + threadIdx.x];   // (scene coordinates)
-            tbnd[threadIdx.x] = make_float4(bb.x - og.x, bb.y - og.y, bb.z, 0.0f);
-        }
+        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
         if (DYN && threadIdx.x == BLOCK - 1) next_recv = 0;
     };
     // first tile and the workgroup's receiver records travel together: one global round trip, not two
     if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
-    if (!SKIP) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
+    if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
     if (threadIdx.x < RPB) {
-        const int64_t j = jg + threadIdx.x;
-        const int64_t p = recv_place(d, j < nrecv ? j : nrecv - 1);   // clamp: results of the duplicates are not stored
-        const int32_t a = d.perm[p];
-        const float4 q = d.recs_valid ? d.recs[p] : d.rec[a];
-        const float2 o = d.orgs[p];
-        rrec[threadIdx.x] = make_float4(q.x + (o.x - og.x), q.y + (o.y - og.y), q.z, q.w);
-        ragent[threadIdx.x] = (j < nrecv && a < d.n) ? a : -1;   // (a place of padding holds no slot)
+        const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
+        const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
+        if (BINR) {  // receiver slot jc - lo of this rank -> place of the binned order -> slot
+            const int64_t p = d.rlist ? (int64_t)d.rlist[jc - d.lo] : jc;
+            rrec[threadIdx.x] = d.recs[p];
+            ragent[threadIdx.x] = j < d.hi ? d.perm[p] : -1;
+        } else {
+            if (d.recs_valid) {                               // (uniform) scene coordinates, identical with the slot's entry of recs
+                rrec[threadIdx.x] = d.recg[jc];
+            } else {
+                const float2 o = d.rorg[jc];
+                float4 q = d.rec[jc];
+                q.x += o.x, q.y += o.y;
+                rrec[threadIdx.x] = q;
+            }
+            ragent[threadIdx.x] = j < d.hi ? (int)jc : -1;
+        }
         if (DYN) racc[0][threadIdx.x] = racc[1][threadIdx.x] = 0.0f;
     }
     __syncthreads();
-    float gx = 0.f, gy = 0.f, gr = 0.f;   // SKIP: bounding circle of the workgroup's receivers (the same in every wave)
-    if (SKIP) {
+    float gx = 0.f, gy = 0.f, gr = 0.f;   // BINR: bounding circle of the workgroup's receivers (the same in every wave)
+    if (BINR) {
         const float4 q = rrec[lane & (RPB - 1)];
         float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
 #pragma unroll
@@ -494,11 +519,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     for (int64_t base = ibeg; base < iend; base += TILE2) {
         const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
         const int nb = cnt >> 6;
-        if (SKIP) {
+        if (BINR) {
             // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
             // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
             const float4 bb = d.bnd[(base >> 6) + ((lane & 15) < nb ? (lane & 15) : 0)];
-            const float ex = (bb.x - og.x) - gx, ey = (bb.y - og.y) - gy;
+            const float ex = bb.x - gx, ey = bb.y - gy;
             const float reach = k.rfar + bb.z + gr;
             if (__ballot(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
             if (filled) __syncthreads();
@@ -530,6 +555,56 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             }
             if (DYN) __syncthreads();
         }
+        // The near pairs this wave has noted in this tile (receiver, tile index), one per lane: the pair from the precise
+        // records (precise_delta: two levels of global loads - once per wave and tile, not per receiver), field of view
+        // decided on the precise pair, MINUS the pair as the fast path evaluated it (scene coordinates from the tile);
+        // the differences are added to the receivers' sums in list order (fixed: bit-reproducible).
+        auto near_drain = [&]() {
+            if (nlen == 0) return;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned ent = nlist[wave][lane];
+            const int urn = lane < nlen ? (int)(ent >> 16) : 0;
+            const int idx = lane < nlen ? (int)(ent & 0xFFFFu) : 0;
+            const int32_t ar = ragent[urn];
+            bool act = (lane < nlen) & (ar >= 0);                   // (a clamped duplicate's results are not stored)
+            const int32_t arc = act ? ar : 0;
+            const int32_t as = act ? d.perm[base + idx] : arc;
+            float dx, dy, F, hx, hy;
+            float4 qs;
+            precise_delta(d, arc, as, dx, dy, qs);
+            const float4 qr = rrec[urn];
+            const Recv rr{qr.x, qr.y, qr.z, qr.w};
+            const float r2p = dx * dx + dy * dy;
+            const bool seen = act & (as != arc) & tracked<P2R>(k.chs, rr, dx, dy, r2p);   // intersection.py:690-745 on the precise pair
+            field_twod(k, rr, qs, dx, dy, fmaxf(r2p, 1e-30f), F, hx, hy);
+            F = seen ? F : 0.0f;
+            float fx = F * hx, fy = F * hy;
+            {   // ... minus what the fast path added for it
+                const float sx = rr.x - tx[idx], sy = rr.y - ty[idx];
+                field_twod(k, rr, make_float4(0.f, 0.f, tc[idx], ts[idx]), sx, sy, fmaxf(sx * sx + sy * sy, 1e-30f), F, hx, hy);
+                F = act ? F : 0.0f;
+                fx -= F * hx;
+                fy -= F * hy;
+            }
+            for (int i = 0; i < nlen; i++) {
+                const int ui = __builtin_amdgcn_readlane(urn, i);
+                const float vx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fx), i));
+                const float vy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fy), i));
+                if (DYN) {
+                    if (lane == 0) racc[0][ui] += vx, racc[1][ui] += vy;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RPW; q++) {
+                        const bool mine = (lane == 0) & (ui == wave * RPW + q);
+                        ax[q] += mine ? vx : 0.0f;
+                        ay[q] += mine ? vy : 0.0f;
+                    }
+                }
+            }
+            evals += (unsigned)nlen;
+            nlen = 0;
+        };
 #pragma unroll DYN ? 1 : RPW
         for (int uu = 0; uu < (DYN ? RPB : RPW); uu++) {
             int ur = wave * RPW + uu;                 // receiver within the workgroup
@@ -540,6 +615,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 if (ur >= RPB) break;
             }
             const int u = DYN ? 0 : uu;               // accumulator slot
+            cur_recv = ur;
             {
                 const float4 q = rrec[ur];
                 ru.x = q.x, ru.y = q.y, ru.c = q.z, ru.s = q.w;
@@ -609,8 +685,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     const int b2 = __builtin_ctz(ins);
                     ins &= ins - 1u;
                     const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
-                    field_twod_x2<true>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
-                                        lds_pair(ts, i0, i1), true, true, ax[u], ay[u]);
+                    bool n0, n1;
+                    field_twod_x2<true, true>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
+                                              lds_pair(ts, i0, i1), true, true, ax[u], ay[u], &n0, &n1);
+                    if (__ballot(n0 | n1) != 0ull) {
+                        near_note(n0, i0);
+                        near_note(n1, i1);
+                    }
                     evals += 2 * WAVE;
                 }
                 cand = (cand & ~inside) | ins;  // an odd one out takes the queue together with the partial batches
@@ -653,15 +734,16 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 ax[0] = ay[0] = 0.0f;
             }
         }
+        near_drain();
     }
     if (DYN) {
         __syncthreads();
         if (threadIdx.x < RPB) {
             const int64_t a = ragent[threadIdx.x];
-            if (a >= 0) d.part[(int64_t)(d.part_base + chunk) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
+            if (a >= 0) d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
         }
     } else {
-        reduce_store(d, 0, lane, ax, ay, &ragent[wave * RPW], chunk);
+        reduce_store(d, j0, lane, ax, ay, &ragent[wave * RPW]);
     }
     if (d.pair_count != nullptr && lane == 0) {
         atomicAdd(d.pair_count, (unsigned long long)evals);
@@ -718,7 +800,10 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
         int cnt = (int)((iend - base) < TILE ? (iend - base) : TILE);  // multiple of 64
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
-            tile[t] = d.rec[base + t];
+            const float2 o = d.rorg[base + t];
+            float4 q = d.rec[base + t];
+            q.x += o.x, q.y += o.y;                               // scene coordinates
+            tile[t] = q;
             if (BICYCLE) tile2[t] = d.rec2[base + t];
             if (HET) tcls[t] = base + t < d.n ? d.cls[base + t] : (uint8_t)0;   // (padding records are sentinels of any set)
         }
@@ -731,6 +816,18 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
             for (int u = 0; u < RPW; u++) {
                 float dx = r[u].x - q.x, dy = r[u].y - q.y;  // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
+                {   // near sources (rare): (dx, dy) from the precise records (precise_delta); this kernel's sources sit in slot order
+                    const bool nr = r2 < d.pc.rnear2;
+                    const int64_t jr = j0 + u;
+                    if (__ballot(nr) != 0ull && jr < d.hi) {
+                        float px, py;
+                        float4 qs;
+                        precise_delta(d, (int32_t)jr, nr ? (int32_t)(base + t) : (int32_t)jr, px, py, qs);
+                        dx = nr ? px : dx;
+                        dy = nr ? py : dy;
+                        r2 = dx * dx + dy * dy;
+                    }
+                }
                 bool in = tracked<P2R>(ks.chs, r[u], dx, dy, r2);
                 r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
@@ -758,30 +855,20 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     __shared__ float2 tile2[TILE];
     __shared__ float4 tbnd[TILE / WAVE];
     __shared__ float4 rrec[WPB * RW];
-    __shared__ int ragent[WPB * RW];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // receivers by place of the binned order, everything relative to the origin of the first one's place (recv_count)
-    const int64_t nrecv = recv_count(d);
-    const int64_t jg = (int64_t)blockIdx.x * WPB * RW;
-    const int64_t pg = recv_place(d, jg);
-    const float2 og = d.orgs[pg];
-    const int chunk = chunk_near_first(d, pg);
+    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RW;
     int64_t ibeg, iend;
-    source_chunk(d, ibeg, iend, chunk);
+    source_chunk(d, ibeg, iend);
     if (d.bnd_next != nullptr && blockIdx.y == 0) {   // the next tick's bounding circles (see pair_cull_kernel)
         for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
     if (ibeg >= iend) return;
     if (threadIdx.x < WPB * RW) {
-        const int64_t j = jg + threadIdx.x;
-        const int64_t p = recv_place(d, j < nrecv ? j : nrecv - 1);   // clamp: results of the duplicates are not stored
-        const int32_t a = d.perm[p];
-        const float4 q = d.recs[p];
-        const float2 o = d.orgs[p];
-        rrec[threadIdx.x] = make_float4(q.x + (o.x - og.x), q.y + (o.y - og.y), q.z, q.w);
-        ragent[threadIdx.x] = (j < nrecv && a < d.n) ? a : -1;
+        const int64_t j = d.lo + (int64_t)blockIdx.x * WPB * RW + threadIdx.x;
+        const int64_t jc = j < d.hi ? j : d.hi - 1;       // clamp: results of the duplicates are not stored
+        rrec[threadIdx.x] = d.recg[jc];                    // scene coordinates, identical with the slot's entry of recs
     }
     float ax[RW], ay[RW];
 #pragma unroll
@@ -794,15 +881,10 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
         const int nb = cnt >> 6;
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
-            const float4 q = d.recs[base + t];
-            const float2 o = d.orgs[base + t];
-            tile[t] = make_float4(q.x + (o.x - og.x), q.y + (o.y - og.y), q.z, q.w);
+            tile[t] = d.recs[base + t];
             tile2[t] = d.recs2[base + t];
         }
-        if ((int)threadIdx.x < nb) {
-            const float4 bb = d.bnd[(base >> 6) + threadIdx.x];       // (scene coordinates)
-            tbnd[threadIdx.x] = make_float4(bb.x - og.x, bb.y - og.y, bb.z, 0.0f);
-        }
+        if ((int)threadIdx.x < nb) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < RW / 4; ps++) {
@@ -831,8 +913,21 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
                 const int t = (b << 6) + lane;
                 const float4 q = tile[t];
                 const float2 qb = tile2[t];
-                const float dx = r.x - q.x, dy = r.y - q.y;          // vehicle.py:1615-1616
+                float dx = r.x - q.x, dy = r.y - q.y;                // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
+                {                                                    // near sources (rare): (dx, dy) from the precise records
+                    const bool nr = r2 < d.pc.rnear2;                // (precise_delta)
+                    const int64_t jr = j0 + u;
+                    if (__ballot(nr) != 0ull && jr < d.hi) {
+                        const int32_t as = nr ? d.perm[base + t] : (int32_t)jr;   // (the receiver itself: a zero, masked below)
+                        float px, py;
+                        float4 qs;
+                        precise_delta(d, (int32_t)jr, as, px, py, qs);
+                        dx = nr ? px : dx;
+                        dy = nr ? py : dy;
+                        r2 = dx * dx + dy * dy;
+                    }
+                }
                 float F, gx, gy;
                 if ((inside >> b) & 1u) {                            // (uniform) every source of the batch is tracked
                     field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
@@ -852,7 +947,7 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
     for (int h = 0; h < RW / 4; h++) {
         const float bx4[4] = {ax[4 * h], ax[4 * h + 1], ax[4 * h + 2], ax[4 * h + 3]};
         const float by4[4] = {ay[4 * h], ay[4 * h + 1], ay[4 * h + 2], ay[4 * h + 3]};
-        reduce_store(d, 0, lane, bx4, by4, &ragent[wave * RW + 4 * h], chunk);
+        reduce_store(d, j0 + 4 * h, lane, bx4, by4);
     }
 }
 
@@ -982,9 +1077,8 @@ void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st) {
     hipLaunchKernelGGL(untracked_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, out);
 }
 
-// by_place: the kernels on binned records take their receivers by place (recv_count); the others by slot [lo, hi)
-static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW, bool by_place = false) {
-    int64_t nloc = (by_place && !d.rlist && d.classify) ? d.n_places : d.hi - d.lo;
+static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
+    int64_t nloc = d.hi - d.lo;
     int64_t per_block = per_block_recv;
     return dim3((unsigned)((nloc + per_block - 1) / per_block), (unsigned)split, 1);
 }
@@ -992,19 +1086,19 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW, b
 // every launch of this file: optional events take the kernel's own start / end time stamps (csf_dev.h)
 #define CSF_LAUNCH(kernel, grid) hipExtLaunchKernelGGL(kernel, grid, dim3(BLOCK), 0, st, t0, t1, 0, d)
 
-template <bool P2R, bool CLASSIFY, bool SKIP>
+template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
-        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32, true));
-        else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split, WPB * RPW, true));
+        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
+        else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
         return;
     }
     if (d.dyn_recv && d.rpb == 32) {
-        CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true, 32>), recv_grid(d, d.n_split, 32, true));
+        CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32>), recv_grid(d, d.n_split, 32));
         return;
     }
-    if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, true>), recv_grid(d, d.n_split, WPB * RPW, true));
-    else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, SKIP, false>), recv_grid(d, d.n_split, WPB * RPW, true));
+    if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), recv_grid(d, d.n_split));
+    else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), recv_grid(d, d.n_split));
 }
 
 static void launch_cull(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
@@ -1039,13 +1133,12 @@ void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
         }
     } else if (d.p.model == CSF_BICYCLE && d.classify && d.recs_valid) {
         if (d.rpb == 32) {
-            const dim3 g8 = recv_grid(d, d.n_split, 32, true);
+            const dim3 g8 = recv_grid(d, d.n_split, 32);
             if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 8>), g8);
             else CSF_LAUNCH((pair_bike_kernel<false, 8>), g8);
         } else {
-            const dim3 g4 = recv_grid(d, d.n_split, WPB * RPW, true);
-            if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 4>), g4);
-            else CSF_LAUNCH((pair_bike_kernel<false, 4>), g4);
+            if (p2r) CSF_LAUNCH((pair_bike_kernel<true, 4>), g);
+            else CSF_LAUNCH((pair_bike_kernel<false, 4>), g);
         }
     } else if (d.p.model == CSF_BICYCLE) {
         if (p2r) CSF_LAUNCH((pair_kernel<1, true>), g);

@@ -507,31 +507,70 @@ def test_road_force_exponent_paths_vs_oracle(amd, sigmas):
     assert np.isfinite(fy[0]) and abs(fy[0] - fdy[0] - r0y[0]) < 2e-5
 
 
+def fov_edge_flips(p, st, recv, fx, fy, fdx, fdy, ox, oy, tol):
+    """Receivers whose force differs from the oracle's by ONE source that sits on the edge of the field of view: the
+    fp32 test |bearing| < hfov / 2 (intersection.py:733-736) decides such a source the other way than fp64 does
+    (DESIGN D6: a pair is 'on the edge' when its bearing is within the rounding of the fp32 scene coordinates,
+    2 x 8e-6 m / distance, + 2e-7 rad of arithmetic).  For every receiver of `recv`: is there such a source whose force,
+    added to / taken out of the oracle's repulsive sum (then clamped to |F_dest| and added to it, intersection.py:
+    841-848), reproduces the engine's force to `tol`?  Returns the list of (receiver, source, distance, rad from the edge)."""
+    half = 0.5 * p.hfov
+    out = []
+    for j in recv:
+        bx, by = st[:, 0] - st[j, 0], st[:, 1] - st[j, 1]
+        rho = np.hypot(bx, by); rho[j] = np.inf
+        bear = (np.arctan2(by, bx) - st[j, 2] + np.pi) % (2 * np.pi) - np.pi
+        edge = np.abs(np.abs(bear) - half)
+        sx, sy = orc.column_sums(p, st[:, 0], st[:, 1], st[:, 2], st[:, 3], np.array([j]))
+        for i in np.where(edge < 2e-7 + 1.6e-5 / rho)[0]:
+            pfx, pfy = orc.pair_twod(p, st[i, :3], st[j:j + 1, 0], st[j:j + 1, 1], st[j:j + 1, 2])
+            sgn = -1.0 if abs(bear[i]) < half else 1.0         # fp64 tracks it: fp32 dropped it; and the other way round
+            rx, ry = sx[0] + sgn * pfx[0], sy[0] + sgn * pfy[0]
+            lim, mag = np.hypot(fdx[j], fdy[j]), np.hypot(rx, ry)
+            if mag > lim:
+                rx, ry = rx * lim / mag, ry * lim / mag
+            if max(abs(fx[j] - fdx[j] - rx), abs(fy[j] - fdy[j] - ry)) < tol:
+                out.append((int(j), int(i), float(rho[i]), float(edge[i])))
+                break
+    return out
+
+
 @pytest.mark.parametrize("model", ["twod", "invpend"])
 def test_full_size_ticks_vs_oracle(amd, model):
     """BASELINE configs 1 and 3 at their full size (16 384 agents, 200 m box): a few whole ticks against the CPU oracle,
-    which evaluates every pair in fp64 (the engine runs with its far-field cull on)."""
+    which evaluates every pair in fp64 (the engine runs with its far-field cull on).  Forces: 1e-4 of the largest force
+    for EVERY receiver, except those where one source sits on the edge of the field of view (fov_edge_flips: a handful
+    among 2.7e8 pairs; shown, counted, and bounded)."""
     n, box, ticks = 16384, 200.0, 3
     x, y, psi, v, off, dq = synthetic_population(n, box)
     ns = orc.N_STATES[MODELS[model]]
     s0 = np.zeros((n, ns)); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
     e = make_engine(amd, model, s0, 5.0, off, dq)
     assert np.isfinite(e.far_radius()) and e.far_radius() < box * 2 ** 0.5
-    pop = orc.Population(orc.default_params(model), s0, 5.0, off, dq)
-    e.step(ticks); pop.step(ticks)
+    p = orc.default_params(model)
+    pop = orc.Population(p, s0, 5.0, off, dq)
+    e.step(ticks); pop.step(ticks - 1)
+    st = pop.state()                                            # what the forces of the last tick are evaluated on
+    pop.step(1)
     got, ref = e.state(), pop.state()
     moved = np.abs(ref[:, :2] - s0[:, :2]).max()
     err = np.abs(got[:, :2] - ref[:, :2]).max()
     print(f"{model} N={n}: max |dpos| after {ticks} ticks = {err:.3e} m (agents moved up to {moved:.3f} m)")
     assert err < 1e-4 * moved                                   # 1e-4 relative to the distance covered
     fx, fy = e.forces(); ox, oy = pop.forces()
+    fdx, fdy, _, _ = e.force_parts()
     scale = np.hypot(ox, oy).max()
     df = np.abs(np.c_[fx - ox, fy - oy]).max(axis=1)
+    suspects = np.where(df > 2e-5 * scale)[0]
+    flips = fov_edge_flips(p, st, suspects, fx, fy, fdx, fdy, ox, oy, 2e-5 * scale)
+    for j, i, rho, edge in flips:
+        print(f"   receiver {j}: error {df[j] / scale:.2e} of the largest force = source {i}, {rho:.1f} m away, {edge:.1e} rad from the edge of the field of view")
+    rest = np.ones(n, dtype=bool); rest[[f[0] for f in flips]] = False
     print(f"   force error / max force: median {np.median(df) / scale:.2e}, 99.9 % {np.percentile(df, 99.9) / scale:.2e}, "
-          f"max {df.max() / scale:.2e}")
-    # (a few of the 2.7e8 pairs are centimetres apart: the records are offsets from origins of their own and the pair
-    # kernel works relative to an origin beside its receivers, so the fp32 pair distance holds there as well)
-    assert np.median(df) < 2e-6 * scale and np.percentile(df, 99.9) < 2e-5 * scale and df.max() < 1e-4 * scale
+          f"max {df.max() / scale:.2e}; without the {len(flips)} edge cases max {df[rest].max() / scale:.2e}")
+    # (pairs centimetres apart are corrected from the precise records, csf_pair.hip: precise_delta)
+    assert np.median(df) < 2e-6 * scale and np.percentile(df, 99.9) < 2e-5 * scale
+    assert df[rest].max() < 1e-4 * scale and len(flips) <= 6 and df.max() < 5e-3 * scale
     assert (e.status() == 0).all()
 
 
