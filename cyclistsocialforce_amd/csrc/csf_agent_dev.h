@@ -1,0 +1,681 @@
+// csf_agent_dev.h — the per-agent tick as device functions (fp64, one lane per agent): destination queue and navigation
+// state machine, destination force (straight line / spline planner), controller + kinematics of the five rider models,
+// ring-buffer bookkeeping and the fp32 source record.  Shared by agent_kernel (csf_agent.hip) and the one-launch tick of
+// small populations (csf_tick.hip).  Reference lines are cited at every function.
+#pragma once
+#include "csf_dev.h"
+
+namespace csf {
+
+
+constexpr double PI = 3.141592653589793238462643383279502884;
+
+// utils.py:124-139
+__device__ __forceinline__ double limit_angle(double th) {
+    th = floor(th / (2 * PI)) * (-2 * PI) + th;
+    if (th > PI) th -= 2 * PI;
+    else if (th < -PI) th += 2 * PI;
+    return th;
+}
+
+// utils.py:167-182: signed shortest rotation a1 -> a2 (ties resolve to +)
+__device__ __forceinline__ double angle_diff(double a1, double a2) {
+    double da = fabs(a1 - a2);
+    if (da > PI) da = 2 * PI - da;
+    double t1 = fabs(limit_angle(a1 - da) - a2), t2 = fabs(limit_angle(a1 + da) - a2);
+    return t1 < t2 ? -da : da;
+}
+
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmax(fmin(x, hi), lo); }
+
+// Registers of one agent while it is being ticked.
+struct Agent {
+    int64_t a;
+    double x, y, psi, v, delta, theta;
+    double vdes;
+    int64_t qb;   // first row of the destination queue
+    int32_t K;    // rows
+    int32_t ptr;
+    int32_t zn;   // 0 cruise, 1 brake, 2 arrived
+    double zv0, zd0, zd1;
+    int32_t ti;
+    uint32_t st;
+    double cpsi, spsi;  // cos / sin of psi when the integrator has just computed them (cs_fresh), for the fp32 record
+    bool cs_fresh;
+    // the parameter set of this road user (vehicle.py:64-204: every vehicle owns one): the engine's only one in the kernel
+    // arguments, or its row of the class table; pb: the PlanarBicycle step matrices that belong to it (Dev::pb)
+    const csf_params *p;
+    const double *pb;
+};
+
+// HET: the population holds more than one parameter set (csf_set_param_classes)
+template <bool HET>
+__device__ __forceinline__ void agent_params(const Dev &d, int64_t a, Agent &g) {
+    if (HET) {
+        const int c = d.cls[a];
+        g.p = d.ptab + c;
+        g.pb = d.pbtab + 7 * c;
+    } else {
+        g.p = &d.p;
+        g.pb = d.pb;
+    }
+}
+
+__device__ __forceinline__ double qx(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k)]; }
+__device__ __forceinline__ double qy(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k) + 1]; }
+__device__ __forceinline__ bool qstop(const Dev &d, const Agent &g, int k) {
+    return d.q[3 * (g.qb + k) + 2] != 0.0;
+}
+
+// vehicle.py:596-604
+__device__ __forceinline__ double dest_dist(const Dev &d, const Agent &g) {
+    double ex = qx(d, g, g.ptr) - g.x, ey = qy(d, g, g.ptr) - g.y;
+    return sqrt(ex * ex + ey * ey);
+}
+
+// vehicle.py:545-594
+__device__ __forceinline__ void update_destination(const Dev &d, Agent &g) {
+    if (g.zn != 0) return;                                    // :567-568
+    double dnext = dest_dist(d, g);
+    if (dnext <= g.p->d_arrived_inter) g.ptr = min(g.ptr + 1, g.K - 1);   // :571-574
+    if (g.ptr < g.K - 1) {                                    // :577-583
+        double ex = qx(d, g, g.ptr + 1) - g.x, ey = qy(d, g, g.ptr + 1) - g.y;
+        if (sqrt(ex * ex + ey * ey) < dnext) g.ptr += 1;
+    }
+}
+
+// vehicle.py:354-457.  Returns the desired speed; ddest through the reference argument.
+__device__ __forceinline__ double update_nav(const Dev &d, Agent &g, double &ddest) {
+    const csf_params &p = *g.p;
+    const double k = 1.5;                                     // :377
+    double d0, d1;
+    if (g.zn == 0) {                                          // :379-386
+        d0 = 0.5 * (p.v_max_harddecel * p.v_max_harddecel - g.v * g.v) / p.a_desired_default[0];
+        d1 = 0.5 * -(p.v_max_harddecel * p.v_max_harddecel) / p.a_max[0];
+    } else {
+        d0 = g.zd0;
+        d1 = g.zd1;
+    }
+    ddest = dest_dist(d, g);
+    bool x0 = qstop(d, g, g.ptr);                             // :397-400
+    bool x1 = ddest <= k * (d0 + d1), x2 = ddest <= p.d_arrived_stop, x3 = g.v <= p.v_max_stop;
+    bool z0 = g.zn == 0, z1 = g.zn == 1, z2 = g.zn == 2;
+    bool n0 = !x0 || (x0 && !x1 && ((z0 && !x2) || z1));      // :404-406
+    bool n1 = x0 && ((z0 && ((!x2 && x1) || (x2 && !x3))) || (z1 && x1 && (!x2 || !x3)));
+    bool n2 = x0 && (((z0 || z1) && x2 && x3) || z2);         // :414
+    if ((int)n0 + (int)n1 + (int)n2 != 1) g.st |= CSF_ST_NAVSTATE;  // reference only prints (:416-425)
+    if (z0 && n1) {                                           // :428-430
+        g.zv0 = g.v;
+        g.zd0 = d0;
+        g.zd1 = d1;
+    }
+    g.zn = n0 ? 0 : (n1 ? 1 : 2);
+    if (n0) return g.vdes;                                    // :434-435
+    if (n1) {                                                 // :436-450
+        if (ddest < k * g.zd1) return p.v_max_harddecel / g.zd1 * ddest * 1 / k;
+        return (g.zv0 - p.v_max_harddecel) / g.zd0 * (ddest - g.zd1) * 1 / k + p.v_max_harddecel;
+    }
+    return 0.0;                                               // :452-453
+}
+
+// vehicle.py:1150-1194 / 2078-2108
+__device__ __forceinline__ void direct_approach(const Dev &d, Agent &g, double &fx, double &fy) {
+    update_destination(d, g);
+    double ddest, vd = update_nav(d, g, ddest);
+    if (ddest > 0) {
+        fx = -vd * (g.x - qx(d, g, g.ptr)) / ddest;
+        fy = -vd * (g.y - qy(d, g, g.ptr)) / ddest;
+    } else {
+        fx = 0;
+        fy = 0;
+    }
+}
+
+// ---- cubic B-spline through M in {4,5,6} points (scipy splprep(s=0) + splev, vehicle.py:1496-1510) ----
+// Chord-length parameter u, clamped knots with interior knots u[2..M-3] (FITPACK's rule for s = 0).  The end
+// conditions make the first and last coefficient equal the end points, so only an (M-2)x(M-2) totally positive
+// system remains; it is eliminated without pivoting.  Everything is templated on M and unrolled so that knots
+// and coefficients live in registers: a span is chosen with selects, never with an indexed load (indexed
+// per-lane arrays go to scratch memory, which made this kernel latency-bound).
+template <int M>
+struct Spline {
+    double t[M + 4];
+    double cx[M], cy[M];
+};
+
+// the six knots t[l-2..l+3] and four coefficients c[l-3..l] of the span l = 3 + si that contains u
+struct Window {
+    double k[6];
+    double x[4], y[4];
+};
+
+template <int M>
+__device__ __forceinline__ void window_at(const Spline<M> &s, double u, Window &w) {
+    int si = 0;  // interior knots <= u; u = 1 falls into the last span (fpbspl / splev convention)
+#pragma unroll
+    for (int j = 0; j < M - 4; j++) si += (u >= s.t[4 + j]) ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        double v = s.t[1 + q];
+#pragma unroll
+        for (int c = 1; c <= M - 4; c++) v = (si == c) ? s.t[1 + q + c] : v;
+        w.k[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double vx = s.cx[q], vy = s.cy[q];
+#pragma unroll
+        for (int c = 1; c <= M - 4; c++) {
+            vx = (si == c) ? s.cx[q + c] : vx;
+            vy = (si == c) ? s.cy[q + c] : vy;
+        }
+        w.x[q] = vx;
+        w.y[q] = vy;
+    }
+}
+
+// non-zero cubic basis values N3[0..3] at u for the window's span (Cox - de Boor), plus the quadratic and
+// linear ones that the derivatives use.  k[2] = t[l], k[3] = t[l+1].
+__device__ __forceinline__ void basis(const double (&k)[6], double u, double N3[4], double N2[3], double N1[2]) {
+    const double a1 = u - k[2], b1 = k[3] - u;
+    const double w = 1.0 / (k[3] - k[2]);
+    N1[0] = b1 * w;
+    N1[1] = a1 * w;
+    const double a2 = u - k[1], b2 = k[4] - u;
+    const double w0 = N1[0] / (k[3] - k[1]), w1 = N1[1] / (k[4] - k[2]);
+    N2[0] = b1 * w0;
+    N2[1] = a2 * w0 + b2 * w1;
+    N2[2] = a1 * w1;
+    const double a3 = u - k[0], b3 = k[5] - u;
+    const double v0 = N2[0] / (k[3] - k[0]), v1 = N2[1] / (k[4] - k[1]), v2 = N2[2] / (k[5] - k[2]);
+    N3[0] = b1 * v0;
+    N3[1] = a3 * v0 + b2 * v1;
+    N3[2] = a2 * v1 + b3 * v2;
+    N3[3] = a1 * v2;
+}
+
+template <int M>
+__device__ __forceinline__ bool spline_fit(Spline<M> &s, const double (&px)[M], const double (&py)[M]) {
+    double u[M];
+    u[0] = 0;
+    bool ok = true;
+#pragma unroll
+    for (int r = 1; r < M; r++) {
+        const double ex = px[r] - px[r - 1], ey = py[r] - py[r - 1];
+        const double dd = sqrt(ex * ex + ey * ey);
+        ok = ok && (dd > 0.0);  // splprep raises ValueError on duplicate consecutive points
+        u[r] = u[r - 1] + dd;
+    }
+    if (!ok) return false;
+    const double tot = u[M - 1];
+#pragma unroll
+    for (int r = 1; r < M - 1; r++) u[r] /= tot;
+    u[M - 1] = 1.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        s.t[j] = 0.0;
+        s.t[M + j] = 1.0;
+    }
+#pragma unroll
+    for (int j = 0; j < M - 4; j++) s.t[4 + j] = u[2 + j];
+    // collocation rows of the interior points u_1 .. u_{M-2}; the span of u_r is known statically:
+    // u_1 is in the first span, u_r (2 <= r <= M-3) is the interior knot t[r+2], u_{M-2} is in the last span
+    constexpr int Q = M - 2;
+    double A[Q][Q], bx[Q], by[Q];
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+#pragma unroll
+        for (int c = 0; c < Q; c++) A[r][c] = 0.0;
+        const int si = (r == 0) ? 0 : ((r < M - 4) ? r : M - 4);  // row r is point r+1
+        double k[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) k[q] = s.t[1 + si + q];
+        double N3[4], N2[3], N1[2];
+        basis(k, u[r + 1], N3, N2, N1);
+        double rx = px[r + 1], ry = py[r + 1];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int c = si + j;  // coefficient index
+            if (c == 0) {
+                rx -= N3[j] * px[0];
+                ry -= N3[j] * py[0];
+            } else if (c == M - 1) {
+                rx -= N3[j] * px[M - 1];
+                ry -= N3[j] * py[M - 1];
+            } else {
+                A[r][c - 1] = N3[j];
+            }
+        }
+        bx[r] = rx;
+        by[r] = ry;
+    }
+#pragma unroll
+    for (int c = 0; c < Q; c++) {
+        const double ip = 1.0 / A[c][c];
+#pragma unroll
+        for (int r = c + 1; r < Q; r++) {
+            const double f = A[r][c] * ip;
+#pragma unroll
+            for (int j = c; j < Q; j++) A[r][j] -= f * A[c][j];
+            bx[r] -= f * bx[c];
+            by[r] -= f * by[c];
+        }
+    }
+#pragma unroll
+    for (int r = Q - 1; r >= 0; r--) {
+        double sx = bx[r], sy = by[r];
+#pragma unroll
+        for (int j = r + 1; j < Q; j++) {
+            sx -= A[r][j] * bx[j];
+            sy -= A[r][j] * by[j];
+        }
+        bx[r] = sx / A[r][r];
+        by[r] = sy / A[r][r];
+    }
+    s.cx[0] = px[0];
+    s.cy[0] = py[0];
+#pragma unroll
+    for (int r = 0; r < Q; r++) {
+        s.cx[r + 1] = bx[r];
+        s.cy[r + 1] = by[r];
+    }
+    s.cx[M - 1] = px[M - 1];
+    s.cy[M - 1] = py[M - 1];
+    return true;
+}
+
+template <int M>
+__device__ __forceinline__ void spline_pos(const Spline<M> &s, double u, double &X, double &Y) {
+    Window w;
+    window_at(s, u, w);
+    double N3[4], N2[3], N1[2];
+    basis(w.k, u, N3, N2, N1);
+    X = N3[0] * w.x[0] + N3[1] * w.x[1] + N3[2] * w.x[2] + N3[3] * w.x[3];
+    Y = N3[0] * w.y[0] + N3[1] * w.y[1] + N3[2] * w.y[2] + N3[3] * w.y[3];
+}
+
+// position, first and second derivative at u (splev with der = 0, 1, 2)
+template <int M>
+__device__ __forceinline__ void spline_all(const Spline<M> &s, double u, double &X, double &Y, double &dX,
+                                           double &dY, double &ddX, double &ddY) {
+    Window w;
+    window_at(s, u, w);
+    double N3[4], N2[3], N1[2];
+    basis(w.k, u, N3, N2, N1);
+    X = N3[0] * w.x[0] + N3[1] * w.x[1] + N3[2] * w.x[2] + N3[3] * w.x[3];
+    Y = N3[0] * w.y[0] + N3[1] * w.y[1] + N3[2] * w.y[2] + N3[3] * w.y[3];
+    double ex[3], ey[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {  // c'_j = 3 (c_{j+1} - c_j) / (t_{j+4} - t_{j+1})
+        const double f = 3.0 / (w.k[q + 3] - w.k[q]);
+        ex[q] = f * (w.x[q + 1] - w.x[q]);
+        ey[q] = f * (w.y[q + 1] - w.y[q]);
+    }
+    dX = N2[0] * ex[0] + N2[1] * ex[1] + N2[2] * ex[2];
+    dY = N2[0] * ey[0] + N2[1] * ey[1] + N2[2] * ey[2];
+    double gx[2], gy[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const double f = 2.0 / (w.k[q + 3] - w.k[q + 1]);
+        gx[q] = f * (ex[q + 1] - ex[q]);
+        gy[q] = f * (ey[q + 1] - ey[q]);
+    }
+    ddX = N1[0] * gx[0] + N1[1] * gx[1];
+    ddY = N1[0] * gy[0] + N1[1] * gy[1];
+}
+
+// vehicle.py:1494-1558 once the M control points are known
+template <int M>
+__device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const double (&px)[M], const double (&py)[M], bool last,
+                             double vd, double &fx, double &fy) {
+    const int nS = 20, ipred = 3, ipredlast = 5;              // :1446-1448
+    Spline<M> s;
+    if (!spline_fit(s, px, py)) {                             // :1495-1507 raises in the reference
+        g.st |= CSF_ST_SPLINE;
+        fx = 0;
+        fy = 0;
+        return;
+    }
+    int i = 1;                                                // :1516-1522
+    if (last) {
+        double best = INFINITY;
+        for (int k = 0; k < nS; k++) {
+            double X, Y;
+            spline_pos(s, k == nS - 1 ? 1.0 : (double)k / (nS - 1), X, Y);
+            const double dd = (X - g.x) * (X - g.x) + (Y - g.y) * (Y - g.y);
+            if (dd < best) {
+                best = dd;
+                i = k;
+            }
+        }
+    }
+    const int iprev = i + (qstop(d, g, g.ptr) ? ipredlast : ipred);  // :1523-1526
+    if (iprev < nS) {                                         // :1529-1553
+        const double ui = i == nS - 1 ? 1.0 : (double)i / (nS - 1);
+        const double up = iprev == nS - 1 ? 1.0 : (double)iprev / (nS - 1);
+        double X0, Y0, X1, Y1, dX, dY, ddX, ddY;
+        spline_all(s, ui, X0, Y0, dX, dY, ddX, ddY);
+        spline_pos(s, up, X1, Y1);
+        const double sp = sqrt(dX * dX + dY * dY);
+        const double R = sp * sp * sp / fabs(dX * ddY - dY * ddX);  // :1532-1537
+        const double thetacomf = 10 * (2 * PI / 360);         // :1541
+        double v = fmax(2.5, sqrt(thetacomf * g.p->g * R));    // :1542-1544
+        v = fmin(v, vd);                                      // :1545
+        const double ex = X1 - X0, ey = Y1 - Y0;
+        const double tmp = v / sqrt(ex * ex + ey * ey);       // :1548-1553
+        fx = tmp * ex;
+        fy = tmp * ey;
+    } else {
+        direct_approach(d, g, fx, fy);                        // :1555-1556 (second queue + nav update)
+    }
+}
+
+// vehicle.py:1416-1558
+__device__ __forceinline__ void twod_dest(const Dev &d, Agent &g, double &fx, double &fy) {
+    update_destination(d, g);                                 // :1451
+    double ddest, vd = update_nav(d, g, ddest);               // :1452
+    if (g.ti == 0) {                                          // :1455-1458
+        fx = vd * cos(g.psi);
+        fy = vd * sin(g.psi);
+        return;
+    }
+    if (g.zn == 2) {                                          // :1461-1462
+        fx = 0;
+        fy = 0;
+        return;
+    }
+    const int hm = d.hist_len - 1;
+    const double h1x = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a], h1y = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
+    const double h0x = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a], h0y = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
+    const bool last = g.ptr + 1 >= g.K;                       // :537-543
+    if (!last) {                                              // :1465-1479: two trajectory points + up to 4 destinations
+        const int cnt = min(g.ptr + 4, g.K) - g.ptr;          // >= 2
+        if (cnt == 2) {
+            const double px[4] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1)};
+            const double py[4] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1)};
+            spline_force<4>(d, g, px, py, false, vd, fx, fy);
+        } else if (cnt == 3) {
+            const double px[5] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1), qx(d, g, g.ptr + 2)};
+            const double py[5] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1), qy(d, g, g.ptr + 2)};
+            spline_force<5>(d, g, px, py, false, vd, fx, fy);
+        } else {
+            const double px[6] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1), qx(d, g, g.ptr + 2), qx(d, g, g.ptr + 3)};
+            const double py[6] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1), qy(d, g, g.ptr + 2), qy(d, g, g.ptr + 3)};
+            spline_force<6>(d, g, px, py, false, vd, fx, fy);
+        }
+    } else {                                                  // :1486-1492: last leg, three trajectory points
+        const int back = max(0, g.ti - d.back);
+        const double px[4] = {d.hx[(int64_t)(back & hm) * d.cap + g.a], h1x, h0x, qx(d, g, g.ptr)};
+        const double py[4] = {d.hy[(int64_t)(back & hm) * d.cap + g.a], h1y, h0y, qy(d, g, g.ptr)};
+        spline_force<4>(d, g, px, py, true, vd, fx, fy);
+    }
+}
+
+template <int MODEL>
+__device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, double &fy) {
+    if (MODEL == CSF_BICYCLE) direct_approach(d, g, fx, fy);  // vehicle.py:1189-1194
+    else {
+        if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) update_destination(d, g);  // Vehicle.calcDestinationForce :295-297
+        twod_dest(d, g, fx, fy);
+    }
+}
+
+// vehicle.py:1218-1272 (Bicycle.control + Bicycle.move; PIDcontroller with ki = kd = 0, dynamics.py:33-54)
+__device__ __forceinline__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) {
+    const csf_params &p = *g.p;
+    double theta = atan2(Fy, Fx);                             // :1223
+    double vd = sqrt(Fx * Fx + Fy * Fy);                      // :1224
+    double ddest = dest_dist(d, g);                           // :1226-1229
+    if (ddest < 3 && g.ptr + 1 >= g.K) vd = (vd / 3) * ddest; // :1231-1232
+    double target = angle_diff(g.psi, theta);                 // :1235
+    double om = p.k_p_delta * angle_diff(g.delta, target);    // :1239-1242
+    double acc = p.k_p_v * (vd - g.v);                        // :1240-1243
+    acc = clampd(acc, p.a_max[0], p.a_max[1]);                // :1249
+    double delta = limit_angle(g.delta + p.t_s * om);         // :1254
+    double v = g.v + p.t_s * acc;                             // :1255
+    delta = clampd(delta, -p.delta_max, p.delta_max);         // :1257
+    v = clampd(v, p.v_max_riding[0], p.v_max_riding[1]);      // :1258
+    double psi = limit_angle(g.psi + p.t_s * v * tan(delta) / p.l);  // :1260-1262
+    sincos(psi, &g.spsi, &g.cpsi);                            // once: the next tick's record needs the same two
+    g.cs_fresh = true;
+    g.y += p.t_s * v * g.spsi;                                // :1264
+    g.x += p.t_s * v * g.cpsi;                                // :1265
+    g.psi = psi;
+    g.v = v;
+    g.delta = delta;
+}
+
+// ---- InvPendulum: exact zero-order-hold step of the speed-dependent closed loop -------------------------
+// vehicle.py:1738-1786, 1810-1848; parameters.py:1832-1892.  control.forced_response over [0, t_s] with
+// constant input equals x+ = E11 x + E12 u with E = exp([[A h, B h],[0, 0]]).  E is formed by scaling and
+// squaring of a degree-12 Taylor polynomial (||M/2^s||_1 <= 1/2); only the 5 non-trivial rows are carried.
+__device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, double Fy) {
+    const csf_params &p = *g.p;
+    const double v = g.v;
+    const double iv = 1.0 / v, iv2 = iv * iv, iv3 = iv2 * iv;
+    const double kx0 = 3.48203226e02 - 5.12057324e03 * iv + 1.58364873e04 * iv2 - 1.98073306e04 * iv3;
+    const double kx1 = -4.51700000e01;
+    const double kx2 = -9.16379250e02 + 1.31769807e04 * iv - 6.57341643e04 * iv2 + 8.22163589e04 * iv3;
+    const double kx3 = 3.20214069e02 - 4.69953797e03 * iv + 1.66378680e04 * iv2 - 2.43114309e04 * iv3;
+    const double kx4 = 2.87549256e-08 - 2.27913445e03 * iv;
+    const double ku = -3.38638984e-09 - 2.27913445e+03 * iv;
+    const double Ktau2 = (v * p.l_2) / (p.g * p.l), K = (v * v) / (p.g * p.l), tau3 = p.l / v;
+    const double tau1sq = (p.i_bike_longlong + p.m * p.h * p.h) / (p.m * p.g * p.h);
+    const double bI = 1.0 / p.i_steer_vertvert, h = p.t_s;
+    double M[5][6];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) M[r][c] = 0.0;
+    M[0][1] = h;
+    M[1][0] = -bI * kx0 * h;
+    M[1][1] = (-p.c_steer * bI - bI * kx1) * h;
+    M[1][2] = -bI * kx2 * h;
+    M[1][3] = -bI * kx3 * h;
+    M[1][4] = -bI * kx4 * h;
+    M[1][5] = ku * bI * h;
+    M[2][3] = h;
+    M[3][0] = -K / tau1sq * h;
+    M[3][1] = -Ktau2 / tau1sq * h;
+    M[3][2] = 1 / tau1sq * h;
+    M[4][0] = 1 / tau3 * h;
+    double nrm = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double col = 0;
+#pragma unroll
+        for (int r = 0; r < 5; r++) col += fabs(M[r][c]);
+        nrm = fmax(nrm, col);
+    }
+    int sq = 0;
+    while (nrm > 0.5 && sq < 40) {
+        nrm *= 0.5;
+        sq++;
+    }
+    const double sc = ldexp(1.0, -sq);
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) M[r][c] *= sc;
+    // Horner: E = I + M (I + M/2 (I + M/3 (... (I + M/12))))   — rows 0..4; row 5 of every term is e5
+    double E[5][6];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) E[r][c] = (r == c ? 1.0 : 0.0) + M[r][c] * (1.0 / 12);
+    // M has 12 non-zero entries (rows 0, 2, 4 one each, row 3 three, row 1 six): the products M E are written out
+    const double m01 = M[0][1], m23 = M[2][3], m40 = M[4][0], m30 = M[3][0], m31 = M[3][1], m32 = M[3][2];
+    for (int k = 11; k >= 1; k--) {
+        double T[5][6];
+        const double ik = 1.0 / k;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            double r1 = (c == 5) ? M[1][5] : 0.0;  // M[:,5] * E[5][c], E row 5 = e5
+#pragma unroll
+            for (int q = 0; q < 5; q++) r1 += M[1][q] * E[q][c];
+            T[0][c] = (c == 0 ? 1.0 : 0.0) + (m01 * E[1][c]) * ik;
+            T[1][c] = (c == 1 ? 1.0 : 0.0) + r1 * ik;
+            T[2][c] = (c == 2 ? 1.0 : 0.0) + (m23 * E[3][c]) * ik;
+            T[3][c] = (c == 3 ? 1.0 : 0.0) + (m30 * E[0][c] + m31 * E[1][c] + m32 * E[2][c]) * ik;
+            T[4][c] = (c == 4 ? 1.0 : 0.0) + (m40 * E[0][c]) * ik;
+        }
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) E[r][c] = T[r][c];
+    }
+    for (int it = 0; it < sq; it++) {
+        double T[5][6];
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double acc = (c == 5) ? E[r][5] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 5; q++) acc += E[r][q] * E[q][c];
+                T[r][c] = acc;
+            }
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) E[r][c] = T[r][c];
+    }
+    const double psi_d = atan2(Fy, Fx);                       // :1832
+    double xn[5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        double acc = E[r][5] * psi_d;
+#pragma unroll
+        for (int c = 0; c < 5; c++) acc += E[r][c] * xl[c];
+        xn[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < 5; r++) xl[r] = xn[r];                // :1843
+    g.psi = limit_angle(xn[4]);                               // :1844
+    g.delta = limit_angle(xn[0]);                             // :1845
+    g.theta = limit_angle(xn[2]);                             // :1846
+}
+
+__device__ __forceinline__ int64_t a_idx(int c, int64_t cap, int64_t a) { return (int64_t)c * cap + a; }
+
+template <int MODEL>
+__device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
+    const csf_params &p = *g.p;
+    const int64_t a = g.a, cap = d.cap;
+    if (MODEL == CSF_BICYCLE) {                               // vehicle.py:1274-1289
+        bike_control_move(d, g, Fx, Fy);
+    } else if (MODEL == CSF_TWOD) {                           // vehicle.py:1386-1414
+        if (g.zn == 2) {
+            g.v = 0;
+            g.delta = 0;
+        } else bike_control_move(d, g, Fx, Fy);
+    } else if (MODEL == CSF_INVPEND) {                        // vehicle.py:1883-1950
+        bool riding = d.zrid[a] != 0;
+        // updateRidingState (:1932-1950): the slice traj[4, imin:i+1] is all inside +-delta_max_walk iff the
+        // run of good samples ending at column i is at least as long as the slice
+        bool cvwalk = g.v < p.v_max_walk;
+        int imin = max(0, (int)((double)g.ti - 1.0 / p.t_s));
+        bool cdelta = d.dgood[a] >= (g.ti - imin + 1);
+        riding = !cvwalk && ((!riding && cdelta) || riding);
+        d.zrid[a] = riding ? 1 : 0;
+        double xl[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) xl[k] = d.lti[k * cap + a];
+        if (g.zn == 2) {                                      // :1898-1899
+            g.v = 0;
+            g.delta = 0;
+            g.theta = 0;
+        } else if (riding) {
+            double vd = sqrt(Fx * Fx + Fy * Fy);              // step_pos :1850-1881 (old psi)
+            double acc = clampd(p.k_p_v * (vd - g.v), p.a_max[0], p.a_max[1]);
+            double v = clampd(g.v + p.t_s * acc, p.v_max_riding[0], p.v_max_riding[1]);
+            g.y += p.t_s * v * sin(g.psi);
+            g.x += p.t_s * v * cos(g.psi);
+            g.v = v;
+            invpend_step_yaw(d, g, xl, Fx, Fy);               // uses the new speed (:1902-1903)
+        } else {                                              // walking :1905-1916
+            g.v = p.v_max_walk;
+            g.theta = 0;
+            bike_control_move(d, g, Fx, Fy);
+            xl[0] = g.delta;
+            xl[1] = 0;
+            xl[2] = g.theta;
+            xl[3] = 0;
+            xl[4] = g.psi;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) d.lti[k * cap + a] = xl[k];
+    } else if (MODEL == CSF_PLANARBIKE) {                     // PlanarTwoWheelerDynamics.step: dynamics.py:225-258
+        // x = (delta, psi) follows x' = (A - B K_x) x + B K_u psi_d with A = [[0, 0], [v / l, 0]], B = (1, 0)^T, K_x placed
+        // for the class's two poles and K_u from a simulated step response, both re-derived for the current speed every
+        // step (dynamics.py:203-223, 1167-1226).  In z = (v delta / l, psi) the closed loop is the same for every speed
+        // (csf_engine.hip: derive_planarbike), so one precomputed exact step does it.
+        const double a = g.v / p.l;                           // the speed BEFORE the speed update (:228)
+        double del = d.lti[a_idx(0, cap, g.a)], psu = d.ppsi[g.a];   // unwrapped (dynamics.py:195-197, 244)
+        const double psi_d = atan2(Fy, Fx), v_d = sqrt(Fy * Fy + Fx * Fx);   // :231-232
+        if (a > 0.0) {
+            const double z0 = a * del, z1 = psu;
+            del = (g.pb[0] * z0 + g.pb[1] * z1 + g.pb[4] * psi_d) / a;   // :235-244
+            psu = g.pb[2] * z0 + g.pb[3] * z1 + g.pb[5] * psi_d;
+        } else {
+            g.st |= CSF_ST_UNCONTROLLABLE;                    // dynamics.py:1212-1214 asserts; here the yaw loop holds still
+        }
+        d.lti[a_idx(0, cap, g.a)] = del;
+        d.ppsi[g.a] = psu;
+        g.psi = limit_angle(psu);                             // :246-247
+        g.delta = limit_angle(del);
+        g.v = v_d + (g.v - v_d) * g.pb[6];                    // PPointSpeedDynamics: dynamics.py:156, 175
+        g.y += p.t_s * g.v * sin(g.psi);                      // :251-258
+        g.x += p.t_s * g.v * cos(g.psi);
+    } else {                                                  // PlanarPoint: dynamics.py:996-1079
+        double vd = sqrt(Fx * Fx + Fy * Fy);                  // :1018
+        double acc = clampd(p.k_p_v * (vd - g.v), p.a_max[0], p.a_max[1]);
+        double v = clampd(g.v + p.t_s * acc, p.v_max_riding[0], p.v_max_riding[1]);
+        double psi_c = limit_angle(atan2(Fy, Fx));            // dynamics.py:112-121
+        double vbar = 0.5 * (v + g.v);                        // :1065
+        // implicit midpoint of psi' = -k (psi - psi_c), x' = v cos psi, y' = v sin psi in closed form
+        double hk = p.t_s * p.k_psi, pu = d.ppsi[a];
+        double pn = (pu * (1 - 0.5 * hk) + hk * psi_c) / (1 + 0.5 * hk);
+        double pm = 0.5 * (pu + pn);
+        g.x += p.t_s * vbar * cos(pm);
+        g.y += p.t_s * vbar * sin(pm);
+        d.ppsi[a] = pn;
+        g.psi = limit_angle(pn);                              // :959-964
+        g.v = v;
+    }
+    // ring-buffer bookkeeping — vehicle.py:1279-1282, 1407-1410, 1923-1926
+    g.ti = (g.ti + 1) % p.traj_len;
+    const int slot = g.ti & (d.hist_len - 1);
+    d.hx[(int64_t)slot * cap + a] = g.x;
+    d.hy[(int64_t)slot * cap + a] = g.y;
+    if (MODEL == CSF_INVPEND) {
+        bool good = (-p.delta_max_walk < g.delta) && (p.delta_max_walk > g.delta);
+        int run = d.dgood[a];
+        d.dgood[a] = good ? min(run + 1, 1 << 30) : 0;
+    }
+}
+
+// fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677.  The position is stored as
+// an offset from `o`, the road user's own origin (csf_dev.h: rorg), formed in fp64: one rounding, of a few metres.
+__device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, int64_t a, const float2 o, double x, double y,
+                                             double psi, double v, bool cs_fresh = false, double c = 0.0, double s = 0.0) {
+    if (!cs_fresh) sincos(psi, &s, &c);
+    const float4 q = make_float4((float)((x - d.ox) - (double)o.x), (float)((y - d.oy) - (double)o.y), (float)c, (float)s);
+    d.rec[a] = q;
+    // scene coordinates = offset + origin, in fp32 (the same sum a rank forms from the records it has gathered, so that
+    // every path sees the same numbers): by slot (the receivers), and the copy in binned order (csf_bin.hip) that the
+    // pair kernel's tiles are filled with
+    const float4 g = make_float4(q.x + o.x, q.y + o.y, q.z, q.w);
+    d.recg[a] = g;
+    if (d.recs_valid) d.recs[d.pos[a]] = g;
+    if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
+        double e = 0.0;
+        if (p.model == CSF_BICYCLE && v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
+        const float2 q2 = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
+        d.rec2[a] = q2;
+        if (d.recs_valid) d.recs2[d.pos[a]] = q2;
+    }
+}
+
+
+}  // namespace csf

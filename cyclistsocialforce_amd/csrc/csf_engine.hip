@@ -101,7 +101,7 @@ struct Knobs {
     int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
     bool comm_second = false;                 // CSF_COMM_STREAM=second
-    int fused = -1;                           // CSF_FUSED: the one-launch tick of small populations (-1: the engine's choice)
+    int fused = 0;                            // CSF_FUSED=1: the one-launch tick of small populations (csf_tick.hip; opt-in)
     double rnear = 1.0;                       // CSF_RNEAR: pairs closer than this (m) are evaluated from the precise records (0: none)
     void read() {
         auto geti = [](const char *name, int dflt) {
@@ -124,7 +124,7 @@ struct Knobs {
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second";
-        fused = geti("CSF_FUSED", -1);
+        fused = geti("CSF_FUSED", 0);
         if (const char *v = getenv("CSF_RNEAR")) rnear = atof(v);
     }
 };
@@ -230,6 +230,12 @@ struct csf_engine {
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, recs2, part, froad, kat2;
     DevBuf<float2> rorg;         // the origin every precise record is relative to, by slot
+    // the one-launch tick of small populations (csf_tick.hip): exchange records (two buffers each), barrier words
+    DevBuf<float4> tk_xa;
+    DevBuf<float2> tk_xb, tk_xc;
+    DevBuf<unsigned long long> tk_bar;
+    unsigned long long tk_bar_base = 0;   // what the barrier's arrival counter has reached
+    bool tick_launched = false;  // a one-launch tick ran since the barrier's abort flag was last read
     bool state_all_current = true;   // every live slot's fp64 state on this device is current (false once a rank has ticked)
     double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
     double last_gather_ms = 0.0;  // all-gather time accumulated by the last csf_profile_read
@@ -559,6 +565,13 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->rorg.alloc(nrec));
+    if (e->cap_user <= TICK_MAX_AGENTS) {
+        const size_t m = TICK_MAX_AGENTS + 64;
+        HIPCHK(e, e->tk_xa.alloc(2 * m));
+        HIPCHK(e, e->tk_xb.alloc(2 * m));
+        HIPCHK(e, e->tk_xc.alloc(2 * m));
+        HIPCHK(e, e->tk_bar.alloc(2));
+    }
     HIPCHK(e, e->sort_vals.alloc(nrec));
     HIPCHK(e, e->rlist.alloc(nrec));
     HIPCHK(e, e->sort_keys.alloc(nrec));
@@ -1384,7 +1397,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -1884,6 +1897,44 @@ static int loopback_exchange(csf_engine *const *g, int world) {
     return CSF_OK;
 }
 
+// csf_step on a small population: the whole tick in one launch, all n_ticks of them in one launch (csf_tick.hip).
+// Opt-in (CSF_FUSED=1): measured on MI355X it only pays for resident loops (csf_step(e, many)) of a handful of road
+// users - 9.0 against 11.4 us per tick for the 3-bike demo, 16 against 13 us at 128 road users, 28 against 15 us at
+// 1 024 (profiles/r3_small_n_rate.txt) - because a tick is bound by the ~7 us of dependent fp64 instructions of ONE
+// road user's planner, controller and kinematics, which a launch more or less does not change, while the exchange of
+// the records between workgroups (a device-scope barrier per tick) costs more than the launch it saves.
+// For one parameter set on one device without the history ring and without per-kernel time stamps.
+static bool one_launch_tick(const csf_engine *e) {
+    const int want = e->knobs.fused > 0;
+    return want && e->tk_bar.p != nullptr && e->classes.size() == 1 && e->world == 1 && !e->nccl && !e->loopback &&
+           e->d.hist == nullptr && e->profile == 0 && e->knobs.fake_world <= 1 && e->d.n_live >= 1 && tick_fits(e->d);
+}
+
+static int step_one_launch(csf_engine *e, int64_t n_ticks) {
+    Dev &d = e->d;
+    const size_t m = TICK_MAX_AGENTS + 64;
+    while (n_ticks > 0) {
+        const int64_t k = std::min<int64_t>(n_ticks, 1 << 16);       // (bounds the run time of one launch)
+        TickArgs t{};
+        for (int b = 0; b < 2; b++) t.xa[b] = e->tk_xa.p + b * m, t.xb[b] = e->tk_xb.p + b * m, t.xc[b] = e->tk_xc.p + b * m;
+        t.barrier = e->tk_bar.p;
+        t.n_ticks = k;
+        t.barrier_base = e->tk_bar_base;
+        if (tick_blocks(d) > 1)                                      // (a single workgroup never touches the counter)
+            e->tk_bar_base += (unsigned long long)tick_blocks(d) * (unsigned long long)(k + 1);   // a barrier per tick + one at the start
+        launch_tick(d, t, e->main);
+        HIPCHK(e, hipGetLastError());
+        d.tick += k;
+        n_ticks -= k;
+    }
+    // the general path finds the records moved by many ticks: circles and order are renewed before its next pair launch
+    e->ticks_since_rebin = REBIN_TICKS;
+    e->bounds_fresh = false;
+    e->tick_launched = true;
+    e->device_ahead = true;
+    return CSF_OK;
+}
+
 int csf_step(csf_engine *e, int64_t n_ticks) {
     if (!e) return CSF_E_ARG;
     if (n_ticks < 0) return fail(e, CSF_E_ARG, "n_ticks must be >= 0");
@@ -1896,6 +1947,7 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
         e->d.tick += n_ticks;
         return CSF_OK;
     }
+    if (n_ticks > 0 && one_launch_tick(e)) return step_one_launch(e, n_ticks);
     for (int64_t t = 0; t < n_ticks; t++) {
         rc = enqueue_tick(e);
         if (rc) return rc;
@@ -1913,6 +1965,12 @@ int csf_sync(csf_engine *e) {
     }
     HIPCHK(e, hipStreamSynchronize(e->main));
     HIPCHK(e, hipStreamSynchronize(e->comm));
+    if (e->tick_launched) {      // did every workgroup of the one-launch tick pass every barrier?
+        unsigned long long flag = 0;
+        HIPCHK(e, hipMemcpy(&flag, e->tk_bar.p + 1, sizeof flag, hipMemcpyDeviceToHost));
+        e->tick_launched = false;
+        if (flag) return fail(e, CSF_E_DEVICE, "the one-launch tick gave up at its grid barrier (the device could not hold the grid): the state is not valid; CSF_FUSED=0 takes the general path");
+    }
     return CSF_OK;
 }
 
@@ -2435,6 +2493,11 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     if (rc) return rc;
     Dev &d = e->d;
     const char *name = pair_kernel_name(d);
+    if (one_launch_tick(e)) {                                    // csf_step takes the one-launch tick: nothing to count
+        if (kernel_name) *kernel_name = "tick_kernel";
+        for (int k = 0; k < 4; k++) counts[k] = -1;
+        return CSF_OK;
+    }
     if (!e->segs.empty()) {                                      // one launch per parameter set: the kernel of the first
         Dev d0 = d;
         d0.p = e->classes[(size_t)e->segs[0].cls];
