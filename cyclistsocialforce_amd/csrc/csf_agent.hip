@@ -286,7 +286,10 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         const float4 q = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
         d.rec[a] = q;
         d.recg[a] = q;
-        if (d.recs_valid) d.recs[d.pos[a]] = q;
+        if (d.recs_valid) {
+            d.recs[d.pos[a]] = q;
+            ((float2 *)&d.recp[d.pos[a]])[0] = make_float2(q.x, q.y);   // (the place keeps its origin)
+        }
         if (d.has_bike) {
             d.rec2[a] = make_float2(0.0f, 1.0f);
             if (d.recs_valid) d.recs2[d.pos[a]] = make_float2(0.0f, 1.0f);

@@ -667,7 +667,11 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     // pair kernel's tiles are filled with
     const float4 g = make_float4(q.x + o.x, q.y + o.y, q.z, q.w);
     d.recg[a] = g;
-    if (d.recs_valid) d.recs[d.pos[a]] = g;
+    if (d.recs_valid) {
+        const int32_t p = d.pos[a];
+        d.recs[p] = g;
+        d.recp[p] = make_float4(q.x, q.y, o.x, o.y);
+    }
     if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
         double e = 0.0;
         if (p.model == CSF_BICYCLE && v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);

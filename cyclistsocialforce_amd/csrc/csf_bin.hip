@@ -75,8 +75,11 @@ __global__ void sorted_copy_kernel(const Dev d) {
     float4 q = d.rec[a];
     if (rec_is_real(q)) {                                     // scene coordinates: offset + the slot's origin
         const float2 o = d.rorg[a];
+        d.recp[p] = make_float4(q.x, q.y, o.x, o.y);
         q.x += o.x, q.y += o.y;
         d.recg[a] = q;                                        // (a receiver must coincide with itself as a source)
+    } else {
+        ((float2 *)&d.recp[p])[0] = make_float2(q.x, q.y);   // (the place keeps its origin)
     }
     d.recs[p] = q;
     if (d.has_bike) d.recs2[p] = d.rec2[a];
@@ -122,6 +125,12 @@ __global__ __launch_bounds__(256) void rebase_kernel(const Dev d) {
         d.pos[a] = (int32_t)p;
     } else if (a < d.n_pad) {
         d.pos[a] = (int32_t)p;                                 // (a free slot's place: where an arrival spawned into it will sit)
+    }
+    {   // the precise record by place; an empty place takes the origin of the batch's first road user (0 if there is none)
+        const unsigned long long m = __ballot(real);
+        const int first = m ? __builtin_ctzll(m) : 0;
+        const float fx = __shfl(on.x, first, 64), fy = __shfl(on.y, first, 64);
+        d.recp[p] = real ? make_float4(q.x, q.y, on.x, on.y) : make_float4(q.x, q.y, fx, fy);
     }
     // the binned copy holds scene coordinates, offset + origin (what the tiles of the pair kernels are filled with)
     if (real) q.x += on.x, q.y += on.y;

@@ -98,6 +98,9 @@ struct Dev {
     // kernels hold scene coordinates (recs, or offset + origin), 2^-24 of the scene extent.
     float4 *rec;       // [n_pad] by slot
     float2 *rorg;      // [n_pad] by slot: the origin its record is relative to, itself relative to (ox, oy)
+    float4 *recp;      // [n_pad] by place of the binned order: the precise record as (offset x, offset y, origin x, origin y); a
+                       // place without a road user keeps an origin of its neighbourhood (large populations: the pair
+                       // kernel works relative to the origin of its receiver group, csf_pair.hip BINR)
     float4 *recg;      // [cap] by slot: the record in scene coordinates, bit for bit what recs holds at the slot's place (the
                        // receivers of the kernels on binned records: a receiver must coincide with itself as a source)
     int32_t rebase_from_state;   // re-binning: every live slot's fp64 state is current on this device (else: re-express the old record)
@@ -116,7 +119,9 @@ struct Dev {
     float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
     float2 *part;      // [MAX_SPLIT][cap] partial repulsive sums of the pair kernel
     float2 *froad;     // [cap]
-    float4 *rv;        // [nv_pad] road vertices (x-ox, y-oy, -F0, -(sigma+1)/2)
+    float4 *rv;        // [nv_pad] road vertices (x - ox - rvo.x, y - oy - rvo.y, -F0, -(sigma+1)/2): offsets from the origin of
+                       // their tile of 1024 vertices (a multiple of 1/4 m), so that a vertex resolves to 2^-24 of a tile's extent
+    float2 *rvo;       // [nv_pad / 1024 + 1] those origins, relative to (ox, oy)
     int64_t nv, nv_pad;
     int32_t road_np;   // sigma + 1 when every road edge shares one integer sigma in 1..5, else 0 (road_kernel)
 

@@ -221,7 +221,8 @@ struct csf_engine {
     PinnedSlot pinned[4];
     int pinned_next = 0;
     DevBuf<uint32_t> status;
-    DevBuf<float4> rec, recs, recg, rv, kat4, bnd, bnd2;
+    DevBuf<float4> rec, recs, recg, recp, rv, kat4, bnd, bnd2;
+    DevBuf<float2> rvo;          // origins of the road-vertex tiles
     DevBuf<int32_t> pos;
     bool bounds_fresh = false;   // d.bnd describes the current records (else: recompute before the pair kernel)
     DevBuf<int32_t> perm, sort_vals, rlist;
@@ -562,6 +563,7 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->pos.alloc(nrec));
     HIPCHK(e, e->recs.alloc(nrec));
     HIPCHK(e, e->recg.alloc(nrec));
+    HIPCHK(e, e->recp.alloc(nrec));
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->rorg.alloc(nrec));
@@ -629,6 +631,7 @@ int alloc_all(csf_engine *e) {
     d.pos = e->pos.p;
     d.recs = e->recs.p;
     d.recg = e->recg.p;
+    d.recp = e->recp.p;
     d.bnd = e->bnd.p;
     d.bnd_next = e->bnd2.p;
     d.rorg = e->rorg.p;
@@ -1051,17 +1054,36 @@ int upload_all(csf_engine *e) {
         if (!std::isfinite(d.ox)) d.ox = 0;
         if (!std::isfinite(d.oy)) d.oy = 0;
     }
-    // road vertices (x - ox, y - oy, -F0, -(sigma+1)/2), padded with inert vertices
+    // Road vertices (x, y, -F0, -(sigma+1)/2), padded with inert vertices.  Positions are offsets from the origin of
+    // their tile of 1024 consecutive vertices (the centre of its box, rounded to 1/4 m): consecutive vertices of a
+    // polyline are neighbours, so a vertex resolves to 2^-24 of ~50 m whatever the extent of the scene, and the road
+    // kernel forms receiver - vertex relative to the tile (csf_pair.hip: road_kernel).
     d.nv = (int64_t)e->h_road.size() / 4;
     d.nv_pad = (d.nv + 63) / 64 * 64;
     if (d.nv > 0) {
+        const int64_t tiles = (d.nv_pad + 1023) / 1024;
         if ((size_t)d.nv_pad > e->rv.n) HIPCHK(e, e->rv.alloc((size_t)d.nv_pad));
+        if ((size_t)tiles > e->rvo.n) HIPCHK(e, e->rvo.alloc((size_t)tiles));
         std::vector<float4> rv((size_t)d.nv_pad, make_float4(1e15f, 1e15f, 0.f, -1.f));
-        for (int64_t k = 0; k < d.nv; k++)
-            rv[(size_t)k] = make_float4((float)(e->h_road[4 * k] - d.ox), (float)(e->h_road[4 * k + 1] - d.oy),
-                                        (float)(-e->h_road[4 * k + 2]), (float)(-0.5 * (e->h_road[4 * k + 3] + 1.0)));
+        std::vector<float2> rvo((size_t)tiles, make_float2(0.f, 0.f));
+        for (int64_t t = 0; t < tiles; t++) {
+            const int64_t k0 = t * 1024, k1 = std::min<int64_t>(d.nv, k0 + 1024);
+            double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+            for (int64_t k = k0; k < k1; k++) {
+                x0 = std::min(x0, e->h_road[4 * k]), x1 = std::max(x1, e->h_road[4 * k]);
+                y0 = std::min(y0, e->h_road[4 * k + 1]), y1 = std::max(y1, e->h_road[4 * k + 1]);
+            }
+            if (!(k1 > k0)) continue;
+            const double tx = 0.25 * std::nearbyint(4.0 * (0.5 * (x0 + x1) - d.ox)), ty = 0.25 * std::nearbyint(4.0 * (0.5 * (y0 + y1) - d.oy));
+            rvo[(size_t)t] = make_float2((float)tx, (float)ty);
+            for (int64_t k = k0; k < k1; k++)
+                rv[(size_t)k] = make_float4((float)((e->h_road[4 * k] - d.ox) - tx), (float)((e->h_road[4 * k + 1] - d.oy) - ty),
+                                            (float)(-e->h_road[4 * k + 2]), (float)(-0.5 * (e->h_road[4 * k + 3] + 1.0)));
+        }
         HIPCHK(e, hipMemcpy(e->rv.p, rv.data(), rv.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->rvo.p, rvo.data(), rvo.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
+    d.rvo = e->rvo.p;
     d.road_np = 0;
     if (d.nv > 0) {   // one integer sigma for every edge: r^-(sigma+1) as a power of rsq(r^2)
         const double sg = e->h_road[3];
@@ -1396,8 +1418,8 @@ int csf_destroy(csf_engine *e) {
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
     e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
-    e->status.release(); e->rec.release(); e->rv.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release();
+    e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recp.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();

@@ -190,7 +190,10 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // where the contributions are below the resolution of the fp32 column sum.
 // BINR (large populations): the RECEIVERS of a workgroup are consecutive places of the binned order as well, i.e.
 // neighbours in space, so a whole tile of 1024 sources that lies beyond the far-field radius of the group's bounding
-// circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).  (Smaller populations take their
+// circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).  Tile and receivers are then held
+// relative to the ORIGIN OF THE GROUP (that of its first receiver's place, csf_dev.h: recp): a source that matters is
+// near the group, so the fp32 difference receiver - source keeps 2^-24 of (pair distance + group extent) at any extent
+// of the scene - 6e-5 m would be the resolution of scene coordinates in the 1 600 m of config 5.  (Smaller populations take their
 // receivers in slot order: a workgroup then holds a random sample of receivers and every workgroup carries the same
 // load - with neighbours the few workgroups whose tile lies in front of ALL their receivers end the kernel 10 % later.)
 // DYN (small receiver blocks, i.e. shards of a small population: launch_pair): the 16 receivers of the workgroup are
@@ -222,6 +225,12 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
     const uint64_t t_start = d.trace ? wall_clock64() : 0;
+    float2 og = make_float2(0.f, 0.f);   // BINR: origin of the workgroup (uniform: scalar loads), else the scene's
+    if (BINR) {
+        const int64_t jg = d.lo + (int64_t)blockIdx.x * RPB;
+        const float4 pg = d.recp[d.rlist ? (int64_t)d.rlist[jg - d.lo] : jg];
+        og = make_float2(pg.z, pg.w);
+    }
 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
@@ -300,7 +309,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     auto fill_tile = [&](int64_t base, int cnt) {
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
             float4 q;
-            if (d.recs_valid) {
+            if (BINR) {          // relative to the group's origin: offset + (origin - group origin), the bracket exact
+                const float4 pp = d.recp[base + t];
+                q = d.recs[base + t];
+                q.x = pp.x + (pp.z - og.x), q.y = pp.y + (pp.w - og.y);
+            } else if (d.recs_valid) {
                 q = d.recs[base + t];
             } else {
                 const int32_t a = d.perm[base + t];
@@ -313,7 +326,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             tc[t] = q.z;
             ts[t] = q.w;
         }
-        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) tbnd[threadIdx.x] = d.bnd[(base >> 6) + threadIdx.x];
+        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) {
+            float4 bb = d.bnd[(base >> 6) + threadIdx.x];     // (scene coordinates)
+            if (BINR) bb.x -= og.x, bb.y -= og.y;
+            tbnd[threadIdx.x] = bb;
+        }
         if (DYN && threadIdx.x == BLOCK - 1) next_recv = 0;
     };
     // first tile and the workgroup's receiver records travel together: one global round trip, not two
@@ -324,7 +341,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
         if (BINR) {  // receiver slot jc - lo of this rank -> place of the binned order -> slot
             const int64_t p = d.rlist ? (int64_t)d.rlist[jc - d.lo] : jc;
-            rrec[threadIdx.x] = d.recs[p];
+            const float4 pp = d.recp[p];
+            float4 q = d.recs[p];
+            q.x = pp.x + (pp.z - og.x), q.y = pp.y + (pp.w - og.y);   // (the very expression of the tile fill)
+            rrec[threadIdx.x] = q;
             ragent[threadIdx.x] = j < d.hi ? d.perm[p] : -1;
         } else {
             if (d.recs_valid) {                               // (uniform) scene coordinates, identical with the slot's entry of recs
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
             // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
             const float4 bb = d.bnd[(base >> 6) + ((lane & 15) < nb ? (lane & 15) : 0)];
-            const float ex = bb.x - gx, ey = bb.y - gy;
+            const float ex = (bb.x - og.x) - gx, ey = (bb.y - og.y) - gy;
             const float reach = k.rfar + bb.z + gr;
             if (__ballot(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
             if (filled) __syncthreads();
@@ -802,13 +822,31 @@ __global__ __launch_bounds__(BLOCK) void road_kernel(const Dev d) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
+    // the receivers' scene coordinates as two floats each, hi + lo = origin + offset exactly (csf_dev.h: rec, rorg): the
+    // vertices of a tile are offsets from the tile's origin, and (hi - origin) + lo is the receiver's offset from it
+    float rh[RPW][2], rl[RPW][2];
+#pragma unroll
+    for (int u = 0; u < RPW; u++) {
+        const int64_t j = j0 + u < d.hi ? j0 + u : d.hi - 1;  // clamp: results of the duplicates are not stored
+        const float4 q = d.rec[j];
+        const float2 o = d.rorg[j];
+        two_sum(o.x, q.x, rh[u][0], rl[u][0]);
+        two_sum(o.y, q.y, rh[u][1], rl[u][1]);
+    }
     Recv r[RPW];
-    load_receivers(d, j0, r);
     v2f ax[RPW], ay[RPW];
 #pragma unroll
     for (int u = 0; u < RPW; u++) ax[u] = ay[u] = v2f{0.f, 0.f};
+    static_assert(TILE == 1024, "the origins of the road vertices are per tile of 1024");
     for (int64_t base = 0; base < d.nv_pad; base += TILE) {
         const int cnt = (int)((d.nv_pad - base) < TILE ? (d.nv_pad - base) : TILE);  // multiple of 64
+        const float2 ot = d.rvo[base >> 10];
+#pragma unroll
+        for (int u = 0; u < RPW; u++) {
+            r[u].x = (rh[u][0] - ot.x) + rl[u][0];
+            r[u].y = (rh[u][1] - ot.y) + rl[u][1];
+            asm volatile("" : "+v"(r[u].x), "+v"(r[u].y));    // stay in VGPRs
+        }
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
             const float4 v = d.rv[base + t];  // (x, y, -F0, -(sigma+1)/2); padding has F0 = 0

@@ -186,8 +186,9 @@ __global__ __launch_bounds__(TK_BLOCK, 1) void tick_kernel(const Dev d, const Ti
             float qx = 0.f, qy = 0.f;
             if (d.nv > 0) {      // RoadEdge.calcRepulsiveForce (intersection.py:226-242): vertices in the lanes
                 for (int64_t iv = lane; iv < d.nv_pad; iv += WAVE) {
-                    const float4 vtx = d.rv[iv];                        // (x - ox, y - oy, -F0, -(sigma + 1) / 2)
-                    const float ex = (vtx.x - ru.x) - rxl, ey = (vtx.y - ru.y) - ryl;
+                    const float4 vtx = d.rv[iv];                        // (offset from the tile's origin, -F0, -(sigma + 1) / 2)
+                    const float2 ot = d.rvo[iv >> 10];
+                    const float ex = vtx.x - ((ru.x - ot.x) + rxl), ey = vtx.y - ((ru.y - ot.y) + ryl);
                     const float r2 = ex * ex + ey * ey;
                     const float lg = fminf(vtx.w * fast_log2(r2), 120.0f);   // r = 0: finite, times ex = ey = 0
                     const float m = fast_exp2(lg) * vtx.z;

@@ -51,7 +51,7 @@ def test_config4_262144_twod_column_sums(amd, monkeypatch):
     """262 144 TwoDBicycle in 800 m (BASELINE config 4 on one device): the kernel variant that only runs from 65 536
     agents up (receivers in binned order, far tiles skipped unloaded, at most 16 source chunks).  One calc_forces():
     (a) 96 strided receivers against the oracle's column sums over all 262 144 sources (every pair, fp64);
-    (b) bit-reproducible; (c) the same sums with receivers in index order (CSF_RECV_BINNED=0)."""
+    (b) bit-reproducible; (c) the same sums, to rounding, with receivers in slot order (CSF_RECV_BINNED=0)."""
     n, box = 262144, 800.0
     s0, off, dq = population(n, box)
     big = 1e6                                            # |F_dest| = v_desired on tick 0: the clamp never acts
@@ -81,7 +81,14 @@ def test_config4_262144_twod_column_sums(amd, monkeypatch):
     assert np.array_equal(x1, x2) and np.array_equal(y1, y2) and cnt2 == cnt            # (b)
     monkeypatch.setenv("CSF_RECV_BINNED", "0")
     _, x3, y3, _, _ = rep()
-    assert np.array_equal(x1, x3) and np.array_equal(y1, y3)                            # (c)
+    # (c) the same terms: in slot order the pairs are formed in scene coordinates (3e-5 m at 400 m from the origin; + the
+    # near-pair correction), in binned order relative to the receiver group's origin.  Rounding apart - and apart from the
+    # sources that sit within (3e-5 m / distance) rad of a field-of-view edge in scene coordinates, which the two
+    # variants decide differently (DESIGN D6: a few hundred of 6.9e10 pairs; (a) pins the binned variant to the oracle)
+    sc = max(np.hypot(x1, y1).max(), 1.0)
+    dd = np.maximum(np.abs(x1 - x3), np.abs(y1 - y3))
+    print(f"   binned vs slot order: median {np.median(dd) / sc:.1e}, 99.9 % {np.percentile(dd, 99.9) / sc:.1e}, {(dd > 1e-4 * sc).sum()} receivers beyond 1e-4")
+    assert np.median(dd) < 1e-6 * sc and np.percentile(dd, 99.9) < 1e-4 * sc and (dd > 1e-4 * sc).sum() < 200
 
 
 # --------------------------------------------------------------------------- BASELINE config 5
@@ -105,8 +112,6 @@ def test_config5_1048576_planarpoint_with_road(amd):
     assert np.isfinite(fx).all() and np.isfinite(fy).all() and (e.status() == 0).all()
     e.close()
     recv = np.arange(11, n, n // 64)[:64]
-    # agents closer than 0.3 m to a vertex: the fp32 record (6e-5 m at 800 m from the origin) is amplified by
-    # (sigma + 1) / r in r^-(sigma+1); they are checked with the absolute bound that resolution implies
     p = orc.default_params("planarpoint")
     ox, oy = orc.column_sums(p, s0[:, 0], s0[:, 1], s0[:, 2], s0[:, 3], recv)
     scale = np.maximum(1.0, np.hypot(ox, oy))
@@ -115,13 +120,13 @@ def test_config5_1048576_planarpoint_with_road(amd):
     gx, gy = fx[recv] - fdx[recv] - frx[recv], fy[recv] - fdy[recv] - fry[recv]
     dmin = np.array([np.sqrt(((verts - s0[j, :2]) ** 2).sum(axis=1).min()) for j in recv])
     rscale = np.maximum(np.hypot(rx, ry), 1e-3)
-    # relative error bound from the position resolution: d|F|/|F| <= (sigma + 1) dr / r with dr = 1.2e-4 m
-    bound = 5e-5 + 3 * 1.2e-4 / np.maximum(dmin, 1e-3)
+    # (road vertices are offsets from the origin of their tile and the receiver is taken relative to it as two floats:
+    # a road user 0.05 m from a vertex, 800 m from the scene origin, is resolved like one in the middle)
     rerr = np.maximum(np.abs(gx - rx), np.abs(gy - ry)) / rscale
     print(f"config 5: pair column sums max err {perr.max():.2e}; road term max err {rerr.max():.2e} "
           f"(closest vertex {dmin.min():.2f} m, |F_road| up to {np.hypot(rx, ry).max():.3f})")
     assert perr.max() < 1e-4
-    assert (rerr < bound).all(), (rerr / bound).max()
+    assert rerr.max() < 1e-4
 
 
 # --------------------------------------------------------------------------- BASELINE config 2, full length
@@ -832,3 +837,117 @@ def test_calls_that_meet_in_one_pending_batch(amd):
     for e in engines:
         assert (e.status() == 0).all()
         e.close()
+
+
+# --------------------------------------------------------------------------- BASELINE configs 3, 4, 5: stepped
+
+def sampled_force_check(e, p, recv, road=None, st=None):
+    """One force evaluation of the engine on the state it is in (csf_calc_forces) against the oracle on a sample of
+    receivers: every source of the population, fp64 (intersection.py:814-848; + the road-edge term :226-242, 854-857).
+    Returns (error of the clamped repulsive sums, error of the road term) relative to the largest sampled force."""
+    e.calc_forces()
+    fx, fy = e.forces()
+    fdx, fdy, frx, fry = e.force_parts()
+    if st is None:                                              # (a rank of a group: the caller passes the gathered state)
+        st = e.state()
+    ox, oy = orc.column_sums(p, st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv)
+    cx, cy = clamped(ox, oy, fdx[recv], fdy[recv])
+    scale = max(np.hypot(cx, cy).max(), 1.0)
+    err = max(np.abs(frx[recv] - cx).max(), np.abs(fry[recv] - cy).max()) / scale
+    rerr = 0.0
+    if road is not None:
+        roff, verts, F0, sg = road
+        rx, ry = orc.road_forces(verts, roff, F0, sg, st[recv, 0], st[recv, 1])
+        gx, gy = fx[recv] - fdx[recv] - frx[recv], fy[recv] - fdy[recv] - fry[recv]
+        rerr = max(np.abs(gx - rx).max(), np.abs(gy - ry).max()) / max(np.hypot(rx, ry).max(), 1e-3)
+    return err, rerr, st
+
+
+def test_config3_16384_invpend_200_ticks(amd):
+    """BASELINE config 3 stepped: 16 384 InvertedPendulumBicycle in 200 m, 200 ticks (six re-binnings); every 25 ticks the
+    forces of 128 receivers on the state as it is against the oracle."""
+    n, box = 16384, 200.0
+    s0, off, dq = population(n, box, seed=3)
+    s = np.zeros((n, 6)); s[:, :4] = s0[:, :4]
+    e = make_engine(amd, "invpend", s, 5.0, off, dq)
+    p = orc.default_params("invpend")
+    recv = np.arange(5, n, n // 128)[:128]
+    worst = 0.0
+    for k in range(8):
+        e.step(25)
+        err, _, st = sampled_force_check(e, p, recv)
+        worst = max(worst, err)
+        assert err < 1e-4, (k, err)
+        assert np.isfinite(st).all()
+    moved = np.hypot(st[:, 0] - s[:, 0], st[:, 1] - s[:, 1])
+    print(f"config 3: 200 ticks, clamped repulsive sums vs oracle at 8 stations: worst {worst:.1e}; road users moved {moved.mean():.1f} m on average")
+    assert (e.status() == 0).all() and 0.5 < moved.mean() < 12.0
+    e.close()
+
+
+def test_config4_262144_twod_40_ticks_and_two_shards(amd):
+    """BASELINE config 4 stepped on one device: 262 144 TwoDBicycle in 800 m, 40 ticks across a re-binning (the variant
+    with receivers in binned order and far tiles skipped unloaded), the forces of 96 receivers against the oracle every 8
+    ticks; and the same population as a 2-way loopback group (the sharded code path: receiver lists per rank, records
+    exchanged every tick, re-binning from gathered records) against the unsharded engine."""
+    n, box = 262144, 800.0
+    s0, off, dq = population(n, box, seed=1)
+    p = orc.default_params("twod")
+    e = make_engine(amd, "twod", s0, 5.0, off, dq)
+    recv = np.arange(37, n, n // 96)[:96]
+    worst = 0.0
+    for k in range(5):
+        e.step(8)
+        err, _, st = sampled_force_check(e, p, recv)
+        worst = max(worst, err)
+        assert err < 1e-4, (k, err)
+    print(f"config 4: 40 ticks, clamped repulsive sums vs oracle at 5 stations: worst {worst:.1e}")
+    assert (e.status() == 0).all() and np.isfinite(st).all()
+    ref = st
+    e.close()
+    members = [make_engine(amd, "twod", s0, 5.0, off, dq) for _ in range(2)]
+    amd.Engine.loopback_group(members)
+    for k in range(5):
+        amd.Engine.step_group(members, 8)
+        for m in members:
+            m.calc_forces()                                   # (the unsharded run evaluated its forces at these stations too)
+    amd.Engine.step_group(members, 0, sync=True)
+    devs = []
+    whole, _ = gather_blocks(members)                           # every rank's own block: the state the group is in
+    for m in members:
+        lo, hi = m.shard_range()
+        devs.append(np.abs(whole[lo:hi, :2] - ref[lo:hi, :2]).max(axis=1))
+        assert (m.status()[lo:hi] == 0).all()
+        # the rank's own forces against the oracle, on that state (every rank holds every record)
+        mine = recv[(recv >= lo) & (recv < hi)]
+        err, _, _ = sampled_force_check(m, p, mine, st=whole)
+        assert err < 1e-4, err
+    devs = np.concatenate(devs)
+    print(f"config 4: 2-way loopback group vs the unsharded engine after 40 ticks: median {np.median(devs):.1e} m, 99.9 % {np.percentile(devs, 99.9):.1e} m, max {devs.max():.1e} m")
+    # (another grouping of the receivers, another fp32 summation order per rank; a source on a field-of-view edge decided the
+    # other way sends one road user elsewhere, and 262 144 road users x 40 ticks hold a few of those)
+    assert np.median(devs) < 1e-6 * box and np.percentile(devs, 99.9) < 1e-4 * box and devs.max() < 2.0
+    for m in members[::-1]:
+        m.close()
+
+
+def test_config5_1048576_planarpoint_with_road_5_ticks(amd):
+    """BASELINE config 5 stepped on one device: 1 048 576 PlanarPointBicycle in 1 600 m with the tiled curve road
+    (391 680 vertices), 5 ticks; after every tick the pair term and the road term of 64 receivers against the oracle."""
+    import bench
+
+    n, box = 1048576, 1600.0
+    s0, off, dq = population(n, box, seed=2)
+    s0 = s0[:, :4]
+    road = bench.tiled_curve_road(box)
+    e = make_engine(amd, "planarpoint", s0, 5.0, off, dq)
+    e.set_road(*road)
+    p = orc.default_params("planarpoint")
+    recv = np.arange(11, n, n // 64)[:64]
+    for k in range(5):
+        e.step(1)
+        err, rerr, st = sampled_force_check(e, p, recv, road)
+        print(f"config 5 tick {k + 1}: clamped repulsive sums vs oracle {err:.1e}, road term {rerr:.1e}")
+        assert err < 1e-4 and rerr < 1e-4, (k, err, rerr)
+    assert (e.status() == 0).all() and np.isfinite(st).all()
+    e.close()
