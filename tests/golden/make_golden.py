@@ -740,11 +740,85 @@ def gen_mixed():
 
 
 
+# ----------------------------------------------------------------------------
+# (15) the SUMO co-simulation seam — intersection.py:341-453 (footprint, lane end points, internal lanes,
+#      entered / exited road users), 458-539 (route prototype of an arrival), 576-634 (departures), 679-688 (moveToXY push-back)
+#      sumolib / traci are absent here: the reference class takes `net` as an argument and talks to a module-level
+#      `traci`, so the duck-typed stand-ins of tests/sumo_fakes.py (the ones the mirror is driven with) are handed to it -
+#      data for the reference's own code, none of which is replaced.
+# ----------------------------------------------------------------------------
+SUMO_SCRIPT = dict(ticks=130, every=25, stay=70, seed=5)
+
+
+def sumo_script():
+    """SUMO's side of the loop (scenario.py:376-437), scripted: who is on the internal lanes at every tick, and the
+    state / route an arrival is handed over with.  Shared with the tests through the fixture."""
+    arms = {"W": (-1, 0), "E": (1, 0), "S": (0, -1), "N": (0, 1)}
+    rng = np.random.default_rng(SUMO_SCRIPT["seed"])
+    on, born, per_tick, specs = {}, 0, [], {}
+    for tick in range(SUMO_SCRIPT["ticks"]):
+        if tick % SUMO_SCRIPT["every"] == 0:
+            a, b = rng.choice(list(arms), 2, replace=False)
+            ax, ay = arms[a]
+            vid = f"veh{born}"
+            specs[vid] = dict(route=(a + "_in", b + "_out"), since=tick,
+                              s=[ax * 9.0 + ay * 1.6, ay * 9.0 - ax * 1.6, float(np.arctan2(-ay, -ax)), 4.0, 0.0])
+            on[vid] = specs[vid]
+            born += 1
+        for vid in [v for v, sp in on.items() if tick - sp["since"] >= SUMO_SCRIPT["stay"]]:
+            del on[vid]
+        per_tick.append(tuple(on))
+    return per_tick, specs
+
+
+def gen_sumo_seam():
+    import json
+
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    from sumo_fakes import FakeNet, FakeTraci
+
+    tr = FakeTraci()
+    ri.traci = tr                                               # the module-level name intersection.py:429-453, 679-688 use
+    ins = ri.SocialForceIntersection([], id="J", activate_sumo_cosimulation=True, net=FakeNet())
+    edges_in, edges_out = sorted(ins.inEdges), sorted(ins.outEdges)
+    lane_in = np.array([[np.r_[x, y] for (x, y) in ins.inEdges[e]] for e in edges_in])       # [edge, lane, (x0 x1 y0 y1)]
+    lane_out = np.array([[np.r_[x, y] for (x, y) in ins.outEdges[e]] for e in edges_out])
+    per_tick, specs = sumo_script()
+    entered_log, exited_log, ids_log, queues, moves, states = [], [], [], {}, [], []
+    for tick, occ in enumerate(per_tick):
+        tr.occupancy = {":J_0_0": occ}
+        entered, exited = ins.find_entered_exited_roadusers()
+        entered_log.append([str(v) for v in entered])
+        exited_log.append([str(v) for v in exited])
+        ins.remove_road_users_by_id(list(exited))
+        for vid in entered:
+            sp = specs[str(vid)]
+            v = make_vehicle("twod", sp["s"], id=str(vid), route=sp["route"])
+            np.random.seed(1000 + int(str(vid)[3:]))            # (the exit lane is drawn at random: one lane per arm here)
+            ins.add_road_user(v)
+            queues[str(vid)] = v.destqueue.copy()
+        n0 = len(tr.moves)
+        ins.step()
+        tr.simulationStep()
+        ids_log.append(ins.get_road_user_ids())
+        for m in tr.moves[n0:]:
+            moves.append([tick, int(m[1][3:]), m[4], m[5], m[6], m[7]])
+        states.append(np.array([np.r_[int(v.id[3:]), v.s] for v in ins.vehicles]).reshape(-1, 6))
+    qids = sorted(queues, key=lambda q: int(q[3:]))
+    qoff = np.cumsum([0] + [queues[q].shape[0] for q in qids])
+    save("sumo_seam", shape=np.asarray(ins.shape.vertices), edges_in=np.array(edges_in), edges_out=np.array(edges_out),
+         lane_in=lane_in, lane_out=lane_out, internal_lane_ids=np.array(ins.internal_lane_ids),
+         script=np.array(json.dumps(SUMO_SCRIPT)), entered=np.array(json.dumps(entered_log)), exited=np.array(json.dumps(exited_log)),
+         ids=np.array(json.dumps(ids_log)), queue_ids=np.array(qids), queue_off=qoff, queue_rows=np.vstack([queues[q] for q in qids]),
+         moves=np.array(moves), state_off=np.cumsum([0] + [s.shape[0] for s in states]), states=np.vstack(states),
+         hist_n=np.array(ins.hist_n_vecs))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero", "mixed"]
+    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero", "mixed", "sumo"]
     gens = {"pair": gen_pair_fields, "masks": gen_masks_and_totals, "control": gen_control_move,
             "dest": gen_dest_force, "pp": gen_planarpoint_steps, "road": gen_road,
             "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep,
-            "planarbike": gen_planarbike, "hetero": gen_hetero, "mixed": gen_mixed}
+            "planarbike": gen_planarbike, "hetero": gen_hetero, "mixed": gen_mixed, "sumo": gen_sumo_seam}
     for w in which:
         gens[w]()

@@ -336,6 +336,48 @@ def test_sumo_cosimulation_loop():
     assert len(gone) == 16 and all(np.hypot(last[vid][0] - entry[vid][0], last[vid][1] - entry[vid][1]) > 2.0 for vid in gone)
 
 
+def test_sumo_cosimulation_loop_against_the_reference(golden):
+    """The same per-tick loop, scripted, against what the REFERENCE class did with the same duck-typed net / traci
+    (tests/golden/sumo_seam.npz, make_golden.py: gen_sumo_seam): who is on the junction after every tick, every moveToXY
+    call (road user, position, SUMO angle, keepRoute) and every state - the trajectories after the hand-over run on the
+    HIP path."""
+    import json
+
+    from sumo_fakes import FakeNet, FakeTraci
+    from test_host_api import sumo_script
+
+    g = golden("sumo_seam")
+    tr = FakeTraci()
+    ins = SocialForceIntersection([], id="J", activate_sumo_cosimulation=True, net=FakeNet(), traci=tr, capacity=16)
+    per_tick, specs = sumo_script(g)
+    ids_ref = json.loads(str(g["ids"]))
+    moves_ref, soff, states_ref = g["moves"], g["state_off"], g["states"]
+    mk = 0
+    worst = 0.0
+    for tick, occ in enumerate(per_tick):
+        tr.occupancy = {":J_0_0": occ}
+        entered, exited = ins.find_entered_exited_roadusers()
+        ins.remove_road_users_by_id(list(exited))
+        for vid in entered:
+            sp = specs[str(vid)]
+            np.random.seed(1000 + int(str(vid)[3:]))
+            ins.add_road_user(TwoDBicycle(tuple(sp["s"]), id=str(vid), route=sp["route"]))
+        n0 = len(tr.moves)
+        ins.step()
+        tr.simulationStep()
+        assert ins.get_road_user_ids() == ids_ref[tick], tick
+        for m in tr.moves[n0:]:
+            ref = moves_ref[mk]
+            mk += 1
+            assert (tick, int(m[1][3:])) == (int(ref[0]), int(ref[1])) and m[2:4] == ("", -1) and m[7] == int(ref[5])
+            worst = max(worst, abs(m[4] - ref[2]), abs(m[5] - ref[3]))
+            assert abs(m[4] - ref[2]) < 1e-5 and abs(m[5] - ref[3]) < 1e-5 and abs((m[6] - ref[4] + 180.0) % 360.0 - 180.0) < 1e-3, (tick, m, ref)
+        got = np.array([np.r_[int(v.id[3:]), v.s] for v in ins.vehicles]).reshape(-1, 6)
+        np.testing.assert_allclose(got, states_ref[soff[tick]:soff[tick + 1]], rtol=0, atol=1e-5, err_msg=f"tick {tick}")
+    assert mk == moves_ref.shape[0] and ins.hist_n_vecs == list(g["hist_n"])
+    print(f"SUMO loop vs the reference: {mk} moveToXY calls, worst position deviation {worst:.1e} m")
+
+
 def test_animated_demo_on_agg_canvas(tmp_path):
     """the reference's demo with animate=True (demo/demoCSFstandalone.py:120-156) - drawings created on
     the first tick, refreshed from the read-back of every tick, blitted by Scenario, histories plotted afterwards."""

@@ -603,3 +603,46 @@ def test_history_ring_with_several_vehicle_classes(amd):
     with pytest.raises(Exception, match="csf_enable_history"):
         e.set_param_classes(pods)                                           # six states where the ring holds five
     e.close()
+
+
+def test_class_segmented_order_at_headline_size_vs_oracle(amd):
+    """The class-segmented order at N = 16 384 in 200 m (the headline population with four parameter sets, the engine's own
+    choice of kernels: no environment knob): 70 ticks across two re-binnings, and at five stations the clamped repulsive
+    sums of 160 receivers - every source with ITS set's field, field of view and far-field radius - against the oracle
+    on the state the engine is in."""
+    n, box = 16384, 200.0
+    rng = np.random.default_rng(123)
+    s0 = np.zeros((n, 5))
+    s0[:, 0] = rng.uniform(0, box, n); s0[:, 1] = rng.uniform(0, box, n)
+    s0[:, 2] = rng.uniform(-np.pi, np.pi, n); s0[:, 3] = rng.uniform(3, 6, n)
+    d = np.array([50.0, 99.0, 100.0])
+    dq = np.zeros((n, 4, 3))
+    dq[:, 0, 0] = s0[:, 0]; dq[:, 0, 1] = s0[:, 1]
+    dq[:, 1:, 0] = s0[:, 0, None] + d[None, :] * np.cos(s0[:, 2])[:, None]
+    dq[:, 1:, 1] = s0[:, 1, None] + d[None, :] * np.sin(s0[:, 2])[:, None]
+    field = [dict(), dict(hfov=1.2 * np.pi, f_0=10.0, sigma_0=0.6, sigma_1=5.5), dict(hfov=1.0, e_0=0.9, e_1=0.4, sigma_2=0.25, sigma_3=4.0),
+             dict(hfov=2.5, f_0=4.0, d_arrived_inter=3.0)]
+    pods = [amd.pod("twod", **kw) for kw in field]
+    cls = rng.integers(0, len(pods), n).astype(np.uint8)
+    e = amd.Engine(pods[0], n)
+    e.add_agents(s0, 5.0)
+    e.set_dest_queue(np.arange(n), np.arange(n + 1) * 4, dq.reshape(-1, 3), reset=True)
+    e.set_param_classes(pods, cls)
+    tab = [orc_params(p) for p in pods]
+    recv = np.sort(rng.choice(n, 160, replace=False))
+    worst = 0.0
+    for station in range(5):
+        e.step(14)
+        e.calc_forces()
+        fdx, fdy, rx, ry = e.force_parts()
+        st = e.state()
+        ox, oy = orc.column_sums(tab, st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv, cls=cls)
+        lim, mag = np.hypot(fdx[recv], fdy[recv]), np.maximum(np.hypot(ox, oy), 1e-300)
+        sc = np.minimum(1.0, lim / mag)
+        scale = max(np.hypot(ox * sc, oy * sc).max(), 1.0)
+        df = np.maximum(np.abs(rx[recv] - ox * sc), np.abs(ry[recv] - oy * sc)) / scale
+        worst = max(worst, df.max())
+        assert np.median(df) < 2e-6 and (df > 1e-4).sum() <= 1, (station, df.max())     # (at most one field-of-view edge case: D6)
+    assert e.count_pairs()[1] == "pair_cull_kernel" and (e.status() == 0).all() and np.isfinite(st).all()
+    print(f"four parameter sets at N = 16 384: clamped repulsive sums vs oracle at 5 stations, worst {worst:.1e}")
+    e.close()

@@ -287,6 +287,72 @@ def test_sumo_seam_host_side():
     assert tr.moves[-1][1:] == ("veh0", "", -1, -9.0, -1.6, 90.0, 6)
 
 
+def sumo_script(g):
+    """SUMO's side of the scripted loop of tests/golden/sumo_seam.npz (make_golden.py: sumo_script - the same recipe)."""
+    import json
+
+    cfg = json.loads(str(g["script"]))
+    arms = {"W": (-1, 0), "E": (1, 0), "S": (0, -1), "N": (0, 1)}
+    rng = np.random.default_rng(cfg["seed"])
+    on, born, per_tick, specs = {}, 0, [], {}
+    for tick in range(cfg["ticks"]):
+        if tick % cfg["every"] == 0:
+            a, b = rng.choice(list(arms), 2, replace=False)
+            ax, ay = arms[a]
+            vid = f"veh{born}"
+            specs[vid] = dict(route=(a + "_in", b + "_out"), since=tick,
+                              s=[ax * 9.0 + ay * 1.6, ay * 9.0 - ax * 1.6, float(np.arctan2(-ay, -ax)), 4.0, 0.0])
+            on[vid] = specs[vid]
+            born += 1
+        for vid in [v for v, sp in on.items() if tick - sp["since"] >= cfg["stay"]]:
+            del on[vid]
+        per_tick.append(tuple(on))
+    return per_tick, specs
+
+
+def test_sumo_seam_against_the_reference(golden):
+    """The host side of the SUMO seam against what the REFERENCE class computed from the same duck-typed net / traci
+    (tests/golden/sumo_seam.npz, captured by make_golden.py: gen_sumo_seam): footprint, the end points of every approach
+    and exit lane, the internal lanes, the entered / exited road users of every tick of a scripted occupancy, and the
+    spline prototype every arrival is given across the junction (intersection.py:341-453, 458-539, 576-634)."""
+    import json
+
+    from sumo_fakes import FakeNet, FakeTraci
+
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import TwoDBicycle
+
+    g = golden("sumo_seam")
+    tr = FakeTraci()
+    ins = SocialForceIntersection([], id="J", activate_sumo_cosimulation=True, net=FakeNet(), traci=tr)
+    np.testing.assert_array_equal(ins.shape_vertices, g["shape"])
+    assert sorted(ins.inEdges) == list(g["edges_in"]) and sorted(ins.outEdges) == list(g["edges_out"])
+    for k, e in enumerate(g["edges_in"]):
+        for lane, (x, y) in enumerate(ins.inEdges[str(e)]):
+            np.testing.assert_allclose(np.r_[x, y], g["lane_in"][k, lane], rtol=0, atol=1e-12)
+    for k, e in enumerate(g["edges_out"]):
+        for lane, (x, y) in enumerate(ins.outEdges[str(e)]):
+            np.testing.assert_allclose(np.r_[x, y], g["lane_out"][k, lane], rtol=0, atol=1e-12)
+    assert ins.internal_lane_ids == list(g["internal_lane_ids"])
+    per_tick, specs = sumo_script(g)
+    entered_ref, exited_ref = json.loads(str(g["entered"])), json.loads(str(g["exited"]))
+    qids, qoff, qrows = list(g["queue_ids"]), g["queue_off"], g["queue_rows"]
+    for tick, occ in enumerate(per_tick):                      # bookkeeping only: no tick is run (no GPU here)
+        tr.occupancy = {":J_0_0": occ}
+        entered, exited = ins.find_entered_exited_roadusers()
+        assert [str(v) for v in entered] == entered_ref[tick] and [str(v) for v in exited] == exited_ref[tick], tick
+        ins.remove_road_users_by_id(list(exited))
+        for vid in entered:
+            sp = specs[str(vid)]
+            u = TwoDBicycle(tuple(sp["s"]), id=str(vid), route=sp["route"])
+            np.random.seed(1000 + int(str(vid)[3:]))
+            ins.add_road_user(u)
+            k = qids.index(str(vid))
+            np.testing.assert_allclose(u.destqueue, qrows[qoff[k]:qoff[k + 1]], rtol=0, atol=1e-12, err_msg=str(vid))
+        assert len(ins.vehicles) == len(occ)
+    assert len(qids) == 6
+
+
 def test_visual_hook_drawings():
     """Vehicle.add_drawing / update_drawing / plot_states / plot_forces on matplotlib's Agg canvas
     (vehicle.py:695-917); no GPU involved - the drawings read the host mirror."""

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Differential run: the same random calls on two engines whose road users own several parameter sets of several vehicle
-classes - one re-bins into the class-segmented order (CSF_SEGMENTS=1: a launch of the culling kernel per set), the other
-keeps the plain kernel that looks every source's set up (CSF_SEGMENTS=0; the variable is read at every re-binning, so it
-is switched between the two engines' calls).  usage: fuzz_segments.py FIRST_SEED N_SEEDS"""
+"""Random population calls on two engines whose road users own several parameter sets of several vehicle classes - one
+re-bins into the class-segmented order (CSF_SEGMENTS=1: a launch of the culling kernel per set), the other keeps the
+plain kernel that looks every source's set up (CSF_SEGMENTS=0; read when an engine is created) - and after EVERY call
+each engine's clamped repulsive sums against the oracle on that engine's own state.  usage: fuzz_segments.py FIRST_SEED N_SEEDS"""
 import os
 import sys
 
@@ -14,6 +14,7 @@ os.environ["CSF_PAIR_VARIANT"] = "0"
 from bench import synthetic_population  # noqa: E402
 from cyclistsocialforce_amd import parameters  # noqa: E402
 from cyclistsocialforce_amd.engine import Engine  # noqa: E402
+from oracle import csf_oracle as orc  # noqa: E402
 
 
 def run(seed):
@@ -89,59 +90,37 @@ def run(seed):
             n += args.size
             cls_now.extend(cls_of[args].tolist())
         hist.append(op)
+        # The two engines run on (chaos apart); what is checked after EVERY call is each engine against the ORACLE on the
+        # state that engine is in: the clamped repulsive sums of a sample of receivers, every source with its own parameter
+        # set (a wrong set, a missed run of the class-segmented order, a stale circle shows here at once; rounding that a
+        # crowd amplifies does not, and neither does the harness).  The engines' positions are compared for information.
         A, B = engines[0][1].state(), engines[1][1].state()
         assert A.shape == B.shape and A.shape[0] == n, (A.shape, B.shape, n)
+        if not (np.isfinite(A).all() and np.isfinite(B).all()):
+            raise AssertionError(f"seed {seed} call {it} ({op}): non-finite state; calls {hist}")
         dp = np.abs(A[:, :2] - B[:, :2]).max(axis=1)
-        out = int((dp > 1e-4).sum())
-        worst = max(worst, float(dp.max()))
-        # (a crowd amplifies rounding differences: the second engine is put back on the first one's state after every call,
-        # so that what is compared is the last call alone; a source crossing a field-of-view edge a tick apart - D6 - still
-        # moves a handful of road users by millimetres within a few ticks)
-        if (out > max(40, n // 50) or dp.max() > 0.5 or not np.isfinite(A).all()) and os.environ.get("FUZZ_DEBUG"):
-            bad = np.where(dp > 1e-4)[0]
-            cl = np.array(cls_now)
-            print("  deviating road users by set:", np.bincount(cl[bad], minlength=K), "of", np.bincount(cl, minlength=K), "models", [p.model for p in pods])
-            for r in bad[:6]:
-                print("   ", r, "set", cl[r], "A", A[r], "B", B[r])
-        if out > max(40, n // 50) or dp.max() > 0.5 or not np.isfinite(A).all():
-            raise AssertionError(f"seed {seed} call {it} ({op}): {out} road users differ, max {dp.max():.2e} m; kernels {names}; calls {hist}")
-        os.environ["CSF_SEGMENTS"] = "0"
-        engines[1][1].push_state(np.arange(n), A)
-        # ... and on that common state the two kernels must agree on every receiver's repulsive sum (the sharp check: a
-        # wrong set, a missed run, a stale circle shows here at once; chaos does not)
-        os.environ["CSF_SEGMENTS"] = "1"
-        engines[0][1].calc_forces()
-        _, _, ax, ay = engines[0][1].force_parts()
-        os.environ["CSF_SEGMENTS"] = "0"
-        engines[1][1].calc_forces()
-        _, _, bx, by = engines[1][1].force_parts()
-        scale = max(np.hypot(ax, ay).max(), 1.0)
-        # (the repulsive sum is clamped to |F_dest|, intersection.py:841-845, and the second engine's destination force
-        # comes from its own ring history: where the clamp is active the two sums are compared after bringing them to the
-        # same length)
-        ma, mb = np.hypot(ax, ay), np.hypot(bx, by)
-        fa_, fb_ = engines[0][1].force_parts(), engines[1][1].force_parts()
-        clamped = (ma > 0.98 * np.hypot(fa_[0], fa_[1])) | (mb > 0.98 * np.hypot(fb_[0], fb_[1]))
-        k = np.where(clamped & (mb > 0), ma / np.maximum(mb, 1e-300), 1.0)
-        df = np.maximum(np.abs(ax - k * bx), np.abs(ay - k * by)) / scale
-        nbad = int((df > 1e-3).sum())
-        worst_f = max(worst_f, float(np.percentile(df, 99.9)))
-        if nbad > 2:
-            w = int(df.argmax())
-            if os.environ.get("FUZZ_DEBUG"):
-                sys.path.insert(0, os.path.join(ROOT))
-                from oracle import csf_oracle as orc
-                tab = [orc.Params.from_buffer_copy(bytes(p)) for p in pods]
-                cl = np.array([cls_now[i] for i in range(n)], dtype=np.uint8)
-                bad = np.where(df > 1e-3)[0]
-                ox, oy = orc.column_sums(tab, A[:, 0], A[:, 1], A[:, 2], A[:, 3], bad, cls=cl)
-                fa = engines[0][1].force_parts(); fb = engines[1][1].force_parts()
-                for j, r in enumerate(bad):
-                    lim = np.hypot(fa[0][r], fa[1][r]); mag = np.hypot(ox[j], oy[j]); sc = lim / mag if mag > lim else 1.0
-                    print("  receiver", r, "class", cl[r], "oracle (clamped)", ox[j] * sc, oy[j] * sc, "A", ax[r], ay[r], "B", bx[r], by[r],
-                          "destA", fa[0][r], fa[1][r], "destB", fb[0][r], fb[1][r])
-            raise AssertionError(f"seed {seed} call {it} ({op}): repulsive sums of {nbad} receivers differ on the same state, worst {df.max():.2e} at {w} "
-                                 f"(A {ax[w]:.4f} {ay[w]:.4f}, B {bx[w]:.4f} {by[w]:.4f}); kernels {names}; calls {hist}")
+        worst = max(worst, float(np.percentile(dp, 99)))
+        tab = [orc.Params.from_buffer_copy(bytes(p)) for p in pods]
+        cl = np.array(cls_now, dtype=np.uint8)
+        recv = np.sort(rng.choice(n, min(n, 160), replace=False))
+        for seg, e in engines:
+            os.environ["CSF_SEGMENTS"] = seg
+            e.calc_forces()
+            fdx, fdy, rx, ry = e.force_parts()
+            st = e.state()
+            ox, oy = orc.column_sums(tab, st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv, cls=cl)
+            lim, mag = np.hypot(fdx[recv], fdy[recv]), np.maximum(np.hypot(ox, oy), 1e-300)
+            sc = np.minimum(1.0, lim / mag)
+            cx, cy = ox * sc, oy * sc
+            scale = max(np.hypot(cx, cy).max(), 1.0)
+            df = np.maximum(np.abs(rx[recv] - cx), np.abs(ry[recv] - cy)) / scale
+            worst_f = max(worst_f, float(df.max()))
+            # (one source on the edge of a field of view - DESIGN D6 - may differ by its whole force: at most two receivers)
+            if (df > 1e-4).sum() > 2 or np.median(df) > 2e-6:
+                w = int(df.argmax())
+                raise AssertionError(f"seed {seed} call {it} ({op}), engine CSF_SEGMENTS={seg}: clamped repulsive sums of {(df > 1e-4).sum()} of "
+                                     f"{recv.size} sampled receivers differ from the oracle, worst {df.max():.2e} at receiver {recv[w]} (set {cl[recv[w]]}); "
+                                     f"kernels {names}; calls {hist}")
     for _, e in engines:
         e.close()
     return n, K, names, worst, worst_f
