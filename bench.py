@@ -78,10 +78,21 @@ def tiled_curve_road(box, pitch=100.0):
     return flatten_road_elements(els)
 
 
+def build_id():
+    """what identifies the build of libcsf_hip.so that is loaded (the first 16 hex digits of its SHA-256)"""
+    import hashlib
+
+    from cyclistsocialforce_amd import _ffi
+
+    with open(_ffi.LIB_PATH, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE are
     collected in their own runs, tools/pmc_passes.sh; bench.py cannot run under rocprofv3 itself).  The newest file by
-    (round, version) whose recorded kernel name matches is taken."""
+    (round, version) whose recorded kernel name matches is taken - and refused when it was measured on another build of
+    the library than the one that is benched (`build_id`)."""
     best = None
     for path in glob.glob(os.path.join(ROOT, "profiles", "r*_v*_pair_kernel_pmc.json")):
         m = re.match(r"r(\d+)_v(\d+)_", os.path.basename(path))
@@ -96,7 +107,10 @@ def measured_traffic(kernel):
             best = (key, rec, path)
     if best is None:
         return None, None
-    return best[1].get("hbm_bytes_per_launch"), os.path.relpath(best[2], ROOT)
+    src = os.path.relpath(best[2], ROOT)
+    if best[1].get("build_id") != build_id():
+        return None, f"{src} was measured on build {best[1].get('build_id')}, this is build {build_id()}: not used"
+    return best[1].get("hbm_bytes_per_launch"), src
 
 
 def cpu_baseline(n, box, ticks):
@@ -209,6 +223,22 @@ def main():
         eng.step(preroll)
     fence()
 
+    def window_state():
+        """what the population looks like at an end of the timed window: extent (it disperses as it runs) and the work of
+        one pair launch on it (device counters, one extra launch - outside the timed region)"""
+        lo_, hi_ = eng.shard_range()
+        s_ = eng.state()
+        w_, _ = eng.count_pairs(detail=True)
+        return {"tick": int(eng.tick), "extent_m": [float(np.ptp(s_[:, 0])), float(np.ptp(s_[:, 1]))],
+                "rms_radius_m": float(np.sqrt(((s_[:, :2] - s_[:, :2].mean(axis=0)) ** 2).sum(axis=1).mean())),
+                "pairs_evaluated": None if w_ is None else int(w_["evaluated"]), "sources_tested": None if w_ is None else int(w_["tested"])}
+
+    # (taken before 256 further untimed ticks and the W warm-up ticks - its `tick` says where: the read-back lets the device
+    # fall idle for a millisecond, and the pair kernel then runs ~10 % slower for the next 100 - 200 ticks)
+    win0 = window_state() if world == 1 else None
+    if win0 is not None:
+        eng.step(256)
+        preroll += 256
     eng.step(args.warmup)
     fence()
     # the kernels' own start / end time stamps (hipExtLaunchKernelGGL events on the engine's stream); at least 16
@@ -233,6 +263,7 @@ def main():
     healthy = bool(np.isfinite(st).all() and (eng.status()[lo:hi] == 0).all())
     work, kernel = eng.count_pairs(detail=True)     # one extra launch on the final snapshot, outside the timed region
     evaluated = None if work is None else work["evaluated"]
+    win1 = window_state() if world == 1 else None
 
     if rank == 0:
         value = n * args.steps / dt
@@ -253,6 +284,7 @@ def main():
             ops = OPS_PER_PAIR * evaluated + OPS_PER_TEST * work["tested"]
             roof["achieved"] = ops / pair_s / 1e12
             roof["frac"] = roof["achieved"] / VALU_PEAK_TFLOPS
+            roof["field_only_frac"] = OPS_PER_PAIR * evaluated / pair_s / 1e12 / VALU_PEAK_TFLOPS   # crediting the field alone
             roof["work_per_launch"] = dict(work, op_equivalents=ops)
             roof["note"] = ("(100 fp32 op-equivalents x pairs evaluated + 25 x sources tested per lane) by one launch "
                             "(device counters) / mean kernel duration; the stream of source records is served from "
@@ -277,6 +309,8 @@ def main():
                        "parallelism": f"index-sharded x{world}, RCCL all-gather of fp32 records per tick"
                        if world > 1 else "single GPU"},
             "healthy": healthy,
+            "build_id": build_id(),
+            "timed_window": {"start": win0, "end": win1},
             "roofline": roof,
             "kernels_us": {"pair": pair_s * 1e6, "road": road_s * 1e6, "agent": agent_s * 1e6,
                            "all_gather": mean_s["gather"] * 1e6, "tick": dt / args.steps * 1e6,

@@ -31,7 +31,12 @@ if __name__ == "__main__":
     for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as fh:
             names |= {row["Kernel_Name"] for row in csv.DictReader(fh) if needle in row["Kernel_Name"]}
-    rec = {"kernel": sorted(names)[0] if names else needle, "config": config, "launches_averaged": n,
+    import hashlib
+
+    lib = os.environ.get("CSF_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cyclistsocialforce_amd", "libcsf_hip.so")
+    with open(lib, "rb") as fh:
+        bid = hashlib.sha256(fh.read()).hexdigest()[:16]
+    rec = {"kernel": sorted(names)[0] if names else needle, "config": config, "launches_averaged": n, "build_id": bid,
            "note": "rocprofv3 --pmc, one counter set per run (tools/pmc_passes.sh). FETCH_SIZE/WRITE_SIZE are reported in "
                    "KiB; on gfx950 FETCH_SIZE counts half of wide streaming reads (MI355X_MICROARCH.md), so HBM bytes "
                    "per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024."}
