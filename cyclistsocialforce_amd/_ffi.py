@@ -10,9 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # CSF_LIB selects another build of the same library (kernel A/B measurements, tools/ab.sh)
 LIB_PATH = os.environ.get("CSF_LIB") or os.path.join(HERE, "libcsf_hip.so")
 
-BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE = 0, 1, 2, 3, 4
+BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE, UNCONTROLLED = 0, 1, 2, 3, 4, 5
 UNREGULATED, P2R = 0, 1
-N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5}
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5, UNCONTROLLED: 4}
 UNIQUE_ID_BYTES = 128
 ST_SPLINE, ST_NAN, ST_NAVSTATE, ST_UNCONTROLLABLE = 1, 2, 4, 8
 
@@ -26,7 +26,7 @@ SYMBOLS = (
     "csf_comm_unique_id", "csf_comm_init", "csf_shard_range", "csf_profile_enable", "csf_profile_read",
     "csf_far_radius", "csf_get_tick", "csf_profile_gather", "csf_profile_kernels", "csf_profile_samples",
     "csf_count_pairs", "csf_comm_init_loopback", "csf_step_group", "csf_untracked", "csf_update_destination",
-    "csf_update_nav_state", "csf_set_dest_pointer", "csf_set_incremental",
+    "csf_update_nav_state", "csf_set_dest_pointer", "csf_set_incremental", "csf_set_script",
 )
 
 
@@ -124,7 +124,8 @@ def load():
     L.csf_update_nav_state.argtypes = [vp, i64, vp, vp, dp, dp]
     L.csf_set_dest_pointer.argtypes = [vp, i64, vp, vp]
     L.csf_set_incremental.argtypes = [vp, i32]
-    if L.csf_abi_version() != 3:
-        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 3")
+    L.csf_set_script.argtypes = [vp, i64, vp, vp, dp]
+    if L.csf_abi_version() != 4:
+        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 4")
     _lib = L
     return L

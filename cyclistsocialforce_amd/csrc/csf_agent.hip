@@ -161,9 +161,10 @@ void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0, hipEv
     else hipExtLaunchKernelGGL((agent_kernel<MODEL, false>), g, b, 0, st, t0, t1, 0, d, phases)
     // every vehicle class of the population in turn (one, unless csf_set_param_classes installed sets of several classes;
     // the launches touch disjoint agents).  The time stamps bracket the first launch.
-    for (int m = 0; m < 5; m++) {
+    for (int m = 0; m < 6; m++) {
         if (!(d.model_mask >> m & 1)) continue;
         switch (m) {
+        case CSF_UNCONTROLLED: CSF_AGENT(CSF_UNCONTROLLED); break;
         case CSF_BICYCLE: CSF_AGENT(CSF_BICYCLE); break;
         case CSF_TWOD: CSF_AGENT(CSF_TWOD); break;
         case CSF_INVPEND: CSF_AGENT(CSF_INVPEND); break;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         d.zrid[a] = s[3] < p.v_max_walk ? 0 : 1;                   // vehicle.py:1732-1736
         d.dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
         d.ppsi[a] = s[2];                                          // dynamics.py:828, 987-993
+        d.slen[a] = 0;                                             // (no prescribed trajectory until csf_set_script gives one)
         for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
         d.status[a] = 0;
         d.alive[a] = 1;

@@ -413,7 +413,8 @@ __device__ __forceinline__ void twod_dest(const Dev &d, Agent &g, double &fx, do
 
 template <int MODEL>
 __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, double &fy) {
-    if (MODEL == CSF_BICYCLE) direct_approach(d, g, fx, fy);  // vehicle.py:1189-1194
+    if (MODEL == CSF_UNCONTROLLED) fx = 0, fy = 0;            // vehicle.py:987-988
+    else if (MODEL == CSF_BICYCLE) direct_approach(d, g, fx, fy);  // vehicle.py:1189-1194
     else {
         if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) update_destination(d, g);  // Vehicle.calcDestinationForce :295-297
         twod_dest(d, g, fx, fy);
@@ -562,6 +563,19 @@ template <int MODEL>
 __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, double Fy) {
     const csf_params &p = *g.p;
     const int64_t a = g.a, cap = d.cap;
+    if (MODEL == CSF_UNCONTROLLED) {                          // vehicle.py:964-979: the next prescribed state, if there is one
+        g.ti = g.ti < 2000000000 ? g.ti + 1 : g.ti;           // (:973: the counter never wraps)
+        const int32_t rows = d.slen[a];
+        if (rows > 0) {
+            if (g.ti < rows) {
+                const double *r = d.script + 4 * (d.sbeg[a] + g.ti);
+                g.x = r[0], g.y = r[1], g.psi = r[2], g.v = r[3];
+            }
+        } else if (g.ti < p.traj_len) {                       // no trajectory given: the ring of zeros of Vehicle.__init__ (:158-160)
+            g.x = g.y = g.psi = g.v = 0.0;
+        }
+        return;
+    }
     if (MODEL == CSF_BICYCLE) {                               // vehicle.py:1274-1289
         bike_control_move(d, g, Fx, Fy);
     } else if (MODEL == CSF_TWOD) {                           // vehicle.py:1386-1414

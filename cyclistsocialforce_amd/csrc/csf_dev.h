@@ -89,6 +89,10 @@ struct Dev {
     uint8_t *zrid;     // 1 riding, 0 walking (vehicle.py:1732-1736)
     int32_t *dgood;    // consecutive ring samples with |delta| < delta_max_walk (vehicle.py:1943-1947)
     double *ppsi;      // PlanarPoint unwrapped yaw (dynamics.py:943-966)
+    // UncontrolledVehicle (vehicle.py:920-988): the prescribed trajectory of a slot, rows (x, y, psi, v) of a slab
+    const double *script;
+    const int64_t *sbeg;   // [cap] first row
+    int32_t *slen;         // [cap] rows (0: none given - the reference's ring of zeros behind the start state)
 
     // The PRECISE fp32 source records (x - ox - rorg.x, y - oy - rorg.y, cos psi, sin psi): the position is an offset from
     // the road user's OWN origin - where it was at the last re-binning, rounded to 1/4 m (exact in fp32, and so is the

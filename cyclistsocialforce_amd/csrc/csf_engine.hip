@@ -166,6 +166,10 @@ struct csf_engine {
     std::vector<uint8_t> h_znav, h_zrid;
     std::vector<uint32_t> h_status;
     std::vector<std::vector<double>> h_q;  // per slot: rows of (x, y, stop) - the host is authoritative for the rows
+    std::vector<std::vector<double>> h_script;   // per slot: rows (x, y, psi, v) of an UncontrolledVehicle's prescribed trajectory
+    DevBuf<double> script;
+    DevBuf<int64_t> sbeg;
+    DevBuf<int32_t> slen;
     // The population: road user i of the caller's order lives in slot order[i].  Slots are what every device array is
     // indexed by.  csf_remove_agents on a live device copy only kills slots (they keep a sentinel record), csf_add_agents
     // reuses them; a full upload compacts the slots back into population order.
@@ -300,7 +304,7 @@ int fail(csf_engine *e, int code, const char *fmt, ...) {
             return fail(e, CSF_E_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r));        \
     } while (0)
 
-const int NS_OF[5] = {5, 5, 6, 4, 5};
+const int NS_OF[6] = {5, 5, 6, 4, 5, 4};
 int32_t pair_variant_for(const csf_engine *e, int64_t n);   // (with rebin, below)
 
 double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, vehicle.py:154-155)
@@ -313,7 +317,7 @@ double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, 
 
 int check_params(csf_engine *e, const csf_params *p) {
     if (!p) return fail(e, CSF_E_ARG, "params is NULL");
-    if (p->model < 0 || p->model > 4) return fail(e, CSF_E_ARG, "unknown model %d", p->model);
+    if (p->model < 0 || p->model > 5) return fail(e, CSF_E_ARG, "unknown model %d", p->model);
     if (p->model == CSF_PLANARBIKE) {
         const double sum_im = p->pb_poles[1] + p->pb_poles[3], prod_im = p->pb_poles[0] * p->pb_poles[3] + p->pb_poles[1] * p->pb_poles[2];
         if (std::fabs(sum_im) > 1e-12 || std::fabs(prod_im) > 1e-12 || !(p->pb_poles[0] < 0) || !(p->pb_poles[2] < 0))
@@ -594,6 +598,9 @@ int alloc_all(csf_engine *e) {
     e->h_zrid.assign(cap, 0);
     e->h_status.assign(cap, 0);
     e->h_q.assign(cap, {});
+    e->h_script.assign(cap, {});
+    HIPCHK(e, e->sbeg.alloc(cap));
+    HIPCHK(e, e->slen.alloc(cap));
     e->h_alive.assign(cap, 0);
     e->h_cls.assign(cap, 0);
     HIPCHK(e, e->cls.alloc(cap));
@@ -922,9 +929,11 @@ void compact_host(csf_engine *e) {
         gather(e->h_hx, hl); gather(e->h_hy, hl);
         gather(e->h_vdes, 1); gather(e->h_ppsi, 1); gather(e->h_ptr, 1); gather(e->h_ti, 1); gather(e->h_dgood, 1);
         gather(e->h_znav, 1); gather(e->h_zrid, 1); gather(e->h_status, 1); gather(e->h_cls, 1);
-        std::vector<std::vector<double>> q((size_t)cap);
+        std::vector<std::vector<double>> q((size_t)cap), sc((size_t)cap);
         for (int64_t i = 0; i < n; i++) q[(size_t)i] = std::move(e->h_q[(size_t)e->order[(size_t)i]]);
+        for (int64_t i = 0; i < n; i++) sc[(size_t)i] = std::move(e->h_script[(size_t)e->order[(size_t)i]]);
         e->h_q.swap(q);
+        e->h_script.swap(sc);
         for (int64_t i = 0; i < n; i++) e->order[(size_t)i] = (int32_t)i;
         e->free_tail.clear();
         e->free_recent.clear();
@@ -1022,6 +1031,23 @@ int upload_all(csf_engine *e) {
     const int64_t n = d.n;
     int qrc = upload_queues(e, 0);
     if (qrc) return qrc;
+    {   // the prescribed trajectories of UncontrolledVehicle road users (vehicle.py:958-960): one slab of rows
+        std::vector<int64_t> beg((size_t)e->cap, 0);
+        std::vector<int32_t> len((size_t)e->cap, 0);
+        std::vector<double> flat;
+        for (int64_t a = 0; a < n; a++) {
+            beg[(size_t)a] = (int64_t)(flat.size() / 4);
+            len[(size_t)a] = (int32_t)(e->h_script[(size_t)a].size() / 4);
+            flat.insert(flat.end(), e->h_script[(size_t)a].begin(), e->h_script[(size_t)a].end());
+        }
+        if (flat.size() > e->script.n) HIPCHK(e, e->script.alloc(flat.size()));
+        if (!flat.empty()) HIPCHK(e, hipMemcpy(e->script.p, flat.data(), flat.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->sbeg.p, beg.data(), beg.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->slen.p, len.data(), len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        d.script = e->script.p;
+        d.sbeg = e->sbeg.p;
+        d.slen = e->slen.p;
+    }
     HIPCHK(e, hipMemcpy(e->alive.p, e->h_alive.data(), e->h_alive.size(), hipMemcpyHostToDevice));
     e->dev_alive = e->h_alive;
 #define H2D(vec, buf) HIPCHK(e, hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
@@ -1416,7 +1442,7 @@ int csf_destroy(csf_engine *e) {
     if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
-    e->lti.release(); e->ppsi.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
+    e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recp.release();
@@ -1574,6 +1600,7 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         e->h_alive[(size_t)a] = 0;
         e->h_cls[(size_t)a] = 0;                                // (a dead slot's sentinel record is looked up in set 0: the table may shrink)
         e->h_q[(size_t)a].clear();
+        e->h_script[(size_t)a].clear();
         e->free_recent.push_back(a);
         if (!patch) continue;
         drop_pending_requeue(e, (size_t)a);                      // a queue collected for the road user that leaves
@@ -2348,6 +2375,26 @@ int csf_set_dest_pointer(csf_engine *e, int64_t n, const int32_t *idx, const int
     int rc = prepare_mutation(e);
     if (rc) return rc;
     for (int64_t k = 0; k < n; k++) e->h_ptr[(size_t)e->order[(size_t)idx[k]]] = ptr[k];
+    return CSF_OK;
+}
+
+int csf_set_script(csf_engine *e, int64_t n, const int32_t *agent, const int64_t *offsets, const double *rows) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && (!agent || !offsets))) return fail(e, CSF_E_ARG, "csf_set_script: bad arguments");
+    for (int64_t k = 0; k < n; k++) {
+        if (agent[k] < 0 || agent[k] >= (int64_t)e->order.size()) return fail(e, CSF_E_ARG, "agent index %d out of range", agent[k]);
+        if (offsets[k + 1] < offsets[k]) return fail(e, CSF_E_ARG, "offsets must be non-decreasing");
+        if (offsets[k + 1] > offsets[k] && !rows) return fail(e, CSF_E_ARG, "csf_set_script: NULL rows");
+        if (offsets[k + 1] - offsets[k] > 2000000000) return fail(e, CSF_E_ARG, "a prescribed trajectory holds at most 2e9 states");
+    }
+    if (n == 0) return CSF_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = prepare_mutation(e);                              // (through the host mirror: scripts are set once, before the run)
+    if (rc) return rc;
+    for (int64_t k = 0; k < n; k++) {
+        std::vector<double> &sc = e->h_script[(size_t)e->order[(size_t)agent[k]]];
+        sc.assign(rows + 4 * offsets[k], rows + 4 * offsets[k + 1]);
+    }
     return CSF_OK;
 }
 

@@ -263,7 +263,7 @@ int tick_blocks(const Dev &d) {
 bool tick_fits(const Dev &d) {
     int R, blocks;
     tick_layout(d.n, &R, &blocks);
-    return d.n >= 1 && d.n <= TICK_MAX_AGENTS && blocks <= 256 && R <= WAVE;
+    return d.n >= 1 && d.n <= TICK_MAX_AGENTS && blocks <= 256 && R <= WAVE && d.p.model != CSF_UNCONTROLLED;
 }
 
 template <int MODEL>

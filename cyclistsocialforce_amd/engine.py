@@ -8,9 +8,10 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from ._ffi import BICYCLE, INVPEND, N_STATES, PLANARBIKE, PLANARPOINT, TWOD, EngineError, Params  # noqa: F401
+from ._ffi import BICYCLE, INVPEND, N_STATES, PLANARBIKE, PLANARPOINT, TWOD, UNCONTROLLED, EngineError, Params  # noqa: F401
 
-MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE}
+MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE,
+             "uncontrolled": UNCONTROLLED}
 
 
 def _f64(a, shape=None):
@@ -81,6 +82,15 @@ class Engine:
         if offsets.shape != (agents.size + 1,) or offsets[-1] != xyz.shape[0]:
             raise ValueError("offsets must be [n+1] and end at the number of rows")
         self._ck(self._lib.csf_set_dest_queue(self._h, agents.size, _ptr(agents), _ptr(offsets), _ptr(xyz), int(reset)))  # reset: 0 append, 1 replace, 2 replace + keep pointer
+
+    def set_script(self, agents, offsets, rows):
+        """prescribed trajectories of UncontrolledVehicle road users (include/csf.h: csf_set_script): rows (x, y, psi, v)"""
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        rows = _f64(rows).reshape(-1, 4)
+        if offsets.shape != (agents.size + 1,) or offsets[-1] != rows.shape[0]:
+            raise ValueError("offsets must be [n+1] and end at the number of rows")
+        self._ck(self._lib.csf_set_script(self._h, agents.size, _ptr(agents), _ptr(offsets), _ptr(rows)))
 
     def set_incremental(self, on=True):
         """population changes after the first tick: straight into the device arrays (True, default) or through the host

@@ -412,7 +412,8 @@ class SocialForceIntersection:
         k, w = v._index, type(v).N_STATES       # (a mixed population: the bulk rows are as wide as the widest class)
         v.s = self._S[k, :w]
         v.znav = self._zn[k]
-        v.traj = self._traj[:, k, :w].T
+        if not getattr(v, "uncontrolled", False):             # (an UncontrolledVehicle's traj is its prescription: vehicle.py:958-960)
+            v.traj = self._traj[:, k, :w].T
 
     def _detach(self, v):
         """the vehicle leaves with private copies of everything it saw through the mirror"""
@@ -467,11 +468,11 @@ class SocialForceIntersection:
         s0 = np.zeros((len(new), ns))
         for k, v in enumerate(new):
             s0[k, : v.s.size] = v.s
-        vd = np.array([float(v.params.v_desired_default) for v in new])
+        vd = np.array([float(getattr(v.params, "v_desired_default", 0.0)) for v in new])   # (CarParameters have none)
         first = new[0]._index
         e.add_agents(s0[:, : e.ns], vd)
         # vehicle.traj rows of the bulk history (grown geometrically; every vehicle of an engine shares t_s)
-        T = new[0].traj.shape[1]
+        T = int(30 / new[0].params.t_s)                        # vehicle.py:159
         n = len(self.vehicles)
         if self._traj is None or self._traj.shape[1] < n:
             grown = np.zeros((T, max(n, 2 * (0 if self._traj is None else self._traj.shape[1])), ns))
@@ -479,12 +480,20 @@ class SocialForceIntersection:
                 grown[:, : self._traj.shape[1]] = self._traj
             self._traj = grown
             for v in self.vehicles:
-                if v._live:
+                if v._live and not getattr(v, "uncontrolled", False):
                     v.traj = self._traj[:, v._index, : type(v).N_STATES].T
+        scripted = [v for v in new if getattr(v, "uncontrolled", False)]
+        if scripted:                                          # their prescribed trajectories -> the engine (csf_set_script)
+            rows = [v._script if v._script is not None else np.zeros((0, 4)) for v in scripted]
+            e.set_script([v._index for v in scripted], np.cumsum([0] + [r.shape[0] for r in rows]), np.vstack(rows))
         for v in new:
-            if v.traj.shape[1] != T:
+            if v.traj.shape[1] != T and not getattr(v, "uncontrolled", False):
                 raise NotImplementedError("all road users of one intersection share t_s (one engine per intersection)")
-        if all(type(v).N_STATES == ns for v in new):
+        if scripted:
+            for k, v in enumerate(new):
+                if not getattr(v, "uncontrolled", False):
+                    self._traj[:, first + k, : type(v).N_STATES] = v.traj.T
+        elif all(type(v).N_STATES == ns for v in new):
             for c in range(0, len(new), 512):        # adopt the vehicles' own histories, a slab of rows at a time
                 blk = new[c:c + 512]
                 self._traj[:, first + c:first + c + len(blk), :] = np.stack([v.traj for v in blk]).transpose(2, 0, 1)
@@ -570,7 +579,7 @@ class SocialForceIntersection:
             # rescanned only after some parameter object was assigned to
             if parameters.mutation_count() != self._params_seen:
                 self._params_seen = parameters.mutation_count()
-                vd = np.array([float(v.params.v_desired_default) for v in self.vehicles])
+                vd = np.array([float(getattr(v.params, "v_desired_default", 0.0)) for v in self.vehicles])
                 ch = np.where(vd != self._vd[:n])[0]
                 if ch.size:
                     e.set_v_desired(ch, vd[ch])

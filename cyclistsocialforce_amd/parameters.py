@@ -313,7 +313,17 @@ class PlanarBicycleParameters(BicycleParameters):
         self.poles = poles
 
 
+class CarParameters(VehicleParameters):
+    """parameters.py:752-764: VehicleParameters + the footprint of the car (UncontrolledVehicle, vehicle.py:920-988)."""
+
+    def __init__(self, length=4, width=2.0, **kwargs):
+        VehicleParameters.__init__(self, **kwargs)
+        self.length = length
+        self.width = width
+
+
 PARAMS_OF_MODEL = {
+    _ffi.UNCONTROLLED: CarParameters,
     _ffi.PLANARBIKE: PlanarBicycleParameters,
     _ffi.BICYCLE: BicycleParameters,
     _ffi.TWOD: InvPendulumBicycleParameters,
@@ -325,5 +335,5 @@ PARAMS_OF_MODEL = {
 def default_pod(model, priority_rule=0, **overrides):
     """csf_params of a vehicle class with the reference's defaults (keyword overrides allowed)."""
     if isinstance(model, str):
-        model = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3, "planarbike": 4}[model]
+        model = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3, "planarbike": 4, "uncontrolled": 5}[model]
     return PARAMS_OF_MODEL[model](**overrides).to_pod(model, priority_rule)

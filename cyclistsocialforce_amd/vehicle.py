@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine
-from .parameters import (BicycleParameters, InvPendulumBicycleParameters, PlanarBicycleParameters,
+from .parameters import (BicycleParameters, CarParameters, InvPendulumBicycleParameters, PlanarBicycleParameters,
                          PlanarPointBicycleParameters, VehicleParameters)
 from .utils import limitAngle
 
@@ -419,6 +419,29 @@ class PlanarBicycle(Vehicle):
     def __init__(self, s0, **kwargs):
         assert len(s0) >= 5, ("s0 has to have at least five elements:", " (x, y, psi, v, delta)!")
         Vehicle.__init__(self, s0, **kwargs)
+
+
+class UncontrolledVehicle(Vehicle):
+    """vehicle.py:920-988 — a stationary or externally controlled vehicle (a car): it follows the states prescribed in its
+    `traj` (column i at tick i, while there is one), exerts the TwoDBicycle force field with its CarParameters and feels
+    no force.  Inside a SocialForceIntersection the prescribed trajectory is handed to the engine when the vehicle is
+    attached (csf_set_script); `traj` stays the vehicle's own array."""
+
+    PARAMS_TYPE = CarParameters
+    MODEL = _ffi.UNCONTROLLED
+
+    def __init__(self, s0, trajectory=(), **kwargs):
+        Vehicle.__init__(self, s0, **kwargs)
+        self.uncontrolled = True
+        self._script = None
+        if len(trajectory) > 0:                                        # vehicle.py:958-960
+            self.traj = np.array(trajectory, dtype=float)
+            if self.traj.ndim != 2 or self.traj.shape[0] != self.N_STATES:
+                raise ValueError(f"trajectory must be [{self.N_STATES}, T]: one column of (x, y, psi, v) per tick")
+            self._script = np.ascontiguousarray(self.traj.T)
+
+    def calcDestinationForce(self):                                    # vehicle.py:987-988
+        return 0, 0
 
 
 class BalancingRiderBicycle(Vehicle):

@@ -25,11 +25,12 @@
 extern "C" {
 #endif
 
-#define CSF_ABI_VERSION 3
+#define CSF_ABI_VERSION 4
 
 /* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
- * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle) */
-enum csf_model { CSF_BICYCLE = 0, CSF_TWOD = 1, CSF_INVPEND = 2, CSF_PLANARPOINT = 3, CSF_PLANARBIKE = 4 };
+ * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle); :920 (UncontrolledVehicle: follows a prescribed trajectory
+ * - csf_set_script -, exerts the TwoDBicycle field with its own parameters, feels no force) */
+enum csf_model { CSF_BICYCLE = 0, CSF_TWOD = 1, CSF_INVPEND = 2, CSF_PLANARPOINT = 3, CSF_PLANARBIKE = 4, CSF_UNCONTROLLED = 5 };
 
 /* priority rule — intersection.py:263, 739-741 */
 enum csf_priority_rule { CSF_UNREGULATED = 0, CSF_P2R = 1 };
@@ -213,6 +214,12 @@ int csf_update_destination(csf_engine *e, int64_t n, const int32_t *idx);
 int csf_update_nav_state(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *stop, double *vd, double *ddest);
 /* vehicle.destpointer assigned from the host (Vehicle.stop types 1 and 2 step it back: vehicle.py:486-502) */
 int csf_set_dest_pointer(csf_engine *e, int64_t n, const int32_t *idx, const int32_t *ptr);
+
+/* UncontrolledVehicle.__init__(s0, trajectory) (vehicle.py:925-960): the prescribed trajectory of the listed road users
+ * (of a CSF_UNCONTROLLED parameter set), rows (x, y, psi, v) = the columns of the reference's `traj`; at tick i the
+ * state becomes row i while there is one (vehicle.py:964-979).  An empty range restores the default: the reference's
+ * ring of zeros behind the start state (vehicle.py:158-160), i.e. the vehicle sits at (0, 0) from its first tick on. */
+int csf_set_script(csf_engine *e, int64_t n, const int32_t *agent, const int64_t *offsets, const double *rows);
 
 /* ---- sharding over the GPUs of one node ------------------------------------- */
 

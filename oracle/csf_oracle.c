@@ -41,6 +41,7 @@
 #define CSFO_INVPEND 2
 #define CSFO_PLANARPOINT 3
 #define CSFO_PLANARBIKE 4
+#define CSFO_UNCONTROLLED 5   /* vehicle.py:920-988: follows a prescribed trajectory, exerts the TwoD field, feels nothing */
 
 #define CSFO_ST_SPLINE 1u
 #define CSFO_ST_NAN 2u
@@ -92,6 +93,9 @@ typedef struct csfo {
     double *vx, *vy, *vF0, *vsig;
     uint32_t *status;
     int64_t tick;
+    /* UncontrolledVehicle (vehicle.py:920-988): the prescribed trajectory of every agent, rows of (x, y, psi, v); CSR */
+    int64_t *soff;    /* [n+1] or NULL */
+    double *script;   /* [sum][4] */
 } csfo_t;
 
 /* ------------------------------------------------------------------ utils.py ---- */
@@ -574,6 +578,10 @@ static void twod_dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
 
 static void dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
     switch (PA(o, a)->model) {
+    case CSFO_UNCONTROLLED:                                        /* vehicle.py:987-988 */
+        *Fx = 0;
+        *Fy = 0;
+        break;
     case CSFO_BICYCLE:
         direct_approach(o, a, Fx, Fy);                             /* vehicle.py:1189-1194 */
         break;
@@ -1000,6 +1008,18 @@ void csfo_integrate_range(csfo_t *o, int lo, int hi) {
         case CSFO_PLANARBIKE:
             planarbike_step(o, a, Fx, Fy);
             break;
+        case CSFO_UNCONTROLLED: {                                  /* vehicle.py:964-979: the next prescribed state, if any */
+            int64_t i = (int64_t)o->i[a] + 1;                      /* (:973: the counter never wraps) */
+            if (i > 2000000000) i = 2000000000;
+            o->i[a] = (int32_t)i;
+            int64_t cols = o->soff ? o->soff[a + 1] - o->soff[a] : 0;
+            if (cols > 0) {
+                if (i < cols) memcpy(s, o->script + 4 * (o->soff[a] + i), 4 * sizeof(double));
+            } else if (i < L) {                                    /* no trajectory given: Vehicle.__init__'s ring of zeros (:158-160) */
+                s[0] = s[1] = s[2] = s[3] = 0;
+            }
+            continue;
+        }
         }
         int i = (o->i[a] + 1) % L;                                 /* vehicle.py:1279-1282, D5 */
         o->i[a] = i;
@@ -1033,7 +1053,7 @@ void csfo_step(csfo_t *o, int nticks) {
 
 /* ----------------------------------------------------------------- construction ---- */
 
-static const int NS[5] = {5, 5, 6, 4, 5};
+static const int NS[6] = {5, 5, 6, 4, 5, 4};
 
 /* what the constructors of the rider classes derive from the start state (vehicle.py:1728-1736; dynamics.py:195-197, 828,
  * 987-993), by the class of agent a */
@@ -1156,12 +1176,22 @@ void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const ui
     csfo_update_snapshot_range(o, 0, o->n);
 }
 
+/* the prescribed trajectories of UncontrolledVehicle agents (vehicle.py:958-960): CSR over all n agents, rows (x, y, psi, v) */
+void csfo_set_script(csfo_t *o, const int64_t *off, const double *rows) {
+    free(o->soff);
+    free(o->script);
+    o->soff = (int64_t *)malloc((size_t)(o->n + 1) * sizeof(int64_t));
+    memcpy(o->soff, off, (size_t)(o->n + 1) * sizeof(int64_t));
+    o->script = (double *)malloc((size_t)(4 * off[o->n] + 1) * sizeof(double));
+    memcpy(o->script, rows, (size_t)(4 * off[o->n]) * sizeof(double));
+}
+
 void csfo_destroy(csfo_t *o) {
     if (!o) return;
     free(o->s); free(o->vdes); free(o->qoff); free(o->dq); free(o->ptr); free(o->znav);
     free(o->znavp); free(o->i); free(o->traj); free(o->xlti); free(o->zrid); free(o->xdyn);
     free(o->vdyn); free(o->sx); free(o->sy); free(o->spsi); free(o->sv); free(o->Fx); free(o->Fy);
-    free(o->Fdx); free(o->Fdy); free(o->Frx); free(o->Fry); free(o->status);
+    free(o->Fdx); free(o->Fdy); free(o->Frx); free(o->Fry); free(o->status); free(o->soff); free(o->script);
     free(o->vx); free(o->vy); free(o->vF0); free(o->vsig);
     free(o->ptab); free(o->pcls);
     free(o);

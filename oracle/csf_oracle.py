@@ -12,9 +12,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libcsf_oracle.so")
 
-BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE = 0, 1, 2, 3, 4
-MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE}
-N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5}
+BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE, UNCONTROLLED = 0, 1, 2, 3, 4, 5
+MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE,
+             "uncontrolled": UNCONTROLLED}
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5, UNCONTROLLED: 4}
 
 ST_SPLINE, ST_NAN, ST_NAVSTATE = 1, 2, 4
 
@@ -53,7 +54,9 @@ _INVPEND = dict(_BICYCLE, v_max_riding=(-1.0, 7.0), a_max=(-3.0, 1.0), a_desired
                 c_steer=50.0, v_max_walk=1.5, delta_max_walk=0.174)
 _PLANARPOINT = dict(_BICYCLE, k_psi=2.0)
 _PLANARBIKE = dict(_BICYCLE, pb_poles=(-1.0141284591434665, 1.226826644413086, -1.0141284591434665, -1.226826644413086))
-DEFAULTS = {BICYCLE: _BICYCLE, TWOD: _INVPEND, INVPEND: _INVPEND, PLANARPOINT: _PLANARPOINT, PLANARBIKE: _PLANARBIKE}
+_CAR = dict(_VEHICLE, i_steer_vertvert=1.0)       # CarParameters (parameters.py:752-764): VehicleParameters + a footprint
+DEFAULTS = {BICYCLE: _BICYCLE, TWOD: _INVPEND, INVPEND: _INVPEND, PLANARPOINT: _PLANARPOINT, PLANARBIKE: _PLANARBIKE,
+            UNCONTROLLED: _CAR}
 
 
 def default_params(model, priority_rule=0, **overrides):
@@ -138,6 +141,7 @@ def lib():
         L.csfo_destroy.argtypes = [C.c_void_p]
         L.csfo_set_classes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.csfo_set_road.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_set_script.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_step.argtypes = [C.c_void_p, C.c_int]
         for f in ("csfo_calc_forces_range", "csfo_integrate_range", "csfo_update_snapshot_range"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -308,6 +312,13 @@ class Population:
         cls = np.ascontiguousarray(cls, dtype=np.uint8)
         assert cls.shape == (self.n,) and (len(classes) == 0 or cls.max() < len(classes))
         lib().csfo_set_classes(self.h, len(classes), tab, _p(cls))
+
+    def set_script(self, off, rows):
+        """prescribed trajectories of UncontrolledVehicle agents (vehicle.py:958-960): CSR over all agents, rows (x, y, psi, v)"""
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 4)
+        assert off.shape == (self.n + 1,) and off[-1] == rows.shape[0]
+        lib().csfo_set_script(self.h, _p(off), _p(rows))
 
     def set_road(self, off, verts, F0, sigma):
         off = np.ascontiguousarray(off, dtype=np.int64)

@@ -814,11 +814,59 @@ def gen_sumo_seam():
          hist_n=np.array(ins.hist_n_vecs))
 
 
+# ----------------------------------------------------------------------------
+# (16) UncontrolledVehicle (vehicle.py:920-988) among cyclists: a scripted obstacle that exerts the TwoDBicycle field with
+#      its CarParameters, follows the columns of its prescribed `traj` and feels no force; one with a trajectory that
+#      crosses the cyclists' way (and ends before the run does), one without (the reference then reads the zeros of the
+#      ring Vehicle.__init__ allocated: it sits at the origin from its first tick on)
+# ----------------------------------------------------------------------------
+def gen_uncontrolled():
+    rng = np.random.default_rng(2024)
+    ticks, n_bikes = 250, 8
+    vs, models = [], []
+    for k in range(n_bikes):
+        s0 = np.array([rng.uniform(-14, -2), rng.uniform(-5, 5), rng.uniform(-0.3, 0.3), rng.uniform(3.5, 4.8), 0.0])
+        v = make_vehicle("twod", s0, vdes=rng.uniform(4, 4.9), id=f"b{k}")
+        d = np.array([12.0, 24.0, 25.0])
+        v.setDestinations(s0[0] + d * np.cos(s0[2]), s0[1] + d * np.sin(s0[2]))
+        vs.append(v)
+        models.append("twod")
+    T = 180                                                     # shorter than the run: the car stops where its script ends
+    t = np.arange(T) * 0.01
+    script = np.vstack([6.0 - 0.0 * t, -7.0 + 5.0 * t, np.full(T, np.pi / 2), np.full(T, 5.0)])
+    car = rv.UncontrolledVehicle(tuple(script[:, 0]), trajectory=script, id="car")
+    car.drawing = _NoDrawing()
+    parked = rv.UncontrolledVehicle((3.0, -2.0, 0.5, 0.0), id="parked", params=rp.CarParameters(hfov=2.0, f_0=9.0))
+    parked.drawing = _NoDrawing()
+    vs += [car, parked]
+    models += ["uncontrolled", "uncontrolled"]
+    n = len(vs)
+    s6 = np.zeros((n, 6))
+    for k, v in enumerate(vs):
+        s6[k, : len(v.s)] = v.s
+    vdes = np.array([getattr(v.params, 'v_desired_default', 0.0) for v in vs])
+    off = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
+    dq = np.vstack([v.destqueue for v in vs])
+    soff = np.cumsum([0] * (n_bikes + 1) + [T, 0])
+    ins = ri.SocialForceIntersection(vs)
+    S = np.zeros((ticks // 10 + 1, n, 6))
+    F = np.zeros((ticks // 10, n, 2))
+    S[0] = s6
+    for tk in range(ticks):
+        ins.step()
+        if (tk + 1) % 10 == 0:
+            for k, v in enumerate(vs):
+                S[(tk + 1) // 10, k, : len(v.s)] = v.s
+                F[(tk + 1) // 10 - 1, k] = v.force
+    save("uncontrolled", s0=s6, vdes=vdes, off=off, dq=dq, models=np.array(models), script_off=soff, script_rows=script.T.copy(),
+         parked_hfov=2.0, parked_f0=9.0, S=S, F=F)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero", "mixed", "sumo"]
+    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero", "mixed", "sumo", "uncontrolled"]
     gens = {"pair": gen_pair_fields, "masks": gen_masks_and_totals, "control": gen_control_move,
             "dest": gen_dest_force, "pp": gen_planarpoint_steps, "road": gen_road,
             "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep,
-            "planarbike": gen_planarbike, "hetero": gen_hetero, "mixed": gen_mixed, "sumo": gen_sumo_seam}
+            "planarbike": gen_planarbike, "hetero": gen_hetero, "mixed": gen_mixed, "sumo": gen_sumo_seam, "uncontrolled": gen_uncontrolled}
     for w in which:
         gens[w]()

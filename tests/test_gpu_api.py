@@ -452,3 +452,40 @@ def test_scripts_written_against_the_reference_package_name(golden):
         sys.path.remove(os.path.join(root, "compat"))
         for k in [k for k in sys.modules if k == "cyclistsocialforce" or k.startswith("cyclistsocialforce.")]:
             del sys.modules[k]
+
+
+def test_uncontrolled_vehicle_in_an_intersection(golden):
+    """UncontrolledVehicle through the drop-in classes (vehicle.py:920-988): cyclists, a car on a prescribed trajectory and a
+    parked one in ONE SocialForceIntersection, constructed as the reference's users would - against the trajectories the
+    reference produced (tests/golden/uncontrolled.npz)."""
+    from cyclistsocialforce_amd.parameters import CarParameters
+    from cyclistsocialforce_amd.vehicle import UncontrolledVehicle
+
+    g = golden("uncontrolled")
+    s0, off, dq, vdes = g["s0"], g["off"], g["dq"], g["vdes"]
+    n = s0.shape[0]
+    vs = []
+    for k in range(n - 2):
+        v = TwoDBicycle(tuple(s0[k, :5]), id=f"b{k}")
+        v.params.v_desired_default = float(vdes[k])
+        rows = dq[off[k] + 1:off[k + 1]]
+        v.setDestinations(rows[:, 0], rows[:, 1])
+        vs.append(v)
+    script = g["script_rows"].T
+    car = UncontrolledVehicle(tuple(script[:, 0]), trajectory=script, id="car")
+    parked = UncontrolledVehicle((3.0, -2.0, 0.5, 0.0), id="parked", params=CarParameters(hfov=float(g["parked_hfov"]), f_0=float(g["parked_f0"])))
+    assert car.calcDestinationForce() == (0, 0) and car.traj.shape == script.shape
+    with pytest.raises(ValueError):
+        UncontrolledVehicle((0, 0, 0, 0), trajectory=np.zeros((3, 5)))
+    ins = SocialForceIntersection(vs + [car, parked])
+    S = g["S"]
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    for k in range(1, S.shape[0]):
+        for _ in range(10):
+            ins.step()
+        got = np.zeros((n, 6))
+        for r, v in enumerate(ins.vehicles):
+            got[r, : v.s.size] = v.s
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"sample {k}")
+        np.testing.assert_allclose(got[n - 2:, :4], S[k][n - 2:, :4], rtol=0, atol=1e-12)
+    assert car.traj.shape == script.shape and car.force == (0.0, 0.0)

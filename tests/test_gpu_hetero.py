@@ -646,3 +646,46 @@ def test_class_segmented_order_at_headline_size_vs_oracle(amd):
     assert e.count_pairs()[1] == "pair_cull_kernel" and (e.status() == 0).all() and np.isfinite(st).all()
     print(f"four parameter sets at N = 16 384: clamped repulsive sums vs oracle at 5 stations, worst {worst:.1e}")
     e.close()
+
+
+@pytest.mark.parametrize("fresh_script", [False, True])
+def test_uncontrolled_vehicle_among_cyclists_golden(amd, golden, fresh_script):
+    """UncontrolledVehicle (vehicle.py:920-988) as one more class of the table: cyclists + a car on a prescribed trajectory
+    + one without (the reference's quirk: it sits at the origin from the first tick on), against the trajectories the
+    REFERENCE produced (tests/golden/uncontrolled.npz).  fresh_script: the trajectory is handed over after some ticks
+    have run (through the host mirror), as an externally controlled vehicle's would be."""
+    g = golden("uncontrolled")
+    n = g["s0"].shape[0]
+    pods = [amd.pod("twod"), amd.pod("uncontrolled"), amd.pod("uncontrolled", hfov=float(g["parked_hfov"]), f_0=float(g["parked_f0"]))]
+    cls = np.array([0] * (n - 2) + [1, 2], dtype=np.uint8)
+    e = amd.Engine(pods[0], n)
+    e.set_param_classes(pods)
+    e.add_agents(g["s0"], g["vdes"])
+    e.set_dest_queue(np.arange(n), g["off"], g["dq"], reset=True)
+    e.set_agent_class(np.arange(n), cls)
+    soff, rows = g["script_off"], g["script_rows"]
+    S, F = g["S"], g["F"]
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    if not fresh_script:
+        e.set_script(np.arange(n), soff, rows)
+    worst = 0.0
+    for k in range(1, S.shape[0]):
+        if fresh_script and k == 1:
+            e.step(3)
+            # (the car has been reading zeros for three ticks: put it back on its script, as the reference would have it)
+            st = e.state()
+            st[n - 2, :4] = rows[3]
+            e.push_state([n - 2], st[n - 2])
+            e.set_script(np.arange(n), soff, rows)
+            e.step(7)
+        else:
+            e.step(10)
+        got = e.state()
+        worst = max(worst, np.abs(got[:, :2] - S[k][:, :2]).max() / extent)
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"sample {k}")
+        np.testing.assert_allclose(got[n - 2:, :4], S[k][n - 2:, :4], rtol=0, atol=1e-12, err_msg=f"scripted states, sample {k}")
+        fx, fy = e.forces()
+        np.testing.assert_allclose(np.c_[fx, fy][n - 2:], F[k - 1][n - 2:], rtol=0, atol=1e-12)
+    assert (e.status() == 0).all()
+    print(f"uncontrolled vehicles among cyclists: worst position deviation / extent = {worst:.2e}")
+    e.close()

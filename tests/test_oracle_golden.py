@@ -266,3 +266,25 @@ def test_population_of_several_vehicle_classes(golden):
         np.testing.assert_allclose(pop.state(), S[k], rtol=1e-9, atol=1e-8, err_msg=f"sample {k}")
         fx, fy = pop.forces()
         np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=1e-7, atol=1e-7, err_msg=f"forces {k}")
+
+
+def test_uncontrolled_vehicle_among_cyclists_golden(golden):
+    """UncontrolledVehicle (vehicle.py:920-988) in one intersection with cyclists, as the reference ran it
+    (tests/golden/uncontrolled.npz): a car that follows its prescribed trajectory (and stays where it ends), one without
+    a trajectory (it reads the zeros of the ring it was constructed with: the origin from its first tick on); both exert
+    the TwoDBicycle field with their CarParameters and feel nothing."""
+    g = golden("uncontrolled")
+    n = g["s0"].shape[0]
+    tab = [orc.default_params("twod"), orc.default_params("uncontrolled"),
+           orc.default_params("uncontrolled", hfov=float(g["parked_hfov"]), f_0=float(g["parked_f0"]))]
+    cls = np.array([0] * (n - 2) + [1, 2], dtype=np.uint8)
+    pop = orc.Population(tab[0], g["s0"], g["vdes"], g["off"], g["dq"], ns=6)
+    pop.set_classes(tab, cls)
+    pop.set_script(g["script_off"], g["script_rows"])
+    S, F = g["S"], g["F"]
+    for k in range(1, S.shape[0]):
+        pop.step(10)
+        np.testing.assert_allclose(pop.state(), S[k], rtol=0, atol=1e-9, err_msg=f"sample {k}")
+        fx, fy = pop.forces()
+        np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=0, atol=1e-9, err_msg=f"forces of sample {k}")
+    assert np.array_equal(S[-1, -1], np.zeros(6)) and abs(S[-1, -2, 1] - (-7.0 + 5.0 * 1.79)) < 1e-12
