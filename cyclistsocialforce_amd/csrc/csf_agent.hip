@@ -18,7 +18,9 @@ template <int MODEL, bool HET = false>
 __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
     const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= d.hi) return;
-    if (!d.alive[a]) return;                                   // a slot left behind by csf_remove_agents
+    // a slot left behind by csf_remove_agents; asked only when there is one (n_live != n, uniform): the answer is a round
+    // trip to memory that every other load of the kernel would wait behind
+    if (d.n_live != d.n && !d.alive[a]) return;
     const int64_t cap = d.cap;
     Agent g;
     g.a = a;
