@@ -128,6 +128,16 @@ struct Dev {
     float2 *rvo;       // [nv_pad / 1024 + 1] those origins, relative to (ox, oy)
     int64_t nv, nv_pad;
     int32_t road_np;   // sigma + 1 when every road edge shares one integer sigma in 1..5, else 0 (road_kernel)
+    // Large road networks (csf_road.hip; csf_engine.hip: build_road_grid): the vertices are static, so the road term is split
+    // over a lattice of square cells - a receiver sums the vertices of the 5 x 5 cells around its own directly and takes the
+    // rest of the network from the cell's Chebyshev interpolant of that (smooth) far field, fitted once per network.
+    int32_t rg_nx, rg_ny;      // cells of the lattice (0: no lattice, road_kernel sums every vertex)
+    int32_t rg_by_place;       // receivers are taken in binned order (neighbours share their cells' vertices in cache)
+    float rg_w;                // edge of a cell
+    float rg_x0, rg_y0;        // corner of cell (0, 0) relative to (ox, oy): a multiple of rg_w
+    const float4 *rg_v;        // [nv] vertices sorted by cell: (x, y) relative to the CENTRE of their cell, -F0, -(sigma+1)/2
+    const int32_t *rg_start;   // [nx ny + 1] first vertex of every cell (row-major)
+    const float *rg_c;         // [nx ny][2][64] coefficients c_ab of sum_ab c_ab T_a(xi) T_b(eta), x and y component
 
     double *F;         // [6][cap] Fx, Fy, Fdest_x, Fdest_y, Frep_x, Frep_y
     uint32_t *status;
@@ -147,6 +157,13 @@ enum : int { PH_DEST = 1, PH_COMBINE = 2, PH_INTEGRATE = 4, PH_FIXSPEED = 8 };
 // taken from the dispatch packet, no extra barrier packet in the stream as with hipEventRecord)
 void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_road(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// csf_road.hip: the road term over a lattice (Dev::rg_*).  launch_road_far: the far field of every cell at its 8 x 8
+// Chebyshev nodes, samples[(cell * 64 + node) * 2 + component] (node = 8 ix + iy), from the cell-sorted vertices and
+// their cells (x, y index); launch_road_grid: the per-tick kernel.
+constexpr int RG_NEAR = 2;      // cells on either side of a receiver's own whose vertices are summed directly
+constexpr int RG_NODES = 8;     // Chebyshev nodes per direction
+void launch_road_far(const Dev &d, const short2 *vcell, double *samples, hipStream_t st);
+void launch_road_grid(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 const char *pair_kernel_name(const Dev &d);           // the kernel launch_pair() takes for this engine
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state

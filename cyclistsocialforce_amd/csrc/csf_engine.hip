@@ -103,6 +103,8 @@ struct Knobs {
     bool comm_second = false;                 // CSF_COMM_STREAM=second
     int fused = 0;                            // CSF_FUSED=1: the one-launch tick of small populations (csf_tick.hip; opt-in)
     double rnear = 1.0;                       // CSF_RNEAR: pairs closer than this (m) are evaluated from the precise records (0: none)
+    int road_grid = -1;                       // CSF_ROAD_GRID: 1 the lattice of csf_road.hip for any road, 0 never (-1: large networks)
+    double road_cell = 0.0;                   // CSF_ROAD_CELL: edge of its cells in m (0: 16)
     void read() {
         auto geti = [](const char *name, int dflt) {
             const char *v = getenv(name);
@@ -126,6 +128,8 @@ struct Knobs {
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second";
         fused = geti("CSF_FUSED", 0);
         if (const char *v = getenv("CSF_RNEAR")) rnear = atof(v);
+        road_grid = geti("CSF_ROAD_GRID", -1);
+        if (const char *v = getenv("CSF_ROAD_CELL")) road_cell = atof(v);
     }
 };
 
@@ -197,6 +201,13 @@ struct csf_engine {
     int64_t q_top = 0;                     // rows of the queue slab in use
     int64_t churn = 0;                     // road users spawned into free slots since the last re-binning
     std::vector<double> h_road;            // per vertex (x, y, F0, sigma)
+    // the lattice over a large road network (csf_road.hip; build_road_grid): what was built, and for which vertex set
+    uint64_t road_version = 1, rg_version = 0;
+    double rg_cell = 0, rg_gx0 = 0, rg_gy0 = 0, rg_ox = 0, rg_oy = 0;
+    int rg_nx = 0, rg_ny = 0;
+    DevBuf<float4> rg_v;
+    DevBuf<int32_t> rg_start;
+    DevBuf<float> rg_c;
     bool dirty = true;                     // host mirror changed since the last upload
     bool device_ahead = false;             // ticks ran since the last download
 
@@ -526,6 +537,121 @@ void derive_consts(csf_engine *e) {
         e->d.model_mask |= 1 << c.model;
     }
     e->d.has_bike = e->d.model_mask & 1;
+}
+
+// ---- the lattice over a large road network (csf_road.hip) -----------------------------------------------------------------
+// Worth it when the (2 RG_NEAR + 1)^2 cells around a road user hold a small part of the network.  box: x0, x1, y0, y1 of the
+// vertices.
+static double road_cell_edge(const csf_engine *e) { return e->knobs.road_cell > 0 ? e->knobs.road_cell : 16.0; }
+bool road_grid_wanted(const csf_engine *e, double box[4]) {
+    const int64_t nv = (int64_t)e->h_road.size() / 4;
+    if (nv <= 0 || e->knobs.road_grid == 0) return false;
+    box[0] = box[2] = INFINITY, box[1] = box[3] = -INFINITY;
+    for (int64_t k = 0; k < nv; k++) {
+        box[0] = std::min(box[0], e->h_road[4 * k]), box[1] = std::max(box[1], e->h_road[4 * k]);
+        box[2] = std::min(box[2], e->h_road[4 * k + 1]), box[3] = std::max(box[3], e->h_road[4 * k + 1]);
+    }
+    if (!(std::isfinite(box[0]) && std::isfinite(box[1]) && std::isfinite(box[2]) && std::isfinite(box[3]))) return false;
+    if (e->knobs.road_grid == 1) return true;
+    const double w = road_cell_edge(e);
+    return nv >= 16384 && ((box[1] - box[0]) / w + 1) * ((box[3] - box[2]) / w + 1) >= 4.0 * (2 * RG_NEAR + 1) * (2 * RG_NEAR + 1);
+}
+
+// Sorts the vertices into the cells of the lattice, and - once per vertex set - samples every cell's far field at its
+// Chebyshev nodes on the device (launch_road_far) and turns the samples into the coefficients of the interpolant.
+int build_road_grid(csf_engine *e, const double box[4]) {
+    Dev &d = e->d;
+    const int64_t nv = d.nv;
+    double w = road_cell_edge(e);
+    double gx0 = 0, gy0 = 0;
+    int64_t nx = 0, ny = 0;
+    // The lattice covers the network, the road users as they are now (a road user outside it sums every vertex: correct, and
+    // as slow as without a lattice) and a margin of RG_NEAR cells or 5 % of the extent.
+    double lo[2] = {box[0], box[2]}, hi[2] = {box[1], box[3]};
+    for (int64_t a = 0; a < d.n; a++) {
+        if (!e->h_alive[(size_t)a]) continue;
+        for (int c = 0; c < 2; c++) {
+            const double v = e->h_s[(size_t)c * e->cap + a];
+            if (std::isfinite(v)) lo[c] = std::min(lo[c], v), hi[c] = std::max(hi[c], v);
+        }
+    }
+    for (;;) {   // coarser cells while the lattice (or the sampling: cells x 64 x nv pairs) is too large
+        const double mx = std::max(RG_NEAR * w, 0.05 * (hi[0] - lo[0])), my = std::max(RG_NEAR * w, 0.05 * (hi[1] - lo[1]));
+        gx0 = w * std::floor(((lo[0] - mx) - d.ox) / w);
+        gy0 = w * std::floor(((lo[1] - my) - d.oy) / w);
+        nx = (int64_t)std::floor((((hi[0] + mx) - d.ox) - gx0) / w) + 1;
+        ny = (int64_t)std::floor((((hi[1] + my) - d.oy) - gy0) / w) + 1;
+        if (nx <= 30000 && ny <= 30000 && nx * ny <= (1 << 18) && (double)nx * (double)ny * 64.0 * (double)nv <= 4e12) break;
+        w *= 2;
+    }
+    const int64_t ncell = nx * ny;
+    std::vector<int32_t> start((size_t)ncell + 1, 0), cell((size_t)nv);
+    for (int64_t k = 0; k < nv; k++) {
+        const int64_t ix = std::min<int64_t>(nx - 1, std::max<int64_t>(0, (int64_t)std::floor(((e->h_road[4 * k] - d.ox) - gx0) / w)));
+        const int64_t iy = std::min<int64_t>(ny - 1, std::max<int64_t>(0, (int64_t)std::floor(((e->h_road[4 * k + 1] - d.oy) - gy0) / w)));
+        cell[(size_t)k] = (int32_t)(iy * nx + ix);
+        start[(size_t)cell[(size_t)k] + 1]++;
+    }
+    for (int64_t c = 0; c < ncell; c++) start[(size_t)c + 1] += start[(size_t)c];
+    std::vector<float4> gv((size_t)nv);
+    std::vector<short2> vc((size_t)nv);
+    {
+        std::vector<int32_t> at(start.begin(), start.end() - 1);
+        for (int64_t k = 0; k < nv; k++) {   // (stable: the vertices of a cell keep their order)
+            const int32_t c = cell[(size_t)k];
+            const int64_t ix = c % nx, iy = c / nx;
+            const size_t o = (size_t)at[(size_t)c]++;
+            gv[o] = make_float4((float)(((e->h_road[4 * k] - d.ox) - gx0) - ((double)ix + 0.5) * w),
+                                (float)(((e->h_road[4 * k + 1] - d.oy) - gy0) - ((double)iy + 0.5) * w),
+                                (float)(-e->h_road[4 * k + 2]), (float)(-0.5 * (e->h_road[4 * k + 3] + 1.0)));
+            vc[o] = make_short2((short)ix, (short)iy);
+        }
+    }
+    HIPCHK(e, e->rg_v.reserve((size_t)nv));
+    HIPCHK(e, e->rg_start.reserve((size_t)ncell + 1));
+    HIPCHK(e, hipMemcpy(e->rg_v.p, gv.data(), gv.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->rg_start.p, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    d.rg_nx = (int32_t)nx, d.rg_ny = (int32_t)ny;
+    d.rg_w = (float)w, d.rg_x0 = (float)gx0, d.rg_y0 = (float)gy0;
+    d.rg_v = e->rg_v.p, d.rg_start = e->rg_start.p;
+    d.rg_by_place = 0;
+    const bool same = e->rg_version == e->road_version && e->rg_cell == w && e->rg_gx0 == gx0 && e->rg_gy0 == gy0 &&
+                      e->rg_nx == (int)nx && e->rg_ny == (int)ny && e->rg_ox == d.ox && e->rg_oy == d.oy && e->rg_c.p != nullptr;
+    if (!same) {
+        DevBuf<short2> dvc;
+        DevBuf<double> dsm;
+        HIPCHK(e, dvc.alloc((size_t)nv));
+        HIPCHK(e, dsm.alloc((size_t)ncell * 128));
+        HIPCHK(e, hipMemcpy(dvc.p, vc.data(), vc.size() * sizeof(short2), hipMemcpyHostToDevice));
+        launch_road_far(d, dvc.p, dsm.p, e->main);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        std::vector<double> sm((size_t)ncell * 128);
+        HIPCHK(e, hipMemcpy(sm.data(), dsm.p, sm.size() * sizeof(double), hipMemcpyDeviceToHost));
+        dvc.release();
+        dsm.release();
+        // c_ab = k_a k_b (2/8)^2 sum_ij f(x_i, y_j) cos(a pi (i + 1/2) / 8) cos(b pi (j + 1/2) / 8), k_0 = 1/2
+        double cs[RG_NODES][RG_NODES];
+        for (int a = 0; a < RG_NODES; a++)
+            for (int i = 0; i < RG_NODES; i++) cs[a][i] = std::cos(a * 3.14159265358979323846 * (i + 0.5) / RG_NODES);
+        std::vector<float> co((size_t)ncell * 128);
+        for (int64_t c = 0; c < ncell; c++)
+            for (int comp = 0; comp < 2; comp++)
+                for (int a = 0; a < RG_NODES; a++)
+                    for (int b = 0; b < RG_NODES; b++) {
+                        double acc = 0;
+                        for (int i = 0; i < RG_NODES; i++)
+                            for (int j = 0; j < RG_NODES; j++) acc += sm[((size_t)c * 64 + (size_t)(8 * i + j)) * 2 + (size_t)comp] * cs[a][i] * cs[b][j];
+                        acc *= (a ? 1.0 : 0.5) * (b ? 1.0 : 0.5) * (2.0 / RG_NODES) * (2.0 / RG_NODES);
+                        co[((size_t)c * 2 + (size_t)comp) * 64 + (size_t)(8 * a + b)] = (float)acc;
+                    }
+        HIPCHK(e, e->rg_c.reserve(co.size()));
+        HIPCHK(e, hipMemcpy(e->rg_c.p, co.data(), co.size() * sizeof(float), hipMemcpyHostToDevice));
+        e->rg_version = e->road_version;
+        e->rg_cell = w, e->rg_gx0 = gx0, e->rg_gy0 = gy0, e->rg_nx = (int)nx, e->rg_ny = (int)ny, e->rg_ox = d.ox, e->rg_oy = d.oy;
+    }
+    d.rg_c = e->rg_c.p;
+    return CSF_OK;
 }
 
 int alloc_all(csf_engine *e) {
@@ -1080,6 +1206,12 @@ int upload_all(csf_engine *e) {
         if (!std::isfinite(d.ox)) d.ox = 0;
         if (!std::isfinite(d.oy)) d.oy = 0;
     }
+    double rbox[4];
+    const bool road_grid = road_grid_wanted(e, rbox);
+    if (road_grid) {   // a lattice over the road network (csf_road.hip) is anchored at the origin: the network's centre, which stays
+        d.ox = std::nearbyint(0.5 * (rbox[0] + rbox[1]));
+        d.oy = std::nearbyint(0.5 * (rbox[2] + rbox[3]));
+    }
     // Road vertices (x, y, -F0, -(sigma+1)/2), padded with inert vertices.  Positions are offsets from the origin of
     // their tile of 1024 consecutive vertices (the centre of its box, rounded to 1/4 m): consecutive vertices of a
     // polyline are neighbours, so a vertex resolves to 2^-24 of ~50 m whatever the extent of the scene, and the road
@@ -1118,6 +1250,11 @@ int upload_all(csf_engine *e) {
         if (same) d.road_np = (int32_t)sg + 1;
     }
     d.rv = e->rv.p;
+    d.rg_nx = d.rg_ny = 0;
+    if (road_grid) {
+        const int rc = build_road_grid(e, rbox);
+        if (rc) return rc;
+    }
     set_shard(e);
     if ((size_t)d.n_pad > e->rec.n) return fail(e, CSF_E_CAPACITY, "record buffer too small for this shard layout");
     HIPCHK(e, hipMemsetAsync(e->part.p, 0, e->part.n * sizeof(float2), e->main));   // a new layout starts from clean partial sums
@@ -1444,7 +1581,7 @@ int csf_destroy(csf_engine *e) {
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
-    e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
+    e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
     e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recp.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
@@ -1706,6 +1843,7 @@ int csf_set_road_vertices(csf_engine *e, int32_t n_edges, const int64_t *offsets
     int rc = prepare_mutation(e);
     if (rc) return rc;
     e->h_road.clear();
+    e->road_version++;
     for (int32_t k = 0; k < n_edges; k++)
         for (int64_t v = offsets[k]; v < offsets[k + 1]; v++) {
             e->h_road.push_back(xy[2 * v]);

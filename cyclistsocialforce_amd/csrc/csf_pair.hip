@@ -1039,6 +1039,12 @@ const char *pair_kernel_name(const Dev &d) {
 
 void launch_road(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo || d.nv == 0) return;
+    if (d.rg_nx > 0) {     // a large, static network: near field summed, far field interpolated (csf_road.hip)
+        Dev dd = d;        // receivers in binned order where this device bins and integrates every slot
+        dd.rg_by_place = d.recs_valid && !d.seg_keys && d.rlist == nullptr && d.lo == 0 && d.hi == d.n;
+        launch_road_grid(dd, st, t0, t1);
+        return;
+    }
     const dim3 g = recv_grid(d, 1);
     switch (d.road_np) {
     case 2: CSF_LAUNCH(road_kernel<2>, g); break;

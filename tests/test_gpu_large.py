@@ -129,6 +129,73 @@ def test_config5_1048576_planarpoint_with_road(amd):
     assert rerr.max() < 1e-4
 
 
+def test_road_lattice_against_the_direct_sum_and_the_oracle(amd, monkeypatch):
+    """Large static road networks (csf_road.hip): the vertices of the 5 x 5 lattice cells around a road user summed directly,
+    the rest of the network from the cell's Chebyshev interpolant.  4 096 PlanarPointBicycle on the curve-scenario road
+    tiled over 400 m (24 480 vertices), three engines - every vertex summed (CSF_ROAD_GRID=0), lattice of 16 m and of 32 m
+    cells - against the oracle's road term (intersection.py:226-242), among the receivers one 1 cm from a vertex, one
+    exactly ON a vertex (the reference divides by zero there; the engine gives it no force from that vertex) and two far
+    outside the lattice (no interpolant: they sum every vertex).  Then 20 ticks, lattice against direct sum."""
+    import bench
+
+    n, box = 4096, 400.0
+    s0, off, dq = population(n, box, seed=9)
+    s0 = s0[:, :4]
+    roff, verts, F0, sg = bench.tiled_curve_road(box)
+    assert verts.shape[0] > 20000
+    for k, to in enumerate((verts[100],                         # on a vertex
+                            verts[5000] + [0.01, 0.0],          # 1 cm from one
+                            [-900.0, -500.0],                   # far outside the lattice
+                            [box + 400.0, box / 2])):
+        dq[off[k]:off[k + 1], :2] += np.asarray(to) - s0[k, :2]  # (its destinations move with it)
+        s0[k, :2] = to
+    rx, ry = orc.road_forces(verts, roff, F0, sg, s0[:, 0], s0[:, 1])
+    assert not np.isfinite(rx[0]) and np.isfinite(rx[1:]).all()
+    dmin = np.array([np.sqrt(((verts - s0[j, :2]) ** 2).sum(axis=1).min()) for j in range(n)])
+    own = np.maximum(np.hypot(rx, ry), 1e-3)
+    out, fin = {}, {}
+    for label, grid, cell in (("direct", "0", None), ("lattice 16 m", "1", None), ("lattice 32 m", "1", "32")):
+        monkeypatch.setenv("CSF_ROAD_GRID", grid)
+        if cell is None:
+            monkeypatch.delenv("CSF_ROAD_CELL", raising=False)
+        else:
+            monkeypatch.setenv("CSF_ROAD_CELL", cell)
+        e = make_engine(amd, "planarpoint", s0, 5.0, off, dq)
+        e.set_road(roff, verts, F0, sg)
+        fx, fy = e.calc_forces()
+        fdx, fdy, frx, fry = e.force_parts()
+        out[label] = np.c_[fx - fdx - frx, fy - fdy - fry]
+        e.step(20)
+        fin[label] = e.state()
+        assert (e.status() == 0).all()
+        e.close()
+    ok = np.arange(n) != 0
+    checks = []
+    for label, g in out.items():
+        err = np.maximum(np.abs(g[:, 0] - rx), np.abs(g[:, 1] - ry))
+        rel = err[ok] / own[ok]
+        print(f"road term, {label}: vs oracle, relative to the receiver's own road force: median {np.median(rel):.1e} max {rel.max():.1e} "
+              f"(receiver {np.arange(n)[ok][rel.argmax()]}, nearest vertex {dmin[np.arange(n)[ok][rel.argmax()]]:.3f} m)")
+        # the plain tolerance, per receiver and relative to its OWN road force - plus, centimetres from a vertex, the fp32
+        # resolution of a position within its tile or cell (~1e-6 m) over the distance, times sigma + 1
+        far = dmin[ok] > 0.25
+        print(f"      beyond 0.25 m of every vertex: max {rel[far].max():.1e}; worst of rel / (1e-4 + 1e-5 / dmin): "
+              f"{(rel / (1e-4 + 1e-5 / np.maximum(dmin[ok], 1e-3))).max():.2f}")
+        checks.append((label, (rel < 1e-4 + 1e-5 / np.maximum(dmin[ok], 1e-3)).all(), rel[far].max()))
+        assert np.isfinite(g[0]).all()                           # (on a vertex: that vertex adds nothing)
+    for label, near_ok, far_max in checks:
+        assert near_ok and far_max < 1e-4, (label, near_ok, far_max)
+    for label in ("lattice 16 m", "lattice 32 m"):
+        d = np.abs(out[label] - out["direct"]).max(axis=1)
+        away = ok & (dmin > 0.5)
+        print(f"   {label} - direct: max {(d[away] / own[away]).max():.1e} of the own force where no vertex is within 0.5 m; "
+              f"20 ticks later |dpos| {np.abs(fin[label][:, :2] - fin['direct'][:, :2]).max():.1e} m")
+        assert (d[away] / own[away]).max() < 5e-5               # (both carry their own fp32 rounding: see the lines above)
+        assert np.abs(fin[label][ok, :2] - fin["direct"][ok, :2]).max() < 1e-6 * box
+    # the receivers outside the lattice took the same sum as the direct path, to the rounding of another origin
+    assert np.abs(out["lattice 16 m"][2:4] - out["direct"][2:4]).max() < 1e-5 * own[2:4].max()
+
+
 # --------------------------------------------------------------------------- BASELINE config 2, full length
 
 def test_config2_1024_twod_10000_ticks(amd):

@@ -26,12 +26,22 @@ def run():
     eng = Engine(parameters.default_pod("twod"), n)
     eng.add_agents(s0, 5.0)
     eng.set_dest_queue(np.arange(n), off, dq, reset=True)
-    eng.step(60, sync=True)
+    eng.step(int(os.environ.get("TICKS", "60")), sync=True)
     eng.close()
 
 
 def show(path):
     w = np.fromfile(path, dtype=np.uint64).reshape(-1, 3)
+    if len(sys.argv) > 3:   # source chunks of the launch (16 at N = 16 384): when does each chunk's work run, how long is it
+        nch = int(sys.argv[3])
+        used = np.nonzero(w[:, 1] > 0)[0]
+        per = (used.max() + 1 + nch - 1) // nch
+        b = int(w[used, 0].min())
+        print("chunk  waves  first_entry_us  last_exit_us  wave_duration_mean_us  wave-microseconds")
+        for c in range(nch):
+            k = used[(used >= c * per) & (used < (c + 1) * per)]
+            a0, a1 = (w[k, 0].astype(np.int64) - b) / 100.0, (w[k, 1].astype(np.int64) - b) / 100.0
+            print(f"{c:5d}  {len(k):5d}  {a0.min():8.1f}  {a1.max():8.1f}  {(a1 - a0).mean():8.2f}  {(a1 - a0).sum():10.0f}")
     w = w[w[:, 1] > 0]
     t0, t1, hw = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64), w[:, 2]
     base = t0.min()
