@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         d.recg[a] = q;
         if (d.recs_valid) {
             d.recs[d.pos[a]] = q;
-            ((float2 *)&d.recp[d.pos[a]])[0] = make_float2(q.x, q.y);   // (the place keeps its origin)
+            d.recb[d.pos[a]] = q;
         }
         if (d.has_bike) {
             d.rec2[a] = make_float2(0.0f, 1.0f);

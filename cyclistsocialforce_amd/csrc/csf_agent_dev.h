@@ -684,7 +684,10 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     if (d.recs_valid) {
         const int32_t p = d.pos[a];
         d.recs[p] = g;
-        d.recp[p] = make_float4(q.x, q.y, o.x, o.y);
+        if (d.recv_binned) {                                   // (large populations only: csf_dev.h recb)
+            const float2 bo = d.borg[p >> 6];
+            d.recb[p] = make_float4(q.x + (o.x - bo.x), q.y + (o.y - bo.y), q.z, q.w);
+        }
     }
     if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
         double e = 0.0;

@@ -75,11 +75,12 @@ __global__ void sorted_copy_kernel(const Dev d) {
     float4 q = d.rec[a];
     if (rec_is_real(q)) {                                     // scene coordinates: offset + the slot's origin
         const float2 o = d.rorg[a];
-        d.recp[p] = make_float4(q.x, q.y, o.x, o.y);
+        const float2 bo = d.borg[p >> 6];                     // (the batches keep their origins between re-binnings)
+        d.recb[p] = make_float4(q.x + (o.x - bo.x), q.y + (o.y - bo.y), q.z, q.w);
         q.x += o.x, q.y += o.y;
         d.recg[a] = q;                                        // (a receiver must coincide with itself as a source)
     } else {
-        ((float2 *)&d.recp[p])[0] = make_float2(q.x, q.y);   // (the place keeps its origin)
+        d.recb[p] = q;
     }
     d.recs[p] = q;
     if (d.has_bike) d.recs2[p] = d.rec2[a];
@@ -126,11 +127,12 @@ __global__ __launch_bounds__(256) void rebase_kernel(const Dev d) {
     } else if (a < d.n_pad) {
         d.pos[a] = (int32_t)p;                                 // (a free slot's place: where an arrival spawned into it will sit)
     }
-    {   // the precise record by place; an empty place takes the origin of the batch's first road user (0 if there is none)
+    {   // the record by place relative to the batch's origin: the new origin of its first road user (0 if there is none)
         const unsigned long long m = __ballot(real);
         const int first = m ? __builtin_ctzll(m) : 0;
         const float fx = __shfl(on.x, first, 64), fy = __shfl(on.y, first, 64);
-        d.recp[p] = real ? make_float4(q.x, q.y, on.x, on.y) : make_float4(q.x, q.y, fx, fy);
+        d.recb[p] = real ? make_float4(q.x + (on.x - fx), q.y + (on.y - fy), q.z, q.w) : q;
+        if (lane == 0) d.borg[b] = make_float2(fx, fy);
     }
     // the binned copy holds scene coordinates, offset + origin (what the tiles of the pair kernels are filled with)
     if (real) q.x += on.x, q.y += on.y;

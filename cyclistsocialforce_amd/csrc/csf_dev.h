@@ -102,9 +102,12 @@ struct Dev {
     // kernels hold scene coordinates (recs, or offset + origin), 2^-24 of the scene extent.
     float4 *rec;       // [n_pad] by slot
     float2 *rorg;      // [n_pad] by slot: the origin its record is relative to, itself relative to (ox, oy)
-    float4 *recp;      // [n_pad] by place of the binned order: the precise record as (offset x, offset y, origin x, origin y); a
-                       // place without a road user keeps an origin of its neighbourhood (large populations: the pair
-                       // kernel works relative to the origin of its receiver group, csf_pair.hip BINR)
+    // Large populations (recv_binned; csf_pair.hip BINR works relative to the origin of its receiver group): the record by
+    // place of the binned order, its position relative to the origin of its BATCH of 64 places - the own origin of the
+    // batch's first road user at the last re-binning - formed as offset + (own origin - batch origin), the bracket exact:
+    // one rounding at the extent of a batch (2e-6 m), whatever the extent of the scene.
+    float4 *recb;      // [n_pad] by place: (x, y relative to borg[place / 64], cos psi, sin psi)
+    float2 *borg;      // [n_pad / 64] those origins, relative to (ox, oy); (0, 0) for a batch without a road user
     float4 *recg;      // [cap] by slot: the record in scene coordinates, bit for bit what recs holds at the slot's place (the
                        // receivers of the kernels on binned records: a receiver must coincide with itself as a source)
     int32_t rebase_from_state;   // re-binning: every live slot's fp64 state is current on this device (else: re-express the old record)

@@ -236,7 +236,8 @@ struct csf_engine {
     PinnedSlot pinned[4];
     int pinned_next = 0;
     DevBuf<uint32_t> status;
-    DevBuf<float4> rec, recs, recg, recp, rv, kat4, bnd, bnd2;
+    DevBuf<float4> rec, recs, recg, recb, rv, kat4, bnd, bnd2;
+    DevBuf<float2> borg;
     DevBuf<float2> rvo;          // origins of the road-vertex tiles
     DevBuf<int32_t> pos;
     bool bounds_fresh = false;   // d.bnd describes the current records (else: recompute before the pair kernel)
@@ -693,7 +694,8 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->pos.alloc(nrec));
     HIPCHK(e, e->recs.alloc(nrec));
     HIPCHK(e, e->recg.alloc(nrec));
-    HIPCHK(e, e->recp.alloc(nrec));
+    HIPCHK(e, e->recb.alloc(nrec));
+    HIPCHK(e, e->borg.alloc(nrec / 64 + 1));
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->rorg.alloc(nrec));
@@ -764,7 +766,8 @@ int alloc_all(csf_engine *e) {
     d.pos = e->pos.p;
     d.recs = e->recs.p;
     d.recg = e->recg.p;
-    d.recp = e->recp.p;
+    d.recb = e->recb.p;
+    d.borg = e->borg.p;
     d.bnd = e->bnd.p;
     d.bnd_next = e->bnd2.p;
     d.rorg = e->rorg.p;
@@ -1582,7 +1585,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recp.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();

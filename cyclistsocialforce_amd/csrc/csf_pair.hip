@@ -191,7 +191,7 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // BINR (large populations): the RECEIVERS of a workgroup are consecutive places of the binned order as well, i.e.
 // neighbours in space, so a whole tile of 1024 sources that lies beyond the far-field radius of the group's bounding
 // circle is skipped before it is loaded (at 262 144 agents in 800 m: 4 of 5 tiles).  Tile and receivers are then held
-// relative to the ORIGIN OF THE GROUP (that of its first receiver's place, csf_dev.h: recp): a source that matters is
+// relative to the ORIGIN OF THE GROUP (that of the batch of its first receiver's place, csf_dev.h: recb, borg): a source that matters is
 // near the group, so the fp32 difference receiver - source keeps 2^-24 of (pair distance + group extent) at any extent
 // of the scene - 6e-5 m would be the resolution of scene coordinates in the 1 600 m of config 5.  (Smaller populations take their
 // receivers in slot order: a workgroup then holds a random sample of receivers and every workgroup carries the same
@@ -228,8 +228,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     float2 og = make_float2(0.f, 0.f);   // BINR: origin of the workgroup (uniform: scalar loads), else the scene's
     if (BINR) {
         const int64_t jg = d.lo + (int64_t)blockIdx.x * RPB;
-        const float4 pg = d.recp[d.rlist ? (int64_t)d.rlist[jg - d.lo] : jg];
-        og = make_float2(pg.z, pg.w);
+        og = d.borg[(d.rlist ? (int64_t)d.rlist[jg - d.lo] : jg) >> 6];
     }
 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
@@ -309,10 +308,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     auto fill_tile = [&](int64_t base, int cnt) {
         for (int t = threadIdx.x; t < cnt; t += BLOCK) {
             float4 q;
-            if (BINR) {          // relative to the group's origin: offset + (origin - group origin), the bracket exact
-                const float4 pp = d.recp[base + t];
-                q = d.recs[base + t];
-                q.x = pp.x + (pp.z - og.x), q.y = pp.y + (pp.w - og.y);
+            if (BINR) {          // relative to the group's origin: (relative to its batch's) + (batch origin - group origin), the bracket exact
+                const float2 bo = d.borg[__builtin_amdgcn_readfirstlane((int)((base + t) >> 6))];   // (one batch per wave and round: a scalar load)
+                q = d.recb[base + t];
+                q.x += bo.x - og.x, q.y += bo.y - og.y;
             } else if (d.recs_valid) {
                 q = d.recs[base + t];
             } else {
@@ -341,9 +340,9 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
         if (BINR) {  // receiver slot jc - lo of this rank -> place of the binned order -> slot
             const int64_t p = d.rlist ? (int64_t)d.rlist[jc - d.lo] : jc;
-            const float4 pp = d.recp[p];
-            float4 q = d.recs[p];
-            q.x = pp.x + (pp.z - og.x), q.y = pp.y + (pp.w - og.y);   // (the very expression of the tile fill)
+            const float2 bo = d.borg[p >> 6];
+            float4 q = d.recb[p];
+            q.x += bo.x - og.x, q.y += bo.y - og.y;                   // (the very expression of the tile fill)
             rrec[threadIdx.x] = q;
             ragent[threadIdx.x] = j < d.hi ? d.perm[p] : -1;
         } else {

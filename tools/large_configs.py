@@ -54,7 +54,7 @@ if __name__ == "__main__":
     if "3" in which:
         run("3: 16,384 InvertedPendulumBicycle", "invpend", 16384, 200.0, 1000)
     if "4" in which:
-        run("4: 262,144 TwoDBicycle (single GPU)", "twod", 262144, 800.0, 5, warm=1)
+        run("4: 262,144 TwoDBicycle (single GPU)", "twod", 262144, 800.0, 20, warm=1)
     if "5" in which:
-        run("5: 1,048,576 PlanarPointBicycle + road (single GPU)", "planarpoint", 1048576, 1600.0, 2,
+        run("5: 1,048,576 PlanarPointBicycle + road (single GPU)", "planarpoint", 1048576, 1600.0, 10,
             road=tiled_curve_road(1600.0), warm=1)
