@@ -845,7 +845,7 @@ void set_chunks(csf_engine *e) {
     // 32 receivers per workgroup where that still leaves thousands of workgroups (N = 16 384 unsharded: 8192): measured
     // better from 8192 receivers up, worse for the few workgroups of small populations and 4-way shards
     d.rpb = nloc >= 8192 ? 32 : 16;
-    if (e->knobs.rpb > 0) d.rpb = e->knobs.rpb == 32 ? 32 : 16;
+    if (e->knobs.rpb > 0) d.rpb = e->knobs.rpb == 32 ? 32 : e->knobs.rpb == 8 ? 8 : 16;
 }
 
 constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long

@@ -206,7 +206,7 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // time, and only the sources it keeps are queued for the field.
 template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false>
 __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
-    static_assert(RPB == WPB * RPW || (DYN && RPB % (WPB * RPW) == 0 && RPB <= WAVE), "wider workgroups need the dynamic hand-out");
+    static_assert(RPB == WPB * RPW || (DYN && (RPB % (WPB * RPW) == 0 || RPB == 2 * RPW) && RPB <= WAVE), "other workgroup sizes need the dynamic hand-out");
     static_assert(!REACH || (CLASSIFY && DYN), "the reach test is built into the classified, dynamically handed-out variant");
     __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
     __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
@@ -399,9 +399,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         static_assert(TILE2 / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
         unsigned long long cand_all = ~0ull, inside_all = 0ull;
         if (CLASSIFY) {
-            constexpr int PASSES = RPB / (WPB * RPW);   // four receivers x 16 batches per pass
+            constexpr int PASSES = RPB >= WPB * RPW ? RPB / (WPB * RPW) : 1;   // four receivers x 16 batches per pass
 #pragma unroll
             for (int ps = 0; ps < PASSES; ps++) {
+                if (RPB < WPB * RPW && wave * RPW >= RPB) break;   // (8 receivers: two waves classify)
                 const int r0 = (wave * PASSES + ps) * RPW;   // first receiver of this pass
                 bool out, in;
                 classify_batch<P2R>(k, rrec[r0 + (lane >> 4)], tbnd[lane & 15], out, in);
@@ -967,6 +968,7 @@ template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
         if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
+        else if (d.rpb == 8) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 8, CLASSIFY>), recv_grid(d, d.n_split, 8));
         else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
         return;
     }

@@ -409,7 +409,7 @@ def test_single_rank_communicator_path(amd):
     np.testing.assert_array_equal(e.state(), ref.state())
 
 
-@pytest.mark.parametrize("rpb", [16, 32])
+@pytest.mark.parametrize("rpb", [8, 16, 32])
 @pytest.mark.parametrize("hfov,rule", [(0.6, 0), (np.pi * 2 / 3, 1), (np.pi, 0), (4.0, 0), (4.0, 1), (2 * np.pi, 0)])
 def test_field_of_view_variants_vs_oracle(amd, monkeypatch, hfov, rule, rpb):
     """Narrow, half-plane, wide and full-circle fields of view, with and without priority-to-the-right
