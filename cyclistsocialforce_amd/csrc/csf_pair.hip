@@ -305,8 +305,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
 
     // a tile: 1024 places of the binned order in scene coordinates (recs: the copy the per-agent kernel maintains beside
     // the precise records; without it - unbinned - offset + origin of the slot)
-    auto fill_tile = [&](int64_t base, int cnt) {
-        for (int t = threadIdx.x; t < cnt; t += BLOCK) {
+    auto fill_tile = [&](int64_t base, int cnt, int tid) {
+        for (int t = tid; t < cnt; t += BLOCK) {
             float4 q;
             if (BINR) {          // relative to the group's origin: (relative to its batch's) + (batch origin - group origin), the bracket exact
                 const float2 bo = d.borg[__builtin_amdgcn_readfirstlane((int)((base + t) >> 6))];   // (one batch per wave and round: a scalar load)
@@ -325,16 +325,16 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             tc[t] = q.z;
             ts[t] = q.w;
         }
-        if (CLASSIFY && (int)threadIdx.x < (cnt >> 6)) {
-            float4 bb = d.bnd[(base >> 6) + threadIdx.x];     // (scene coordinates)
+        if (CLASSIFY && tid < (cnt >> 6)) {
+            float4 bb = d.bnd[(base >> 6) + tid];             // (scene coordinates)
             if (BINR) bb.x -= og.x, bb.y -= og.y;
-            tbnd[threadIdx.x] = bb;
+            tbnd[tid] = bb;
         }
-        if (DYN && threadIdx.x == BLOCK - 1) next_recv = 0;
+        if (DYN && tid == BLOCK - 1) next_recv = 0;
     };
     // first tile and the workgroup's receiver records travel together: one global round trip, not two
     if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
-    if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2));
+    if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2), (int)threadIdx.x);
     if (threadIdx.x < RPB) {
         const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
         const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
@@ -378,6 +378,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     for (int64_t base = ibeg; base < iend; base += TILE2) {
         const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
         const int nb = cnt >> 6;
+        // the LDS and global addresses of the fill and the classification are formed HERE, once per tile: hoisted out of the
+        // tile loop (they only depend on the thread's number) they cost six registers, which were spilled to scratch memory
+        int tid = (int)threadIdx.x, ln = lane;
+        asm volatile("" : "+v"(tid), "+v"(ln));
         if (BINR) {
             // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
             // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
@@ -386,12 +390,12 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             const float reach = k.rfar + bb.z + gr;
             if (__ballot(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
             if (filled) __syncthreads();
-            fill_tile(base, cnt);
+            fill_tile(base, cnt, tid);
             __syncthreads();
             filled = true;
         } else if (base != ibeg) {
             __syncthreads();
-            fill_tile(base, cnt);
+            fill_tile(base, cnt, tid);
             __syncthreads();
         }
         // classification of the tile's (at most 16) batches for all four receivers in one pass:
@@ -405,13 +409,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 if (RPB < WPB * RPW && wave * RPW >= RPB) break;   // (8 receivers: two waves classify)
                 const int r0 = (wave * PASSES + ps) * RPW;   // first receiver of this pass
                 bool out, in;
-                classify_batch<P2R>(k, rrec[r0 + (lane >> 4)], tbnd[lane & 15], out, in);
-                const bool valid = (lane & 15) < nb;
+                classify_batch<P2R>(k, rrec[r0 + (ln >> 4)], tbnd[ln & 15], out, in);
+                const bool valid = (ln & 15) < nb;
                 cand_all = __ballot(valid & !out);
                 inside_all = __ballot(valid & in);
-                if (DYN && lane < RPW)
-                    bmask[r0 + lane] = ((unsigned)(cand_all >> (16 * lane)) & 0xFFFFu) |
-                                       (((unsigned)(inside_all >> (16 * lane)) & 0xFFFFu) << 16);
+                if (DYN && ln < RPW)
+                    bmask[r0 + ln] = ((unsigned)(cand_all >> (16 * ln)) & 0xFFFFu) |
+                                     (((unsigned)(inside_all >> (16 * ln)) & 0xFFFFu) << 16);
             }
             if (DYN) __syncthreads();
         }
