@@ -373,6 +373,12 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         const float w = x1 - x0, h = y1 - y0;
         gx = 0.5f * (x0 + x1), gy = 0.5f * (y0 + y1);
         gr = 0.5f * fast_sqrt(w * w + h * h) * 1.0001f + 1e-4f;   // rounded up: must contain
+        // the same in every lane: kept in scalar registers (as vector registers one of them was spilled, and reloaded from
+        // scratch memory in front of every tile's far test)
+        asm volatile("" : "+v"(gx), "+v"(gy), "+v"(gr));   // (the finished values, not an operand of theirs, go to the scalar registers)
+        gx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gx)));
+        gy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gy)));
+        gr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gr)));
     }
     bool filled = false;
     for (int64_t base = ibeg; base < iend; base += TILE2) {
@@ -386,8 +392,10 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
             // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
             const float4 bb = d.bnd[(base >> 6) + ((lane & 15) < nb ? (lane & 15) : 0)];
-            const float ex = (bb.x - og.x) - gx, ey = (bb.y - og.y) - gy;
-            const float reach = k.rfar + bb.z + gr;
+            float gxv = gx, gyv = gy, grv = gr;   // (copied from the scalar registers here, per tile)
+            asm volatile("" : "+v"(gxv), "+v"(gyv), "+v"(grv));
+            const float ex = (bb.x - og.x) - gxv, ey = (bb.y - og.y) - gyv;
+            const float reach = k.rfar + bb.z + grv;
             if (__ballot(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
             if (filled) __syncthreads();
             fill_tile(base, cnt, tid);
