@@ -129,7 +129,8 @@ def test_config5_1048576_planarpoint_with_road(amd):
     assert rerr.max() < 1e-4
 
 
-def test_road_lattice_against_the_direct_sum_and_the_oracle(amd, monkeypatch):
+@pytest.mark.parametrize("edges", ["one sigma", "sigma and F0 per edge"])
+def test_road_lattice_against_the_direct_sum_and_the_oracle(amd, monkeypatch, edges):
     """Large static road networks (csf_road.hip): the vertices of the 5 x 5 lattice cells around a road user summed directly,
     the rest of the network from the cell's Chebyshev interpolant.  4 096 PlanarPointBicycle on the curve-scenario road
     tiled over 400 m (24 480 vertices), three engines - every vertex summed (CSF_ROAD_GRID=0), lattice of 16 m and of 32 m
@@ -143,6 +144,11 @@ def test_road_lattice_against_the_direct_sum_and_the_oracle(amd, monkeypatch):
     s0 = s0[:, :4]
     roff, verts, F0, sg = bench.tiled_curve_road(box)
     assert verts.shape[0] > 20000
+    if edges != "one sigma":                                    # (the general exponent: exp2(w log2 r^2) per vertex, road_np = 0)
+        sg = sg.copy(); F0 = F0.copy()
+        sg[::2] = 3.0
+        sg[1::4] = 2.5
+        F0[::3] *= 2.0
     for k, to in enumerate((verts[100],                         # on a vertex
                             verts[5000] + [0.01, 0.0],          # 1 cm from one
                             [-900.0, -500.0],                   # far outside the lattice
