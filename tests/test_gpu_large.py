@@ -632,16 +632,20 @@ def test_arrivals_in_the_sentinel_tail(amd):
     e.close()
 
 
-@pytest.mark.parametrize("seed,n0,box,sets", [(1, 1300, 420.0, 1), (2, 3300, 700.0, 1), (3, 1100, 400.0, 3), (18, 1100, 400.0, 3),
-                                              (17, 3300, 700.0, 1), (30, 1100, 400.0, 3), (5, 1200, 420.0, -3), (6, 1200, 420.0, -3),
-                                              (101, 1400, 420.0, 3), (102, 2600, 600.0, -3)])
-def test_random_population_calls_device_path_vs_host_mirror(amd, monkeypatch, seed, n0, box, sets):
+@pytest.mark.parametrize("seed,n0,box,sets,every", [(1, 1300, 420.0, 1, 1), (2, 3300, 700.0, 1, 1), (3, 1100, 400.0, 3, 1), (18, 1100, 400.0, 3, 1),
+                                                    (17, 3300, 700.0, 1, 1), (30, 1100, 400.0, 3, 1), (5, 1200, 420.0, -3, 1), (6, 1200, 420.0, -3, 1),
+                                                    (101, 1400, 420.0, 3, 1), (102, 2600, 600.0, -3, 1),
+                                                    (7, 1300, 420.0, 1, 5), (8, 1100, 400.0, 3, 6), (9, 1200, 420.0, -3, 4)])
+def test_random_population_calls_device_path_vs_host_mirror(amd, monkeypatch, seed, n0, box, sets, every):
     """A random sequence of the population calls SUMO co-simulation makes - arrivals, departures, queues replaced / edited
     / extended, desired speeds, now and then a state pushed from the host, a few ticks in between - through the
     device-side path (pending lists, sentinel tail, slot reuse, slab rewrites, re-binning) and through the host mirror
     (csf_set_incremental(0)); sets = 3: three parameter sets, every arrival with a set of its own choice (the spawn record
     carries it).  A sparse population (few pairs interact: differences stay at rounding level), so the two
-    engines are compared tightly after every call: positions, pointers, navigation states, status."""
+    engines are compared tightly after every call: positions, pointers, navigation states, status.  every > 1: the states are
+    read back (which applies the pending batch) only after every `every`-th call, so that one batch holds several KINDS of
+    change - a spawn into a slot retired in the same batch, a queue replaced twice, a desired speed for a road user whose
+    spawn is still pending."""
     if seed > 100:                                             # the class-segmented order from 1 024 road users: an arrival
         monkeypatch.setenv("CSF_SEGMENTS", "1")                # belongs into its set's run, which the next re-binning gives it
     rng = np.random.default_rng(seed)
@@ -718,6 +722,9 @@ def test_random_population_calls_device_path_vs_host_mirror(amd, monkeypatch, se
             st[:, 0] += 0.25
             for e in engines:
                 e.push_state(idx, st)
+        history.append(str(op))
+        if every > 1 and it % every != every - 1 and it != 159:
+            continue
         (A, pa, za, _), (B, pb, zb, _) = engines[0].state(with_nav=True), engines[1].state(with_nav=True)
         assert A.shape == B.shape == (n, width), (it, op)
         assert np.array_equal(pa, pb) and np.array_equal(za, zb), (it, op)
@@ -728,7 +735,6 @@ def test_random_population_calls_device_path_vs_host_mirror(amd, monkeypatch, se
         # A source that crosses a receiver's field-of-view edge can do so one tick apart in the two runs (D6; the force of a
         # close neighbour jumps, and that receiver then steers differently for a while): a handful of road users may
         # differ by millimetres and hundredths of a radian.
-        history.append(str(op))
         dp = np.abs(A[:, :2] - B[:, :2]).max(axis=1)
         da = np.abs((A[:, [2, 4]] - B[:, [2, 4]] + np.pi) % (2 * np.pi) - np.pi).max(axis=1)      # (angles live in [-pi, pi])
         dv = np.abs(A[:, 3] - B[:, 3])
