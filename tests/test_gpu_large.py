@@ -200,6 +200,21 @@ def test_road_lattice_against_the_direct_sum_and_the_oracle(amd, monkeypatch, ed
         assert np.abs(fin[label][ok, :2] - fin["direct"][ok, :2]).max() < 1e-6 * box
     # the receivers outside the lattice took the same sum as the direct path, to the rounding of another origin
     assert np.abs(out["lattice 16 m"][2:4] - out["direct"][2:4]).max() < 1e-5 * own[2:4].max()
+    # a rank of a sharded run takes ITS receivers (in slot order) over the same lattice: a 3-way loopback group
+    monkeypatch.setenv("CSF_ROAD_GRID", "1")
+    monkeypatch.delenv("CSF_ROAD_CELL", raising=False)
+    members = [make_engine(amd, "planarpoint", s0, 5.0, off, dq) for _ in range(3)]
+    for m in members:
+        m.set_road(roff, verts, F0, sg)
+    amd.Engine.loopback_group(members)
+    for m in members:
+        fx, fy = m.calc_forces()
+        fdx, fdy, frx, fry = m.force_parts()
+        lo, hi = m.shard_range()
+        g = np.c_[fx - fdx - frx, fy - fdy - fry][lo:hi]
+        # the same sums in the same order; what differs is the repulsive term g is freed of (another fp32 summation order)
+        assert np.abs(g - out["lattice 16 m"][lo:hi]).max(axis=1)[lo == 0:].max() < 1e-6 * own[max(lo, 1):hi].max(), (lo, hi)
+        m.close()
 
 
 # --------------------------------------------------------------------------- BASELINE config 2, full length
