@@ -477,14 +477,42 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             evals += (unsigned)nlen;
             nlen = 0;
         };
+        // About half of the (receiver, tile) visits at N = 16 384 are EMPTY - the tile lies behind the receiver or beyond the
+        // far-field radius - and a visit costs two LDS round trips (the claim, the mask) and a column sum before any source is
+        // looked at.  COMPACT (receivers in slot order): every wave reads ALL the workgroup's batch masks once per tile (lane r:
+        // receiver r) and only the receivers some batch can act on are handed out: the k-th claim is the k-th such receiver.
+        // With receivers in binned order (neighbours: a tile concerns all of them or, mostly, none - and then it was never
+        // loaded) an empty visit is just left at once.
+        constexpr bool COMPACT = DYN && CLASSIFY && !BINR;
+        const unsigned live = nb >= 16 ? 0xFFFFu : ((1u << nb) - 1u);
+        unsigned mymask = 0u;
+        unsigned long long wanted = 0ull;
+        if (COMPACT) {
+            mymask = bmask[ln & (RPB - 1)];
+            wanted = __ballot(ln < RPB && (mymask & live) != 0u);
+        }
+        const int n_wanted = COMPACT ? __builtin_popcountll(wanted) : RPB;
 #pragma unroll DYN ? 1 : RPW
         for (int uu = 0; uu < (DYN ? RPB : RPW); uu++) {
             int ur = wave * RPW + uu;                 // receiver within the workgroup
+            unsigned bm = 0u;
             if (DYN) {
                 int got = 0;
                 if (lane == 0) got = atomicAdd(&next_recv, 1);
                 ur = __builtin_amdgcn_readfirstlane(got);
-                if (ur >= RPB) break;
+                if (COMPACT) {                        // the ur-th set bit of `wanted`: the lane whose bit it is has `ur` set bits below it
+                    if (ur >= n_wanted) break;
+                    const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wanted >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wanted, 0u));
+                    const unsigned long long hit = __ballot(((wanted >> lane) & 1ull) != 0ull && below == ur);
+                    ur = __builtin_ctzll(hit);
+                    bm = (unsigned)__builtin_amdgcn_readlane((int)mymask, ur);
+                } else {
+                    if (ur >= RPB) break;
+                }
+            }
+            if (!COMPACT && DYN && CLASSIFY) {
+                bm = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask[ur]);
+                if ((bm & live) == 0u) continue;      // no batch of this tile can act on this receiver: nothing to add
             }
             const int u = DYN ? 0 : uu;               // accumulator slot
             cur_recv = ur;
@@ -493,8 +521,6 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 ru.x = q.x, ru.y = q.y, ru.c = q.z, ru.s = q.w;
                 asm volatile("" : "+v"(ru.x), "+v"(ru.y), "+v"(ru.c), "+v"(ru.s));  // stay in VGPRs, not SGPRs
             }
-            const unsigned live = nb >= 16 ? 0xFFFFu : ((1u << nb) - 1u);
-            const unsigned bm = (DYN && CLASSIFY) ? (unsigned)__builtin_amdgcn_readfirstlane((int)bmask[ur]) : 0u;
             unsigned cand = ((DYN && CLASSIFY) ? (bm & 0xFFFFu) : (unsigned)(cand_all >> (16 * u))) & live;
             const unsigned inside = ((DYN && CLASSIFY) ? (bm >> 16) : (unsigned)(inside_all >> (16 * u))) & live;
             if (REACH) {
