@@ -217,6 +217,55 @@ def test_road_lattice_against_the_direct_sum_and_the_oracle(amd, monkeypatch, ed
         m.close()
 
 
+def test_road_lattice_with_arrivals_and_departures(amd, monkeypatch):
+    """the lattice's per-tick kernel takes its receivers in binned order: road users that leave (dead slots, sentinel
+    records) and arrive (device-side patches into free and fresh slots, among them one OUTSIDE the lattice that was laid
+    over the first population) between ticks; the road term of everyone present against the oracle."""
+    import bench
+
+    n0, box = 3000, 400.0
+    pool, _, pdq = population(n0 + 400, box, seed=12)
+    pool, pdq = pool[:, :4], pdq.reshape(-1, 4, 3)
+    roff, verts, F0, sg = bench.tiled_curve_road(box)
+    monkeypatch.setenv("CSF_ROAD_GRID", "1")
+    e = amd.Engine(amd.pod("planarpoint"), n0 + 400)
+    e.add_agents(pool[:n0], 5.0)
+    e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, pdq[:n0].reshape(-1, 3), reset=True)
+    e.set_road(roff, verts, F0, sg)
+    e.step(3)
+    present = list(range(n0))
+    rng = np.random.default_rng(4)
+    fresh = n0
+    for rnd in range(4):
+        gone = np.sort(rng.choice(len(present), 40, replace=False))
+        e.remove_agents(gone)
+        present = [a for k, a in enumerate(present) if k not in set(gone.tolist())]
+        new = np.arange(fresh, fresh + 25)
+        fresh += 25
+        rows = pool[new].copy()
+        if rnd == 1:
+            shift = np.array([box + 700.0, -300.0]) - rows[0, :2]        # far outside the lattice: it sums every vertex
+            rows[0, :2] += shift
+            pdq[new[0], :, :2] += shift
+        e.add_agents(rows, 5.0)
+        e.set_dest_queue(np.arange(len(present), len(present) + 25), np.arange(26) * 4, pdq[new].reshape(-1, 3), reset=True)
+        present += new.tolist()
+        e.step(2)
+        fx, fy = e.calc_forces()
+        fdx, fdy, frx, fry = e.force_parts()
+        st = e.state()
+        assert st.shape[0] == len(present)
+        g = np.c_[fx - fdx - frx, fy - fdy - fry]
+        rx, ry = orc.road_forces(verts, roff, F0, sg, st[:, 0], st[:, 1])
+        dmin = np.array([np.sqrt(((verts - st[j, :2]) ** 2).sum(axis=1).min()) for j in range(0, len(present), 1)])
+        own = np.maximum(np.hypot(rx, ry), 1e-3)
+        rel = np.maximum(np.abs(g[:, 0] - rx), np.abs(g[:, 1] - ry)) / own
+        print(f"  round {rnd}: {len(present)} road users; road term vs oracle, relative to the own force: median {np.median(rel):.1e} max {rel.max():.1e}")
+        assert (rel < 1e-4 + 1e-5 / np.maximum(dmin, 1e-3)).all()
+    assert (e.status() & ~np.uint32(1) == 0).all()
+    e.close()
+
+
 # --------------------------------------------------------------------------- BASELINE config 2, full length
 
 def test_config2_1024_twod_10000_ticks(amd):
