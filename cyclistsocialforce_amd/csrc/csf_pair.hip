@@ -39,9 +39,9 @@ constexpr int TILE = 1024;           // simple kernels: source records per LDS t
 #define CSF_TILE2 1024
 #endif
 #ifndef CSF_CULL_WAVES
-#define CSF_CULL_WAVES 7
+#define CSF_CULL_WAVES 8
 #endif
-constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 7 waves/SIMD (72 VGPRs, 12 B spilled) measured best (tools/sweep_cull.sh)
+constexpr int TILE2 = CSF_TILE2;     // culling kernel: LDS tile (records); 1024 x 8 workgroups per CU = 8 waves/SIMD (64 VGPRs, 20 228 B of LDS)
 constexpr int QCAP = 256;            // queue slots per receiver (uint16 tile indices); power of two
 constexpr int CHUNK = 128;           // pairs evaluated per pop: two per lane
 
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     __shared__ float4 rrec[RPB];
     __shared__ int ragent[RPB];              // slot of every receiver of the workgroup (-1: none)
     __shared__ unsigned bmask[DYN ? RPB : 1];   // DYN: candidate | inside << 16 batch masks of every receiver
-    constexpr int NCAP = WAVE;                         // near pairs noted by one wave: receiver << 16 | tile index
+    constexpr int NCAP = 32;                           // near pairs noted by one wave and tile: receiver << 16 | tile index (32, not
+                                                       // 64: with 256 bytes less a workgroup fits 20 KB of LDS, eight to a CU)
     __shared__ unsigned nlist[WPB][NCAP];
     __shared__ float racc[2][DYN ? RPB : 1];    // DYN: column sums of the workgroup's receivers
     __shared__ int next_recv;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             if (nlen == 0) return;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const unsigned ent = nlist[wave][lane];
+            const unsigned ent = nlist[wave][lane & (NCAP - 1)];
             const int urn = lane < nlen ? (int)(ent >> 16) : 0;
             const int idx = lane < nlen ? (int)(ent & 0xFFFFu) : 0;
             const int32_t ar = ragent[urn];
@@ -518,8 +519,13 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             cur_recv = ur;
             {
                 const float4 q = rrec[ur];
-                ru.x = q.x, ru.y = q.y, ru.c = q.z, ru.s = q.w;
-                asm volatile("" : "+v"(ru.x), "+v"(ru.y), "+v"(ru.c), "+v"(ru.s));  // stay in VGPRs, not SGPRs
+                // the receiver in SCALAR registers (round 3): every packed instruction of the test and of the field takes at most
+                // one of its four numbers, which the constant bus allows; as vector registers (rounds 1 and 2, when the compiler
+                // answered scalar operands with copies) they were four register PAIRS - with them gone the kernel fits 64 VGPRs
+                ru.x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.x)));
+                ru.y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.y)));
+                ru.c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.z)));
+                ru.s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.w)));
             }
             unsigned cand = ((DYN && CLASSIFY) ? (bm & 0xFFFFu) : (unsigned)(cand_all >> (16 * u))) & live;
             const unsigned inside = ((DYN && CLASSIFY) ? (bm >> 16) : (unsigned)(inside_all >> (16 * u))) & live;
