@@ -67,6 +67,7 @@ struct Dev {
     int32_t chunk_units;  // batches of 64 records per source chunk
     int32_t dyn_recv;  // cull kernel: receivers handed to the waves of a workgroup dynamically
     int32_t rpb;       // ... and receivers per workgroup then: 16 or 32
+    int32_t wide;      // rpb 32, receivers in slot order: workgroups of 8 waves on tiles of 2048 sources (chunk_units is then 32)
     int32_t pair_variant;  // 0: cull-first kernel on binned records (default), 1: evaluate-then-mask, 2: cull-first, unbinned
     int32_t classify;      // the records are binned and every batch of 64 carries a bounding circle
     double ox, oy;     // origin of the scene: what the batch origins (org) and the bounding circles (bnd) are relative to

@@ -95,6 +95,7 @@ struct Knobs {
     int fake_rank = 0, fake_world = 1;        // CSF_FAKE_SHARD=r/w: only rank r's receiver block of w (timing aid)
     int nsplit = 0;                           // CSF_NSPLIT: source chunks of the pair grid (0: the engine's choice)
     int dyn_recv = -1, rpb = 0;               // CSF_DYN_RECV, CSF_RPB
+    int wide = -1;                            // CSF_WIDE: workgroups of 8 waves on tiles of 2048 sources (-1: the engine's choice)
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
     int segments = -1;                        // CSF_SEGMENTS
     int recv_binned = -1;                     // CSF_RECV_BINNED
@@ -120,6 +121,7 @@ struct Knobs {
         nsplit = geti("CSF_NSPLIT", 0);
         dyn_recv = geti("CSF_DYN_RECV", -1);
         rpb = geti("CSF_RPB", 0);
+        wide = geti("CSF_WIDE", -1);
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
         segments = geti("CSF_SEGMENTS", -1);
         recv_binned = geti("CSF_RECV_BINNED", -1);
@@ -837,15 +839,19 @@ void set_chunks(csf_engine *e) {
     // a chunk just over one LDS tile (16 batches) would load a second, nearly empty tile in every workgroup: the few
     // batches of arrivals behind a population that filled whole tiles get a chunk - and workgroups - of their own
     if (per > 16 && per < 32 && (units + 15) / 16 <= MAX_SPLIT && e->knobs.nsplit <= 0) per = 16;
+    // 32 receivers per workgroup where that still leaves thousands of workgroups (N = 16 384 unsharded: 8192): measured
+    // better from 8192 receivers up, worse for the few workgroups of small populations and 4-way shards
+    d.rpb = nloc >= 8192 ? 32 : 16;
+    if (e->knobs.rpb > 0) d.rpb = e->knobs.rpb == 32 ? 32 : e->knobs.rpb == 8 ? 8 : 16;
+    // ... and then workgroups of 8 waves on tiles of 2048 sources (csf_pair.hip: CW), for receivers in slot order: chunks of 32 batches
+    d.wide = d.rpb == 32 && d.n_src < 65536 && d.p.model != CSF_BICYCLE && e->knobs.nsplit <= 0 &&
+             (e->knobs.wide >= 0 ? e->knobs.wide != 0 : true);
+    if (d.wide) per = 32;
     split = (units + per - 1) / per;
     d.n_split = (int32_t)split;
     d.chunk_units = (int32_t)per;
     d.dyn_recv = 1;   // receivers handed to the waves of a workgroup one at a time (csf_pair.hip, DYN; 0: four per wave)
     if (e->knobs.dyn_recv >= 0) d.dyn_recv = e->knobs.dyn_recv != 0;
-    // 32 receivers per workgroup where that still leaves thousands of workgroups (N = 16 384 unsharded: 8192): measured
-    // better from 8192 receivers up, worse for the few workgroups of small populations and 4-way shards
-    d.rpb = nloc >= 8192 ? 32 : 16;
-    if (e->knobs.rpb > 0) d.rpb = e->knobs.rpb == 32 ? 32 : e->knobs.rpb == 8 ? 8 : 16;
 }
 
 constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long

@@ -204,25 +204,35 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // workgroup of twice the receivers shares one tile fill and one start-up between them: 146 -> 141 us at N = 16 384)
 // REACH (with the far-field cull on): every candidate batch goes through the packed reach test keep_x2, two batches at a
 // time, and only the sources it keeps are queued for the field.
-template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false>
-__global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
+// CW: waves of a workgroup, 4, or 8 (DYN, RPB 32, receivers in slot order: launch_cull_dyn): a workgroup of 8 waves holds a
+// tile of 2048 sources (32 batches), so a visit - one receiver against one tile - covers twice the sources: half the visits
+// (each with its claim, record, column sum), and twice the sources to evaluate per visit, i.e. fuller evaluation passes.
+template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false, int CW = WPB>
+__global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     static_assert(RPB == WPB * RPW || (DYN && (RPB % (WPB * RPW) == 0 || RPB == 2 * RPW) && RPB <= WAVE), "other workgroup sizes need the dynamic hand-out");
+    static_assert(CW == WPB || (CW == 2 * WPB && DYN && CLASSIFY && !BINR && RPB == 32), "the wide workgroup is built into one variant");
+    constexpr int BLOCKW = CW * WAVE;             // threads of a workgroup
+    constexpr int TL = TILE2 / WPB * CW;          // sources of a tile
+    constexpr int NBT = TL / WAVE;                // batches of a tile: 16 or 32
+    constexpr int RPP = WAVE / NBT;               // receivers one classification pass of a wave covers: 4 or 2
+    constexpr unsigned NBMASK = NBT >= 32 ? 0xFFFFFFFFu : ((1u << (NBT & 31)) - 1u);
     static_assert(!REACH || (CLASSIFY && DYN), "the reach test is built into the classified, dynamically handed-out variant");
-    __shared__ float tx[TILE2], ty[TILE2], tc[TILE2], ts[TILE2];  // SoA: the two records of a lane load straight
-    __shared__ float4 tbnd[TILE2 / WAVE];                          // into the halves of a packed register pair
-    __shared__ unsigned short queue[WPB][QCAP];  // one queue per wave, drained after each receiver; holds BYTE offsets
+    __shared__ float tx[TL], ty[TL], tc[TL], ts[TL];              // SoA: the two records of a lane load straight
+    __shared__ float4 tbnd[NBT];                                   // into the halves of a packed register pair
+    __shared__ unsigned short queue[CW][QCAP];  // one queue per wave, drained after each receiver; holds BYTE offsets
                                                  // into the tile arrays (4 x index <= 4092)
     __shared__ float4 rrec[RPB];
     __shared__ int ragent[RPB];              // slot of every receiver of the workgroup (-1: none)
-    __shared__ unsigned bmask[DYN ? RPB : 1];   // DYN: candidate | inside << 16 batch masks of every receiver
+    __shared__ unsigned bmask[DYN ? RPB : 1];   // DYN: candidate (| inside << 16, 16 batches) batch masks of every receiver
+    __shared__ unsigned bmask_in[DYN && NBT > 16 ? RPB : 1];   // 32 batches: the inside masks
     constexpr int NCAP = 32;                           // near pairs noted by one wave and tile: receiver << 16 | tile index (32, not
                                                        // 64: with 256 bytes less a workgroup fits 20 KB of LDS, eight to a CU)
-    __shared__ unsigned nlist[WPB][NCAP];
+    __shared__ unsigned nlist[CW][NCAP];
     __shared__ float racc[2][DYN ? RPB : 1];    // DYN: column sums of the workgroup's receivers
     __shared__ int next_recv;
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * WPB + wave) * RPW;
+    const int64_t j0 = d.lo + ((int64_t)blockIdx.x * CW + wave) * RPW;
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend);
     const uint64_t t_start = d.trace ? wall_clock64() : 0;
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
     if (CLASSIFY && d.bnd_next != nullptr && blockIdx.y == 0) {
-        for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * WPB + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * WPB)
+        for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * CW + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * CW)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
 
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
     // a tile: 1024 places of the binned order in scene coordinates (recs: the copy the per-agent kernel maintains beside
     // the precise records; without it - unbinned - offset + origin of the slot)
     auto fill_tile = [&](int64_t base, int cnt, int tid) {
-        for (int t = tid; t < cnt; t += BLOCK) {
+        for (int t = tid; t < cnt; t += BLOCKW) {
             float4 q;
             if (BINR) {          // relative to the group's origin: (relative to its batch's) + (batch origin - group origin), the bracket exact
                 const float2 bo = d.borg[__builtin_amdgcn_readfirstlane((int)((base + t) >> 6))];   // (one batch per wave and round: a scalar load)
@@ -331,11 +341,11 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
             if (BINR) bb.x -= og.x, bb.y -= og.y;
             tbnd[tid] = bb;
         }
-        if (DYN && tid == BLOCK - 1) next_recv = 0;
+        if (DYN && tid == BLOCKW - 1) next_recv = 0;
     };
     // first tile and the workgroup's receiver records travel together: one global round trip, not two
     if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
-    if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TILE2 ? (iend - ibeg) : TILE2), (int)threadIdx.x);
+    if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TL ? (iend - ibeg) : TL), (int)threadIdx.x);
     if (threadIdx.x < RPB) {
         const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
         const int64_t jc = j < d.hi ? j : d.hi - 1;          // clamp: results of the duplicates are not stored
@@ -382,8 +392,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         gr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gr)));
     }
     bool filled = false;
-    for (int64_t base = ibeg; base < iend; base += TILE2) {
-        const int cnt = (int)((iend - base) < TILE2 ? (iend - base) : TILE2);  // multiple of 64
+    for (int64_t base = ibeg; base < iend; base += TL) {
+        const int cnt = (int)((iend - base) < TL ? (iend - base) : TL);  // multiple of 64
         const int nb = cnt >> 6;
         // the LDS and global addresses of the fill and the classification are formed HERE, once per tile: hoisted out of the
         // tile loop (they only depend on the thread's number) they cost six registers, which were spilled to scratch memory
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         if (BINR) {
             // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
             // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
-            const float4 bb = d.bnd[(base >> 6) + ((lane & 15) < nb ? (lane & 15) : 0)];
+            const float4 bb = d.bnd[(base >> 6) + ((lane & (NBT - 1)) < nb ? (lane & (NBT - 1)) : 0)];
             float gxv = gx, gyv = gy, grv = gr;   // (copied from the scalar registers here, per tile)
             asm volatile("" : "+v"(gxv), "+v"(gyv), "+v"(grv));
             const float ex = (bb.x - og.x) - gxv, ey = (bb.y - og.y) - gyv;
@@ -409,22 +419,28 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         }
         // classification of the tile's (at most 16) batches for all four receivers in one pass:
         // lanes 16u .. 16u+15 hold receiver u, lane & 15 selects the batch
-        static_assert(TILE2 / WAVE <= 16 && RPW == 4, "one classification pass covers 4 receivers x 16 batches");
+        static_assert((NBT == 16 || NBT == 32) && RPW == 4, "one classification pass covers 4 receivers x 16 batches, or 2 x 32");
         unsigned long long cand_all = ~0ull, inside_all = 0ull;
         if (CLASSIFY) {
-            constexpr int PASSES = RPB >= WPB * RPW ? RPB / (WPB * RPW) : 1;   // four receivers x 16 batches per pass
+            constexpr int PASSES = RPB >= CW * RPP ? RPB / (CW * RPP) : 1;   // four receivers x 16 batches per pass (two x 32)
 #pragma unroll
             for (int ps = 0; ps < PASSES; ps++) {
-                if (RPB < WPB * RPW && wave * RPW >= RPB) break;   // (8 receivers: two waves classify)
-                const int r0 = (wave * PASSES + ps) * RPW;   // first receiver of this pass
+                if (RPB < CW * RPP && wave * RPP >= RPB) break;   // (8 receivers: two waves classify)
+                const int r0 = (wave * PASSES + ps) * RPP;   // first receiver of this pass
                 bool out, in;
-                classify_batch<P2R>(k, rrec[r0 + (ln >> 4)], tbnd[ln & 15], out, in);
-                const bool valid = (ln & 15) < nb;
+                classify_batch<P2R>(k, rrec[r0 + ln / NBT], tbnd[ln & (NBT - 1)], out, in);
+                const bool valid = (ln & (NBT - 1)) < nb;
                 cand_all = __ballot(valid & !out);
                 inside_all = __ballot(valid & in);
-                if (DYN && ln < RPW)
-                    bmask[r0 + ln] = ((unsigned)(cand_all >> (16 * ln)) & 0xFFFFu) |
-                                     (((unsigned)(inside_all >> (16 * ln)) & 0xFFFFu) << 16);
+                if (DYN && ln < RPP) {
+                    if (NBT > 16) {
+                        bmask[r0 + ln] = (unsigned)(cand_all >> ((NBT & 63) * ln)) & NBMASK;
+                        bmask_in[r0 + ln] = (unsigned)(inside_all >> ((NBT & 63) * ln)) & NBMASK;
+                    } else {
+                        bmask[r0 + ln] = ((unsigned)(cand_all >> (16 * ln)) & 0xFFFFu) |
+                                         (((unsigned)(inside_all >> (16 * ln)) & 0xFFFFu) << 16);
+                    }
+                }
             }
             if (DYN) __syncthreads();
         }
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         // With receivers in binned order (neighbours: a tile concerns all of them or, mostly, none - and then it was never
         // loaded) an empty visit is just left at once.
         constexpr bool COMPACT = DYN && CLASSIFY && !BINR;
-        const unsigned live = nb >= 16 ? 0xFFFFu : ((1u << nb) - 1u);
+        const unsigned live = nb >= NBT ? NBMASK : ((1u << (nb & 31)) - 1u);
         unsigned mymask = 0u;
         unsigned long long wanted = 0ull;
         if (COMPACT) {
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
 #pragma unroll DYN ? 1 : RPW
         for (int uu = 0; uu < (DYN ? RPB : RPW); uu++) {
             int ur = wave * RPW + uu;                 // receiver within the workgroup
-            unsigned bm = 0u;
+            unsigned bm = 0u, bm_in = 0u;
             if (DYN) {
                 int got = 0;
                 if (lane == 0) got = atomicAdd(&next_recv, 1);
@@ -507,6 +523,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                     const unsigned long long hit = __ballot(((wanted >> lane) & 1ull) != 0ull && below == ur);
                     ur = __builtin_ctzll(hit);
                     bm = (unsigned)__builtin_amdgcn_readlane((int)mymask, ur);
+                    if (NBT > 16) bm_in = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask_in[ur]);   // (with the receiver's record: one round trip)
                 } else {
                     if (ur >= RPB) break;
                 }
@@ -527,8 +544,8 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
                 ru.c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.z)));
                 ru.s = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(q.w)));
             }
-            unsigned cand = ((DYN && CLASSIFY) ? (bm & 0xFFFFu) : (unsigned)(cand_all >> (16 * u))) & live;
-            const unsigned inside = ((DYN && CLASSIFY) ? (bm >> 16) : (unsigned)(inside_all >> (16 * u))) & live;
+            unsigned cand = ((DYN && CLASSIFY) ? (NBT > 16 ? bm : (bm & 0xFFFFu)) : (unsigned)(cand_all >> (16 * u))) & live;
+            const unsigned inside = ((DYN && CLASSIFY) ? (NBT > 16 ? bm_in : (bm >> 16)) : (unsigned)(inside_all >> (16 * u))) & live;
             if (REACH) {
                 // two candidate batches at a time through the packed reach test (+ the exact field-of-view test unless
                 // both are wholly inside); what it keeps is appended to the queue, first batch first.
@@ -656,7 +673,7 @@ __global__ __launch_bounds__(BLOCK, CSF_CULL_WAVES) void pair_cull_kernel(const 
         atomicAdd(d.pair_count + 3, (unsigned long long)(pops >> 16));
     }
     if (d.trace && lane == 0) {   // tools/block_trace.py: when did every wave run, and where
-        uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WPB + wave);
+        uint64_t *o = d.trace + 3 * (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * CW + wave);
         o[0] = t_start;
         o[1] = wall_clock64();
         o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))                 // HW_REG_HW_ID
@@ -1011,7 +1028,10 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
 template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
-        if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
+        if (d.rpb == 32 && d.wide && !BINR && CLASSIFY) {   // 8 waves, tiles of 2048 sources (csf_engine.hip set_shard: chunks of 32 batches)
+            hipExtLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, false, true, 32, CLASSIFY, CLASSIFY ? 2 * WPB : WPB>), recv_grid(d, d.n_split, 32),
+                                  dim3(2 * BLOCK), 0, st, t0, t1, 0, d);
+        } else if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
         else if (d.rpb == 8) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 8, CLASSIFY>), recv_grid(d, d.n_split, 8));
         else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
         return;
