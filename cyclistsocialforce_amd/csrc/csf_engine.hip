@@ -841,7 +841,7 @@ void set_chunks(csf_engine *e) {
     if (per > 16 && per < 32 && (units + 15) / 16 <= MAX_SPLIT && e->knobs.nsplit <= 0) per = 16;
     // 32 receivers per workgroup where that still leaves thousands of workgroups (N = 16 384 unsharded: 8192): measured
     // better from 8192 receivers up, worse for the few workgroups of small populations and 4-way shards
-    d.rpb = nloc >= 8192 ? 32 : 16;
+    d.rpb = (nloc >= 8192 || (nloc >= 4096 && d.n_src >= 16384)) ? 32 : 16;   // (4-way shard of 16 384: 38.9 -> 36.6 us with the wide workgroups below)
     if (e->knobs.rpb > 0) d.rpb = e->knobs.rpb == 32 ? 32 : e->knobs.rpb == 8 ? 8 : 16;
     // ... and then workgroups of 8 waves on tiles of 2048 sources (csf_pair.hip: CW), for receivers in slot order: chunks of 32 batches
     d.wide = d.rpb == 32 && d.n_src < 65536 && d.p.model != CSF_BICYCLE && e->knobs.nsplit <= 0 &&
@@ -907,7 +907,7 @@ int rebin(csf_engine *e) {
         units_total = place / 64;
         if (place > d.n_pad || sorted != d.n_live) seg = false;      // (no room for the padding: the plain kernel)
         if (seg) {
-            const int64_t per_min = std::max<int64_t>(16, (units_total + (MAX_SPLIT - d.n_classes) - 1) / std::max(1, MAX_SPLIT - d.n_classes));
+            const int64_t per_min = std::max<int64_t>(d.wide ? 32 : 16, (units_total + (MAX_SPLIT - d.n_classes) - 1) / std::max(1, MAX_SPLIT - d.n_classes));
             int32_t slots = 0;
             for (int c = 0; c < d.n_classes; c++) {
                 const int64_t units = (count[(size_t)c] + 63) / 64;
