@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-needle = sys.argv[1] if len(sys.argv) > 1 else "pair_cull_kernelILb0ELb1ELb0ELb1ELi32ELb1E"
+needle = sys.argv[1] if len(sys.argv) > 1 else "pair_cull_kernelILb0ELb1ELb0ELb1ELi32ELb1ELi8E"
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "cyclistsocialforce_amd", "csrc", "csf_pair.hip")
 out = "/tmp/isa_spills.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
