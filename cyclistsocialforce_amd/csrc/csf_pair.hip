@@ -204,13 +204,13 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // workgroup of twice the receivers shares one tile fill and one start-up between them: 146 -> 141 us at N = 16 384)
 // REACH (with the far-field cull on): every candidate batch goes through the packed reach test keep_x2, two batches at a
 // time, and only the sources it keeps are queued for the field.
-// CW: waves of a workgroup, 4, or 8 (DYN, RPB 32, receivers in slot order: launch_cull_dyn): a workgroup of 8 waves holds a
+// CW: waves of a workgroup, 4, or 8 (DYN, RPB 32: launch_cull_dyn): a workgroup of 8 waves holds a
 // tile of 2048 sources (32 batches), so a visit - one receiver against one tile - covers twice the sources: half the visits
 // (each with its claim, record, column sum), and twice the sources to evaluate per visit, i.e. fuller evaluation passes.
 template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false, int CW = WPB>
 __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     static_assert(RPB == WPB * RPW || (DYN && (RPB % (WPB * RPW) == 0 || RPB == 2 * RPW) && RPB <= WAVE), "other workgroup sizes need the dynamic hand-out");
-    static_assert(CW == WPB || (CW == 2 * WPB && DYN && CLASSIFY && !BINR && RPB == 32), "the wide workgroup is built into one variant");
+    static_assert(CW == WPB || (CW == 2 * WPB && DYN && CLASSIFY && RPB == 32), "the wide workgroup is built into the variants with 32 receivers");
     constexpr int BLOCKW = CW * WAVE;             // threads of a workgroup
     constexpr int TL = TILE2 / WPB * CW;          // sources of a tile
     constexpr int NBT = TL / WAVE;                // batches of a tile: 16 or 32
@@ -531,6 +531,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
             if (!COMPACT && DYN && CLASSIFY) {
                 bm = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask[ur]);
                 if ((bm & live) == 0u) continue;      // no batch of this tile can act on this receiver: nothing to add
+                if (NBT > 16) bm_in = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask_in[ur]);
             }
             const int u = DYN ? 0 : uu;               // accumulator slot
             cur_recv = ur;
@@ -1028,8 +1029,8 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
 template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
-        if (d.rpb == 32 && d.wide && !BINR && CLASSIFY) {   // 8 waves, tiles of 2048 sources (csf_engine.hip set_shard: chunks of 32 batches)
-            hipExtLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, false, true, 32, CLASSIFY, CLASSIFY ? 2 * WPB : WPB>), recv_grid(d, d.n_split, 32),
+        if (d.rpb == 32 && d.wide && CLASSIFY) {   // 8 waves, tiles of 2048 sources (csf_engine.hip set_chunks: chunks of 32 batches)
+            hipExtLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY, CLASSIFY ? 2 * WPB : WPB>), recv_grid(d, d.n_split, 32),
                                   dim3(2 * BLOCK), 0, st, t0, t1, 0, d);
         } else if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
         else if (d.rpb == 8) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 8, CLASSIFY>), recv_grid(d, d.n_split, 8));
