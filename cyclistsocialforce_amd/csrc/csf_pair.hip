@@ -210,7 +210,7 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false, int CW = WPB>
 __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
     static_assert(RPB == WPB * RPW || (DYN && (RPB % (WPB * RPW) == 0 || RPB == 2 * RPW) && RPB <= WAVE), "other workgroup sizes need the dynamic hand-out");
-    static_assert(CW == WPB || (CW == 2 * WPB && DYN && CLASSIFY && RPB == 32), "the wide workgroup is built into the variants with 32 receivers");
+    static_assert(CW == WPB || (CW == 2 * WPB && DYN && CLASSIFY && (RPB == 32 || RPB == 16)), "the wide workgroup is built into the variants with 16 / 32 receivers");
     constexpr int BLOCKW = CW * WAVE;             // threads of a workgroup
     constexpr int TL = TILE2 / WPB * CW;          // sources of a tile
     constexpr int NBT = TL / WAVE;                // batches of a tile: 16 or 32
@@ -1029,7 +1029,10 @@ static dim3 recv_grid(const Dev &d, int split, int per_block_recv = WPB * RPW) {
 template <bool P2R, bool CLASSIFY, bool BINR>
 static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (CLASSIFY && d.dyn_recv && d.pc.reach) {      // the default: per-pair reach test in front of the field
-        if (d.rpb == 32 && d.wide && CLASSIFY) {   // 8 waves, tiles of 2048 sources (csf_engine.hip set_chunks: chunks of 32 batches)
+        if (d.rpb == 16 && d.wide && CLASSIFY) {
+            hipExtLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 16, CLASSIFY, CLASSIFY ? 2 * WPB : WPB>), recv_grid(d, d.n_split, 16),
+                                  dim3(2 * BLOCK), 0, st, t0, t1, 0, d);
+        } else if (d.rpb == 32 && d.wide && CLASSIFY) {   // 8 waves, tiles of 2048 sources (csf_engine.hip set_chunks: chunks of 32 batches)
             hipExtLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY, CLASSIFY ? 2 * WPB : WPB>), recv_grid(d, d.n_split, 32),
                                   dim3(2 * BLOCK), 0, st, t0, t1, 0, d);
         } else if (d.rpb == 32) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, CLASSIFY>), recv_grid(d, d.n_split, 32));
