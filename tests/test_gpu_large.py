@@ -1074,6 +1074,42 @@ def test_config4_262144_twod_40_ticks_and_two_shards(amd):
         m.close()
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_headline_population_as_loopback_ranks(amd, world):
+    """What `bench.py --gpus 4 / 8` runs, rehearsed on one device: the headline population (16 384 TwoDBicycle in 200 m) as
+    a 4- and an 8-way loopback group - receiver blocks of 4 096 and 2 048 slots, i.e. the kernel variants a rank of that run
+    takes (workgroups of 8 waves with 32 and with 16 receivers) - 40 ticks across a re-binning.  Every rank's own forces
+    against the oracle on the group's state, and the group against the unsharded engine."""
+    n, box = 16384, 200.0
+    s0, off, dq = population(n, box, seed=6)
+    p = orc.default_params("twod")
+    ref = make_engine(amd, "twod", s0, 5.0, off, dq)
+    ref.step(40)
+    ref_state = ref.state()
+    ref.close()
+    members = [make_engine(amd, "twod", s0, 5.0, off, dq) for _ in range(world)]
+    amd.Engine.loopback_group(members)
+    amd.Engine.step_group(members, 40, sync=True)
+    whole, _ = gather_blocks(members)
+    recv = np.arange(3, n, n // 256)[:256]
+    devs, worst = [], 0.0
+    for m in members:
+        lo, hi = m.shard_range()
+        assert hi - lo == n // world and (m.status()[lo:hi] == 0).all()
+        devs.append(np.abs(whole[lo:hi, :2] - ref_state[lo:hi, :2]).max(axis=1))
+        mine = recv[(recv >= lo) & (recv < hi)]
+        err, _, _ = sampled_force_check(m, p, mine, st=whole)
+        worst = max(worst, err)
+        assert err < 1e-4, err
+    devs = np.concatenate(devs)
+    print(f"{world}-way loopback group of the headline population after 40 ticks: forces vs oracle {worst:.1e}; positions vs the "
+          f"unsharded engine: median {np.median(devs):.1e} m, 99.9 % {np.percentile(devs, 99.9):.1e} m, max {devs.max():.1e} m")
+    # (another fp32 summation order per rank; a source on a field-of-view edge decided the other way moves one road user)
+    assert np.median(devs) < 1e-6 * box and np.percentile(devs, 99.5) < 1e-4 * box and devs.max() < 0.5
+    for m in members[::-1]:
+        m.close()
+
+
 def test_config5_1048576_planarpoint_with_road_5_ticks(amd):
     """BASELINE config 5 stepped on one device: 1 048 576 PlanarPointBicycle in 1 600 m with the tiled curve road
     (391 680 vertices), 5 ticks; after every tick the pair term and the road term of 64 receivers against the oracle."""
