@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     for (int c = 0; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
     const float2 froad = d.froad[a];
     const float2 rorg = d.rorg[a];                             // (for the record written at the end)
+    // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge (csf_dev.h:
+    // EdgeRec): 0 for all but a few dozen road users of a large population
+    const int32_t edge_head = (d.edge != nullptr && (phases & PH_COMBINE)) ? d.edge_head[a] : 0;
 
     double fdx, fdy;
     if (phases & PH_DEST) {
@@ -87,6 +90,26 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
                 const float2 pr = d.part[(int64_t)c * cap + a];
                 rx += (double)pr.x;
                 ry += (double)pr.y;
+            }
+            if (edge_head != 0) {   // rare: decide those pairs as the reference does (intersection.py:711-741) and put the sum right
+                double cx = 0, cy = 0;   // (fp64: the order in which the entries were appended does not show)
+                int32_t at = edge_head;
+                for (int guard = 0; at != 0 && guard < 64; guard++) {
+                    const EdgeRec er = d.edge[(unsigned)(at - 1) % EDGE_CAP];
+                    if (er.recv != (int32_t)a || er.stamp != d.edge_stamp) {   // left over from another launch, or a ring that overflowed
+                        if (er.stamp == d.edge_stamp) atomicAdd(d.near_dropped, 1u);
+                        break;
+                    }
+                    const bool seen = !untracked_exact_xy(er.xi, er.yi, g.x, g.y, g.psi, er.hfov, d.p.priority_rule == CSF_P2R);
+                    if (seen != (er.seen != 0)) {
+                        cx += seen ? (double)er.fx : -(double)er.fx;
+                        cy += seen ? (double)er.fy : -(double)er.fy;
+                    }
+                    at = er.next;
+                }
+                d.edge_head[a] = 0;
+                rx += cx;
+                ry += cy;
             }
             double rin = sqrt(rx * rx + ry * ry), lim = sqrt(fdx * fdx + fdy * fdy);
             if (rin > lim) {                                  // utils.py:79-84

@@ -8,24 +8,6 @@
 namespace csf {
 
 
-constexpr double PI = 3.141592653589793238462643383279502884;
-
-// utils.py:124-139
-__device__ __forceinline__ double limit_angle(double th) {
-    th = floor(th / (2 * PI)) * (-2 * PI) + th;
-    if (th > PI) th -= 2 * PI;
-    else if (th < -PI) th += 2 * PI;
-    return th;
-}
-
-// utils.py:167-182: signed shortest rotation a1 -> a2 (ties resolve to +)
-__device__ __forceinline__ double angle_diff(double a1, double a2) {
-    double da = fabs(a1 - a2);
-    if (da > PI) da = 2 * PI - da;
-    double t1 = fabs(limit_angle(a1 - da) - a2), t2 = fabs(limit_angle(a1 + da) - a2);
-    return t1 < t2 ? -da : da;
-}
-
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmax(fmin(x, hi), lo); }
 
 // Registers of one agent while it is being ticked.
@@ -674,8 +656,10 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
 __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, int64_t a, const float2 o, double x, double y,
                                              double psi, double v, bool cs_fresh = false, double c = 0.0, double s = 0.0) {
     if (!cs_fresh) sincos(psi, &s, &c);
-    const float4 q = make_float4((float)((x - d.ox) - (double)o.x), (float)((y - d.oy) - (double)o.y), (float)c, (float)s);
+    const double px = (x - d.ox) - (double)o.x, py = (y - d.oy) - (double)o.y;
+    const float4 q = make_float4((float)px, (float)py, (float)c, (float)s);
     d.rec[a] = q;
+    d.reclo[a] = make_float2((float)(px - (double)q.x), (float)(py - (double)q.y));   // (what fp32 left over: csf_dev.h reclo)
     // scene coordinates = offset + origin, in fp32 (the same sum a rank forms from the records it has gathered, so that
     // every path sees the same numbers): by slot (the receivers), and the copy in binned order (csf_bin.hip) that the
     // pair kernel's tiles are filled with

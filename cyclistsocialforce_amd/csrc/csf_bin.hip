@@ -114,14 +114,21 @@ __global__ __launch_bounds__(256) void rebase_kernel(const Dev d) {
     float2 on = make_float2(0.f, 0.f);
     if (real) on = make_float2(0.25f * rintf(4.0f * x), 0.25f * rintf(4.0f * y));
     if (real) {
+        float2 lo;
         if (d.rebase_from_state) {
-            q.x = (float)((d.s[a] - d.ox) - (double)on.x);
-            q.y = (float)((d.s[d.cap + a] - d.oy) - (double)on.y);
-        } else {
-            q.x = (o.x - on.x) + q.x;
-            q.y = (o.y - on.y) + q.y;
+            const double px = (d.s[a] - d.ox) - (double)on.x, py = (d.s[d.cap + a] - d.oy) - (double)on.y;
+            q.x = (float)px;
+            q.y = (float)py;
+            lo = make_float2((float)(px - (double)q.x), (float)(py - (double)q.y));
+        } else {   // (the rounding of the sum goes to the low part: the position a rank holds of a foreign source stays what it was)
+            const float2 lo0 = d.reclo[a];
+            float ex, ey;
+            two_sum(o.x - on.x, q.x, q.x, ex);
+            two_sum(o.y - on.y, q.y, q.y, ey);
+            lo = make_float2(ex + lo0.x, ey + lo0.y);
         }
         d.rec[a] = q;
+        d.reclo[a] = lo;
         d.rorg[a] = on;
         d.pos[a] = (int32_t)p;
     } else if (a < d.n_pad) {

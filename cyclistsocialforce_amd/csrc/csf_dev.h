@@ -32,7 +32,36 @@ struct PairConsts {
     // pairs closer than rnear are evaluated from the precise records (csf_pair.hip: precise_delta); rnear2 = rnear^2,
     // rn2big = 1e20 rnear^2 (what makes the fast path drop such a pair without a branch)
     float rnear, rnear2, rn2big;
+    // Field-of-view decisions within fp32 rounding of an edge (csf_field.h: keep_x2 / tracked_m; csf_engine.hip: set_fov_band).
+    // With t = rho cos(bearing) the fast test is g = t|t| + chs rho^2 > 0; positions in the tiles are off by eps_p (2^-24 of the
+    // largest coordinate), headings by 2^-24, so |g - exact| < 12 eps_p rho + 18 2^-24 rho^2.  A pair with |g| below twice that
+    // - fovA r2 + fovB after rho <= r2 / 16 + 4 - is MARGINAL: the fast path keeps it, and it is decided as the reference
+    // decides (fp64 atan2 -> limitAngle -> angleDifference, intersection.py:711-736) where it is corrected.  sideA / sideB:
+    // the same band for the side test of priority-to-the-right (:739-741), |rho sin(bearing)| < sideA r2 + sideB.
+    float fovA, fovB, sideA, sideB;
+    // the packed test of the cull-first kernel (keep_x2) works on the cosine of the bearing, t / rho against chk = cos(hfov/2)
+    // (-2 for a full circle), band fovT0 + fovT1 / rho = 2 (8 u + 3 eps_p / rho)
+    float chk, fovT0, fovT1;
+    float clsclear;                    // classify_batch: the receiver must be this far outside a batch's circle (csf_engine.hip: set_fov_band)
+    // the same band for a pair formed from the PRECISE records (csf_pair.hip: precise_delta; offsets of a few metres from
+    // origins whose difference is exact): |g| < fovP1 rho + fovP2 r2, |rho sin(bearing)| < sideP0 + sideP1 rho
+    float fovP1, fovP2, sideP0, sideP1;
 };
+
+// A pair whose field-of-view decision is within rounding even on the precise records (about one in 1e7): the pair kernel
+// hands it to the per-agent kernel, which decides it as the reference does - fp64, atan2 -> limitAngle -> angleDifference
+// (intersection.py:711-741; csf_dev.h: untracked_exact_xy) - on the receiver's own fp64 state and the source's position
+// as it was when the pair kernel ran, and adds or removes the pair's force (csf_agent.hip: COMBINE).
+struct EdgeRec {
+    double xi, yi;        // the source's position (fp64 state at the time of the pair launch)
+    double hfov;          // ... and its field of view (intersection.py:733-735: the source's parameter set)
+    float fx, fy;         // the force of the pair, from the precise records
+    int32_t recv;         // the receiver's slot
+    int32_t next;         // 1 + ring index of the next entry of this receiver, 0: none
+    uint32_t stamp;       // Dev::edge_stamp of the launch that wrote it
+    int32_t seen;         // what the pair kernel decided (and added accordingly)
+};
+constexpr unsigned EDGE_CAP = 4096;   // ring of entries; a tick produces a few dozen at N = 16 384
 
 // All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
 struct Dev {
@@ -103,6 +132,9 @@ struct Dev {
     // kernels hold scene coordinates (recs, or offset + origin), 2^-24 of the scene extent.
     float4 *rec;       // [n_pad] by slot
     float2 *rorg;      // [n_pad] by slot: the origin its record is relative to, itself relative to (ox, oy)
+    float2 *reclo;     // [n_pad] by slot: what the record's position left over, (offset - fp32(offset)) in fp32: origin +
+                       // record + this is the fp64 position to ~1e-14 m.  Exchanged with the records, so that a rank can
+                       // hand a foreign source's position to the exact field-of-view decision (csf_field.h: edge_handover)
     // Large populations (recv_binned; csf_pair.hip BINR works relative to the origin of its receiver group): the record by
     // place of the binned order, its position relative to the origin of its BATCH of 64 places - the own origin of the
     // batch's first road user at the last re-binning - formed as offset + (own origin - batch origin), the bracket exact:
@@ -111,6 +143,13 @@ struct Dev {
     float2 *borg;      // [n_pad / 64] those origins, relative to (ox, oy); (0, 0) for a batch without a road user
     float4 *recg;      // [cap] by slot: the record in scene coordinates, bit for bit what recs holds at the slot's place (the
                        // receivers of the kernels on binned records: a receiver must coincide with itself as a source)
+    int32_t state_current;       // pair kernels: the fp64 state d.s of EVERY live slot is current on this device (not on a rank of a
+                                 // sharded run once it has ticked): marginal field-of-view decisions are then taken from it
+    EdgeRec *edge;               // [EDGE_CAP] ring (NULL: the pair launch hands nothing over - shards, csf_count_pairs)
+    unsigned *edge_n;            // [1] entries appended since the engine was created (ring index = count % EDGE_CAP)
+    int32_t *edge_head;          // [cap] 1 + ring index of the newest entry of the receiver in this slot, 0: none
+    uint32_t edge_stamp;         // names the pair launch(es) of this tick; entries of another stamp are stale
+    unsigned *near_dropped;      // [1] near / marginal pairs a full per-wave list could not take (csf_pair.hip: near_note); never reset
     int32_t rebase_from_state;   // re-binning: every live slot's fp64 state is current on this device (else: re-express the old record)
     float2 *rec2;      // [n_pad] Bicycle field only: (e, 1/sqrt(1-e^2))
     int32_t *perm;     // [n_pad] spatially binned order of the source records (position -> record index)
@@ -235,6 +274,38 @@ void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const
                     double *ddest_out, hipStream_t st);
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
                      int apply_fov, float2 *out, hipStream_t st);
+
+constexpr double PI = 3.141592653589793238462643383279502884;
+
+// utils.py:124-139
+__device__ __forceinline__ double limit_angle(double th) {
+    th = floor(th / (2 * PI)) * (-2 * PI) + th;
+    if (th > PI) th -= 2 * PI;
+    else if (th < -PI) th += 2 * PI;
+    return th;
+}
+
+// utils.py:167-182: signed shortest rotation a1 -> a2 (ties resolve to +)
+__device__ __forceinline__ double angle_diff(double a1, double a2) {
+    double da = fabs(a1 - a2);
+    if (da > PI) da = 2 * PI - da;
+    double t1 = fabs(limit_angle(a1 - da) - a2), t2 = fabs(limit_angle(a1 + da) - a2);
+    return t1 < t2 ? -da : da;
+}
+
+// intersection.py:711-741 as the reference decides it - fp64, atan2 -> limitAngle -> angleDifference - on the fp64 state
+// of both road users: does the receiver in slot aj ignore the source in slot ai (ai != aj)?  hfov: the SOURCE's (:733-735).
+__device__ __forceinline__ bool untracked_exact_xy(double xi, double yi, double xj, double yj, double psij, double hfov, bool p2r);
+__device__ __forceinline__ bool untracked_exact(const Dev &d, int64_t ai, int64_t aj, double hfov, bool p2r) {
+    return untracked_exact_xy(d.s[ai], d.s[d.cap + ai], d.s[aj], d.s[d.cap + aj], d.s[2 * d.cap + aj], hfov, p2r);
+}
+
+// the same decision for a source at (xi, yi) and the receiver (xj, yj, psij)
+__device__ __forceinline__ bool untracked_exact_xy(double xi, double yi, double xj, double yj, double psij, double hfov, bool p2r) {
+    const double az = limit_angle(atan2(yi - yj, xi - xj));        // :711-718
+    const double rel = angle_diff(psij, az);                       // :724-726
+    return (fabs(rel) > hfov / 2) | (p2r & (rel > 0));             // :733-741
+}
 
 // a + b as an unevaluated sum hi + lo (Knuth's TwoSum: no ordering of |a|, |b| assumed)
 __device__ __forceinline__ void two_sum(float a, float b, float &hi, float &lo) {

@@ -103,6 +103,7 @@ struct Knobs {
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
     bool comm_second = false;                 // CSF_COMM_STREAM=second
     int fused = 0;                            // CSF_FUSED=1: the one-launch tick of small populations (csf_tick.hip; opt-in)
+    double fov_band = 1.0;                    // CSF_FOV_BAND: scale of the rounding band of the field-of-view test (0: every pair decided in fp32, as in round 3)
     double rnear = 1.0;                       // CSF_RNEAR: pairs closer than this (m) are evaluated from the precise records (0: none)
     int road_grid = -1;                       // CSF_ROAD_GRID: 1 the lattice of csf_road.hip for any road, 0 never (-1: large networks)
     double road_cell = 0.0;                   // CSF_ROAD_CELL: edge of its cells in m (0: 16)
@@ -130,6 +131,7 @@ struct Knobs {
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second";
         fused = geti("CSF_FUSED", 0);
         if (const char *v = getenv("CSF_RNEAR")) rnear = atof(v);
+        if (const char *v = getenv("CSF_FOV_BAND")) fov_band = std::max(0.0, atof(v));
         road_grid = geti("CSF_ROAD_GRID", -1);
         if (const char *v = getenv("CSF_ROAD_CELL")) road_cell = atof(v);
     }
@@ -249,6 +251,7 @@ struct csf_engine {
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, recs2, part, froad, kat2;
     DevBuf<float2> rorg;         // the origin every precise record is relative to, by slot
+    DevBuf<float2> reclo;        // what the record's position left over in fp32 (csf_dev.h); all-gathered with the records
     // the one-launch tick of small populations (csf_tick.hip): exchange records (two buffers each), barrier words
     DevBuf<float4> tk_xa;
     DevBuf<float2> tk_xb, tk_xc;
@@ -256,6 +259,16 @@ struct csf_engine {
     unsigned long long tk_bar_base = 0;   // what the barrier's arrival counter has reached
     bool tick_launched = false;  // a one-launch tick ran since the barrier's abort flag was last read
     bool state_all_current = true;   // every live slot's fp64 state on this device is current (false once a rank has ticked)
+    // Field-of-view decisions within fp32 rounding of an edge (csf_dev.h: PairConsts::fovA, EdgeRec; set_fov_band): the
+    // largest |coordinate| relative to the scene origin at the last upload (road users, prescribed trajectories, arrivals
+    // since), and the integration steps since - nobody moves farther than t_s * v_max per step
+    double coord_bound0 = 0.0;
+    int64_t moves = 0;
+    bool bound_stale = false;        // positions moved without a speed clamp (csf_replay_forces with fix_speed): measure them
+    uint32_t edge_stamp = 0;
+    DevBuf<EdgeRec> edge;
+    DevBuf<unsigned> edge_n;         // [0] ring counter, [1] near / marginal pairs that could not be noted (csf_near_dropped)
+    DevBuf<int32_t> edge_head;
     double far_kappa = 0.0;   // lower bound of the field's decay rate (far_kappa())
     double last_gather_ms = 0.0;  // all-gather time accumulated by the last csf_profile_read
     bool ev_gather_recorded = false;
@@ -412,6 +425,74 @@ void update_far_radius(csf_engine *e) {   // depends on the parameters and on th
     set_far_consts(e->knobs, e->d.p, e->far_kappa, e->d.n, k);
 }
 
+// The rounding band of the fp32 field-of-view test (csf_dev.h: PairConsts::fovA ...; csf_field.h: keep_x2, tracked_m), for the
+// pair launches that follow.  With u = 2^-24: a position in a tile is off by eps_p = u * (largest |coordinate|) per
+// component (offset + origin rounded once), a heading (cos, sin) by u per component; t = rho cos(bearing) is then off by
+// < 3 eps_p + 5 u rho and g = t|t| + chs rho^2 by < 12 eps_p rho + 18 u rho^2.  Twice that, with rho <= r2 / 16 + 4:
+//     band = (36 u + 1.5 eps_p) r2 + 96 eps_p;   side test (priority to the right): 0.625 u r2 + 6 eps_p + 40 u
+// (tracked_m: the plain kernels).  The packed test of the cull-first kernel (keep_x2) compares cos(bearing) = t rsq(rho^2)
+// with cos(hfov / 2): off by < 3 eps_p / rho + 8 u (the rsq included); twice that is its band, and that of sin(bearing).
+// A pair formed from the precise records (offsets of at most a few metres from origins whose difference is exact) has
+// eps_p = u * (largest offset), and its band is evaluated with rho itself: 24 eps_p rho + 36 u r2; 6 eps_p + 10 u rho.
+int set_fov_band(csf_engine *e) {
+    Dev &d = e->d;
+    const double u = 5.9604644775390625e-8;
+    if (e->bound_stale) {   // (single device: every slot's state is here)
+        std::vector<double> xy(2 * (size_t)e->cap);
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        HIPCHK(e, hipMemcpy(xy.data(), e->s.p, xy.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double cb = e->coord_bound0;
+        for (int32_t a : e->order) {
+            const double bx = std::fabs(xy[(size_t)a] - d.ox), by = std::fabs(xy[(size_t)e->cap + (size_t)a] - d.oy);
+            if (std::isfinite(bx) && std::isfinite(by)) cb = std::max({cb, bx, by});
+        }
+        e->coord_bound0 = cb;
+        e->moves = 0;
+        e->bound_stale = false;
+    }
+    double vmax = 0;
+    for (const csf_params &c : e->classes)
+        vmax = std::max({vmax, std::fabs(c.v_max_riding[0]), std::fabs(c.v_max_riding[1]), std::fabs(c.v_max_walk)});
+    const double step = d.p.t_s * vmax * 1.01 + 1e-4;
+    // receivers in binned order work relative to the origin of their group: up to twice the bound from the scene origin
+    double cmax = e->coord_bound0 + step * (double)(e->moves + 2) + 1.0;
+    // receivers in binned order work relative to the origin of their group: at most twice the bound from the scene origin
+    // (a tighter one - far-field radius + the extent of a group and of a batch - would need the circles, which only the
+    // device knows; the band only decides how many pairs take the exact path, a few per thousand receivers either way)
+    if (d.recv_binned) cmax *= 2.0;
+    const double eps_p = u * cmax * 1.01 + 4 * u;
+    // (full circle: chs = 4, g > 3 r2 - never inside a band that small)
+    PairConsts &k = d.pc;
+    const double sc = e->knobs.fov_band;
+    k.fovA = (float)(sc * (36 * u + 1.5 * eps_p));
+    k.fovB = (float)(sc * 96 * eps_p);
+    k.sideA = (float)(sc * 0.625 * u);
+    k.sideB = (float)(sc * (6 * eps_p + 40 * u));
+    k.fovT0 = (float)(sc * 16 * u);
+    k.fovT1 = (float)(sc * 6 * eps_p);
+    // whole batches are classified against the field-of-view cone with a margin of 1e-4 in the cosine (csf_pair.hip:
+    // classify_batch): the bearing of a source nearer than this is not known that well in fp32, so a batch whose circle
+    // comes closer goes to the per-lane test
+    k.clsclear = (float)std::max(0.05, 2.9 * eps_p / 5e-5);
+    // offsets: a quarter-metre grid of origins + what a road user covers between two re-binnings (REBIN_TICKS = 32 steps;
+    // arrivals take their position as their origin)
+    const double off = 0.25 + step * 40.0;
+    const double eps_o = u * off * 1.5;
+    k.fovP1 = (float)(sc * 24 * eps_o);
+    k.fovP2 = (float)(sc * 36 * u);
+    k.sideP0 = (float)(sc * 6 * eps_o);
+    k.sideP1 = (float)(sc * 10 * u);
+    for (csf_engine::Segment &sg : e->segs) {
+        sg.pc.fovA = k.fovA, sg.pc.fovB = k.fovB, sg.pc.sideA = k.sideA, sg.pc.sideB = k.sideB;
+        sg.pc.fovT0 = k.fovT0, sg.pc.fovT1 = k.fovT1, sg.pc.clsclear = k.clsclear;
+        sg.pc.fovP1 = k.fovP1, sg.pc.fovP2 = k.fovP2, sg.pc.sideP0 = k.sideP0, sg.pc.sideP1 = k.sideP1;
+    }
+    d.state_current = e->state_all_current ? 1 : 0;
+    d.edge = e->edge.p;
+    d.edge_stamp = ++e->edge_stamp;
+    return CSF_OK;
+}
+
 // exp(A) of a small dense matrix (n <= 4, row major): scaling and squaring of a degree-18 Taylor polynomial
 void expm_small(int n, const double *A, double *E) {
     double nrm = 0;
@@ -492,6 +573,7 @@ void derive_pair_consts(const csf_params &p, PairConsts &k, double rnear) {
     k.chs = (float)(p.hfov <= PI_ ? -ch * ch : ch * ch);
     if (p.hfov >= 2 * PI_) k.chs = 4.0f;  // full circle: every bearing is inside (t|t| + 4 rho^2 > 0)
     k.ch = (float)ch;
+    k.chk = p.hfov >= 2 * PI_ ? -2.0f : (float)ch;      // (keep_x2: cos(bearing) > chk)
     k.p2r = p.priority_rule == CSF_P2R;
     if (p.model == CSF_BICYCLE) {
         k.lf0 = (float)std::log2(p.p_0 / p.p_decay);
@@ -701,6 +783,7 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->rorg.alloc(nrec));
+    HIPCHK(e, e->reclo.alloc(nrec));
     if (e->cap_user <= TICK_MAX_AGENTS) {
         const size_t m = TICK_MAX_AGENTS + 64;
         HIPCHK(e, e->tk_xa.alloc(2 * m));
@@ -735,6 +818,9 @@ int alloc_all(csf_engine *e) {
     e->h_cls.assign(cap, 0);
     HIPCHK(e, e->cls.alloc(cap));
     HIPCHK(e, e->ticket.alloc(1));
+    HIPCHK(e, e->edge.alloc(EDGE_CAP));
+    HIPCHK(e, e->edge_n.alloc(2));
+    HIPCHK(e, e->edge_head.alloc(cap));
     e->pend_spawn_at.assign(cap, -1);
     e->pend_requeue_at.assign(cap, -1);
     e->pend_retire_at.assign(cap, -1);
@@ -773,6 +859,11 @@ int alloc_all(csf_engine *e) {
     d.bnd = e->bnd.p;
     d.bnd_next = e->bnd2.p;
     d.rorg = e->rorg.p;
+    d.reclo = e->reclo.p;
+    d.edge = e->edge.p;
+    d.edge_n = e->edge_n.p;
+    d.near_dropped = e->edge_n.p + 1;
+    d.edge_head = e->edge_head.p;
     d.trace = nullptr;
     if (!e->knobs.trace_blocks.empty()) {  // 3 words per wave: the grid is at most (cap/16) x MAX_SPLIT workgroups of 4 waves
         e->trace_words = 3 * 4 * ((size_t)cap / 16 + 1) * MAX_SPLIT;
@@ -1222,6 +1313,17 @@ int upload_all(csf_engine *e) {
         d.ox = std::nearbyint(0.5 * (rbox[0] + rbox[1]));
         d.oy = std::nearbyint(0.5 * (rbox[2] + rbox[3]));
     }
+    {   // the largest coordinate a record can take, relative to that origin (set_fov_band): road users and the prescribed
+        // trajectories of UncontrolledVehicles now; arrivals and motion are added as they come
+        double cb = 0;
+        for (int64_t a = 0; a < n; a++) {
+            cb = std::max({cb, std::fabs(e->h_s[a] - d.ox), std::fabs(e->h_s[e->cap + a] - d.oy)});
+            const std::vector<double> &sc = e->h_script[(size_t)a];
+            for (size_t r = 0; r + 3 < sc.size(); r += 4) cb = std::max({cb, std::fabs(sc[r] - d.ox), std::fabs(sc[r + 1] - d.oy)});
+        }
+        e->coord_bound0 = std::isfinite(cb) ? cb : 0.0;
+        e->moves = 0;
+    }
     // Road vertices (x, y, -F0, -(sigma+1)/2), padded with inert vertices.  Positions are offsets from the origin of
     // their tile of 1024 consecutive vertices (the centre of its box, rounded to 1/4 m): consecutive vertices of a
     // polyline are neighbours, so a vertex resolves to 2^-24 of ~50 m whatever the extent of the scene, and the road
@@ -1449,13 +1551,13 @@ int all_gather_records(csf_engine *e) {
     const bool second = comm_second_stream(e);
     hipStream_t cs = second ? e->comm : e->main;
     if (second) HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
-    const bool two = d.has_bike != 0;
-    if (two) NCCLCHK(e, g_rccl.GroupStart());
+    // one group: the records (16 B), what their positions left over in fp32 (8 B: csf_dev.h reclo) and, for the Bicycle
+    // field, the second record (8 B)
+    NCCLCHK(e, g_rccl.GroupStart());
     NCCLCHK(e, g_rccl.AllGather(d.rec + (size_t)e->rank * shard, d.rec, shard * 4, ncclFloat32, e->nccl, cs));
-    if (two) {
-        NCCLCHK(e, g_rccl.AllGather(d.rec2 + (size_t)e->rank * shard, d.rec2, shard * 2, ncclFloat32, e->nccl, cs));
-        NCCLCHK(e, g_rccl.GroupEnd());
-    }
+    NCCLCHK(e, g_rccl.AllGather(d.reclo + (size_t)e->rank * shard, d.reclo, shard * 2, ncclFloat32, e->nccl, cs));
+    if (d.has_bike) NCCLCHK(e, g_rccl.AllGather(d.rec2 + (size_t)e->rank * shard, d.rec2, shard * 2, ncclFloat32, e->nccl, cs));
+    NCCLCHK(e, g_rccl.GroupEnd());
     if (second) {
         HIPCHK(e, hipEventRecord(e->ev_gather, e->comm));
         e->gather_pending = true;
@@ -1592,7 +1694,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -1675,6 +1777,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             r.qlen = 1;
             r.qbeg = (int64_t)(e->pend.rows.size() / 3);
             for (int c = 0; c < 6; c++) r.s[c] = c < ns ? s[c] : 0.0;
+            e->coord_bound0 = std::max({e->coord_bound0, std::fabs(s[0] - d.ox), std::fabs(s[1] - d.oy)});   // (set_fov_band)
             r.vdes = v_desired[k];
             r.cls = 0;
             r.pad = 0;
@@ -2048,6 +2151,7 @@ static int enqueue_tick(csf_engine *e) {
     // sharded: the other ranks' records arrived in index order; a coalesced tile fill from the binned copy saves the
     // pair kernel 5 - 7 us at every shard size, the copy costs ~3 us
     if (sharded && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
+    if ((rc = set_fov_band(e))) return rc;
     if (d.n_live > 1 && d.hi > d.lo) {
         launch_pair_all(e, d, ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr);
         if (ps) ps->pair = true;
@@ -2061,6 +2165,7 @@ static int enqueue_tick(csf_engine *e) {
                  po ? po->ev[4] : nullptr, po ? po->ev[5] : nullptr);
     // a rank integrates its own block only: the others' fp64 state is stale from now on (a 1-rank communicator owns every block)
     if (e->world > 1 || e->loopback) e->state_all_current = false;
+    e->moves++;
     if (po) po->agent = true;
     HIPCHK(e, hipGetLastError());
     d.tick++;
@@ -2085,6 +2190,8 @@ static int loopback_exchange(csf_engine *const *g, int world) {
         for (int p = 0; p < world; p++) {
             if (p == r) continue;
             HIPCHK(g[p], hipMemcpyAsync(g[p]->rec.p + r * shard, src->rec.p + r * shard, shard * sizeof(float4),
+                                        hipMemcpyDeviceToDevice, src->main));
+            HIPCHK(g[p], hipMemcpyAsync(g[p]->reclo.p + r * shard, src->reclo.p + r * shard, shard * sizeof(float2),
                                         hipMemcpyDeviceToDevice, src->main));
             if (src->d.has_bike)
                 HIPCHK(g[p], hipMemcpyAsync(g[p]->rec2.p + r * shard, src->rec2.p + r * shard, shard * sizeof(float2),
@@ -2122,6 +2229,7 @@ static int step_one_launch(csf_engine *e, int64_t n_ticks) {
         launch_tick(d, t, e->main);
         HIPCHK(e, hipGetLastError());
         d.tick += k;
+        e->moves += k;
         n_ticks -= k;
     }
     // the general path finds the records moved by many ticks: circles and order are renewed before its next pair launch
@@ -2182,6 +2290,7 @@ int csf_calc_forces(csf_engine *e) {
     rc = bounds_before_pair(e);
     if (rc) return rc;
     if ((e->world > 1 || e->nccl != nullptr || e->loopback) && e->d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(e->d, e->main);
+    if ((rc = set_fov_band(e))) return rc;
     if (e->d.n_live > 1) launch_pair_all(e, e->d);
     bounds_after_pair(e, false);                     // the records do not move: recompute next time
     launch_road(e->d, e->main);
@@ -2212,6 +2321,7 @@ int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy) {
     launch_agent(e->d, PH_INTEGRATE, e->main);
     HIPCHK(e, hipGetLastError());
     e->bounds_fresh = false;
+    e->moves++;
     e->d.tick++;
     e->device_ahead = true;
     return CSF_OK;
@@ -2262,6 +2372,8 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
         HIPCHK(e, hipStreamSynchronize(e->main));
     }
     e->d.tick += n_ticks;
+    e->moves += n_ticks;
+    if (fix_speed) e->bound_stale = true;    // (calibration.py:454-458 sets the speed to |F|: no clamp bounds the step)
     e->device_ahead = true;
     e->bounds_fresh = false;
     if (dd.hist)
@@ -2467,6 +2579,7 @@ int csf_untracked(csf_engine *e, uint8_t *out) {
     if ((rc = wait_gather(e))) return rc;
     if ((rc = sync_order(e))) return rc;
     HIPCHK(e, e->scratch_u8.reserve((size_t)(n * n)));         // (every byte of the matrix is written by the kernel)
+    e->d.state_current = e->state_all_current ? 1 : 0;        // (then every pair is decided on the fp64 state, as the reference does)
     launch_untracked(e->d, e->scratch_u8.p, e->main);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
@@ -2733,15 +2846,27 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     DevBuf<unsigned long long> &cnt = e->scratch_cnt;
     HIPCHK(e, cnt.reserve(4));
     HIPCHK(e, hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned long long), e->main));
+    if ((rc = set_fov_band(e))) return rc;
     Dev dd = d;                 // this tick's records and circles; the circles of the next tick are not touched
     dd.pair_count = cnt.p;
     dd.bnd_next = nullptr;
+    dd.edge = nullptr;          // (no per-agent launch follows that would take undecided pairs over)
     launch_pair_all(e, dd);                                      // (the Bicycle-field launches of a mixed population do not count)
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->main));
     unsigned long long h[4] = {0, 0, 0, 0};
     HIPCHK(e, hipMemcpy(h, cnt.p, sizeof h, hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; k++) counts[k] = (int64_t)h[k];
+    return CSF_OK;
+}
+
+int csf_near_dropped(csf_engine *e, int64_t *n_dropped) {
+    if (!e || !n_dropped) return e ? fail(e, CSF_E_ARG, "csf_near_dropped: NULL output") : CSF_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->main));
+    unsigned h = 0;
+    HIPCHK(e, hipMemcpy(&h, e->edge_n.p + 1, sizeof h, hipMemcpyDeviceToHost));
+    *n_dropped = (int64_t)h;
     return CSF_OK;
 }
 

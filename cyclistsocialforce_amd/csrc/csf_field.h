@@ -35,6 +35,90 @@ __device__ __forceinline__ bool tracked(float chs, const Recv &r, float dx, floa
     return in;
 }
 
+// The same test with the band of its fp32 rounding (PairConsts::fovA ...), every result ONE compare (csf_pair.hip: ballot1):
+// kept - tracked, or within rounding of an edge -, lt - below the upper edge of the band.  A source is MARGINAL when
+// kept & lt: it has to be decided as the reference decides it by whoever evaluates it.  rho = 0 is never kept.  The return
+// value is the plain fp32 decision.
+template <bool P2R>
+__device__ __forceinline__ bool tracked_m(const PairConsts &k, float chs, const Recv &r, float dx, float dy, float r2, bool &kept, bool &lt) {
+    const float t = -(dx * r.c + dy * r.s);
+    const float g = t * fabsf(t) + chs * r2;
+    const float band = k.fovA * r2 + k.fovB;
+    bool in = g > 0.0f;
+    if (!P2R) {
+        kept = __builtin_fminf(g + band, r2) > 0.0f;
+        lt = g < band;
+    } else {
+        const float side = r.s * dx - r.c * dy, sb = k.sideA * r2 + k.sideB;
+        in = in & !(side > 0.0f);
+        kept = (__builtin_fminf(g + band, r2) > 0.0f) & !(side > sb);
+        lt = (g < band) | (side > -sb);
+    }
+    return in;
+}
+
+// One source per lane through the very test of keep_x2<FOV> (same arithmetic, so that the variants of the cull-first kernel
+// with and without the reach test keep and flag the same sources): kept - cos(bearing) - cos(hfov/2) > -T -, lt - < T.
+template <bool P2R>
+__device__ __forceinline__ void tracked_c(const PairConsts &k, const Recv &r, float dx, float dy, bool &kept, bool &lt) {
+    const float r2 = dx * dx + dy * dy;
+    const float inv = fast_rsq(r2);
+    const float t = -(dx * r.c + dy * r.s);
+    const float T = k.fovT0 + k.fovT1 * inv;
+    const float dc = t * inv - k.chk;
+    const float z = dc + T;
+    kept = z > 0.0f;                                   // (r2 = 0: NaN - the receiver itself is never kept)
+    lt = dc < T;
+    if (P2R) {
+        const float ss = (r.s * dx - r.c * dy) * inv;
+        kept = kept & !(ss > T);
+        lt = lt | (ss > -T);
+    }
+}
+
+// intersection.py:690-745 for a pair formed from the PRECISE records (csf_pair.hip: precise_delta).  edge: the pair is within
+// rounding of an edge even so (about one in 1e7) - the caller hands it to the per-agent kernel (edge_handover), which
+// decides it as the reference does.
+template <bool P2R>
+__device__ __forceinline__ bool tracked_precise(const PairConsts &k, float chs, const Recv &r, float dx, float dy, float r2, bool &edge) {
+    const float t = -(dx * r.c + dy * r.s), rho = fast_sqrt(r2);
+    const float g = t * fabsf(t) + chs * r2;
+    bool in = g > 0.0f;
+    edge = fabsf(g) < k.fovP1 * rho + k.fovP2 * r2;
+    if (P2R) {
+        const float side = r.s * dx - r.c * dy;
+        in = in & !(side > 0.0f);
+        edge = edge | (fabsf(side) < k.sideP0 + k.sideP1 * rho);
+    }
+    edge = edge & (r2 > 0.0f);
+    return in;
+}
+
+// One undecidable pair -> the ring the per-agent kernel reads (csf_dev.h: EdgeRec; csf_agent.hip: COMBINE): the source's
+// fp64 position as it is now, its field of view, the pair's force (fx, fy) and whether the caller has added it (seen).
+// The source's position: its fp64 state where this device holds it, else (a rank of a sharded run) rebuilt from the record.
+__device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int32_t a_src, double hfov, float fx, float fy, bool seen) {
+    const unsigned at = atomicAdd(d.edge_n, 1u) % EDGE_CAP;
+    EdgeRec er;
+    if (d.state_current) {
+        er.xi = d.s[a_src];
+        er.yi = d.s[d.cap + a_src];
+    } else {   // a rank of a sharded run: origin + record + what the record left over = the owner's fp64 position to ~1e-14 m
+        const float4 q = d.rec[a_src];
+        const float2 o = d.rorg[a_src], lo = d.reclo[a_src];
+        er.xi = (d.ox + (double)o.x) + ((double)q.x + (double)lo.x);
+        er.yi = (d.oy + (double)o.y) + ((double)q.y + (double)lo.y);
+    }
+    er.hfov = hfov;
+    er.fx = fx;
+    er.fy = fy;
+    er.recv = a_recv;
+    er.next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
+    er.stamp = d.edge_stamp;
+    er.seen = seen ? 1 : 0;
+    d.edge[at] = er;
+}
+
 // vehicle.py:1560-1648: force of source (record q) on receiver r, returned as magnitude F and an
 // unnormalised direction (gx, gy) with F already holding 1/|g|.  (dx, dy) = receiver - source.
 __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, const float4 q, float dx,
@@ -75,19 +159,21 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
 // The same field for TWO sources per lane (components .x / .y), float2 arithmetic -> v_pk_* instructions.
 // FULL: both sources of every lane are real, tracked pairs (rho > 0); otherwise valid0 / valid1 mask the lanes
 // of a partial batch, whose dummy record may coincide with the receiver.  Accumulates into (ax, ay).
-// NEARFLAG: near0 / near1 report the pairs closer than k.rnear (pair_cull_kernel corrects them from the precise records).
+// NEARFLAG: near0 / near1 (wave masks) report the pairs closer than k.rnear (pair_cull_kernel corrects them from the precise
+// records).
 template <bool FULL, bool NEARFLAG = false, bool LO = false>
 __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r, const v2f qx, const v2f qy,
                                               const v2f qc, const v2f qs, bool valid0, bool valid1, float &ax,
-                                              float &ay, bool *near0 = nullptr, bool *near1 = nullptr,
+                                              float &ay, unsigned long long *near0 = nullptr, unsigned long long *near1 = nullptr,
                                               const v2f lx = v2f{0.f, 0.f}, const v2f ly = v2f{0.f, 0.f}) {
     // (lx, ly): an optional correction of (dx, dy), the difference of the low parts of two-float positions (csf_tick.hip)
     v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
     if (LO) dx = dx + lx, dy = dy + ly;
     v2f r2 = dx * dx + dy * dy;
-    if (NEARFLAG) {
-        *near0 = valid0 & (r2.x < k.rnear2);
-        *near1 = valid1 & (r2.y < k.rnear2);
+    if (NEARFLAG) {   // (every mask the result of ONE compare: csf_pair.hip ballot1)
+        *near0 = __builtin_amdgcn_ballot_w64(r2.x < k.rnear2);
+        *near1 = __builtin_amdgcn_ballot_w64(r2.y < k.rnear2);
+        if (!FULL) *near0 &= __builtin_amdgcn_ballot_w64(valid0), *near1 &= __builtin_amdgcn_ballot_w64(valid1);
     }
     if (!FULL) r2 = v2f{fmaxf(r2.x, 1e-30f), fmaxf(r2.y, 1e-30f)};
     v2f inv = rsq2(r2), rho = r2 * inv;
@@ -130,28 +216,45 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
 // batches that are not wholly inside the field of view.
 template <bool FOV, bool P2R>
 __device__ __forceinline__ void keep_x2(const PairConsts &k, const Recv &r, const v2f qx, const v2f qy, const v2f qc,
-                                        const v2f qs, bool &k0, bool &k1) {
+                                        const v2f qs, bool &k0, bool &k1, bool &m0, bool &m1) {
     const v2f dx = r.x - qx, dy = r.y - qy;
     const v2f r2 = dx * dx + dy * dy;
     const v2f X = dx * qc + dy * qs;
     const v2f srel = qs * r.c - qc * r.s;
     const v2f s2 = srel * srel;
     const v2f e = k.e0 - k.e1 * s2, A = k.tA0 + k.tA1 * s2, B = k.tB0 + k.tB1 * s2;
-    const v2f c = X * rsq2(r2);                        // r2 = 0 (the receiver itself): NaN -> kept here, masked by FOV
+    const v2f inv = rsq2(r2);
+    const v2f c = X * inv;                             // r2 = 0 (the receiver itself): NaN
     const v2f S = A + B * c;
     const v2f eX = e * X;
-    const v2f f = (r2 - eX * eX) - S * S;
-    k0 = !(f.x > 0.0f);
-    k1 = !(f.y > 0.0f);
-    if (FOV) {
+    const v2f f = (r2 - eX * eX) - S * S;              // > 0: out of reach
+    m0 = m1 = false;
+    if (!FOV) {
+        k0 = !(f.x > 0.0f);                            // (batches wholly inside the field of view never hold the receiver itself)
+        k1 = !(f.y > 0.0f);
+    } else {
+        // Field of view in the cosine of the bearing, c = t / rho against cos(hfov / 2), with the band T of its fp32 rounding
+        // (csf_engine.hip: set_fov_band): a source is kept when c - ch > -T - tracked, or within rounding of the edge: MARGINAL,
+        // decided exactly where the pair is corrected - and marginal when c - ch < T as well.  The rsq is the reach test's.
+        // Each result is ONE compare (a wave mask straight from the instruction; the `and` of two compares would go through a
+        // vector register on its way to a ballot): reach and field of view are merged with a min, the receiver itself
+        // (r2 = 0: NaN in both) fails the compare.  m0 / m1 are meaningful for kept sources only.
         const v2f t = -(dx * r.c + dy * r.s);
-        const v2f g = t * fabs2(t) + k.chs * r2;
-        k0 = k0 & (g.x > 0.0f);
-        k1 = k1 & (g.y > 0.0f);
+        const v2f T = k.fovT0 + k.fovT1 * inv;
+        const v2f dc = t * inv - k.chk;
+        const v2f z = dc + T;
+        if (!P2R) {
+            k0 = __builtin_fminf(-f.x, z.x) > 0.0f;        // in reach (f < 0; NaN: the other operand) and c - ch > -T
+            k1 = __builtin_fminf(-f.y, z.y) > 0.0f;
+        }
+        m0 = dc.x < T.x;
+        m1 = dc.y < T.y;
         if (P2R) {
-            const v2f side = r.s * dx - r.c * dy;      // rho sin(bearing) > 0: the source is to the left
-            k0 = k0 & !(side.x > 0.0f);
-            k1 = k1 & !(side.y > 0.0f);
+            const v2f ss = (r.s * dx - r.c * dy) * inv;    // sin(bearing) > 0: the source is to the left; same band
+            k0 = (!(f.x > 0.0f)) & (z.x > 0.0f) & !(ss.x > T.x);
+            k1 = (!(f.y > 0.0f)) & (z.y > 0.0f) & !(ss.y > T.y);
+            m0 = m0 | (ss.x > -T.x);
+            m1 = m1 | (ss.y > -T.y);
         }
     }
 }

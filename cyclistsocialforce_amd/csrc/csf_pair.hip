@@ -111,6 +111,20 @@ __device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_
     if (iend > d.n_src) iend = d.n_src;   // (the places behind hold sentinels only, csf_engine.hip: rebin)
 }
 
+// The kernel's argument block again, through a pointer the compiler cannot see through: what only the rare paths read
+// (the precise records, the permutation, the hand-over ring ...) is then loaded where it is used.  Read through `d`, those
+// loads are hoisted to the top of the kernel as loop invariants and, for want of scalar registers, parked in the lanes of a
+// vector register - some fifty v_writelane per wave before the first source is looked at (65 536 waves per launch).
+__device__ __forceinline__ const Dev &cold_args() {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const Dev *)p;
+}
+
+// the wave mask of a predicate, straight from the compare that made it (HIP's __ballot takes an int: the bool is widened
+// to 0 / 1 in a vector register and compared with 0 again - two vector instructions per ballot in the test loops)
+__device__ __forceinline__ unsigned long long ballot1(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 // ---- near pairs ---------------------------------------------------------------------------------------------------
 // The kernels work on fp32 positions relative to the scene origin (what the tile holds: 2^-24 of the scene extent, 8e-6 m
 // at 130 m).  The field's direction turns by (position error / distance) and its decay length is as short as 0.2 m, so
@@ -165,7 +179,8 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
     const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
     const float off = rc * ey - rs * ex;                      // centre's offset from the heading line, left > 0
     const float sb = fabsf(off) * invD;
-    const bool apart = D2 > bb.z * bb.z;                      // receiver outside the circle
+    const float keepoff = bb.z + k.clsclear;
+    const bool apart = D2 > keepoff * keepoff;                // receiver outside the circle, by more than fp32 positions blur a bearing
     const bool fov = apart & (k.fov_classify != 0);
     const float reach = k.rfar + bb.z;
     const bool far = D2 > reach * reach;
@@ -265,13 +280,15 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     // Near pairs (precise_delta): what the field evaluation meets closer than k.rnear is noted here - receiver << 16 |
     // tile index - and corrected once per wave and tile (near_drain, in the tile loop).
     int nlen = 0, cur_recv = 0;         // (wave-uniform) entries of the wave's list; the receiver being worked on
+    unsigned ndrop = 0;                 // ... entries that found it full
     auto near_note = [&](bool nr, int tile_index) {
-        const unsigned long long m = __ballot(nr);
+        const unsigned long long m = ballot1(nr);
         if (nr) {
             const int at = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nlen));
             if (at < NCAP) nlist[wave][at] = ((unsigned)cur_recv << 16) | (unsigned)tile_index;   // (full: left uncorrected)
         }
         const int nn = nlen + __builtin_popcountll(m);
+        ndrop += nn > NCAP ? (unsigned)(nn - NCAP) : 0u;      // (reported once, at the end: csf_near_dropped - the tests assert 0)
         nlen = __builtin_amdgcn_readfirstlane(nn < NCAP ? nn : NCAP);
     };
     // pop CHUNK (or, when draining, whatever is left) queued sources of receiver u; the field takes two per lane
@@ -282,17 +299,17 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         int i1 = queue[wave][(qhead + WAVE + lane) & (QCAP - 1)];
         const bool v0 = lane < n, v1 = lane + WAVE < n;
         if (!FULL) i0 = v0 ? i0 : 0, i1 = v1 ? i1 : 0;
-        bool n0, n1;
+        unsigned long long n0, n1;
         field_twod_x2<FULL, true>(k, ru, lds_pair_b(tx, i0, i1), lds_pair_b(ty, i0, i1), lds_pair_b(tc, i0, i1),
                                   lds_pair_b(ts, i0, i1), v0, v1, ax[u], ay[u], &n0, &n1);
-        if (__ballot(n0 | n1) != 0ull) {        // rare: a near pair among the 128 (the queue still holds their offsets)
-            near_note(n0, (int)queue[wave][(qhead + lane) & (QCAP - 1)] >> 2);
-            near_note(n1, (int)queue[wave][(qhead + WAVE + lane) & (QCAP - 1)] >> 2);
+        if (__builtin_expect((n0 | n1) != 0ull, 0)) {   // rare: a pair among the 128 to be corrected (the queue still holds their offsets)
+            near_note(((n0 >> lane) & 1ull) != 0ull, (int)queue[wave][(qhead + lane) & (QCAP - 1)] >> 2);
+            near_note(((n1 >> lane) & 1ull) != 0ull, (int)queue[wave][(qhead + WAVE + lane) & (QCAP - 1)] >> 2);
         }
         qhead = __builtin_amdgcn_readfirstlane((qhead + n) & (QCAP - 1));
         qlen = __builtin_amdgcn_readfirstlane(qlen - n);
-        evals += (unsigned)n;
-        pops += FULL ? 1u : 0x10000u;
+        if (FULL) pops += 1u;             // (the evaluations of the full passes are added at the end: 128 each)
+        else evals += (unsigned)n, pops += 0x10000u;
     };
     // the last (at most 64) queued sources of a receiver: one per lane through the unpacked field - about 60 % of the
     // instructions of a packed evaluation whose second half would be empty
@@ -304,7 +321,10 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         const float dx = ru.x - q.x, dy = ru.y - q.y, r2 = dx * dx + dy * dy;
         float F, gx, gy;
         field_twod(k, ru, q, dx, dy, fmaxf(r2, 1e-30f), F, gx, gy);
-        if (__ballot(v & (r2 < k.rnear2)) != 0ull) near_note(v & (r2 < k.rnear2), o >> 2);
+        {   // (the wave mask of ONE compare, masked as a scalar: ballot1)
+            const unsigned long long nm = ballot1(r2 < k.rnear2) & (qlen >= WAVE ? ~0ull : ((1ull << qlen) - 1ull));
+            if (__builtin_expect(nm != 0ull, 0)) near_note(((nm >> lane) & 1ull) != 0ull, o >> 2);
+        }
         F = v ? F : 0.0f;
         ax[u] += F * gx;
         ay[u] += F * gy;
@@ -407,7 +427,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
             asm volatile("" : "+v"(gxv), "+v"(gyv), "+v"(grv));
             const float ex = (bb.x - og.x) - gxv, ey = (bb.y - og.y) - gyv;
             const float reach = k.rfar + bb.z + grv;
-            if (__ballot(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
+            if (ballot1(ex * ex + ey * ey <= reach * reach) == 0ull) continue;
             if (filled) __syncthreads();
             fill_tile(base, cnt, tid);
             __syncthreads();
@@ -430,8 +450,8 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                 bool out, in;
                 classify_batch<P2R>(k, rrec[r0 + ln / NBT], tbnd[ln & (NBT - 1)], out, in);
                 const bool valid = (ln & (NBT - 1)) < nb;
-                cand_all = __ballot(valid & !out);
-                inside_all = __ballot(valid & in);
+                cand_all = ballot1(valid & !out);
+                inside_all = ballot1(valid & in);
                 if (DYN && ln < RPP) {
                     if (NBT > 16) {
                         bmask[r0 + ln] = (unsigned)(cand_all >> ((NBT & 63) * ln)) & NBMASK;
@@ -450,26 +470,44 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         // the differences are added to the receivers' sums in list order (fixed: bit-reproducible).
         auto near_drain = [&]() {
             if (nlen == 0) return;
+            const Dev &dc = cold_args();
+            const PairConsts &kc = dc.pc;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const unsigned ent = nlist[wave][lane & (NCAP - 1)];
-            const int urn = lane < nlen ? (int)(ent >> 16) : 0;
+            bool act = lane < nlen;
+            // a pair can be noted twice - within rounding of a field-of-view edge (the test) AND near (the field): once is enough
+            for (int i = 0; i + 1 < nlen; i++) {
+                const unsigned ei = (unsigned)__builtin_amdgcn_readlane((int)ent, i);
+                act = act & !((lane > i) & (ent == ei));
+            }
+            const int urn = lane < nlen ? (int)(ent >> 16) : 0;      // (a duplicate keeps its receiver: this wave's own, it adds 0 to it)
             const int idx = lane < nlen ? (int)(ent & 0xFFFFu) : 0;
             const int32_t ar = ragent[urn];
-            bool act = (lane < nlen) & (ar >= 0);                   // (a clamped duplicate's results are not stored)
+            act = act & (ar >= 0);                                   // (a clamped duplicate's results are not stored)
             const int32_t arc = act ? ar : 0;
-            const int32_t as = act ? d.perm[base + idx] : arc;
+            const int32_t as = act ? dc.perm[base + idx] : arc;
+            // intersection.py:690-745 on the precise pair (positions to ~2e-7 m, headings to 6e-8 rad).  A pair that is within
+            // rounding of an edge even so (one in ~1e7) is handed to the per-agent kernel with the source's fp64 position, to
+            // be decided as the reference decides it - fp64 atan2 -> limitAngle -> angleDifference - and put right there
+            // (csf_dev.h: EdgeRec; csf_agent.hip: COMBINE).  A rank of a sharded run holds only the 16-byte record of a foreign
+            // source: there the precise pair decides.
             float dx, dy, F, hx, hy;
             float4 qs;
-            precise_delta(d, arc, as, dx, dy, qs);
+            precise_delta(dc, arc, as, dx, dy, qs);
             const float4 qr = rrec[urn];
             const Recv rr{qr.x, qr.y, qr.z, qr.w};
             const float r2p = dx * dx + dy * dy;
-            const bool seen = act & (as != arc) & tracked<P2R>(k.chs, rr, dx, dy, r2p);   // intersection.py:690-745 on the precise pair
+            bool edge;
+            bool seen = tracked_precise<P2R>(kc, k.chs, rr, dx, dy, r2p, edge) & act & (as != arc);
+            edge = edge & act & (as != arc);
             field_twod(k, rr, qs, dx, dy, fmaxf(r2p, 1e-30f), F, hx, hy);
+            if (ballot1(edge) != 0ull && dc.edge != nullptr) {
+                if (edge) edge_handover(dc, arc, as, dc.p.hfov, F * hx, F * hy, seen);
+            }
             F = seen ? F : 0.0f;
             float fx = F * hx, fy = F * hy;
-            {   // ... minus what the fast path added for it
+            {   // ... minus what the fast path added for it (every noted pair was kept and evaluated there)
                 const float sx = rr.x - tx[idx], sy = rr.y - ty[idx];
                 field_twod(k, rr, make_float4(0.f, 0.f, tc[idx], ts[idx]), sx, sy, fmaxf(sx * sx + sy * sy, 1e-30f), F, hx, hy);
                 F = act ? F : 0.0f;
@@ -506,33 +544,11 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         unsigned long long wanted = 0ull;
         if (COMPACT) {
             mymask = bmask[ln & (RPB - 1)];
-            wanted = __ballot(ln < RPB && (mymask & live) != 0u);
+            wanted = ballot1((mymask & live) != 0u) & (RPB >= 64 ? ~0ull : ((1ull << (RPB & 63)) - 1ull));
         }
         const int n_wanted = COMPACT ? __builtin_popcountll(wanted) : RPB;
-#pragma unroll DYN ? 1 : RPW
-        for (int uu = 0; uu < (DYN ? RPB : RPW); uu++) {
-            int ur = wave * RPW + uu;                 // receiver within the workgroup
-            unsigned bm = 0u, bm_in = 0u;
-            if (DYN) {
-                int got = 0;
-                if (lane == 0) got = atomicAdd(&next_recv, 1);
-                ur = __builtin_amdgcn_readfirstlane(got);
-                if (COMPACT) {                        // the ur-th set bit of `wanted`: the lane whose bit it is has `ur` set bits below it
-                    if (ur >= n_wanted) break;
-                    const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wanted >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wanted, 0u));
-                    const unsigned long long hit = __ballot(((wanted >> lane) & 1ull) != 0ull && below == ur);
-                    ur = __builtin_ctzll(hit);
-                    bm = (unsigned)__builtin_amdgcn_readlane((int)mymask, ur);
-                    if (NBT > 16) bm_in = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask_in[ur]);   // (with the receiver's record: one round trip)
-                } else {
-                    if (ur >= RPB) break;
-                }
-            }
-            if (!COMPACT && DYN && CLASSIFY) {
-                bm = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask[ur]);
-                if ((bm & live) == 0u) continue;      // no batch of this tile can act on this receiver: nothing to add
-                if (NBT > 16) bm_in = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask_in[ur]);
-            }
+        // one VISIT: receiver ur of the workgroup (batch masks bm / bm_in) against this tile
+        auto visit = [&](int ur, unsigned bm, unsigned bm_in, int uu) {
             const int u = DYN ? 0 : uu;               // accumulator slot
             cur_recv = ur;
             {
@@ -548,6 +564,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
             unsigned cand = ((DYN && CLASSIFY) ? (NBT > 16 ? bm : (bm & 0xFFFFu)) : (unsigned)(cand_all >> (16 * u))) & live;
             const unsigned inside = ((DYN && CLASSIFY) ? (NBT > 16 ? bm_in : (bm >> 16)) : (unsigned)(inside_all >> (16 * u))) & live;
             if (REACH) {
+                tests += (unsigned)WAVE * (unsigned)__builtin_popcount(cand | inside);   // every candidate batch goes through the per-lane test
                 // two candidate batches at a time through the packed reach test (+ the exact field-of-view test unless
                 // both are wholly inside); what it keeps is appended to the queue, first batch first.
                 // (A single loop over both kinds of batch pairs with the records of the next pair requested ahead of the
@@ -555,11 +572,14 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                 // test of the two batches whose records are in (sx, sy, sc, ss), append of what it keeps
                 auto sift2 = [&](int b1, int b2, bool two, auto fov, v2f sx, v2f sy, v2f sc, v2f ss) {
                     constexpr bool FOV = decltype(fov)::value;
-                    bool k0, k1;
-                    keep_x2<FOV, P2R>(k, ru, sx, sy, sc, ss, k0, k1);
+                    bool k0, k1, mg0, mg1;
+                    keep_x2<FOV, P2R>(k, ru, sx, sy, sc, ss, k0, k1, mg0, mg1);
+                    // (wave masks straight from the compares: a ballot of `k1 & two` would go through a vector register)
+                    const unsigned long long m0 = ballot1(k0), m1 = ballot1(k1) & (0ull - (unsigned long long)two);
                     k1 = k1 & two;
-                    tests += two ? 2u * WAVE : (unsigned)WAVE;
-                    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+                    // sources within rounding of a field-of-view edge (rare; kept): as wave masks, so that nothing but two scalars
+                    // lives across the queue append
+                    const unsigned long long g0 = FOV ? (ballot1(mg0) & m0) : 0ull, g1 = FOV ? (ballot1(mg1) & m1) : 0ull;
                     const int n0 = __builtin_popcountll(m0);
                     if (k0) {                       // slot = (head + length) + kept lanes below this one: v_mbcnt adds onto its operand
                         const int at = __builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, (unsigned)(qhead + qlen)));
@@ -570,6 +590,10 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                         queue[wave][at & (QCAP - 1)] = (unsigned short)(4 * ((b2 << 6) + lane));
                     }
                     qlen = __builtin_amdgcn_readfirstlane(qlen + n0 + __builtin_popcountll(m1));
+                    if (FOV && __builtin_expect((g0 | g1) != 0ull, 0)) {     // ... noted: decided exactly where the noted pairs are corrected (near_drain)
+                        near_note(((g0 >> lane) & 1ull) != 0ull, (b1 << 6) + lane);
+                        near_note(((g1 >> lane) & 1ull) != 0ull, (b2 << 6) + lane);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     while (qlen >= CHUNK) pop(u, std::true_type{});
@@ -607,12 +631,12 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                     const int b2 = __builtin_ctz(ins);
                     ins &= ins - 1u;
                     const int i0 = (b1 << 6) + lane, i1 = (b2 << 6) + lane;
-                    bool n0, n1;
+                    unsigned long long n0, n1;
                     field_twod_x2<true, true>(k, ru, lds_pair(tx, i0, i1), lds_pair(ty, i0, i1), lds_pair(tc, i0, i1),
                                               lds_pair(ts, i0, i1), true, true, ax[u], ay[u], &n0, &n1);
-                    if (__ballot(n0 | n1) != 0ull) {
-                        near_note(n0, i0);
-                        near_note(n1, i1);
+                    if (__builtin_expect((n0 | n1) != 0ull, 0)) {
+                        near_note(((n0 >> lane) & 1ull) != 0ull, i0);
+                        near_note(((n1 >> lane) & 1ull) != 0ull, i1);
                     }
                     evals += 2 * WAVE;
                 }
@@ -627,14 +651,16 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                     qlen = __builtin_amdgcn_readfirstlane(qlen + WAVE);
                 } else {
                     const float dx = ru.x - *(const float *)((const char *)tx + tb), dy = ru.y - *(const float *)((const char *)ty + tb);
-                    const bool in = tracked<P2R>(k.chs, ru, dx, dy, dx * dx + dy * dy);
+                    bool in, lt;   // kept: tracked, or within rounding of an edge - then noted, and decided exactly in near_drain
+                    tracked_c<P2R>(k, ru, dx, dy, in, lt);
                     tests += (unsigned)WAVE;
-                    const unsigned long long m = __ballot(in);
+                    const unsigned long long m = ballot1(in), mg = ballot1(lt) & m;
                     if (in) {
                         const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                         queue[wave][(qhead + qlen + pre) & (QCAP - 1)] = (unsigned short)tb;
                     }
                     qlen = __builtin_amdgcn_readfirstlane(qlen + __builtin_popcountll(m));
+                    if (__builtin_expect(mg != 0ull, 0)) near_note(((mg >> lane) & 1ull) != 0ull, (b << 6) + lane);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -655,8 +681,43 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                 if ((lane & 31) == 0) racc[lane >> 5][ur] += v;  // one wave per receiver and tile: fixed order, no atomics
                 ax[0] = ay[0] = 0.0f;
             }
+        };
+        if (DYN) {
+            // receivers are claimed from the workgroup's counter until none is left; the wave's list of noted pairs is
+            // corrected when the tile is done - or, in a crowd, as soon as it is half full, between two receivers (every
+            // noted pair then belongs to a receiver whose column sum has been added: the order of the additions is fixed)
+            bool more = true;
+            do {
+                unsigned bm = 0u, bm_in = 0u;
+                int got = 0;
+                if (lane == 0) got = atomicAdd(&next_recv, 1);
+                int ur = __builtin_amdgcn_readfirstlane(got);
+                bool skip = false;
+                if (COMPACT) {                        // the ur-th set bit of `wanted`: the lane whose bit it is has `ur` set bits below it
+                    more = ur < n_wanted;
+                    if (more) {
+                        const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wanted >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wanted, 0u));
+                        const unsigned long long hit = ballot1(below == ur) & wanted;   // (the lanes from the ur-th set bit up to the next one, masked)
+                        ur = __builtin_ctzll(hit);
+                        bm = (unsigned)__builtin_amdgcn_readlane((int)mymask, ur);
+                        if (NBT > 16) bm_in = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask_in[ur]);   // (with the receiver's record: one round trip)
+                    }
+                } else {
+                    more = ur < RPB;
+                    if (more && CLASSIFY) {
+                        bm = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask[ur]);
+                        skip = (bm & live) == 0u;     // no batch of this tile can act on this receiver: nothing to add
+                        if (!skip && NBT > 16) bm_in = (unsigned)__builtin_amdgcn_readfirstlane((int)bmask_in[ur]);
+                    }
+                }
+                if (more && !skip) visit(ur, bm, bm_in, 0);
+                if (!more || nlen >= NCAP / 2) near_drain();
+            } while (more);
+        } else {
+#pragma unroll
+            for (int uu = 0; uu < RPW; uu++) visit(wave * RPW + uu, 0u, 0u, uu);
+            near_drain();
         }
-        near_drain();
     }
     if (DYN) {
         __syncthreads();
@@ -667,8 +728,9 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     } else {
         reduce_store(d, j0, lane, ax, ay, &ragent[wave * RPW]);
     }
+    if (ndrop != 0u && lane == 0) atomicAdd(cold_args().near_dropped, ndrop);
     if (d.pair_count != nullptr && lane == 0) {
-        atomicAdd(d.pair_count, (unsigned long long)evals);
+        atomicAdd(d.pair_count, (unsigned long long)evals + (unsigned long long)CHUNK * (pops & 0xFFFFu));
         atomicAdd(d.pair_count + 1, (unsigned long long)tests);
         atomicAdd(d.pair_count + 2, (unsigned long long)(pops & 0xFFFFu));
         atomicAdd(d.pair_count + 3, (unsigned long long)(pops >> 16));
@@ -738,23 +800,32 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
             for (int u = 0; u < RPW; u++) {
                 float dx = r[u].x - q.x, dy = r[u].y - q.y;  // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
-                {   // near sources (rare): (dx, dy) from the precise records (precise_delta); this kernel's sources sit in slot order
-                    const bool nr = r2 < d.pc.rnear2;
+                bool mg, lt, edge = false;
+                bool in = tracked_m<P2R>(d.pc, ks.chs, r[u], dx, dy, r2, mg, lt);
+                mg = mg & lt;
+                {   // near sources, and sources within rounding of a field-of-view edge (both rare): (dx, dy) from the precise
+                    // records (precise_delta) and the decision on them; this kernel's sources sit in slot order
+                    const bool fix = (r2 < d.pc.rnear2) | mg;
                     const int64_t jr = j0 + u;
-                    if (__ballot(nr) != 0ull && jr < d.hi) {
+                    if (ballot1(fix) != 0ull && jr < d.hi) {
                         float px, py;
                         float4 qs;
-                        precise_delta(d, (int32_t)jr, nr ? (int32_t)(base + t) : (int32_t)jr, px, py, qs);
-                        dx = nr ? px : dx;
-                        dy = nr ? py : dy;
+                        const int32_t as = fix ? (int32_t)(base + t) : (int32_t)jr;
+                        precise_delta(d, (int32_t)jr, as, px, py, qs);
+                        dx = fix ? px : dx;
+                        dy = fix ? py : dy;
                         r2 = dx * dx + dy * dy;
+                        if (fix) in = tracked_precise<P2R>(d.pc, ks.chs, r[u], dx, dy, r2, edge) & (as != (int32_t)jr);
+                        edge = edge & fix & (as != (int32_t)jr);
                     }
                 }
-                bool in = tracked<P2R>(ks.chs, r[u], dx, dy, r2);
                 r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
                 if (FIELD == 1 || (FIELD == 2 && ks.ipd != 0.0f)) field_bicycle(ks, q, qb, dx, dy, r2, F, gx, gy);   // (ipd: Bicycle sets only)
                 else field_twod(ks, r[u], q, dx, dy, r2, F, gx, gy);
+                if (d.edge != nullptr && ballot1(edge) != 0ull) {   // undecidable even on the precise records: the per-agent kernel decides
+                    if (edge) edge_handover(d, (int32_t)(j0 + u), (int32_t)(base + t), HET ? d.ptab[tcls[t]].hfov : d.p.hfov, F * gx, F * gy, in);
+                }
                 F = in ? F : 0.0f;
                 ax[u] += F * gx;
                 ay[u] += F * gy;
@@ -815,8 +886,8 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
             bool out, in;
             classify_batch<P2R>(k, rrec[wave * RW + 4 * ps + (lane >> 4)], tbnd[lane & 15], out, in);
             const bool valid = (lane & 15) < nb;
-            cand_all = __ballot(valid & !out);
-            inside_all = __ballot(valid & in);
+            cand_all = ballot1(valid & !out);
+            inside_all = ballot1(valid & in);
         }
 #pragma unroll
         for (int uq = 0; uq < 4; uq++) {
@@ -837,28 +908,36 @@ __global__ __launch_bounds__(BLOCK) void pair_bike_kernel(const Dev d) {
                 const float2 qb = tile2[t];
                 float dx = r.x - q.x, dy = r.y - q.y;                // vehicle.py:1615-1616
                 float r2 = dx * dx + dy * dy;
-                {                                                    // near sources (rare): (dx, dy) from the precise records
-                    const bool nr = r2 < d.pc.rnear2;                // (precise_delta)
+                const bool whole = (inside >> b) & 1u;               // (uniform) every source of the batch is tracked
+                bool mg = false, edge = false;
+                int32_t esrc = 0;
+                bool lt = false;
+                bool in = whole ? true : tracked_m<P2R>(k, k.chs, r, dx, dy, r2, mg, lt);
+                mg = mg & lt;
+                {   // near sources, and sources within rounding of a field-of-view edge (both rare): (dx, dy) from the precise
+                    // records (precise_delta) and the decision on them
+                    const bool fix = (r2 < d.pc.rnear2) | mg;
                     const int64_t jr = j0 + u;
-                    if (__ballot(nr) != 0ull && jr < d.hi) {
-                        const int32_t as = nr ? d.perm[base + t] : (int32_t)jr;   // (the receiver itself: a zero, masked below)
+                    if (ballot1(fix) != 0ull && jr < d.hi) {
+                        const int32_t as = fix ? d.perm[base + t] : (int32_t)jr;   // (the receiver itself: a zero, masked below)
                         float px, py;
                         float4 qs;
                         precise_delta(d, (int32_t)jr, as, px, py, qs);
-                        dx = nr ? px : dx;
-                        dy = nr ? py : dy;
+                        dx = fix ? px : dx;
+                        dy = fix ? py : dy;
                         r2 = dx * dx + dy * dy;
+                        if (fix) in = tracked_precise<P2R>(k, k.chs, r, dx, dy, r2, edge) & (as != (int32_t)jr);
+                        edge = edge & fix & (as != (int32_t)jr);
+                        esrc = as;
                     }
                 }
                 float F, gx, gy;
-                if ((inside >> b) & 1u) {                            // (uniform) every source of the batch is tracked
-                    field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
-                } else {
-                    const bool in = tracked<P2R>(k.chs, r, dx, dy, r2);
-                    r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
-                    field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
-                    F = in ? F : 0.0f;
+                r2 = fmaxf(r2, 1e-30f);      // self / coincident pair: keep every intermediate finite (F is masked)
+                field_bicycle(k, q, qb, dx, dy, r2, F, gx, gy);
+                if (d.edge != nullptr && ballot1(edge) != 0ull) {   // undecidable even on the precise records: the per-agent kernel decides
+                    if (edge) edge_handover(d, (int32_t)(j0 + u), esrc, d.p.hfov, F * gx, F * gy, in);
                 }
+                F = in ? F : 0.0f;
                 ax[u] += F * gx;
                 ay[u] += F * gy;
             }
@@ -1002,12 +1081,18 @@ __global__ void untracked_kernel(const Dev d, uint8_t *out) {
     if (t >= n * n) return;
     const int64_t i = t / n, j = t - i * n;
     const int64_t ai = d.order ? d.order[i] : i, aj = d.order ? d.order[j] : j;
-    const float4 q = d.rec[ai], rr = d.rec[aj];
-    const float2 qo = d.rorg[ai], ro = d.rorg[aj];             // the records are offsets from their batches' origins
-    const Recv r{rr.x, rr.y, rr.z, rr.w};
-    const float dx = (r.x - q.x) + (ro.x - qo.x), dy = (r.y - q.y) + (ro.y - qo.y), r2 = dx * dx + dy * dy;
-    const float chs = d.pctab[d.cls[d.order ? d.order[i] : i]].chs;      // the hfov of the source's parameter set (:733-735)
-    const bool in = (i != j) & (d.pc.p2r ? tracked<true>(chs, r, dx, dy, r2) : tracked<false>(chs, r, dx, dy, r2));
+    const csf_params &ps = d.ptab[d.cls[ai]];                   // the hfov of the source's parameter set (:733-735)
+    bool in;
+    if (d.state_current) {   // as the reference decides it: fp64, atan2 -> limitAngle -> angleDifference on the fp64 state
+        in = (i != j) && !untracked_exact(d, ai, aj, ps.hfov, d.pc.p2r != 0);
+    } else {                 // a rank of a sharded run: the precise records of the pair
+        const float4 q = d.rec[ai], rr = d.rec[aj];
+        const float2 qo = d.rorg[ai], ro = d.rorg[aj];         // the records are offsets from origins of their own
+        const Recv r{rr.x, rr.y, rr.z, rr.w};
+        const float dx = (r.x - q.x) + (ro.x - qo.x), dy = (r.y - q.y) + (ro.y - qo.y), r2 = dx * dx + dy * dy;
+        const float chs = d.pctab[d.cls[ai]].chs;
+        in = (i != j) & (d.pc.p2r ? tracked<true>(chs, r, dx, dy, r2) : tracked<false>(chs, r, dx, dy, r2));
+    }
     out[t] = in ? 0 : 1;
 }
 

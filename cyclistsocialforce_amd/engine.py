@@ -367,6 +367,12 @@ class Engine:
             return dict(evaluated=n[0], tested=n[1], full_passes=n[2], partial_passes=n[3]), kernel
         return n[0], kernel
 
+    def near_dropped(self):
+        """near / field-of-view-edge pairs the pair kernels could not hand to their exact path since creation (expected 0)"""
+        n = C.c_int64(0)
+        self._ck(self._lib.csf_near_dropped(self._h, C.byref(n)))
+        return n.value
+
     def profile_gather(self):
         """all-gather milliseconds accumulated over the launches of the last profile_read() (sharded engines)"""
         g = C.c_double(0)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSF_ABI_VERSION 4
+#define CSF_ABI_VERSION 5
 
 /* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
  * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle); :920 (UncontrolledVehicle: follows a prescribed trajectory
@@ -268,6 +268,14 @@ int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_
  * Runs one extra launch with device counters; the state of the simulation is not advanced.  All -1 when the engine's
  * pair kernel does not count (kernel_name, if not NULL, names the kernel either way). */
 int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name);
+/* Pairs the pair kernels could NOT hand to their exact path since the engine was created (0 in every run seen so far).
+ * The kernels decide the field of view (intersection.py:690-745) in fp32 and note every pair inside the rounding band of
+ * an edge, and every pair closer than 1 m, in a per-wave list of 32 entries (emptied between receivers when half full);
+ * noted pairs are re-decided and re-evaluated from the precise records, and what is undecidable even there goes to the
+ * per-agent kernel, which decides as the reference does (fp64 atan2 -> limitAngle -> angleDifference).  An entry that
+ * found its list full, or a hand-over ring that overflowed within one tick, is counted here; such a pair keeps the fp32
+ * result. */
+int csf_near_dropped(csf_engine *e, int64_t *n_dropped);
 /* milliseconds between the end of the agent kernel and the end of the RCCL all-gather, accumulated over the launches
  * of the last csf_profile_read (0 for an unsharded engine) */
 int csf_profile_gather(const csf_engine *e, double *gather_ms);

@@ -208,6 +208,15 @@ int csfo_untracked(double hfov_i, int rule, int i, int j, double xi, double yi, 
     return 0;
 }
 
+/* intersection.py:690-745 — the whole matrix (row = source i with ITS hfov, :733-735; column = receiver j) */
+void csfo_untracked_matrix(const double *hfov, int rule, int64_t n, const double *x, const double *y, const double *psi,
+                           uint8_t *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < n; j++)
+            out[i * n + j] = (uint8_t)csfo_untracked(hfov[i], rule, (int)(i != j), 0, x[i], y[i], x[j], y[j], psi[j]);
+}
+
 /* intersection.py:226-242 — one vertex list with per-vertex F0 and sigma (summed over edges: 36-48, 81-94) */
 void csfo_road_force(int64_t nv, const double *vx, const double *vy, const double *vF0,
                      const double *vsig, double x, double y, double *Fx, double *Fy) {
@@ -1153,22 +1162,26 @@ void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const ui
         trj(o, a, 0)[i] = s[0];
         trj(o, a, 1)[i] = s[1];
         trj(o, a, 2)[i] = s[4];
+        /* the integrators keep angles UNWRAPPED (vehicle.py:1844-1846, dynamics.py:943-966) while s holds them wrapped: keep
+         * the winding number the oracle has, i.e. the multiple of 2 pi nearest to its own unwrapped value */
+#define REWIND(own, wrapped) ((wrapped) + 2 * PI * nearbyint(((own) - (wrapped)) / (2 * PI)))
         if (PA(o, a)->model == CSFO_INVPEND) {
             double *x = o->xlti + 5 * a;
-            x[0] = s[4];
-            x[2] = s[5];
-            x[4] = s[2];
+            x[0] = REWIND(x[0], s[4]);
+            x[2] = REWIND(x[2], s[5]);
+            x[4] = REWIND(x[4], s[2]);
         }
         if (PA(o, a)->model == CSFO_PLANARBIKE) {
-            o->xdyn[3 * a] = s[4];
-            o->xdyn[3 * a + 1] = s[2];
+            o->xdyn[3 * a] = REWIND(o->xdyn[3 * a], s[4]);
+            o->xdyn[3 * a + 1] = REWIND(o->xdyn[3 * a + 1], s[2]);
         }
         if (PA(o, a)->model == CSFO_PLANARPOINT) {
-            o->xdyn[3 * a] = s[2];
+            o->xdyn[3 * a] = REWIND(o->xdyn[3 * a], s[2]);
             o->xdyn[3 * a + 1] = s[0];
             o->xdyn[3 * a + 2] = s[1];
             o->vdyn[a] = s[3];
         }
+#undef REWIND
         if (ptr) o->ptr[a] = ptr[a];
         if (znav)
             for (int k = 0; k < 3; k++) o->znav[3 * a + k] = znav[3 * a + k];

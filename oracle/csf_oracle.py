@@ -123,6 +123,7 @@ def lib():
         L.csfo_pair_bicycle.argtypes = [C.POINTER(Params)] + [C.c_double] * 6 + [dp, dp]
         L.csfo_untracked.restype = C.c_int
         L.csfo_untracked.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int] + [C.c_double] * 5
+        L.csfo_untracked_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int64] + [C.c_void_p] * 4
         L.csfo_road_force.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_double, C.c_double, dp, dp]
         L.csfo_column_sums.argtypes = [C.POINTER(Params), C.c_int64] + [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3
@@ -204,12 +205,13 @@ def pair_bicycle(params, src, v, x, y):
 
 
 def untracked_matrix(hfov, rule, x, y, psi):
+    """get_untracked_foes (intersection.py:690-745): U[i, j] = receiver j ignores source i; hfov a scalar or one per source"""
     n = len(x)
-    U = np.zeros((n, n), dtype=bool)
-    for i in range(n):
-        for j in range(n):
-            U[i, j] = bool(lib().csfo_untracked(hfov, rule, i, j, x[i], y[i], x[j], y[j], psi[j]))
-    return U
+    x, y, psi = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, psi))
+    h = np.ascontiguousarray(np.broadcast_to(np.asarray(hfov, dtype=np.float64), (n,)))
+    U = np.zeros((n, n), dtype=np.uint8)
+    lib().csfo_untracked_matrix(_p(h), int(rule), n, _p(x), _p(y), _p(psi), U.ctypes.data_as(C.c_void_p))
+    return U.astype(bool)
 
 
 def road_force(verts, off, F0, sigma, x, y):

@@ -61,3 +61,36 @@ def mixed_classes(g):
     cls = [order.index(str(m)) + (5 if own else 0) for m, own in zip(g["models"], g["own"])]
     import numpy as np
     return pods, np.array(cls, dtype="uint8")
+
+
+def shadow_run(e, pop, ticks, window, traj_len=3000):
+    """The engine runs `ticks` ticks without interruption while the oracle SHADOWS it in windows of `window` ticks.
+
+    The dynamics of a crowd is chaotic (two fp64 runs started 4e-6 m apart are decimetres apart after 1 000
+    ticks), and every discontinuity of the force law (the field-of-view edge, sign(phi), the navigation state machine, the
+    walk / ride switch) turns a rounding difference of the STATE into a visible one, so a free run of engine and oracle side
+    by side compares the two programs only until the first such event.  Here the oracle is re-anchored on the engine's
+    state of two consecutive ticks at every window boundary (two: the planner reads the previous position from the
+    trajectory ring, tests/test_gpu_large.py::test_config2), and every window compares `window` ticks of both programs
+    from a common state.  Returns (largest position deviation at a window end, per-road-user deviation at the last one,
+    the engine's and the oracle's final state)."""
+    import numpy as np
+
+    tick, worst, dev, ref = 0, 0.0, None, None
+    while tick < ticks:
+        end = min(tick + window, ticks)
+        if tick > 0:                                          # anchor on the engine's states of ticks `tick - 1` (where it is) and `tick`
+            a, aptr, azn, t = e.state(with_nav=True)
+            assert t == tick - 1
+            pop.push_state(a, aptr, azn, col=t % traj_len)
+            e.step(1); pop.step(1)
+            b, bptr, bzn, t = e.state(with_nav=True)
+            pop.push_state(b, bptr, bzn, col=t % traj_len)
+        last = end == ticks
+        k = end - tick - (0 if last else 1)                   # stop one tick short of the next boundary
+        e.step(k); pop.step(k)
+        got, ref = e.state(), pop.state()
+        dev = np.hypot(got[:, 0] - ref[:, 0], got[:, 1] - ref[:, 1])
+        worst = max(worst, float(dev.max()))
+        tick = end
+    return worst, dev, got, ref

@@ -232,19 +232,22 @@ def test_random_mixed_population_vs_oracle(amd, monkeypatch, n, box, segments):
     fx, fy = e.forces(); ox, oy = pop.forces()
     err = max(np.abs(fx - ox).max(), np.abs(fy - oy).max()) / max(np.hypot(ox, oy).max(), 1.0)
     assert err < 1e-4, err
-    e.step(ticks); pop.step(ticks)
-    got, ref = e.state(), pop.state()
-    devs = np.abs(got[:, :2] - ref[:, :2]).max(axis=1)
-    print(f"mixed random: forces vs oracle {err:.1e}; after {ticks} ticks |dpos| max {devs.max():.1e} m, 99 % {np.percentile(devs, 99):.1e} m")
-    # A crowd this dense (wide fields of view, five rider models) amplifies: one source crossing a receiver's field-of-view
-    # edge a tick apart in fp32 and fp64 (DESIGN D6; the first one around tick 10 of these runs) sends that receiver
-    # another way, and its neighbours follow within tens of ticks (engine vs oracle tick by tick: median 1e-6 m
-    # throughout, 1 road user beyond 1e-4 m at tick 10, 14 at tick 32, 116 of 900 at tick 50).  The force check above is
-    # the parity check; here: the bulk stays together and nobody leaves the scene.
-    assert np.median(devs) < 1e-5 and np.percentile(devs, 75) < 1e-4 * box and devs.max() < 0.5 and (e.status() == 0).all()
+    # (a crowd this dense - wide fields of view, five rider models - is chaotic within tens of ticks: the oracle shadows the
+    # engine's uninterrupted run in windows of 10 ticks, conftest.shadow_run)
+    from conftest import shadow_run
+    worst, devs, got, ref = shadow_run(e, pop, ticks, 10)
+    print(f"mixed random: forces vs oracle {err:.1e}; {ticks} ticks in windows of 10: |dpos| worst {worst:.1e} m, last window 99 % {np.percentile(devs, 99):.1e} m")
+    assert worst < 1e-4 * box and (e.status() == 0).all() and e.near_dropped() == 0
     # invpend road users slower than their set's v_max_walk start walking (vehicle.py:1732-1736 with THEIR limit)
     slow = (cls == 7) & (s0[:, 3] < 3.5)
     assert slow.any()
+    dd = np.abs((got[:, 2:] - ref[:, 2:] + np.pi) % (2 * np.pi) - np.pi)      # headings, speeds, steer / lean angles
+    # (within a window of 10 ticks: headings to 2e-3 rad; speeds, steer and lean angles - which answer a change of the force's
+    # direction within a tick - to 5e-3)
+    off = (dd > np.array([2e-3, 5e-3, 5e-3, 5e-3])[: dd.shape[1]]).any(axis=1)
+    for j in np.where(off)[0]:
+        print(f"   road user {j} (set {cls[j]}, model {pods[cls[j]].model}): |d(psi, v, delta, theta)| = {dd[j]}, |dpos| {devs[j]:.1e}")
+    assert off.sum() == 0, off.sum()
     e.close()
 
 
@@ -642,7 +645,7 @@ def test_class_segmented_order_at_headline_size_vs_oracle(amd):
         scale = max(np.hypot(ox * sc, oy * sc).max(), 1.0)
         df = np.maximum(np.abs(rx[recv] - ox * sc), np.abs(ry[recv] - oy * sc)) / scale
         worst = max(worst, df.max())
-        assert np.median(df) < 2e-6 and (df > 1e-4).sum() <= 1, (station, df.max())     # (at most one field-of-view edge case: D6)
+        assert np.median(df) < 2e-6 and df.max() < 1e-4, (station, df.max())
     assert e.count_pairs()[1] == "pair_cull_kernel" and (e.status() == 0).all() and np.isfinite(st).all()
     print(f"four parameter sets at N = 16 384: clamped repulsive sums vs oracle at 5 stations, worst {worst:.1e}")
     e.close()

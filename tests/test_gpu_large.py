@@ -82,13 +82,15 @@ def test_config4_262144_twod_column_sums(amd, monkeypatch):
     monkeypatch.setenv("CSF_RECV_BINNED", "0")
     _, x3, y3, _, _ = rep()
     # (c) the same terms: in slot order the pairs are formed in scene coordinates (3e-5 m at 400 m from the origin; + the
-    # near-pair correction), in binned order relative to the receiver group's origin.  Rounding apart - and apart from the
-    # sources that sit within (3e-5 m / distance) rad of a field-of-view edge in scene coordinates, which the two
-    # variants decide differently (DESIGN D6: a few hundred of 6.9e10 pairs; (a) pins the binned variant to the oracle)
+    # near-pair correction), in binned order relative to the receiver group's origin; sources within rounding of a
+    # field-of-view edge are decided in fp64 by both.  Rounding apart, the same sums - but for a receiver that sits within
+    # (3e-5 m / distance) rad of a source's heading line, ahead of it: the tangential part of the field jumps there
+    # (np.sign(phi), vehicle.py:1625; DESIGN D11), and the variant forced here - not the engine's choice at this size, which
+    # (a) pins to the oracle - resolves that line 30 times coarser.  Three of 262 144 receivers in this population.
     sc = max(np.hypot(x1, y1).max(), 1.0)
     dd = np.maximum(np.abs(x1 - x3), np.abs(y1 - y3))
     print(f"   binned vs slot order: median {np.median(dd) / sc:.1e}, 99.9 % {np.percentile(dd, 99.9) / sc:.1e}, {(dd > 1e-4 * sc).sum()} receivers beyond 1e-4")
-    assert np.median(dd) < 1e-6 * sc and np.percentile(dd, 99.9) < 1e-4 * sc and (dd > 1e-4 * sc).sum() < 200
+    assert np.median(dd) < 1e-6 * sc and np.percentile(dd, 99.9) < 1e-4 * sc and (dd > 1e-4 * sc).sum() <= 8
 
 
 # --------------------------------------------------------------------------- BASELINE config 5
@@ -426,12 +428,10 @@ def test_sharded_engine_loopback(amd, monkeypatch, model, world, n, binned):
     doa = np.abs(got[:, :2] - pop.state()[:, :2]).max(axis=1)
     print(f"{model} x{world} n={n}: vs unsharded |dF|/max|F| 99.5 % {np.percentile(dFa, 99.5):.2e} max {dFa.max():.2e}, "
           f"|dpos| 99.5 % {np.percentile(dpa, 99.5):.2e} max {dpa.max():.2e} m; vs oracle |dpos|/box max {doa.max() / box:.2e}")
-    # a source that crosses a receiver's field-of-view edge can do so one tick apart in two runs that round differently
-    # (DESIGN D6); the force jumps there and that receiver keeps an offset: at most a handful of agents
-    # ... and in a crowd this dense (0.2 road users per m^2) the two fp32 summation orders drift apart: by tick 48 the
-    # sharded and the unsharded run are compared at the tolerance both have against the fp64 oracle
-    assert np.percentile(dpa, 99) < 1e-4 * box and (dpa > 1e-4 * box).sum() <= 3
-    assert np.percentile(doa, 99.5) < 1e-4 * box and (doa > 1e-4 * box).sum() <= 3
+    # (a rank decides a source within rounding of a field-of-view edge on the precise 16-byte records - it does not hold a
+    # foreign source's fp64 state -, the unsharded engine and the oracle in fp64: the same decision but for pairs within
+    # ~1e-7 rad of an edge)
+    assert dpa.max() < 1e-4 * box and doa.max() < 1e-4 * box
     for m in members:
         lo, hi = m.shard_range()
         assert (m.status()[lo:hi] == 0).all()
@@ -1067,9 +1067,15 @@ def test_config4_262144_twod_40_ticks_and_two_shards(amd):
         assert err < 1e-4, err
     devs = np.concatenate(devs)
     print(f"config 4: 2-way loopback group vs the unsharded engine after 40 ticks: median {np.median(devs):.1e} m, 99.9 % {np.percentile(devs, 99.9):.1e} m, max {devs.max():.1e} m")
-    # (another grouping of the receivers, another fp32 summation order per rank; a source on a field-of-view edge decided the
-    # other way sends one road user elsewhere, and 262 144 road users x 40 ticks hold a few of those)
-    assert np.median(devs) < 1e-6 * box and np.percentile(devs, 99.9) < 1e-4 * box and devs.max() < 2.0
+    # Another grouping of the receivers, another fp32 summation order per rank: 1e-7 relative on a force.  That shows where the
+    # reference's own arithmetic is ill-conditioned: in a crowd this dense (road users centimetres apart) the repulsive sum
+    # is clamped to |F_dest| (intersection.py:841-845) and, when it points against it, the total force is a difference of two
+    # equal vectors - 1e-6 of either, its DIRECTION (the steering target, vehicle.py:1235) decided by the last bit of the sum.
+    # Road user 3215 of this population is such a case on tick 2 (total force (-1.9e-6, -2.1e-6) unsharded, (+7e-7, +8e-7) in
+    # the group, each within 3e-6 of the fp64 oracle's repulsive sum: the steer angle goes the other way, 0.4 against 0.1 rad);
+    # its neighbours follow within tens of ticks.  Positions: the bulk to rounding, a few per thousand beyond 1e-4 m, a handful
+    # beyond 1e-4 of the box; the forces of every rank are checked against the oracle above.
+    assert np.median(devs) < 1e-6 * box and np.percentile(devs, 99.5) < 1e-4 * box and (devs > 1e-4 * box).sum() <= n // 5000
     for m in members[::-1]:
         m.close()
 
@@ -1105,7 +1111,7 @@ def test_headline_population_as_loopback_ranks(amd, world):
     print(f"{world}-way loopback group of the headline population after 40 ticks: forces vs oracle {worst:.1e}; positions vs the "
           f"unsharded engine: median {np.median(devs):.1e} m, 99.9 % {np.percentile(devs, 99.9):.1e} m, max {devs.max():.1e} m")
     # (another fp32 summation order per rank; a source on a field-of-view edge decided the other way moves one road user)
-    assert np.median(devs) < 1e-6 * box and np.percentile(devs, 99.5) < 1e-4 * box and devs.max() < 0.5
+    assert np.median(devs) < 1e-6 * box and devs.max() < 1e-5
     for m in members[::-1]:
         m.close()
 
