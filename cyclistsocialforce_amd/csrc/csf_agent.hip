@@ -17,6 +17,16 @@ namespace csf {
 template <int MODEL, bool HET = false>
 __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
     const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // CSF_TRACE_AGENT (measurement aid, tools/agent_timeline.py): where does a wave's time go?  Every stamp waits for what
+    // was issued before it, so the traced kernel is a little slower than the product's.
+    uint64_t *const tr = d.atrace ? d.atrace + 8 * ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+    auto stamp = [&](int k) {
+        if (tr != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if ((threadIdx.x & 63) == 0) tr[k] = wall_clock64();
+        }
+    };
+    if (tr != nullptr && (threadIdx.x & 63) == 0) tr[0] = wall_clock64();
     if (a >= d.hi) return;
     // a slot left behind by csf_remove_agents; asked only when there is one (n_live != n, uniform): the answer is a round
     // trip to memory that every other load of the kernel would wait behind
@@ -52,10 +62,11 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     for (int c = 0; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
     const float2 froad = d.froad[a];
     const float2 rorg = d.rorg[a];                             // (for the record written at the end)
-    // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge (csf_dev.h:
-    // EdgeRec): 0 for all but a few dozen road users of a large population
-    const int32_t edge_head = (d.edge != nullptr && (phases & PH_COMBINE)) ? d.edge_head[a] : 0;
-
+    // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge wait in a ring
+    // (csf_dev.h: EdgeRec): bit 31 of the status word says so - a few dozen road users of a large population, per tick
+    const bool edge_pending = (phases & PH_COMBINE) && (g.st & CSF_ST_EDGE) != 0u;
+    if (edge_pending) g.st &= ~CSF_ST_EDGE;
+    stamp(1);
     double fdx, fdy;
     if (phases & PH_DEST) {
         dest_force<MODEL>(d, g, fdx, fdy);
@@ -70,6 +81,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         fdx = d.F[2 * cap + a];
         fdy = d.F[3 * cap + a];
     }
+    stamp(2);
     double Fx, Fy;
     if (phases & PH_COMBINE) {
         double rx = 0, ry = 0;
@@ -91,9 +103,9 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
                 rx += (double)pr.x;
                 ry += (double)pr.y;
             }
-            if (edge_head != 0) {   // rare: decide those pairs as the reference does (intersection.py:711-741) and put the sum right
+            if (edge_pending) {     // rare: decide those pairs as the reference does (intersection.py:711-741) and put the sum right
                 double cx = 0, cy = 0;   // (fp64: the order in which the entries were appended does not show)
-                int32_t at = edge_head;
+                int32_t at = d.edge_head[a];
                 for (int guard = 0; at != 0 && guard < 64; guard++) {
                     const EdgeRec er = d.edge[(unsigned)(at - 1) % EDGE_CAP];
                     if (er.recv != (int32_t)a || er.stamp != d.edge_stamp) {   // left over from another launch, or a ring that overflowed
@@ -132,12 +144,14 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         Fx = d.F[a];
         Fy = d.F[cap + a];
     }
+    stamp(4);
     if (phases & PH_INTEGRATE) {
         const bool frozen = d.replay_len != nullptr && d.replay_tick >= d.replay_len[a];  // replay sequence ended
         if (!frozen) {
             if (phases & PH_FIXSPEED) g.v = sqrt(Fx * Fx + Fy * Fy);   // calibration.py:454-458
             integrate<MODEL>(d, g, Fx, Fy);
         }
+        stamp(5);
         d.s[a] = g.x;
         d.s[cap + a] = g.y;
         d.s[2 * cap + a] = g.psi;
@@ -161,6 +175,8 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         }
     }
     d.status[a] = g.st;
+    if (tr != nullptr && (threadIdx.x & 63) == 0) tr[6] = wall_clock64();
+    stamp(7);
 }
 
 // (re)build the fp32 records, the short position ring and the model side-state from the fp64 state:

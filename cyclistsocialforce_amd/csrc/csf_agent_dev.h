@@ -659,7 +659,7 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     const double px = (x - d.ox) - (double)o.x, py = (y - d.oy) - (double)o.y;
     const float4 q = make_float4((float)px, (float)py, (float)c, (float)s);
     d.rec[a] = q;
-    d.reclo[a] = make_float2((float)(px - (double)q.x), (float)(py - (double)q.y));   // (what fp32 left over: csf_dev.h reclo)
+    if (d.keep_lo) d.reclo[a] = make_float2((float)(px - (double)q.x), (float)(py - (double)q.y));   // (what fp32 left over: csf_dev.h reclo)
     // scene coordinates = offset + origin, in fp32 (the same sum a rank forms from the records it has gathered, so that
     // every path sees the same numbers): by slot (the receivers), and the copy in binned order (csf_bin.hip) that the
     // pair kernel's tiles are filled with

@@ -61,7 +61,8 @@ struct EdgeRec {
     uint32_t stamp;       // Dev::edge_stamp of the launch that wrote it
     int32_t seen;         // what the pair kernel decided (and added accordingly)
 };
-constexpr unsigned EDGE_CAP = 4096;   // ring of entries; a tick produces a few dozen at N = 16 384
+constexpr unsigned EDGE_CAP = 4096;
+constexpr uint32_t CSF_ST_EDGE = 0x80000000u;   // status[slot], internal: entries wait in the ring for this receiver (masked by csf_status)   // ring of entries; a tick produces a few dozen at N = 16 384
 
 // All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
 struct Dev {
@@ -132,6 +133,7 @@ struct Dev {
     // kernels hold scene coordinates (recs, or offset + origin), 2^-24 of the scene extent.
     float4 *rec;       // [n_pad] by slot
     float2 *rorg;      // [n_pad] by slot: the origin its record is relative to, itself relative to (ox, oy)
+    int32_t keep_lo;   // this engine is a rank of a sharded run (or a member of a loopback group): reclo is maintained
     float2 *reclo;     // [n_pad] by slot: what the record's position left over, (offset - fp32(offset)) in fp32: origin +
                        // record + this is the fp64 position to ~1e-14 m.  Exchanged with the records, so that a rank can
                        // hand a foreign source's position to the exact field-of-view decision (csf_field.h: edge_handover)
@@ -147,7 +149,8 @@ struct Dev {
                                  // sharded run once it has ticked): marginal field-of-view decisions are then taken from it
     EdgeRec *edge;               // [EDGE_CAP] ring (NULL: the pair launch hands nothing over - shards, csf_count_pairs)
     unsigned *edge_n;            // [1] entries appended since the engine was created (ring index = count % EDGE_CAP)
-    int32_t *edge_head;          // [cap] 1 + ring index of the newest entry of the receiver in this slot, 0: none
+    int32_t *edge_head;          // [cap] 1 + ring index of the newest entry of the receiver in this slot, 0: none; valid while
+                                 // bit 31 of status[slot] is set (CSF_ST_EDGE: the per-agent kernel loads the status word anyway)
     uint32_t edge_stamp;         // names the pair launch(es) of this tick; entries of another stamp are stale
     unsigned *near_dropped;      // [1] near / marginal pairs a full per-wave list could not take (csf_pair.hip: near_note); never reset
     int32_t rebase_from_state;   // re-binning: every live slot's fp64 state is current on this device (else: re-express the old record)
@@ -190,6 +193,9 @@ struct Dev {
     double *hist;      // opt-in history [hist_cap][n][ns]
     int32_t hist_stride, hist_cap;
     unsigned long long *pair_count;  // csf_count_pairs: [4] pair evaluations, per-lane tests, full and partial evaluation passes of the launch (NULL: not counted)
+    uint64_t *atrace;  // CSF_TRACE_AGENT: eight time stamps (wall_clock64, 100 MHz) of every wave of the last per-agent launch, else NULL:
+                       // entry, own scalars loaded, destination force done, partial sums loaded, combine done, integrate done, stores
+                       // issued, stores done
     uint64_t *trace;   // CSF_TRACE_BLOCKS: (start, end, hw id) of every pair-kernel workgroup of the last tick, else NULL
 };
 

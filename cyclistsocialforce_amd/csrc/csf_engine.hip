@@ -92,6 +92,7 @@ struct Knobs {
     double far_eps = 5.9604644775390625e-8;   // CSF_FAR_EPS: bound of the far-field / reach cull (2^-24; 0: off)
     bool reach = true;                        // CSF_REACH=0: no per-pair reach test
     std::string trace_blocks;                 // CSF_TRACE_BLOCKS=<file>: per-wave timeline of the last pair launch
+    std::string trace_agent;                  // CSF_TRACE_AGENT=<file>: eight time stamps per wave of the last per-agent launch
     int fake_rank = 0, fake_world = 1;        // CSF_FAKE_SHARD=r/w: only rank r's receiver block of w (timing aid)
     int nsplit = 0;                           // CSF_NSPLIT: source chunks of the pair grid (0: the engine's choice)
     int dyn_recv = -1, rpb = 0;               // CSF_DYN_RECV, CSF_RPB
@@ -115,6 +116,7 @@ struct Knobs {
         if (const char *v = getenv("CSF_FAR_EPS")) far_eps = atof(v);
         reach = geti("CSF_REACH", 1) != 0;
         if (const char *v = getenv("CSF_TRACE_BLOCKS")) trace_blocks = v;
+        if (const char *v = getenv("CSF_TRACE_AGENT")) trace_agent = v;
         if (const char *v = getenv("CSF_FAKE_SHARD")) {
             int fr = 0, fw = 1;
             if (sscanf(v, "%d/%d", &fr, &fw) == 2 && fw > 1 && fr >= 0 && fr < fw) fake_rank = fr, fake_world = fw;
@@ -276,6 +278,7 @@ struct csf_engine {
     double *snap_dev = nullptr;
     size_t snap_bytes = 0;
     DevBuf<uint64_t> trace;   // CSF_TRACE_BLOCKS (measurement aid)
+    DevBuf<uint64_t> atrace;  // CSF_TRACE_AGENT (measurement aid)
     size_t trace_words = 0;
 
     // sharding
@@ -490,6 +493,7 @@ int set_fov_band(csf_engine *e) {
     d.state_current = e->state_all_current ? 1 : 0;
     d.edge = e->edge.p;
     d.edge_stamp = ++e->edge_stamp;
+    d.keep_lo = (e->world > 1 || e->loopback || e->nccl != nullptr) ? 1 : 0;
     return CSF_OK;
 }
 
@@ -864,6 +868,11 @@ int alloc_all(csf_engine *e) {
     d.edge_n = e->edge_n.p;
     d.near_dropped = e->edge_n.p + 1;
     d.edge_head = e->edge_head.p;
+    d.atrace = nullptr;
+    if (!e->knobs.trace_agent.empty()) {   // 8 words per wave of 64 road users
+        HIPCHK(e, e->atrace.alloc(8 * ((size_t)cap / 64 + 2)));
+        d.atrace = e->atrace.p;
+    }
     d.trace = nullptr;
     if (!e->knobs.trace_blocks.empty()) {  // 3 words per wave: the grid is at most (cap/16) x MAX_SPLIT workgroups of 4 waves
         e->trace_words = 3 * 4 * ((size_t)cap / 16 + 1) * MAX_SPLIT;
@@ -879,6 +888,7 @@ void set_chunks(csf_engine *e);
 
 void set_shard(csf_engine *e) {
     Dev &d = e->d;
+    d.keep_lo = (e->world > 1 || e->loopback || e->nccl != nullptr) ? 1 : 0;   // (csf_dev.h: reclo)
     if (e->world <= 1) {
         d.lo = 0;
         d.hi = d.n;
@@ -1674,6 +1684,16 @@ int csf_destroy(csf_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->main) (void)hipStreamSynchronize(e->main);
     if (e->comm) (void)hipStreamSynchronize(e->comm);
+    if (e->atrace.p) {  // CSF_TRACE_AGENT=<file>: the stamps of the last per-agent launch
+        std::vector<uint64_t> h(e->atrace.n);
+        if (hipMemcpy(h.data(), e->atrace.p, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(e->knobs.trace_agent.c_str(), "wb")) {
+                fwrite(h.data(), sizeof(uint64_t), h.size(), f);
+                fclose(f);
+            }
+        }
+        e->atrace.release();
+    }
     if (e->trace.p) {  // CSF_TRACE_BLOCKS=<file>: workgroup timeline of the last pair-kernel launch
         std::vector<uint64_t> h(e->trace_words);
         if (hipMemcpy(h.data(), e->trace.p, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1694,7 +1714,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -2500,7 +2520,9 @@ int csf_status(csf_engine *e, uint32_t *per_agent_flags) {
     rc = csf_sync(e);
     if (rc) return rc;
     if (e->order.empty()) return CSF_OK;
-    return read_rows(e, e->status.p, 1, per_agent_flags, false);
+    rc = read_rows(e, e->status.p, 1, per_agent_flags, false);
+    for (size_t i = 0; rc == CSF_OK && i < e->order.size(); i++) per_agent_flags[i] &= ~CSF_ST_EDGE;   // (internal: csf_dev.h)
+    return rc;
 }
 
 int csf_enable_history(csf_engine *e, int32_t stride, int32_t capacity) {

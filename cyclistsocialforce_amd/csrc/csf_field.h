@@ -98,7 +98,6 @@ __device__ __forceinline__ bool tracked_precise(const PairConsts &k, float chs, 
 // fp64 position as it is now, its field of view, the pair's force (fx, fy) and whether the caller has added it (seen).
 // The source's position: its fp64 state where this device holds it, else (a rank of a sharded run) rebuilt from the record.
 __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int32_t a_src, double hfov, float fx, float fy, bool seen) {
-    const unsigned at = atomicAdd(d.edge_n, 1u) % EDGE_CAP;
     EdgeRec er;
     if (d.state_current) {
         er.xi = d.s[a_src];
@@ -113,10 +112,13 @@ __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int3
     er.fx = fx;
     er.fy = fy;
     er.recv = a_recv;
-    er.next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
+    er.next = 0;
     er.stamp = d.edge_stamp;
     er.seen = seen ? 1 : 0;
+    const unsigned at = atomicAdd(d.edge_n, 1u) % EDGE_CAP;
+    er.next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
     d.edge[at] = er;
+    atomicOr(&d.status[a_recv], CSF_ST_EDGE);
 }
 
 // vehicle.py:1560-1648: force of source (record q) on receiver r, returned as magnitude F and an

@@ -502,8 +502,8 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
             bool seen = tracked_precise<P2R>(kc, k.chs, rr, dx, dy, r2p, edge) & act & (as != arc);
             edge = edge & act & (as != arc);
             field_twod(k, rr, qs, dx, dy, fmaxf(r2p, 1e-30f), F, hx, hy);
-            if (ballot1(edge) != 0ull && dc.edge != nullptr) {
-                if (edge) edge_handover(dc, arc, as, dc.p.hfov, F * hx, F * hy, seen);
+            if (__builtin_expect(ballot1(edge) != 0ull, 0)) {
+                if (edge && dc.edge != nullptr) edge_handover(dc, arc, as, dc.p.hfov, F * hx, F * hy, seen);
             }
             F = seen ? F : 0.0f;
             float fx = F * hx, fy = F * hy;
