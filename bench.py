@@ -17,8 +17,12 @@ What the line reports beside `value`:
                 from the committed rocprofv3 --pmc passes of this kernel, `hbm_frac` the physical HBM fraction.
   algorithmic   SURVEY.md §8(d)'s byte/flop rates over ALL N x n_loc pairs (what BASELINE.json's "HBM GB/s fraction" is
                 quoted on).  These are rates of a stream that is served from LDS, not fractions of a peak.
-  preroll_ticks untimed ticks before the W warm-up ticks: a fresh process starts with the GPU in a low power state and
-                the first ticks run slower (profiles/r2_tick_sequence.json); `warmup` is left as passed.
+  preroll_ticks untimed ticks of a SCRATCH engine (same population, thrown away) that bring the GPU out of its idle power
+                state before anything is timed: a fresh process finds the first ticks up to 1.7 x slower
+                (profiles/r2_tick_sequence.json).  The W warm-up ticks run on it too, but for the first min(W, 8), which the
+                timed engine runs itself (first launches, first re-binning): the timed window starts at tick <= 8 of the
+                population `config.workload` names (`timed_window.start`).
+  dispersed     the same engine from tick ~740 on, when the crowd has spread to ~270 m (what rounds 1 - 3 timed).
 """
 import argparse
 import glob
@@ -191,12 +195,18 @@ def main():
             e.set_road(*road)
         return e
 
+    # Clocks first: a fresh process finds the GPU in a low power state, and the first ~200 ticks run up to 1.7 x slower
+    # (profiles/r2_tick_sequence.json).  A SCRATCH engine (the same population, unsharded, on this rank's device) runs the
+    # untimed pre-roll - about 0.1 s of ticks - and the W warm-up ticks, and is thrown away; the population the line names
+    # is then created afresh and timed from its first ticks (`timed_window.start.tick`).
+    scratch = populate()
     eng = populate()
     if world > 1:
         shard_engine(eng, dist, rank, world)
     elif rehearse:
         from cyclistsocialforce_amd.parallel import broadcast_unique_id
         eng.comm_init(broadcast_unique_id(dist, rank, Engine.comm_unique_id), rank, world)
+    first = min(8, max(0, args.warmup))                       # untimed ticks of the timed engine itself (re-binning, first launches)
 
     def fence():
         eng.sync()
@@ -205,46 +215,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # pre-roll: one tick to see how long a tick is at this size, then ~0.1 s worth of ticks (every rank the same count)
-    preroll = args.preroll
-    if preroll < 0:
-        eng.step(2, sync=True)
-        t0 = time.perf_counter()
-        eng.step(4, sync=True)
-        tick_s = (time.perf_counter() - t0) / 4
-        preroll = int(min(1000, max(0, 0.1 / max(tick_s, 1e-6))))
-        if dist is not None:
-            t = torch.tensor([preroll], dtype=torch.int64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            preroll = int(t.item())
-        eng.step(preroll)
-        preroll += 6
-    else:
-        eng.step(preroll)
-    fence()
-
-    def window_state():
+    def window_state(e_):
         """what the population looks like at an end of the timed window: extent (it disperses as it runs) and the work of
         one pair launch on it (device counters, one extra launch - outside the timed region)"""
-        lo_, hi_ = eng.shard_range()
-        s_ = eng.state()
-        w_, _ = eng.count_pairs(detail=True)
-        return {"tick": int(eng.tick), "extent_m": [float(np.ptp(s_[:, 0])), float(np.ptp(s_[:, 1]))],
+        s_ = e_.state()
+        w_, _ = e_.count_pairs(detail=True)
+        return {"tick": int(e_.tick), "extent_m": [float(np.ptp(s_[:, 0])), float(np.ptp(s_[:, 1]))],
                 "rms_radius_m": float(np.sqrt(((s_[:, :2] - s_[:, :2].mean(axis=0)) ** 2).sum(axis=1).mean())),
                 "pairs_evaluated": None if w_ is None else int(w_["evaluated"]), "sources_tested": None if w_ is None else int(w_["tested"])}
 
-    # (taken before 256 further untimed ticks and the W warm-up ticks - its `tick` says where: the read-back lets the device
-    # fall idle for a millisecond, and the pair kernel then runs ~10 % slower for the next 100 - 200 ticks)
-    win0 = window_state() if world == 1 else None
-    if win0 is not None:
-        eng.step(256)
-        preroll += 256
-    eng.step(args.warmup)
-    fence()
     # the kernels' own start / end time stamps (hipExtLaunchKernelGGL events on the engine's stream); at least 16
-    # sampled launches, every 8th tick in long runs
+    # sampled launches, every 8th tick in long runs.  (The event pool is created here, not in front of the timed region.)
     every = max(1, min(8, args.steps // 16))
     eng.profile(every)
+    eng.step(first)
+    fence()
+    scratch.step(first, sync=True)
+    # (the start of the window is read off the scratch engine, which is in the very state the timed engine is in: a read-back
+    # right before the timed region lets the device fall idle for a millisecond, and the pair kernel then runs ~10 % slower
+    # for the next 100 - 200 ticks)
+    win0 = window_state(scratch) if world == 1 else None
+    preroll = args.preroll
+    if preroll < 0:
+        t0 = time.perf_counter()
+        scratch.step(4, sync=True)
+        tick_s = (time.perf_counter() - t0) / 4
+        preroll = int(min(1000, max(0, 0.1 / max(tick_s, 1e-6))))
+    eng.profile_kernels()                                     # (forget the time stamps of the first ticks)
+    scratch.step(preroll + max(0, args.warmup - first), sync=True)
+    # the scratch engine has dispersed by now (tick ~900: what rounds 1 - 3 reported as the headline): K steps of it, timed
+    # the same way, go into the line as `dispersed` - and keep the device busy right up to the timed region
+    dispersed = None
+    if world == 1 and not rehearse:
+        d0 = int(scratch.tick)
+        t0 = time.perf_counter()
+        scratch.step(args.steps, sync=True)
+        dtd = time.perf_counter() - t0
+        dispersed = {"value": n * args.steps / dtd, "unit": "agent-steps/s", "ms_per_step": dtd / args.steps * 1e3, "start_tick": d0,
+                     "note": "the same population later on, when the crowd has spread to ~270 m (the window rounds 1 - 3 timed)"}
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.step(args.steps)
     fence()
@@ -263,8 +275,8 @@ def main():
     healthy = bool(np.isfinite(st).all() and (eng.status()[lo:hi] == 0).all())
     work, kernel = eng.count_pairs(detail=True)     # one extra launch on the final snapshot, outside the timed region
     evaluated = None if work is None else work["evaluated"]
-    win1 = window_state() if world == 1 else None
-
+    win1 = window_state(eng) if world == 1 else None
+    scratch.close()
     if rank == 0:
         value = n * args.steps / dt
         n_loc = hi - lo
@@ -311,6 +323,7 @@ def main():
             "healthy": healthy,
             "build_id": build_id(),
             "timed_window": {"start": win0, "end": win1},
+            "dispersed": dispersed,
             "roofline": roof,
             "kernels_us": {"pair": pair_s * 1e6, "road": road_s * 1e6, "agent": agent_s * 1e6,
                            "all_gather": mean_s["gather"] * 1e6, "tick": dt / args.steps * 1e6,

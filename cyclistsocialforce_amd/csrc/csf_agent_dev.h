@@ -10,6 +10,17 @@ namespace csf {
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmax(fmin(x, hi), lo); }
 
+// 1 / b for the planner's well-scaled operands (chord lengths, knot spans, pivots of a totally positive system: 1e-6 .. 1e6):
+// v_rcp_f64 and two Newton steps - five dependent instructions where the IEEE division (v_div_scale, v_rcp, four fma,
+// v_div_fmas, v_div_fixup) takes ten, and a reciprocal is shared by everything that is divided by the same number.  Within
+// an ulp or two of the quotient; the planner's results are pinned at 2e-7 (the reference runs FITPACK through lm).
+__device__ __forceinline__ double rcp_nr(double b) {
+    double x = __builtin_amdgcn_rcp(b);
+    x = fma(fma(-b, x, 1.0), x, x);
+    x = fma(fma(-b, x, 1.0), x, x);
+    return x;
+}
+
 // Registers of one agent while it is being ticked.
 struct Agent {
     int64_t a;
@@ -160,16 +171,16 @@ __device__ __forceinline__ void window_at(const Spline<M> &s, double u, Window &
 // linear ones that the derivatives use.  k[2] = t[l], k[3] = t[l+1].
 __device__ __forceinline__ void basis(const double (&k)[6], double u, double N3[4], double N2[3], double N1[2]) {
     const double a1 = u - k[2], b1 = k[3] - u;
-    const double w = 1.0 / (k[3] - k[2]);
+    const double w = rcp_nr(k[3] - k[2]);
     N1[0] = b1 * w;
     N1[1] = a1 * w;
     const double a2 = u - k[1], b2 = k[4] - u;
-    const double w0 = N1[0] / (k[3] - k[1]), w1 = N1[1] / (k[4] - k[2]);
+    const double w0 = N1[0] * rcp_nr(k[3] - k[1]), w1 = N1[1] * rcp_nr(k[4] - k[2]);
     N2[0] = b1 * w0;
     N2[1] = a2 * w0 + b2 * w1;
     N2[2] = a1 * w1;
     const double a3 = u - k[0], b3 = k[5] - u;
-    const double v0 = N2[0] / (k[3] - k[0]), v1 = N2[1] / (k[4] - k[1]), v2 = N2[2] / (k[5] - k[2]);
+    const double v0 = N2[0] * rcp_nr(k[3] - k[0]), v1 = N2[1] * rcp_nr(k[4] - k[1]), v2 = N2[2] * rcp_nr(k[5] - k[2]);
     N3[0] = b1 * v0;
     N3[1] = a3 * v0 + b2 * v1;
     N3[2] = a2 * v1 + b3 * v2;
@@ -189,9 +200,9 @@ __device__ __forceinline__ bool spline_fit(Spline<M> &s, const double (&px)[M], 
         u[r] = u[r - 1] + dd;
     }
     if (!ok) return false;
-    const double tot = u[M - 1];
+    const double itot = rcp_nr(u[M - 1]);
 #pragma unroll
-    for (int r = 1; r < M - 1; r++) u[r] /= tot;
+    for (int r = 1; r < M - 1; r++) u[r] *= itot;
     u[M - 1] = 1.0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -231,9 +242,11 @@ __device__ __forceinline__ bool spline_fit(Spline<M> &s, const double (&px)[M], 
         bx[r] = rx;
         by[r] = ry;
     }
+    double ipv[Q];
 #pragma unroll
     for (int c = 0; c < Q; c++) {
-        const double ip = 1.0 / A[c][c];
+        const double ip = rcp_nr(A[c][c]);
+        ipv[c] = ip;
 #pragma unroll
         for (int r = c + 1; r < Q; r++) {
             const double f = A[r][c] * ip;
@@ -251,8 +264,8 @@ __device__ __forceinline__ bool spline_fit(Spline<M> &s, const double (&px)[M], 
             sx -= A[r][j] * bx[j];
             sy -= A[r][j] * by[j];
         }
-        bx[r] = sx / A[r][r];
-        by[r] = sy / A[r][r];
+        bx[r] = sx * ipv[r];
+        by[r] = sy * ipv[r];
     }
     s.cx[0] = px[0];
     s.cy[0] = py[0];
@@ -289,7 +302,7 @@ __device__ __forceinline__ void spline_all(const Spline<M> &s, double u, double 
     double ex[3], ey[3];
 #pragma unroll
     for (int q = 0; q < 3; q++) {  // c'_j = 3 (c_{j+1} - c_j) / (t_{j+4} - t_{j+1})
-        const double f = 3.0 / (w.k[q + 3] - w.k[q]);
+        const double f = 3.0 * rcp_nr(w.k[q + 3] - w.k[q]);
         ex[q] = f * (w.x[q + 1] - w.x[q]);
         ey[q] = f * (w.y[q + 1] - w.y[q]);
     }
@@ -298,7 +311,7 @@ __device__ __forceinline__ void spline_all(const Spline<M> &s, double u, double 
     double gx[2], gy[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const double f = 2.0 / (w.k[q + 3] - w.k[q + 1]);
+        const double f = 2.0 * rcp_nr(w.k[q + 3] - w.k[q + 1]);
         gx[q] = f * (ex[q + 1] - ex[q]);
         gy[q] = f * (ey[q + 1] - ey[q]);
     }
