@@ -1125,6 +1125,11 @@ static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEven
         else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, WPB * RPW, CLASSIFY>), recv_grid(d, d.n_split));
         return;
     }
+    if (CLASSIFY && d.dyn_recv && d.rpb == 32 && d.wide) {   // every pair evaluated (CSF_FAR_EPS=0): the wide workgroup as well
+        hipExtLaunchKernelGGL((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32, false, CLASSIFY ? 2 * WPB : WPB>), recv_grid(d, d.n_split, 32),
+                              dim3(2 * BLOCK), 0, st, t0, t1, 0, d);
+        return;
+    }
     if (d.dyn_recv && d.rpb == 32) {
         CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true, 32>), recv_grid(d, d.n_split, 32));
         return;
