@@ -277,6 +277,16 @@ def main():
     evaluated = None if work is None else work["evaluated"]
     win1 = window_state(eng) if world == 1 else None
     scratch.close()
+    # every rank's own figures (kernel times incl. the all-gather, the stream order its communicator chose, the pairs one launch
+    # of its receiver block evaluates): a scaling curve then explains itself
+    order, cal = eng.comm_stream_order()
+    mine = {"rank": rank, "receivers": [int(lo), int(hi)],
+            "kernels_us": {k: (ms * 1e3 / max(c, 1)) for k, (ms, c) in prof.items()},
+            "pairs_evaluated": evaluated, "comm_stream": order, "comm_calibration_us": cal}
+    ranks = [mine]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
     if rank == 0:
         value = n * args.steps / dt
         n_loc = hi - lo
@@ -322,6 +332,7 @@ def main():
                        if world > 1 else "single GPU"},
             "healthy": healthy,
             "build_id": build_id(),
+            "ranks": ranks,
             "timed_window": {"start": win0, "end": win1},
             "dispersed": dispersed,
             "roofline": roof,

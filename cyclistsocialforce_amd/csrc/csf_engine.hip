@@ -31,6 +31,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -55,6 +56,7 @@ struct Rccl {
         SYM(CommInitRank, "ncclCommInitRank")
         SYM(CommDestroy, "ncclCommDestroy")
         SYM(AllGather, "ncclAllGather")
+        SYM(AllReduce, "ncclAllReduce")
         SYM(GroupStart, "ncclGroupStart")
         SYM(GroupEnd, "ncclGroupEnd")
         SYM(GetErrorString, "ncclGetErrorString")
@@ -102,7 +104,7 @@ struct Knobs {
     int recv_binned = -1;                     // CSF_RECV_BINNED
     int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
-    bool comm_second = false;                 // CSF_COMM_STREAM=second
+    int comm_second = -1;                     // CSF_COMM_STREAM=second / main (-1: the communicator times both on its first tick and keeps the faster)
     int fused = 0;                            // CSF_FUSED=1: the one-launch tick of small populations (csf_tick.hip; opt-in)
     double fov_band = 1.0;                    // CSF_FOV_BAND: scale of the rounding band of the field-of-view test (0: every pair decided in fp32, as in round 3)
     double rnear = 1.0;                       // CSF_RNEAR: pairs closer than this (m) are evaluated from the precise records (0: none)
@@ -130,7 +132,7 @@ struct Knobs {
         recv_binned = geti("CSF_RECV_BINNED", -1);
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
-        if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second";
+        if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second" ? 1 : 0;
         fused = geti("CSF_FUSED", 0);
         if (const char *v = getenv("CSF_RNEAR")) rnear = atof(v);
         if (const char *v = getenv("CSF_FOV_BAND")) fov_band = std::max(0.0, atof(v));
@@ -285,6 +287,12 @@ struct csf_engine {
     int rank = 0, world = 1;
     ncclComm_t nccl = nullptr;
     bool gather_pending = false;
+    // where the all-gather of a tick is issued: in stream order on the main stream, or on the second stream beside the
+    // destination-force phase of the next tick.  Chosen by the communicator itself on its first tick
+    // (calibrate_comm_stream: both orders timed on the REAL communicator, the same answer on every rank) unless
+    // CSF_COMM_STREAM says which.
+    bool comm_second = false, comm_calibrated = false;
+    float comm_cal_us[2] = {0.f, 0.f};       // what the calibration measured per tick: stream order, second stream
 
     // loopback rehearsal of the sharded path: `world` engines of one process on one device share a stream and exchange
     // their record blocks with device-to-device copies where the ranks of a real run call ncclAllGather
@@ -1553,7 +1561,7 @@ int ensure_compact(csf_engine *e) {
 // next tick (launched before the wait) overlaps it.  Measured with a 1-rank communicator the two cross-stream
 // event waits per tick and the extra launch cost 26 us against 8 us in stream order, more than the ~6 us of
 // destination-force work they can hide, so the default keeps the collective in stream order on the main stream.
-bool comm_second_stream(const csf_engine *e) { return e->knobs.comm_second; }
+bool comm_second_stream(const csf_engine *e) { return e->comm_second; }
 
 int all_gather_records(csf_engine *e) {
     Dev &d = e->d;
@@ -2151,6 +2159,68 @@ static void launch_pair_all(csf_engine *e, const Dev &base, hipEvent_t t0 = null
     }
 }
 
+// Which order for the collective?  Timed on the communicator as it is - its ranks, its links - with launches that change
+// nothing: the pair kernel on the records as they are (it writes partial sums and nothing else here) followed by the
+// all-gather of the records (in place: what arrives is what was there), 8 + 32 times in stream order and 8 + 32 times with
+// the collective on the second stream behind an event and a small kernel of the next tick in front of the wait.  The two
+// times are max-reduced over the ranks, so that every rank keeps the same order.
+int calibrate_comm_stream(csf_engine *e) {
+    e->comm_calibrated = true;
+    if (e->knobs.comm_second >= 0 || !e->nccl || e->loopback) {
+        e->comm_second = e->knobs.comm_second > 0;
+        return CSF_OK;
+    }
+    {
+        int rc = set_fov_band(e);
+        if (rc) return rc;
+    }
+    Dev dd = e->d;
+    dd.edge = nullptr;          // (no per-agent launch follows that would take undecided pairs over)
+    dd.bnd_next = nullptr;      // (the circles stay as they are)
+    hipEvent_t a = nullptr, b = nullptr;
+    HIPCHK(e, hipEventCreate(&a));
+    HIPCHK(e, hipEventCreate(&b));
+    float us[2] = {0.f, 0.f};
+    for (int mode = 0; mode < 2; mode++) {
+        e->comm_second = mode == 1;
+        for (int it = 0; it < 40; it++) {
+            if (it == 8) HIPCHK(e, hipEventRecord(a, e->main));
+            if (mode == 1) {
+                if (dd.recs_valid) launch_sorted_copy(dd, e->main);   // (stands for the destination-force phase of the next tick)
+                int rc = wait_gather(e);
+                if (rc) return rc;
+            }
+            if (dd.n_live > 1 && dd.hi > dd.lo) launch_pair_all(e, dd, nullptr, nullptr);
+            if (mode == 1) HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
+            int rc = all_gather_records(e);
+            if (rc) return rc;
+        }
+        int rc = wait_gather(e);
+        if (rc) return rc;
+        HIPCHK(e, hipEventRecord(b, e->main));
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        if (e->comm) HIPCHK(e, hipStreamSynchronize(e->comm));
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, a, b));
+        us[mode] = ms * 1e3f / 32.f;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    {   // the slowest rank's figures, on every rank
+        DevBuf<float> t;
+        HIPCHK(e, t.alloc(2));
+        HIPCHK(e, hipMemcpy(t.p, us, sizeof us, hipMemcpyHostToDevice));
+        NCCLCHK(e, g_rccl.AllReduce(t.p, t.p, 2, ncclFloat32, ncclMax, e->nccl, e->main));
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        HIPCHK(e, hipMemcpy(us, t.p, sizeof us, hipMemcpyDeviceToHost));
+        t.release();
+    }
+    e->comm_cal_us[0] = us[0];
+    e->comm_cal_us[1] = us[1];
+    e->comm_second = us[1] < us[0];
+    return CSF_OK;
+}
+
 //   main:  agent(DEST) - wait(ev_gather) - bounds - pair - road - agent(COMBINE|INTEGRATE) - record(ev_integ)
 //   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)
 static int enqueue_tick(csf_engine *e) {
@@ -2273,6 +2343,7 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
         return CSF_OK;
     }
     if (n_ticks > 0 && one_launch_tick(e)) return step_one_launch(e, n_ticks);
+    if (n_ticks > 0 && !e->comm_calibrated && (rc = calibrate_comm_stream(e))) return rc;
     for (int64_t t = 0; t < n_ticks; t++) {
         rc = enqueue_tick(e);
         if (rc) return rc;
@@ -2889,6 +2960,13 @@ int csf_near_dropped(csf_engine *e, int64_t *n_dropped) {
     unsigned h = 0;
     HIPCHK(e, hipMemcpy(&h, e->edge_n.p + 1, sizeof h, hipMemcpyDeviceToHost));
     *n_dropped = (int64_t)h;
+    return CSF_OK;
+}
+
+int csf_comm_stream_order(const csf_engine *e, int32_t *second_stream, double us_per_tick[2]) {
+    if (!e || !second_stream) return CSF_E_ARG;
+    *second_stream = e->comm_second ? 1 : 0;
+    if (us_per_tick) us_per_tick[0] = e->comm_cal_us[0], us_per_tick[1] = e->comm_cal_us[1];
     return CSF_OK;
 }
 

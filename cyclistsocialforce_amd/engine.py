@@ -373,6 +373,14 @@ class Engine:
         self._ck(self._lib.csf_near_dropped(self._h, C.byref(n)))
         return n.value
 
+    def comm_stream_order(self):
+        """('main' | 'second', [us per tick in stream order, on the second stream]) - where a sharded engine issues its
+        all-gather, and what its communicator measured when it chose (zeros: CSF_COMM_STREAM decided, or not sharded)"""
+        second = C.c_int32(0)
+        us = np.zeros(2)
+        self._ck(self._lib.csf_comm_stream_order(self._h, C.byref(second), _ptr(us)))
+        return ("second" if second.value else "main"), [float(us[0]), float(us[1])]
+
     def profile_gather(self):
         """all-gather milliseconds accumulated over the launches of the last profile_read() (sharded engines)"""
         g = C.c_double(0)

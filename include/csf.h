@@ -276,6 +276,12 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name);
  * found its list full, or a hand-over ring that overflowed within one tick, is counted here; such a pair keeps the fp32
  * result. */
 int csf_near_dropped(csf_engine *e, int64_t *n_dropped);
+/* Where a sharded engine issues the all-gather of a tick: 0 in stream order on its main stream, 1 on a second stream beside
+ * the destination-force phase of the next tick.  Unless CSF_COMM_STREAM=main|second says which, the communicator times both
+ * orders itself on its first tick - 32 launches each of the pair kernel + the collective on the records as they are, the
+ * slowest rank's times shared through the communicator so that every rank decides alike - and keeps the faster;
+ * us_per_tick (may be NULL) receives the two measurements (0 when nothing was measured). */
+int csf_comm_stream_order(const csf_engine *e, int32_t *second_stream, double us_per_tick[2]);
 /* milliseconds between the end of the agent kernel and the end of the RCCL all-gather, accumulated over the launches
  * of the last csf_profile_read (0 for an unsharded engine) */
 int csf_profile_gather(const csf_engine *e, double *gather_ms);
