@@ -155,6 +155,78 @@ __global__ __launch_bounds__(256) void bounds_kernel(const Dev d) {
     batch_circle(d, b, threadIdx.x & 63, 0.0f, d.bnd);
 }
 
+// ---- candidate tiles of every receiver group (csf_dev.h: Dev::clist) ----------------------------------------------------
+// the circle around the batch circles of one tile (scene coordinates), one wave per tile
+__global__ __launch_bounds__(256) void tile_circle_kernel(const Dev d, float4 *tcirc) {
+    const int bpt = d.clist_tile / 64;                              // batches per tile: 16 or 32
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t ntiles = (d.n_src + d.clist_tile - 1) / d.clist_tile;
+    if (t >= ntiles) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = t * bpt + lane;
+    const bool have = lane < bpt && b * 64 < d.n_src;
+    const float4 c = have ? d.bnd[b] : make_float4(0.f, 0.f, -1.f, 0.f);
+    const bool real = have && fabsf(c.x) < 1e14f;                    // (a batch of sentinels sits at 1e15)
+    float x0 = real ? c.x - c.z : 3e38f, x1 = real ? c.x + c.z : -3e38f, y0 = real ? c.y - c.z : 3e38f, y1 = real ? c.y + c.z : -3e38f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
+        y0 = fminf(y0, __shfl_xor(y0, o, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    }
+    if (lane == 0) tcirc[t] = box_circle(x0, x1, y0, y1, 0.0f);
+}
+
+// one wave per group of clist_rpb receivers (places of the binned order; a rank's own receivers through rlist): the tiles
+// whose circle comes within `reach` of the group's circle, in ascending order
+__global__ __launch_bounds__(256) void clist_kernel(const Dev d, const float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach) {
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nloc = d.hi - d.lo, groups = (nloc + d.clist_rpb - 1) / d.clist_rpb;
+    if (g >= groups) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t j = g * d.clist_rpb + (lane % d.clist_rpb);
+    const int64_t jc = j < nloc ? j : nloc - 1;
+    const int64_t p = d.rlist ? (int64_t)d.rlist[jc] : d.lo + jc;
+    const float4 q = d.recs[p];                                     // scene coordinates by place
+    const bool real = rec_is_real(q);
+    float x0 = real ? q.x : 3e38f, x1 = real ? q.x : -3e38f, y0 = real ? q.y : 3e38f, y1 = real ? q.y : -3e38f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o, 64));
+        x1 = fmaxf(x1, __shfl_xor(x1, o, 64));
+        y0 = fminf(y0, __shfl_xor(y0, o, 64));
+        y1 = fmaxf(y1, __shfl_xor(y1, o, 64));
+    }
+    const float4 gc = box_circle(x0, x1, y0, y1, 0.0f);
+    const int64_t ntiles = (int64_t)d.ctail;                         // (tiles from ctail on are always visited)
+    int count = 0;
+    for (int64_t t0 = 0; t0 < ntiles; t0 += 64) {
+        const int64_t t = t0 + lane;
+        bool near = false;
+        if (t < ntiles) {
+            const float4 tc = tcirc[t];
+            const float ex = tc.x - gc.x, ey = tc.y - gc.y, rr = reach + tc.z + gc.z;
+            near = ex * ex + ey * ey <= rr * rr;
+        }
+        const unsigned long long m = __ballot(near);
+        if (near) {
+            const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (at < CLIST_MAX) clist[g * CLIST_MAX + at] = (uint16_t)t;
+        }
+        count += __builtin_popcountll(m);
+    }
+    if (lane == 0) ccount[g] = count <= CLIST_MAX ? count : -1;
+}
+
+void launch_candidate_lists(const Dev &d, float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach, hipStream_t st) {
+    const int64_t ntiles = (d.n_src + d.clist_tile - 1) / d.clist_tile;
+    const int64_t nloc = d.hi - d.lo, groups = (nloc + d.clist_rpb - 1) / d.clist_rpb;
+    if (ntiles <= 0 || groups <= 0) return;
+    hipLaunchKernelGGL(tile_circle_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d, tcirc);
+    hipLaunchKernelGGL(clist_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st, d, tcirc, clist, ccount, reach);
+}
+
 size_t bin_temp_bytes(int64_t n_pad) {
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,

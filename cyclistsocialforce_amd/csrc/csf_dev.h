@@ -42,7 +42,8 @@ struct PairConsts {
     // the packed test of the cull-first kernel (keep_x2) works on the cosine of the bearing, t / rho against chk = cos(hfov/2)
     // (-2 for a full circle), band fovT0 + fovT1 / rho = 2 (8 u + 3 eps_p / rho)
     float chk, fovT0, fovT1;
-    float clsclear;                    // classify_batch: the receiver must be this far outside a batch's circle (csf_engine.hip: set_fov_band)
+    float clsk;                        // classify_batch: the receiver must be outside a batch's circle by clsk x (their coordinates): the
+                                       // position error of fp32, 2^-24 of a coordinate, as an angle below half the 1e-4 margin
     // the same band for a pair formed from the PRECISE records (csf_pair.hip: precise_delta; offsets of a few metres from
     // origins whose difference is exact): |g| < fovP1 rho + fovP2 r2, |rho sin(bearing)| < sideP0 + sideP1 rho
     float fovP1, fovP2, sideP0, sideP1;
@@ -164,6 +165,16 @@ struct Dev {
     int32_t recs_valid;
     int32_t recv_binned;   // the pair kernel takes its receivers in binned order too and skips far tiles (large populations)
     const int32_t *rlist;  // recv_binned on a shard: binned positions of this rank's receivers, ascending (NULL: all of them)
+    // Receivers in binned order (recv_binned): which tiles can matter to a receiver group until the next re-binning.  At every
+    // re-binning one wave per group tests the circle of every tile (csf_bin.hip: clist_kernel) and keeps those within the
+    // far-field radius + what both sides can move in the meantime; the pair kernel then visits the tiles of its group's list
+    // (each still tested against this tick's circles) instead of walking all of them - O(N / tile) tests per group and tick
+    // at 262 144 or a million road users.  Tiles from ctail on (the sentinel tail, where arrivals appear) are always visited.
+    const uint16_t *clist;     // [groups][CLIST_MAX] tile numbers (tile = clist_tile sources of the binned order), ascending; NULL: none
+    const int32_t *ccount;     // [groups] entries, or -1: more than CLIST_MAX candidates - this group walks every tile
+    int32_t clist_tile;        // sources per tile the lists were built for (1024 / 2048), receivers per group (= rpb then)
+    int32_t clist_rpb;
+    int32_t ctail;             // first tile that is always visited
     float4 *bnd;       // [n_pad/64] bounding circle (cx, cy, radius, -) of every batch of 64 binned records
     float4 *bnd_next;  // written by the pair kernel for the next tick (from this tick's records + bnd_margin)
     float bnd_margin;  // largest distance an agent can move in one tick (t_s * v_max)
@@ -237,6 +248,9 @@ void launch_sorted_copy(const Dev &d, hipStream_t st);  // pos[] and recs[] from
 // d.rebase_from_state), pos[] / recs[] and the bounding circles - one launch
 void launch_rebase(const Dev &d, hipStream_t st);
 void launch_bounds(const Dev &d, hipStream_t st);
+// candidate tiles of every receiver group (Dev::clist): tile circles into tcirc [n_pad / tile], then the lists
+constexpr int CLIST_MAX = 128;
+void launch_candidate_lists(const Dev &d, float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach, hipStream_t st);
 // binned positions of the receivers [lo, hi) of this rank in ascending order (the rank's receivers as neighbours in space)
 int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st);
 

@@ -101,6 +101,7 @@ struct Knobs {
     int wide = -1;                            // CSF_WIDE: workgroups of 8 waves on tiles of 2048 sources (-1: the engine's choice)
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
     int segments = -1;                        // CSF_SEGMENTS
+    int clist = 1;                            // CSF_CLIST=0: receivers in binned order walk every tile of their chunk (no candidate lists)
     int recv_binned = -1;                     // CSF_RECV_BINNED
     int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
@@ -130,6 +131,7 @@ struct Knobs {
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
         segments = geti("CSF_SEGMENTS", -1);
         recv_binned = geti("CSF_RECV_BINNED", -1);
+        clist = geti("CSF_CLIST", 1);
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second" ? 1 : 0;
@@ -254,6 +256,10 @@ struct csf_engine {
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
     DevBuf<float2> rec2, recs2, part, froad, kat2;
+    // candidate tiles of every receiver group (large populations, csf_dev.h: Dev::clist): rebuilt at every re-binning
+    DevBuf<float4> tcirc;
+    DevBuf<uint16_t> clist;
+    DevBuf<int32_t> ccount;
     DevBuf<float2> rorg;         // the origin every precise record is relative to, by slot
     DevBuf<float2> reclo;        // what the record's position left over in fp32 (csf_dev.h); all-gathered with the records
     // the one-launch tick of small populations (csf_tick.hip): exchange records (two buffers each), barrier words
@@ -482,9 +488,9 @@ int set_fov_band(csf_engine *e) {
     k.fovT0 = (float)(sc * 16 * u);
     k.fovT1 = (float)(sc * 6 * eps_p);
     // whole batches are classified against the field-of-view cone with a margin of 1e-4 in the cosine (csf_pair.hip:
-    // classify_batch): the bearing of a source nearer than this is not known that well in fp32, so a batch whose circle
-    // comes closer goes to the per-lane test
-    k.clsclear = (float)std::max(0.05, 2.9 * eps_p / 5e-5);
+    // classify_batch): the bearing of a source nearer than 2.9 u (coordinates) / 5e-5 is not known that well in fp32, so a
+    // batch whose circle comes closer goes to the per-lane test
+    k.clsk = (float)(2.9 * u * 1.01 / 5e-5);
     // offsets: a quarter-metre grid of origins + what a road user covers between two re-binnings (REBIN_TICKS = 32 steps;
     // arrivals take their position as their origin)
     const double off = 0.25 + step * 40.0;
@@ -495,7 +501,7 @@ int set_fov_band(csf_engine *e) {
     k.sideP1 = (float)(sc * 10 * u);
     for (csf_engine::Segment &sg : e->segs) {
         sg.pc.fovA = k.fovA, sg.pc.fovB = k.fovB, sg.pc.sideA = k.sideA, sg.pc.sideB = k.sideB;
-        sg.pc.fovT0 = k.fovT0, sg.pc.fovT1 = k.fovT1, sg.pc.clsclear = k.clsclear;
+        sg.pc.fovT0 = k.fovT0, sg.pc.fovT1 = k.fovT1, sg.pc.clsk = k.clsk;
         sg.pc.fovP1 = k.fovP1, sg.pc.fovP2 = k.fovP2, sg.pc.sideP0 = k.sideP0, sg.pc.sideP1 = k.sideP1;
     }
     d.state_current = e->state_all_current ? 1 : 0;
@@ -955,7 +961,7 @@ void set_chunks(csf_engine *e) {
     // ... and then workgroups of 8 waves on tiles of 2048 sources (csf_pair.hip: CW); below 65 536 places in chunks of 32 batches
     // (with 16 receivers for the shards of a large population: 8-way shard of 16 384 26.3 -> 25.1 us; unsharded 115 against 101)
     d.wide = (d.rpb == 32 || (d.rpb == 16 && (e->knobs.wide > 0 || d.n_src >= 16384))) && d.p.model != CSF_BICYCLE &&
-             e->knobs.nsplit <= 0 && (e->knobs.wide >= 0 ? e->knobs.wide != 0 : true);
+             (e->knobs.nsplit <= 0 || d.n_src >= 65536) && (e->knobs.wide >= 0 ? e->knobs.wide != 0 : true);
     if (d.wide && d.n_src < 65536) per = 32;
     split = (units + per - 1) / per;
     d.n_split = (int32_t)split;
@@ -1096,6 +1102,27 @@ int rebin(csf_engine *e) {
                               : (e->world <= 1 && !e->loopback && !binned ? std::max<int64_t>(64, (d.n + 63) / 64 * 64) : d.n_pad);
         d.n_src = std::min(n_src, d.n_pad);
         set_chunks(e);                                               // (also after a segmented period: n_split was the segments')
+    }
+    d.clist = nullptr;
+    d.ccount = nullptr;
+    if (d.recv_binned && e->knobs.clist != 0) {   // which tiles can matter to which receiver group until the next re-binning
+        d.clist_tile = d.wide ? 2048 : 1024;
+        d.clist_rpb = d.rpb;
+        const int64_t nloc = d.hi - d.lo, groups = (nloc + d.rpb - 1) / d.rpb;
+        const int64_t ntiles = (d.n_src + d.clist_tile - 1) / d.clist_tile;
+        if (groups > 0 && ntiles > 0 && ntiles < 65536) {
+            HIPCHK(e, e->tcirc.reserve((size_t)ntiles + 1));
+            HIPCHK(e, e->clist.reserve((size_t)groups * CLIST_MAX));
+            HIPCHK(e, e->ccount.reserve((size_t)groups));
+            // tiles that hold road users as of now are listed; the tile the population ends in and the sentinel tail behind it
+            // (where arrivals appear) are always visited
+            d.ctail = (int32_t)(e->tail_tracked ? d.n_live / d.clist_tile : ntiles);
+            // both sides move until the lists are rebuilt (REBIN_TICKS ticks; a churn-triggered re-binning comes sooner)
+            const float reach = d.pc.rfar + 2.0f * (float)(REBIN_TICKS + 2) * d.bnd_margin + 1e-2f;
+            launch_candidate_lists(d, e->tcirc.p, e->clist.p, e->ccount.p, reach, e->main);
+            d.clist = e->clist.p;
+            d.ccount = e->ccount.p;
+        }
     }
     e->ticks_since_rebin = 0;
     e->churn = 0;
@@ -1722,7 +1749,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -1781,6 +1808,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             e->free_recent.pop_back();
             tail = false;
             e->pend_inplace = true;
+            d.clist = nullptr;                                   // (a real batch's circle stretches: no candidate lists until the re-binning)
         } else {
             a = d.n++;
         }

@@ -179,8 +179,10 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
     const float cb = (ex * rc + ey * rs) * invD;              // cos / |sin| of the centre's bearing
     const float off = rc * ey - rs * ex;                      // centre's offset from the heading line, left > 0
     const float sb = fabsf(off) * invD;
-    const float keepoff = bb.z + k.clsclear;
-    const bool apart = D2 > keepoff * keepoff;                // receiver outside the circle, by more than fp32 positions blur a bearing
+    // receiver outside the circle - by more than fp32 positions blur a bearing: both are off by 2^-24 of their coordinates (in
+    // the frame the tile is held in), which must stay below half the 1e-4 margin of the tests below as an angle
+    const float keepoff = bb.z + 0.05f + k.clsk * (fabsf(bb.x) + fabsf(bb.y) + bb.z + fabsf(rl.x) + fabsf(rl.y));
+    const bool apart = D2 > keepoff * keepoff;
     const bool fov = apart & (k.fov_classify != 0);
     const float reach = k.rfar + bb.z;
     const bool far = D2 > reach * reach;
@@ -363,8 +365,25 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         }
         if (DYN && tid == BLOCKW - 1) next_recv = 0;
     };
+    // BINR: the tiles this receiver group can meet before the next re-binning are listed (csf_dev.h: Dev::clist) - the workgroup
+    // takes its share of the list (source chunk c of n: entries [c L / n, (c + 1) L / n)) and of the tiles of the sentinel
+    // tail, which are always visited, instead of walking every tile of its chunk
+    bool uselist = false;
+    int li = 0, li_end = 0;
+    int64_t tt = 0, ntl = 0;
+    if (BINR && d.clist != nullptr && d.clist_tile == TL && d.clist_rpb == RPB) {
+        const int lc = d.ccount[blockIdx.x];
+        if (lc >= 0) {
+            uselist = true;
+            li = (int)((int64_t)lc * blockIdx.y / gridDim.y);
+            li_end = (int)((int64_t)lc * (blockIdx.y + 1) / gridDim.y);
+            ntl = (d.n_src - d.src_beg + TL - 1) / TL;
+            tt = (int64_t)d.ctail + blockIdx.y;
+            iend = d.n_src;
+        }
+    }
     // first tile and the workgroup's receiver records travel together: one global round trip, not two
-    if (ibeg >= iend) return;  // (uniform) nothing to do for this chunk
+    if (!uselist && ibeg >= iend) return;  // (uniform) nothing to do for this chunk
     if (!BINR) fill_tile(ibeg, (int)((iend - ibeg) < TL ? (iend - ibeg) : TL), (int)threadIdx.x);
     if (threadIdx.x < RPB) {
         const int64_t j = d.lo + (int64_t)blockIdx.x * RPB + threadIdx.x;
@@ -410,9 +429,25 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         gx = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gx)));
         gy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gy)));
         gr = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gr)));
+        // The rounding band of the field-of-view test (csf_field.h: keep_x2) in THIS frame: a source the reach test keeps is
+        // within the far-field radius of its receiver, a receiver within the group's circle around the group's origin - no
+        // coordinate the test sees exceeds |centre| + radius + far-field radius (csf_engine.hip: set_fov_band has the scene's
+        // extent for receivers in slot order).
+        if (REACH) k.fovT1 = k.fovT0 * 0.38f * (fabsf(gx) + fabsf(gy) + 2.0f * gr + k.rfar + 8.0f);   // 6 u (...) with fovT0 = 16 u
     }
     bool filled = false;
-    for (int64_t base = ibeg; base < iend; base += TL) {
+    int64_t walk = ibeg;
+    for (;;) {
+        int64_t base;
+        if (BINR && uselist) {
+            if (li < li_end) base = d.src_beg + (int64_t)d.clist[(int64_t)blockIdx.x * CLIST_MAX + li++] * TL;
+            else if (tt < ntl) base = d.src_beg + tt * TL, tt += gridDim.y;
+            else break;
+        } else {
+            base = walk;
+            if (base >= iend) break;
+            walk += TL;
+        }
         const int cnt = (int)((iend - base) < TL ? (iend - base) : TL);  // multiple of 64
         const int nb = cnt >> 6;
         // the LDS and global addresses of the fill and the classification are formed HERE, once per tile: hoisted out of the
