@@ -1,7 +1,7 @@
 // csf_agent_dev.h — the per-agent tick as device functions (fp64, one lane per agent): destination queue and navigation
 // state machine, destination force (straight line / spline planner), controller + kinematics of the five rider models,
-// ring-buffer bookkeeping and the fp32 source record.  Shared by agent_kernel (csf_agent.hip) and the one-launch tick of
-// small populations (csf_tick.hip).  Reference lines are cited at every function.
+// ring-buffer bookkeeping and the fp32 source record, for agent_kernel (csf_agent.hip).  Reference lines are cited at every
+// function.
 #pragma once
 #include "csf_dev.h"
 

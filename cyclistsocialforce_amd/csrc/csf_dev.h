@@ -275,20 +275,6 @@ struct PatchHeader {
 };
 void launch_patch(const Dev &d, const PatchHeader &h, const void *records, unsigned *ticket, int b0, int b1, int64_t items,
                   hipStream_t st);
-// csf_tick.hip: n_ticks whole ticks of a small population (one parameter set, one device) in ONE launch
-constexpr int TICK_MAX_AGENTS = 2048;
-struct TickArgs {
-    float4 *xa[2];       // [n64] source records as the waves exchange them, double-buffered by tick parity: (x_hi, y_hi, cos psi, sin psi)
-    float2 *xb[2];       // ... (x_lo, y_lo): the position as two floats
-    float2 *xc[2];       // ... Bicycle field: (e, 1 / sqrt(1 - e^2))
-    unsigned long long *barrier;       // [2] arrival counter of the grid barrier (never reset), abort flag
-    unsigned long long barrier_base;   // ... what the counter has reached when this launch starts
-    int64_t n_ticks;
-    int recv_per_wave;
-};
-bool tick_fits(const Dev &d);
-int tick_blocks(const Dev &d);        // workgroups of the launch
-void launch_tick(const Dev &d, TickArgs t, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_untracked(const Dev &d, uint8_t *out, hipStream_t st);   // get_untracked_foes as the reference's matrix
 void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const int32_t *stop, double *vd_out,
                     double *ddest_out, hipStream_t st);

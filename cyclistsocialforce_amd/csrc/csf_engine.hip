@@ -106,7 +106,6 @@ struct Knobs {
     int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
     int comm_second = -1;                     // CSF_COMM_STREAM=second / main (-1: the communicator times both on its first tick and keeps the faster)
-    int fused = 0;                            // CSF_FUSED=1: the one-launch tick of small populations (csf_tick.hip; opt-in)
     double fov_band = 1.0;                    // CSF_FOV_BAND: scale of the rounding band of the field-of-view test (0: every pair decided in fp32, as in round 3)
     double rnear = 1.0;                       // CSF_RNEAR: pairs closer than this (m) are evaluated from the precise records (0: none)
     int road_grid = -1;                       // CSF_ROAD_GRID: 1 the lattice of csf_road.hip for any road, 0 never (-1: large networks)
@@ -135,7 +134,6 @@ struct Knobs {
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second" ? 1 : 0;
-        fused = geti("CSF_FUSED", 0);
         if (const char *v = getenv("CSF_RNEAR")) rnear = atof(v);
         if (const char *v = getenv("CSF_FOV_BAND")) fov_band = std::max(0.0, atof(v));
         road_grid = geti("CSF_ROAD_GRID", -1);
@@ -262,12 +260,6 @@ struct csf_engine {
     DevBuf<int32_t> ccount;
     DevBuf<float2> rorg;         // the origin every precise record is relative to, by slot
     DevBuf<float2> reclo;        // what the record's position left over in fp32 (csf_dev.h); all-gathered with the records
-    // the one-launch tick of small populations (csf_tick.hip): exchange records (two buffers each), barrier words
-    DevBuf<float4> tk_xa;
-    DevBuf<float2> tk_xb, tk_xc;
-    DevBuf<unsigned long long> tk_bar;
-    unsigned long long tk_bar_base = 0;   // what the barrier's arrival counter has reached
-    bool tick_launched = false;  // a one-launch tick ran since the barrier's abort flag was last read
     bool state_all_current = true;   // every live slot's fp64 state on this device is current (false once a rank has ticked)
     // Field-of-view decisions within fp32 rounding of an edge (csf_dev.h: PairConsts::fovA, EdgeRec; set_fov_band): the
     // largest |coordinate| relative to the scene origin at the last upload (road users, prescribed trajectories, arrivals
@@ -668,18 +660,13 @@ int build_road_grid(csf_engine *e, const double box[4]) {
     double w = road_cell_edge(e);
     double gx0 = 0, gy0 = 0;
     int64_t nx = 0, ny = 0;
-    // The lattice covers the network, the road users as they are now (a road user outside it sums every vertex: correct, and
-    // as slow as without a lattice) and a margin of RG_NEAR cells or 5 % of the extent.
-    double lo[2] = {box[0], box[2]}, hi[2] = {box[1], box[3]};
-    for (int64_t a = 0; a < d.n; a++) {
-        if (!e->h_alive[(size_t)a]) continue;
-        for (int c = 0; c < 2; c++) {
-            const double v = e->h_s[(size_t)c * e->cap + a];
-            if (std::isfinite(v)) lo[c] = std::min(lo[c], v), hi[c] = std::max(hi[c], v);
-        }
-    }
+    // The lattice covers the network and a fixed margin around it - RG_NEAR cells or a tenth of the extent, in steps of eight
+    // cells - whatever the road users do: its coefficients are then fitted once per network and survive every re-upload (a
+    // road user outside it sums every vertex: correct, and as slow as without a lattice).
+    const double lo[2] = {box[0], box[2]}, hi[2] = {box[1], box[3]};
     for (;;) {   // coarser cells while the lattice (or the sampling: cells x 64 x nv pairs) is too large
-        const double mx = std::max(RG_NEAR * w, 0.05 * (hi[0] - lo[0])), my = std::max(RG_NEAR * w, 0.05 * (hi[1] - lo[1]));
+        const double mx = std::max(RG_NEAR * w, 8 * w * std::ceil(0.1 * (hi[0] - lo[0]) / (8 * w)));
+        const double my = std::max(RG_NEAR * w, 8 * w * std::ceil(0.1 * (hi[1] - lo[1]) / (8 * w)));
         gx0 = w * std::floor(((lo[0] - mx) - d.ox) / w);
         gy0 = w * std::floor(((lo[1] - my) - d.oy) / w);
         nx = (int64_t)std::floor((((hi[0] + mx) - d.ox) - gx0) / w) + 1;
@@ -802,13 +789,6 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
     HIPCHK(e, e->rorg.alloc(nrec));
     HIPCHK(e, e->reclo.alloc(nrec));
-    if (e->cap_user <= TICK_MAX_AGENTS) {
-        const size_t m = TICK_MAX_AGENTS + 64;
-        HIPCHK(e, e->tk_xa.alloc(2 * m));
-        HIPCHK(e, e->tk_xb.alloc(2 * m));
-        HIPCHK(e, e->tk_xc.alloc(2 * m));
-        HIPCHK(e, e->tk_bar.alloc(2));
-    }
     HIPCHK(e, e->sort_vals.alloc(nrec));
     HIPCHK(e, e->rlist.alloc(nrec));
     HIPCHK(e, e->sort_keys.alloc(nrec));
@@ -1749,7 +1729,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->tk_xa.release(); e->tk_xb.release(); e->tk_xc.release(); e->tk_bar.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -2319,45 +2299,6 @@ static int loopback_exchange(csf_engine *const *g, int world) {
     return CSF_OK;
 }
 
-// csf_step on a small population: the whole tick in one launch, all n_ticks of them in one launch (csf_tick.hip).
-// Opt-in (CSF_FUSED=1): measured on MI355X it only pays for resident loops (csf_step(e, many)) of a handful of road
-// users - 9.0 against 11.4 us per tick for the 3-bike demo, 16 against 13 us at 128 road users, 28 against 15 us at
-// 1 024 (profiles/r3_small_n_rate.txt) - because a tick is bound by the ~7 us of dependent fp64 instructions of ONE
-// road user's planner, controller and kinematics, which a launch more or less does not change, while the exchange of
-// the records between workgroups (a device-scope barrier per tick) costs more than the launch it saves.
-// For one parameter set on one device without the history ring and without per-kernel time stamps.
-static bool one_launch_tick(const csf_engine *e) {
-    const int want = e->knobs.fused > 0;
-    return want && e->tk_bar.p != nullptr && e->classes.size() == 1 && e->world == 1 && !e->nccl && !e->loopback &&
-           e->d.hist == nullptr && e->profile == 0 && e->knobs.fake_world <= 1 && e->d.n_live >= 1 && tick_fits(e->d);
-}
-
-static int step_one_launch(csf_engine *e, int64_t n_ticks) {
-    Dev &d = e->d;
-    const size_t m = TICK_MAX_AGENTS + 64;
-    while (n_ticks > 0) {
-        const int64_t k = std::min<int64_t>(n_ticks, 1 << 16);       // (bounds the run time of one launch)
-        TickArgs t{};
-        for (int b = 0; b < 2; b++) t.xa[b] = e->tk_xa.p + b * m, t.xb[b] = e->tk_xb.p + b * m, t.xc[b] = e->tk_xc.p + b * m;
-        t.barrier = e->tk_bar.p;
-        t.n_ticks = k;
-        t.barrier_base = e->tk_bar_base;
-        if (tick_blocks(d) > 1)                                      // (a single workgroup never touches the counter)
-            e->tk_bar_base += (unsigned long long)tick_blocks(d) * (unsigned long long)(k + 1);   // a barrier per tick + one at the start
-        launch_tick(d, t, e->main);
-        HIPCHK(e, hipGetLastError());
-        d.tick += k;
-        e->moves += k;
-        n_ticks -= k;
-    }
-    // the general path finds the records moved by many ticks: circles and order are renewed before its next pair launch
-    e->ticks_since_rebin = REBIN_TICKS;
-    e->bounds_fresh = false;
-    e->tick_launched = true;
-    e->device_ahead = true;
-    return CSF_OK;
-}
-
 int csf_step(csf_engine *e, int64_t n_ticks) {
     if (!e) return CSF_E_ARG;
     if (n_ticks < 0) return fail(e, CSF_E_ARG, "n_ticks must be >= 0");
@@ -2370,7 +2311,6 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
         e->d.tick += n_ticks;
         return CSF_OK;
     }
-    if (n_ticks > 0 && one_launch_tick(e)) return step_one_launch(e, n_ticks);
     if (n_ticks > 0 && !e->comm_calibrated && (rc = calibrate_comm_stream(e))) return rc;
     for (int64_t t = 0; t < n_ticks; t++) {
         rc = enqueue_tick(e);
@@ -2389,12 +2329,6 @@ int csf_sync(csf_engine *e) {
     }
     HIPCHK(e, hipStreamSynchronize(e->main));
     HIPCHK(e, hipStreamSynchronize(e->comm));
-    if (e->tick_launched) {      // did every workgroup of the one-launch tick pass every barrier?
-        unsigned long long flag = 0;
-        HIPCHK(e, hipMemcpy(&flag, e->tk_bar.p + 1, sizeof flag, hipMemcpyDeviceToHost));
-        e->tick_launched = false;
-        if (flag) return fail(e, CSF_E_DEVICE, "the one-launch tick gave up at its grid barrier (the device could not hold the grid): the state is not valid; CSF_FUSED=0 takes the general path");
-    }
     return CSF_OK;
 }
 
@@ -2944,11 +2878,6 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     if (rc) return rc;
     Dev &d = e->d;
     const char *name = pair_kernel_name(d);
-    if (one_launch_tick(e)) {                                    // csf_step takes the one-launch tick: nothing to count
-        if (kernel_name) *kernel_name = "tick_kernel";
-        for (int k = 0; k < 4; k++) counts[k] = -1;
-        return CSF_OK;
-    }
     if (!e->segs.empty()) {                                      // one launch per parameter set: the kernel of the first
         Dev d0 = d;
         d0.p = e->classes[(size_t)e->segs[0].cls];

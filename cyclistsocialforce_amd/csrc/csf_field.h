@@ -1,7 +1,7 @@
 // csf_field.h — the repulsive force fields and the field-of-view test as device functions (fp32, trig-free): TwoDBicycle
 // field (vehicle.py:1560-1648) one pair per lane and two pairs per lane on packed arithmetic, the reach test, the Bicycle
-// field (vehicle.py:1054-1147).  Shared by the pair kernels (csf_pair.hip) and the one-launch tick of small populations
-// (csf_tick.hip).
+// field (vehicle.py:1054-1147); the rare paths that make the field-of-view decision exact.  Used by the pair kernels
+// (csf_pair.hip).
 #pragma once
 #include "csf_dev.h"
 
@@ -163,14 +163,11 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
 // of a partial batch, whose dummy record may coincide with the receiver.  Accumulates into (ax, ay).
 // NEARFLAG: near0 / near1 (wave masks) report the pairs closer than k.rnear (pair_cull_kernel corrects them from the precise
 // records).
-template <bool FULL, bool NEARFLAG = false, bool LO = false>
+template <bool FULL, bool NEARFLAG = false>
 __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r, const v2f qx, const v2f qy,
                                               const v2f qc, const v2f qs, bool valid0, bool valid1, float &ax,
-                                              float &ay, unsigned long long *near0 = nullptr, unsigned long long *near1 = nullptr,
-                                              const v2f lx = v2f{0.f, 0.f}, const v2f ly = v2f{0.f, 0.f}) {
-    // (lx, ly): an optional correction of (dx, dy), the difference of the low parts of two-float positions (csf_tick.hip)
+                                              float &ay, unsigned long long *near0 = nullptr, unsigned long long *near1 = nullptr) {
     v2f dx = r.x - qx, dy = r.y - qy;                 // vehicle.py:1615-1616
-    if (LO) dx = dx + lx, dy = dy + ly;
     v2f r2 = dx * dx + dy * dy;
     if (NEARFLAG) {   // (every mask the result of ONE compare: csf_pair.hip ballot1)
         *near0 = __builtin_amdgcn_ballot_w64(r2.x < k.rnear2);

@@ -60,13 +60,13 @@ __global__ __launch_bounds__(BLOCK) void road_far_kernel(const Dev d, const shor
     __shared__ float vx[TILE], vy[TILE], vf[TILE], vw[NP ? 1 : TILE];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cell = blockIdx.y, cx = cell % d.rg_nx, cy = cell / d.rg_nx;
+    const int cell = blockIdx.x, cx = cell % d.rg_nx, cy = cell / d.rg_nx;
     const float hw = 0.5f * d.rg_w;
     float rx[RPW], ry[RPW];
     double sx[RPW], sy[RPW];
 #pragma unroll
     for (int u = 0; u < RPW; u++) {
-        const int node = ((int)blockIdx.x * WPB + wave) * RPW + u;   // 8 ix + iy
+        const int node = ((int)blockIdx.y * WPB + wave) * RPW + u;   // 8 ix + iy
         rx[u] = hw * cheb_node(node >> 3);
         ry[u] = hw * cheb_node(node & 7);
         asm volatile("" : "+v"(rx[u]), "+v"(ry[u]));
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(BLOCK) void road_far_kernel(const Dev d, const shor
             b += __shfl_xor(b, o, WAVE);
         }
         if (lane == 0) {
-            const int node = ((int)blockIdx.x * WPB + wave) * RPW + u;
+            const int node = ((int)blockIdx.y * WPB + wave) * RPW + u;
             samples[((int64_t)cell * 64 + node) * 2] = a;
             samples[((int64_t)cell * 64 + node) * 2 + 1] = b;
         }
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(BLOCK) void road_grid_kernel(const Dev d) {
 
 template <int NP>
 static void far_launch(const Dev &d, const short2 *vcell, double *samples, hipStream_t st) {
-    hipLaunchKernelGGL(road_far_kernel<NP>, dim3(64 / (WPB * RPW), (unsigned)(d.rg_nx * d.rg_ny)), dim3(BLOCK), 0, st, d, vcell, samples);
+    // (cells in the x dimension of the grid: up to 2^18 of them, and gridDim.y ends at 65 535)
+    hipLaunchKernelGGL(road_far_kernel<NP>, dim3((unsigned)(d.rg_nx * d.rg_ny), 64 / (WPB * RPW)), dim3(BLOCK), 0, st, d, vcell, samples);
 }
 template <int NP>
 static void grid_launch(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {

@@ -486,6 +486,8 @@ class SocialForceIntersection:
         if scripted:                                          # their prescribed trajectories -> the engine (csf_set_script)
             rows = [v._script if v._script is not None else np.zeros((0, 4)) for v in scripted]
             e.set_script([v._index for v in scripted], np.cumsum([0] + [r.shape[0] for r in rows]), np.vstack(rows))
+            for v in scripted:                                # (what the engine holds: writes to car.traj are noticed, _push_mutations)
+                v._script_sent = np.ascontiguousarray(v.traj.T).copy()
         for v in new:
             if v.traj.shape[1] != T and not getattr(v, "uncontrolled", False):
                 raise NotImplementedError("all road users of one intersection share t_s (one engine per intersection)")
@@ -546,6 +548,19 @@ class SocialForceIntersection:
         """Everything the user may have changed on the Python side since the last tick."""
         e = self._engine_ready()
         n = len(self.vehicles)
+        # UncontrolledVehicle: the reference reads car.traj[:, i] on every step (vehicle.py:964-979), so a trajectory written
+        # after the car joined - external control - has to reach the engine: compare with what was sent, send again on a change
+        changed = []
+        for v in self.vehicles:
+            if getattr(v, "uncontrolled", False) and v._live and getattr(v, "_script_sent", None) is not None:
+                cur = np.ascontiguousarray(v.traj.T)
+                if cur.shape != v._script_sent.shape or not np.array_equal(cur, v._script_sent):
+                    v._script = cur
+                    v._script_sent = cur.copy()
+                    changed.append(v)
+        if changed:
+            e.set_script([v._index for v in changed], np.cumsum([0] + [v._script.shape[0] for v in changed]),
+                         np.vstack([v._script for v in changed]))
         # destination queues (only vehicles whose setDestinations / stop / go ran since the last push):
         # replaced queues go up with reset=1, rows edited in place with reset=2, appended rows with reset=0
         if self._dirty_queues:

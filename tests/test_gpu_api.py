@@ -489,3 +489,27 @@ def test_uncontrolled_vehicle_in_an_intersection(golden):
         np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"sample {k}")
         np.testing.assert_allclose(got[n - 2:, :4], S[k][n - 2:, :4], rtol=0, atol=1e-12)
     assert car.traj.shape == script.shape and car.force == (0.0, 0.0)
+
+
+def test_uncontrolled_vehicle_trajectory_rewritten_while_running():
+    """The reference reads car.traj[:, i] on every step (vehicle.py:964-979) and documents external control by writing
+    `traj` during the run: a trajectory rewritten after the car has joined reaches the engine with the next step."""
+    from cyclistsocialforce_amd.vehicle import UncontrolledVehicle
+
+    T = 60
+    script = np.stack([np.linspace(0.0, 6.0, T), np.full(T, 2.0), np.zeros(T), np.full(T, 1.0)])
+    car = UncontrolledVehicle(tuple(script[:, 0]), trajectory=script.copy(), id="car")
+    bike = TwoDBicycle((10.0, 0.0, np.pi / 2, 4.0, 0.0), id="b")
+    bike.setDestinations([10.0, 10.0], [20.0, 40.0])
+    ins = SocialForceIntersection([bike, car])
+    for _ in range(5):
+        ins.step()
+    i = int(car.i)
+    np.testing.assert_allclose(car.s[:4], car.traj[:4, i], rtol=0, atol=1e-12)
+    car.traj[1, i + 1:] += 0.75                               # external control: the rest of the trajectory moves sideways
+    for _ in range(7):
+        ins.step()
+    j = int(car.i)
+    assert j == i + 7
+    np.testing.assert_allclose(car.s[:4], car.traj[:4, j], rtol=0, atol=1e-12)
+    assert abs(car.s[1] - 2.75) < 1e-12

@@ -208,14 +208,12 @@ def test_population_trajectories_golden(amd, golden, prefix, model, rule):
 
 
 @pytest.mark.auto_variant
-@pytest.mark.parametrize("fused,every_n", [(0, None), (1, None), (1, 1)])
+@pytest.mark.parametrize("every_n", [None, 1])
 @pytest.mark.parametrize("prefix,model,rule", TRAJ)
-def test_population_trajectories_golden_own_choice(amd, golden, monkeypatch, prefix, model, rule, fused, every_n):
-    """The same runs on the kernels the engine chooses itself, which is what a drop-in user of these population sizes
-    gets: the general path with the plain all-pairs kernel (csf_engine.hip: pair_variant_for); and with CSF_FUSED=1 the
-    whole tick in one launch (csf_tick.hip; the ticks between two samples in ONE launch, or - every_n = 1 - a launch per
-    tick as SocialForceIntersection.step() issues them)."""
-    monkeypatch.setenv("CSF_FUSED", str(fused))
+def test_population_trajectories_golden_own_choice(amd, golden, prefix, model, rule, every_n):
+    """The same runs on the kernels the engine chooses itself, which is what a drop-in user of these population sizes gets:
+    the plain all-pairs kernel (csf_engine.hip: pair_variant_for) - the ticks between two samples in one call, or
+    (every_n = 1) a call per tick as SocialForceIntersection.step() issues them."""
     g = golden("trajectories")
     e = make_engine(amd, model, g[f"{prefix}_s0"], g[f"{prefix}_vdes"], g[f"{prefix}_off"], g[f"{prefix}_dq"], rule)
     if f"{prefix}_verts" in g.files:
@@ -223,7 +221,7 @@ def test_population_trajectories_golden_own_choice(amd, golden, monkeypatch, pre
     S = g[f"{prefix}_S"]
     every = {"lap_twod": 50}.get(prefix, 10)
     if every_n == 1 and prefix == "lap_twod":
-        pytest.skip("3100 single-tick launches: covered by the other samples")
+        pytest.skip("3100 single-tick calls: covered by the other samples")
     extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
     worst = 0.0
     for k in range(1, S.shape[0]):
@@ -236,20 +234,16 @@ def test_population_trajectories_golden_own_choice(amd, golden, monkeypatch, pre
         worst = max(worst, np.abs(got[:, :2] - S[k][:, :2]).max() / extent)
         np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"{prefix} sample {k}")
         np.testing.assert_allclose(got[:, 3], S[k][:, 3], rtol=0, atol=2e-3, err_msg=f"{prefix} speed sample {k}")
-    assert (e.status() == 0).all() and e.count_pairs()[1] == ("tick_kernel" if fused else "pair_kernel")
-    print(f"{prefix} ({'one launch' if fused else 'general path'}): worst position deviation / extent = {worst:.3e}")
+    assert (e.status() == 0).all() and e.count_pairs()[1] == "pair_kernel" and e.near_dropped() == 0
+    print(f"{prefix}: worst position deviation / extent = {worst:.3e}")
 
 
 @pytest.mark.auto_variant
 @pytest.mark.parametrize("model,n,kernel", [("twod", 1024, "pair_kernel"), ("twod", 2900, "pair_kernel"), ("twod", 3100, "pair_cull_kernel"),
                                              ("bicycle", 2900, "pair_kernel"), ("bicycle", 3100, "pair_bike_kernel"),
-                                             ("twod", 1024, "tick_kernel"), ("bicycle", 2000, "tick_kernel"), ("invpend", 300, "tick_kernel"),
-                                             ("planarpoint", 70, "tick_kernel")])
+                                             ("invpend", 300, "pair_kernel"), ("planarpoint", 70, "pair_kernel")])
 def test_pair_kernel_chosen_by_population_size(amd, monkeypatch, model, n, kernel):
-    """plain below 3 072 road users, cull-first (binned) from there, and on request (CSF_FUSED=1, up to 2 048 road users)
-    the whole tick in one launch with a device-scope barrier between the ticks (csf_tick.hip) - each against the oracle"""
-    if kernel == "tick_kernel":
-        monkeypatch.setenv("CSF_FUSED", "1")
+    """plain below 3 072 road users, cull-first (binned) from there - each against the oracle"""
     box = float(np.sqrt(n / 0.2))
     x, y, psi, v, off, dq = synthetic_population(n, box, seed=4)
     s0 = np.zeros((n, orc.N_STATES[MODELS[model]])); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
