@@ -65,6 +65,15 @@ struct EdgeRec {
 constexpr unsigned EDGE_CAP = 4096;
 constexpr uint32_t CSF_ST_EDGE = 0x80000000u;   // status[slot], internal: entries wait in the ring for this receiver (masked by csf_status)   // ring of entries; a tick produces a few dozen at N = 16 384
 
+// one run of the class-segmented order (csf_engine.hip: rebin), as the segmented grid of the pair kernel reads it
+struct SegDev {
+    PairConsts pc;           // the set's constants (the rounding bands of the tick come from the launch's own Dev::pc)
+    double hfov;
+    int64_t src_beg, n_src;  // its places
+    int32_t chunk_units, n_split, part_base;
+    int32_t first_by;        // its first source chunk in the grid's y dimension
+};
+
 // All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
 struct Dev {
     csf_params p;
@@ -90,6 +99,8 @@ struct Dev {
     int64_t n_src;     // places of the source order that can hold a road user (multiple of 64, <= n_pad): the pair kernel stops there
     int64_t src_beg;   // ... and starts here (0, or the first place of a class segment: csf_engine.hip launch_pair_segments)
     int32_t part_base; // first slot of d.part this launch writes (its source chunks follow: one launch per class segment)
+    const SegDev *segtab;  // the runs whose field is the TwoD one, for the segmented grid (NULL: one launch per run)
+    int32_t n_seg;
     int32_t seg_keys;  // re-binning: the parameter set leads the sort key (csf_bin.hip), so that every set is a run of places
     int32_t ns;        // states per agent
     int32_t hist_len;  // power of two > int(1/t_s) + 1: short on-device position ring
@@ -216,6 +227,7 @@ enum : int { PH_DEST = 1, PH_COMBINE = 2, PH_INTEGRATE = 4, PH_FIXSPEED = 8 };
 // t0 / t1 (may be NULL): HIP events that receive the start / end time stamp of the kernel itself (hipExtLaunchKernelGGL:
 // taken from the dispatch packet, no extra barrier packet in the stream as with hipEventRecord)
 void launch_pair(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void launch_pair_segments(const Dev &d, int total_by, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_road(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 // csf_road.hip: the road term over a lattice (Dev::rg_*).  launch_road_far: the far field of every cell at its 8 x 8
 // Chebyshev nodes, samples[(cell * 64 + node) * 2 + component] (node = 8 ix + iy), from the cell-sorted vertices and

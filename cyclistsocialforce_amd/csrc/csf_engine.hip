@@ -101,6 +101,7 @@ struct Knobs {
     int wide = -1;                            // CSF_WIDE: workgroups of 8 waves on tiles of 2048 sources (-1: the engine's choice)
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
     int segments = -1;                        // CSF_SEGMENTS
+    int seg_grid = 1;                         // CSF_SEG_GRID=0: one launch per parameter set (class-segmented order) instead of one grid
     int clist = 1;                            // CSF_CLIST=0: receivers in binned order walk every tile of their chunk (no candidate lists)
     int recv_binned = -1;                     // CSF_RECV_BINNED
     int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
@@ -131,6 +132,7 @@ struct Knobs {
         segments = geti("CSF_SEGMENTS", -1);
         recv_binned = geti("CSF_RECV_BINNED", -1);
         clist = geti("CSF_CLIST", 1);
+        seg_grid = geti("CSF_SEG_GRID", 1);
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second" ? 1 : 0;
@@ -159,6 +161,10 @@ struct csf_engine {
         PairConsts pc;
     };
     std::vector<Segment> segs;
+    // ... the runs of the TwoD-field sets as ONE grid (csf_pair.hip: SEG): their table on the device, the grid's y extent
+    DevBuf<SegDev> segtab;
+    std::vector<SegDev> h_segtab;
+    int seg_total_by = 0;
     int32_t sent_slot = 0;               // index of a record that is a sentinel for ever
     std::vector<uint8_t> h_cls;
     DevBuf<csf_params> ptab;
@@ -976,6 +982,8 @@ int rebin(csf_engine *e) {
     // culling kernel per run with that set's constants, far-field radius and field (launch_pair_all).  Otherwise the
     // plain kernel looks every source's set up (csf_pair.hip: HET).
     e->segs.clear();
+    e->h_segtab.clear();
+    e->seg_total_by = 0;
     d.seg_keys = 0;
     d.src_beg = 0;
     d.part_base = 0;
@@ -1029,6 +1037,30 @@ int rebin(csf_engine *e) {
                 d.seg_keys = 1;
                 d.n_split = std::max(1, slots);                       // what the per-agent kernel sums
                 d.n_src = place;
+            }
+            // the runs whose field is the TwoD one, as the segmented grid reads them
+            e->h_segtab.clear();
+            e->seg_total_by = 0;
+            for (const csf_engine::Segment &sg : e->segs) {
+                if (e->classes[(size_t)sg.cls].model == CSF_BICYCLE) continue;
+                SegDev t{};
+                t.pc = sg.pc;
+                t.hfov = e->classes[(size_t)sg.cls].hfov;
+                t.src_beg = sg.beg;
+                t.n_src = sg.end;
+                t.chunk_units = sg.chunk_units;
+                t.n_split = sg.n_split;
+                t.part_base = sg.part_base;
+                t.first_by = e->seg_total_by;
+                e->seg_total_by += sg.n_split;
+                e->h_segtab.push_back(t);
+            }
+            bool same_reach = true;
+            for (const SegDev &t : e->h_segtab) same_reach = same_reach && t.pc.reach != 0;
+            if (e->h_segtab.size() < 2 || !same_reach || e->h_segtab.size() > 16) e->seg_total_by = 0;   // (one run: nothing to merge)
+            else {
+                HIPCHK(e, e->segtab.reserve(16));
+                HIPCHK(e, hipMemcpyAsync(e->segtab.p, e->h_segtab.data(), e->h_segtab.size() * sizeof(SegDev), hipMemcpyHostToDevice, e->main));
             }
         }
     }
@@ -1729,7 +1761,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->segtab.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -2150,7 +2182,18 @@ static void launch_pair_all(csf_engine *e, const Dev &base, hipEvent_t t0 = null
         launch_pair(base, e->main, t0, t1);
         return;
     }
+    const bool one_grid = e->seg_total_by > 0 && base.pair_count == nullptr && base.dyn_recv && e->knobs.seg_grid != 0;
+    if (one_grid) {      // the runs of all TwoD-field sets in one grid
+        Dev dd = base;
+        dd.n_classes = 1;
+        dd.recv_binned = 0;
+        dd.segtab = e->segtab.p;
+        dd.n_seg = (int32_t)e->h_segtab.size();
+        launch_pair_segments(dd, e->seg_total_by, e->main, t0, t1);
+        t0 = t1 = nullptr;
+    }
     for (const csf_engine::Segment &sg : e->segs) {
+        if (one_grid && e->classes[(size_t)sg.cls].model != CSF_BICYCLE) continue;   // (done above; the Bicycle field has a kernel of its own)
         Dev dd = base;
         dd.p = e->classes[(size_t)sg.cls];
         dd.p.priority_rule = base.p.priority_rule;

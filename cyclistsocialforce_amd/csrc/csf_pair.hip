@@ -104,9 +104,9 @@ __device__ __forceinline__ void reduce_store(const Dev &d, int64_t j0, int lane,
     }
 }
 
-__device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend) {
-    const int64_t per = d.chunk_units;  // blockIdx.y selects a chunk of sources, in units of 64 records
-    ibeg = d.src_beg + (int64_t)blockIdx.y * per * WAVE;
+__device__ __forceinline__ void source_chunk(const Dev &d, int64_t &ibeg, int64_t &iend, int by = (int)blockIdx.y) {
+    const int64_t per = d.chunk_units;  // `by` (blockIdx.y) selects a chunk of sources, in units of 64 records
+    ibeg = d.src_beg + (int64_t)by * per * WAVE;
     iend = ibeg + per * WAVE;
     if (iend > d.n_src) iend = d.n_src;   // (the places behind hold sentinels only, csf_engine.hip: rebin)
 }
@@ -224,8 +224,34 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
 // CW: waves of a workgroup, 4, or 8 (DYN, RPB 32: launch_cull_dyn): a workgroup of 8 waves holds a
 // tile of 2048 sources (32 batches), so a visit - one receiver against one tile - covers twice the sources: half the visits
 // (each with its claim, record, column sum), and twice the sources to evaluate per visit, i.e. fuller evaluation passes.
-template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false, int CW = WPB>
-__global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(const Dev d) {
+// SEG (several parameter sets in the class-segmented order, csf_engine.hip: rebin): ONE grid for the runs of all sets whose
+// field is the TwoD one - blockIdx.y counts the source chunks of all runs, and a workgroup takes its run's constants, source
+// range and partial-sum slots from Dev::segtab (a launch per run left the device idle while each run's last workgroups ended).
+template <bool P2R, bool CLASSIFY, bool BINR, bool DYN, int RPB = WPB * RPW, bool REACH = false, int CW = WPB, bool SEG = false>
+__global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(const Dev dk) {
+    static_assert(!SEG || (DYN && CLASSIFY && !BINR), "the segmented grid is built into the classified variants with receivers in slot order");
+    Dev dseg;
+    int by = (int)blockIdx.y;
+    double seg_hfov = 0.0;
+    if (SEG) {
+        const int ln = threadIdx.x & (WAVE - 1);
+        const int fb = dk.segtab[ln < dk.n_seg ? ln : 0].first_by;
+        const int sg = __builtin_popcountll(ballot1(ln < dk.n_seg && (int)blockIdx.y >= fb)) - 1;
+        const SegDev &t = dk.segtab[sg];
+        dseg = dk;
+        by = (int)blockIdx.y - t.first_by;
+        dseg.src_beg = t.src_beg;
+        dseg.n_src = t.n_src;
+        dseg.chunk_units = t.chunk_units;
+        dseg.part_base = t.part_base;
+        PairConsts pc = t.pc;                 // the set's field, field of view, far-field radius and reach test ...
+        pc.fovA = dk.pc.fovA, pc.fovB = dk.pc.fovB, pc.sideA = dk.pc.sideA, pc.sideB = dk.pc.sideB;   // ... the rounding bands of this tick
+        pc.fovT0 = dk.pc.fovT0, pc.fovT1 = dk.pc.fovT1, pc.clsk = dk.pc.clsk;
+        pc.fovP1 = dk.pc.fovP1, pc.fovP2 = dk.pc.fovP2, pc.sideP0 = dk.pc.sideP0, pc.sideP1 = dk.pc.sideP1;
+        dseg.pc = pc;
+        seg_hfov = t.hfov;
+    }
+    const Dev &d = SEG ? (const Dev &)dseg : dk;
     static_assert(RPB == WPB * RPW || (DYN && (RPB % (WPB * RPW) == 0 || RPB == 2 * RPW) && RPB <= WAVE), "other workgroup sizes need the dynamic hand-out");
     static_assert(CW == WPB || (CW == 2 * WPB && DYN && CLASSIFY && (RPB == 32 || RPB == 16)), "the wide workgroup is built into the variants with 16 / 32 receivers");
     constexpr int BLOCKW = CW * WAVE;             // threads of a workgroup
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t j0 = d.lo + ((int64_t)blockIdx.x * CW + wave) * RPW;
     int64_t ibeg, iend;
-    source_chunk(d, ibeg, iend);
+    source_chunk(d, ibeg, iend, by);
     const uint64_t t_start = d.trace ? wall_clock64() : 0;
     float2 og = make_float2(0.f, 0.f);   // BINR: origin of the workgroup (uniform: scalar loads), else the scene's
     if (BINR) {
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
 
     // the workgroups of the first source chunk also emit the bounding circles of the next tick (one wave per
     // batch): a separate launch per tick would cost more in launch gaps than in work
-    if (CLASSIFY && d.bnd_next != nullptr && blockIdx.y == 0) {
+    if (CLASSIFY && d.bnd_next != nullptr && by == 0) {
         for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * CW + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * CW)
             batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
     }
@@ -538,7 +564,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
             edge = edge & act & (as != arc);
             field_twod(k, rr, qs, dx, dy, fmaxf(r2p, 1e-30f), F, hx, hy);
             if (__builtin_expect(ballot1(edge) != 0ull, 0)) {
-                if (edge && dc.edge != nullptr) edge_handover(dc, arc, as, dc.p.hfov, F * hx, F * hy, seen);
+                if (edge && dc.edge != nullptr) edge_handover(dc, arc, as, SEG ? seg_hfov : dc.p.hfov, F * hx, F * hy, seen);
             }
             F = seen ? F : 0.0f;
             float fx = F * hx, fy = F * hy;
@@ -758,7 +784,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         __syncthreads();
         if (threadIdx.x < RPB) {
             const int64_t a = ragent[threadIdx.x];
-            if (a >= 0) d.part[(int64_t)(d.part_base + blockIdx.y) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
+            if (a >= 0) d.part[(int64_t)(d.part_base + by) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
         }
     } else {
         reduce_store(d, j0, lane, ax, ay, &ragent[wave * RPW]);
@@ -1171,6 +1197,23 @@ static void launch_cull_dyn(const Dev &d, hipStream_t st, hipEvent_t t0, hipEven
     }
     if (d.dyn_recv) CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, true>), recv_grid(d, d.n_split));
     else CSF_LAUNCH((pair_cull_kernel<P2R, CLASSIFY, BINR, false>), recv_grid(d, d.n_split));
+}
+
+// the runs of all TwoD-field parameter sets in one grid (Dev::segtab; receivers per workgroup and tile as launch_cull_dyn chooses)
+void launch_pair_segments(const Dev &d, int total_by, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
+    if (d.hi <= d.lo || total_by <= 0) return;
+    const bool p2r = d.pc.p2r != 0;
+    const int rpb = d.rpb == 32 ? 32 : 16;
+    const dim3 g = recv_grid(d, total_by, rpb);
+#define CSF_SEG_LAUNCH(P2R_, RPB_) hipExtLaunchKernelGGL((pair_cull_kernel<P2R_, true, false, true, RPB_, true, 2 * WPB, true>), g, dim3(2 * BLOCK), 0, st, t0, t1, 0, d)
+    if (rpb == 32) {
+        if (p2r) CSF_SEG_LAUNCH(true, 32);
+        else CSF_SEG_LAUNCH(false, 32);
+    } else {
+        if (p2r) CSF_SEG_LAUNCH(true, 16);
+        else CSF_SEG_LAUNCH(false, 16);
+    }
+#undef CSF_SEG_LAUNCH
 }
 
 static void launch_cull(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
