@@ -224,9 +224,11 @@ def main():
                 "rms_radius_m": float(np.sqrt(((s_[:, :2] - s_[:, :2].mean(axis=0)) ** 2).sum(axis=1).mean())),
                 "pairs_evaluated": None if w_ is None else int(w_["evaluated"]), "sources_tested": None if w_ is None else int(w_["tested"])}
 
-    # the kernels' own start / end time stamps (hipExtLaunchKernelGGL events on the engine's stream); at least 16
-    # sampled launches, every 8th tick in long runs.  (The event pool is created here, not in front of the timed region.)
-    every = max(1, min(8, args.steps // 16))
+    # the kernels' own start / end time stamps (hipExtLaunchKernelGGL events on the engine's stream).  A launch that carries
+    # events costs the tick ~5 us (profiles/r4_v2_tick_sequence.json: 120.1 us per tick with every launch sampled, 114.6 with
+    # none), so not every launch is sampled: every 8th tick in long runs, every other tick of the driver's 20-step command.
+    # (The event pool is created here, not in front of the timed region.)
+    every = max(1, min(8, args.steps // 8))
     eng.profile(every)
     eng.step(first)
     fence()
@@ -347,13 +349,17 @@ def main():
         }
         if world == 1 and not rehearse and np.isfinite(rfar) and args.every_pair_steps > 0:
             # the same population with the far-field cull off (reported beside the headline, never as `value`)
+            # (timed like the headline: the read-backs above have let the clocks drop, so a scratch engine runs ~0.1 s first
+            # and the population is then timed from tick 8)
             os.environ["CSF_FAR_EPS"] = "0"
-            ex = populate()
-            ex.step(40, sync=True)
+            sx, ex = populate(), populate()
+            ex.step(8, sync=True)
+            sx.step(600, sync=True)
             t0 = time.perf_counter()
             ex.step(args.every_pair_steps, sync=True)
             dte = time.perf_counter() - t0
             ex.close()
+            sx.close()
             del os.environ["CSF_FAR_EPS"]
             out["every_pair"] = {"value": n * args.every_pair_steps / dte, "unit": "agent-steps/s",
                                  "ms_per_step": dte / args.every_pair_steps * 1e3, "steps": args.every_pair_steps,

@@ -895,7 +895,9 @@ void set_shard(csf_engine *e) {
         // (sentinel slots behind the population take the arrivals between two re-binnings, csf_add_agents)
         d.n_pad = (std::min<int64_t>(e->cap, d.n + (e->loopback ? 0 : TAIL_SLOTS)) + 63) / 64 * 64;
     } else {
-        int64_t shard = (d.n + e->world - 1) / e->world;
+        // (several parameter sets: the class-segmented order starts every set's run at a multiple of 64 - room for that)
+        const int64_t nk = (int64_t)e->classes.size(), seg_pad = nk > 1 && nk <= 16 ? 64 * nk : 0;
+        int64_t shard = (d.n + seg_pad + e->world - 1) / e->world;
         shard = (shard + 63) / 64 * 64;
         d.lo = std::min<int64_t>(d.n, (int64_t)e->rank * shard);
         d.hi = std::min<int64_t>(d.n, d.lo + shard);
@@ -977,7 +979,8 @@ int rebin(csf_engine *e) {
         launch_records(d, e->main);     // sentinels in the new tail (the records of the road users are rewritten as they are)
     }
     d.pair_variant = pair_variant_for(e, d.n_live);
-    // Several parameter sets: up to 16 of them on an unsharded engine get the class-segmented order - the set leads the
+    // Several parameter sets: up to 16 of them get the class-segmented order (a rank of a sharded run too: the order is one of
+    // the SOURCES, which every rank holds in full, and the same on every rank) - the set leads the
     // sort key, every set becomes a run of places that starts at a multiple of 64, and the pair term is one launch of the
     // culling kernel per run with that set's constants, far-field radius and field (launch_pair_all).  Otherwise the
     // plain kernel looks every source's set up (csf_pair.hip: HET).
@@ -991,8 +994,8 @@ int rebin(csf_engine *e) {
     // tick against 387 us, at 8 192 104 against 119, at 4 096 68 against 41 (tools/hetero_rate.py; CSF_SEGMENTS=1 forces
     // it from 1 024 road users, 0 switches it off).
     const int seg_env = e->knobs.segments;
-    bool seg = d.n_classes > 1 && d.n_classes <= 16 && d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS && e->world <= 1 && !e->loopback &&
-               !e->nccl && e->class_kappa.size() == e->classes.size() &&
+    bool seg = d.n_classes > 1 && d.n_classes <= 16 && d.pair_variant == 0 && d.n >= BIN_MIN_AGENTS &&
+               e->class_kappa.size() == e->classes.size() &&
                (seg_env >= 0 ? seg_env != 0 : d.n_live >= 2048 * (int64_t)d.n_classes);
     SegTable tab{};
     if (seg) {

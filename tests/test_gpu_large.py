@@ -500,6 +500,65 @@ def test_sharded_engine_with_parameter_sets(amd):
     ref.close()
 
 
+@pytest.mark.parametrize("world,n", [(2, 8192), (3, 9000)])
+def test_sharded_engine_with_parameter_sets_in_the_class_segmented_order(amd, world, n):
+    """Ranks of a sharded run with several parameter sets take the class-segmented order too (csf_engine.hip: rebin - the order
+    is one of the SOURCES, which every rank holds in full): four sets over two vehicle classes, N >= 8 192, a loopback group
+    of `world` ranks; the culling kernel must be the one that runs.  41 ticks (across the re-binning from gathered records at
+    tick 32) against the unsharded engine; the clamped repulsive sums of 200 receivers on the state the group is in
+    against the oracle, every source with ITS set's field, field of view and far-field radius."""
+    box = 180.0
+    s0, off, dq = population(n, box, seed=21)
+    s = np.zeros((n, 6)); s[:, :4] = s0[:, :4]
+    pods = [amd.pod("twod"), amd.pod("invpend", hfov=1.0, f_0=10.0), amd.pod("twod", hfov=3.6, sigma_0=0.6),
+            amd.pod("twod", hfov=2.5, f_0=4.0, sigma_1=5.5)]
+    rng = np.random.default_rng(5)
+    cls = rng.integers(0, 4, n).astype(np.uint8)
+
+    def build():
+        e = amd.Engine(pods[0], n)
+        e.set_param_classes(pods)
+        e.add_agents(s, 5.0)
+        e.set_dest_queue(np.arange(n), off, dq, reset=True)
+        e.set_agent_class(np.arange(n), cls)
+        return e
+
+    ref = build()
+    members = [build() for _ in range(world)]
+    amd.Engine.loopback_group(members)
+    tab = [orc.Params.from_buffer_copy(bytes(p)) for p in pods]
+    recv = np.sort(rng.choice(n, 200, replace=False))
+    done = 0
+    for chunk in (1, 9, 31):
+        ref.step(chunk)
+        amd.Engine.step_group(members, chunk)
+        done += chunk
+        got, _ = gather_blocks(members)
+        dev = np.abs(got[:, :2] - ref.state()[:, :2]).max()
+        # forces on the state the group is in: every member evaluates its block
+        worst = 0.0
+        ox, oy = orc.column_sums(tab, got[:, 0], got[:, 1], got[:, 2], got[:, 3], recv, cls=cls)
+        for m in members:
+            m.calc_forces()
+            lo, hi = m.shard_range()
+            fdx, fdy, rx, ry = m.force_parts()
+            mine = (recv >= lo) & (recv < hi)
+            r = recv[mine]
+            lim, mag = np.hypot(fdx[r], fdy[r]), np.maximum(np.hypot(ox[mine], oy[mine]), 1e-300)
+            sc = np.minimum(1.0, lim / mag)
+            scale = max(np.hypot(ox[mine] * sc, oy[mine] * sc).max(), 1.0)
+            df = np.maximum(np.abs(rx[r] - ox[mine] * sc), np.abs(ry[r] - oy[mine] * sc)) / scale
+            worst = max(worst, df.max())
+        print(f"  tick {done:2d}: vs unsharded {dev:.1e} m, clamped sums vs oracle {worst:.1e}")
+        assert dev < (2e-6 if done <= 10 else 1e-4 * box), (done, dev)
+        assert worst < 1e-4, (done, worst)
+    assert all(m.count_pairs()[1] == "pair_cull_kernel" for m in members)
+    assert all((m.status()[slice(*m.shard_range())] == 0).all() and m.near_dropped() == 0 for m in members)
+    for m in members[::-1]:
+        m.close()
+    ref.close()
+
+
 # --------------------------------------------------------------------------- measurement plumbing
 
 def test_profiling_event_pool_is_bounded(amd):

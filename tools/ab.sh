@@ -13,7 +13,7 @@ shift
 for rep in 1 2; do
   for name in "$@"; do
     echo -n "$name: "
-    CSF_LIB=$ROOT/build/ab/$name.so python3 $ROOT/bench.py --steps ${STEPS:-600} --warmup 30 --cpu-ticks 0 ${BENCH_ARGS} |
+    CSF_LIB=$ROOT/build/ab/$name.so python3 $ROOT/bench.py --steps ${STEPS:-600} --warmup ${WARMUP:-30} --cpu-ticks 0 ${BENCH_ARGS} |
       grep -o '"value": [0-9.]*\|"launch_us": [0-9.]*\|"healthy": [a-z]*' | tr '\n' ' '
     echo
   done

@@ -9,6 +9,8 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 bash $ROOT/tools/pmc_passes.sh $TAG --steps 200 --warmup 20 > $OUT/pmc_passes.log 2>&1
 python3 $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/pmc_$TAG pair_cull_kernel "N=16384 TwoDBicycle, bench.py --steps 200 --warmup 20 (warm: ~0.1 s pre-roll)" > $OUT/pair_kernel_pmc.json
+# bench.py takes roofline.traffic from the newest profiles/r*_v*_pair_kernel_pmc.json of the SAME build: put it there first
+case $TAG in r[0-9]*_v[0-9]*) cp $OUT/pair_kernel_pmc.json $ROOT/profiles/${TAG}_pair_kernel_pmc.json ;; esac
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 20 --warmup 5 --cpu-ticks 0 --every-pair-steps 0 > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
