@@ -2231,9 +2231,16 @@ int calibrate_comm_stream(csf_engine *e) {
     Dev dd = e->d;
     dd.edge = nullptr;          // (no per-agent launch follows that would take undecided pairs over)
     dd.bnd_next = nullptr;      // (the circles stay as they are)
-    hipEvent_t a = nullptr, b = nullptr;
-    HIPCHK(e, hipEventCreate(&a));
-    HIPCHK(e, hipEventCreate(&b));
+    struct Events {   // (destroyed on every way out)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } evs;
+    HIPCHK(e, hipEventCreate(&evs.a));
+    HIPCHK(e, hipEventCreate(&evs.b));
+    const hipEvent_t a = evs.a, b = evs.b;
     float us[2] = {0.f, 0.f};
     for (int mode = 0; mode < 2; mode++) {
         e->comm_second = mode == 1;
@@ -2258,8 +2265,6 @@ int calibrate_comm_stream(csf_engine *e) {
         HIPCHK(e, hipEventElapsedTime(&ms, a, b));
         us[mode] = ms * 1e3f / 32.f;
     }
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
     {   // the slowest rank's figures, on every rank
         DevBuf<float> t;
         HIPCHK(e, t.alloc(2));
