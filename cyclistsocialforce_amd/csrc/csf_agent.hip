@@ -113,10 +113,33 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
                         break;
                     }
                     const bool seen = !untracked_exact_xy(er.xi, er.yi, g.x, g.y, g.psi, er.hfov, d.p.priority_rule == CSF_P2R);
-                    if (seen != (er.seen != 0)) {
-                        cx += seen ? (double)er.fx : -(double)er.fx;
-                        cy += seen ? (double)er.fy : -(double)er.fy;
+                    double wx = 0, wy = 0;                       // what the reference adds for this pair ...
+                    // (road users that coincide in fp64 contribute nothing - deviation D2 - though their records may be an ulp apart)
+                    if (seen && (g.x != er.xi || g.y != er.yi)) {
+                        wx = (double)er.fx;
+                        wy = (double)er.fy;
+                        if (er.flags & EDGE_SIDE) {              // np.sign(phi) by the reference's own chain (vehicle.py:1617-1625)
+                            double psii = er.psi;
+                            if (er.flags & EDGE_HEADING_REC)
+                                psii = atan2((double)__int_as_float(__double2hiint(er.psi)), (double)__int_as_float(__double2loint(er.psi)));
+                            const int sg = sign_phi_exact(er.xi, er.yi, psii, g.x, g.y);
+                            if (sg < 0) {
+                                wx = (double)er.fx2;
+                                wy = (double)er.fy2;
+                            } else if (sg == 0) {                // phi = 0 exactly: no tangential part, |F| = P along the line
+                                const double ex = g.x - er.xi, ey = g.y - er.yi, P = sqrt(wx * wx + wy * wy);
+                                const double il = 1.0 / sqrt(ex * ex + ey * ey);
+                                wx = P * ex * il;
+                                wy = P * ey * il;
+                            }
+                        }
                     }
+                    if (er.flags & EDGE_SEEN) {                  // ... minus what the pair kernel added
+                        wx -= (double)er.fx;
+                        wy -= (double)er.fy;
+                    }
+                    cx += wx;
+                    cy += wy;
                     at = er.next;
                 }
                 d.edge_head[a] = 0;

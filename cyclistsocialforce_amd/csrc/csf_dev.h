@@ -53,15 +53,21 @@ struct PairConsts {
 // hands it to the per-agent kernel, which decides it as the reference does - fp64, atan2 -> limitAngle -> angleDifference
 // (intersection.py:711-741; csf_dev.h: untracked_exact_xy) - on the receiver's own fp64 state and the source's position
 // as it was when the pair kernel ran, and adds or removes the pair's force (csf_agent.hip: COMBINE).
+// The same for np.sign(phi) of the TwoD field (vehicle.py:1625): where the receiver sits within rounding of the line ahead of
+// the source the pair kernel evaluates the pair with sign +1 (fx, fy) and with sign -1 (fx2, fy2), and the per-agent kernel
+// picks by the reference's own chain - acos -> limitAngle -> sign (csf_dev.h: sign_phi_exact).
 struct EdgeRec {
     double xi, yi;        // the source's position (fp64 state at the time of the pair launch)
+    double psi;           // ... its heading (EDGE_SIDE entries; EDGE_HEADING_REC: (cos, sin) of the record, low and high word)
     double hfov;          // ... and its field of view (intersection.py:733-735: the source's parameter set)
-    float fx, fy;         // the force of the pair, from the precise records
+    float fx, fy;         // the force of the pair, from the precise records (EDGE_SIDE: with np.sign(phi) = +1)
+    float fx2, fy2;       // EDGE_SIDE: the force with np.sign(phi) = -1
     int32_t recv;         // the receiver's slot
     int32_t next;         // 1 + ring index of the next entry of this receiver, 0: none
     uint32_t stamp;       // Dev::edge_stamp of the launch that wrote it
-    int32_t seen;         // what the pair kernel decided (and added accordingly)
+    int32_t flags;        // EDGE_SEEN: the pair kernel took the source for tracked (and added fx, fy); EDGE_SIDE
 };
+constexpr int32_t EDGE_SEEN = 1, EDGE_SIDE = 2, EDGE_HEADING_REC = 4;   // HEADING_REC: psi holds the record's (cos, sin) as two floats
 constexpr unsigned EDGE_CAP = 4096;
 constexpr uint32_t CSF_ST_EDGE = 0x80000000u;   // status[slot], internal: entries wait in the ring for this receiver (masked by csf_status)   // ring of entries; a tick produces a few dozen at N = 16 384
 
@@ -323,6 +329,17 @@ __device__ __forceinline__ bool untracked_exact_xy(double xi, double yi, double 
     const double az = limit_angle(atan2(yi - yj, xi - xj));        // :711-718
     const double rel = angle_diff(psij, az);                       // :724-726
     return (fabs(rel) > hfov / 2) | (p2r & (rel > 0));             // :733-741
+}
+
+// np.sign(phi) of vehicle.py:1617-1625 as the reference computes it - cart2polar (acos, utils.py:185-194), limitAngle - for
+// the source (xi, yi, psii) and a receiver at (xj, yj): -1, 0 or +1
+__device__ __forceinline__ int sign_phi_exact(double xi, double yi, double psii, double xj, double yj) {
+    const double dx = xj - xi, dy = yj - yi;                       // :1615-1616
+    const double rho = sqrt(dx * dx + dy * dy);
+    double p = acos(dx / rho);
+    if (dy < 0) p = -p;
+    const double phi = limit_angle(p - psii);                      // :1618
+    return (phi > 0) - (phi < 0);
 }
 
 // a + b as an unevaluated sum hi + lo (Knuth's TwoSum: no ordering of |a|, |b| assumed)

@@ -94,27 +94,43 @@ __device__ __forceinline__ bool tracked_precise(const PairConsts &k, float chs, 
     return in;
 }
 
+// np.sign(phi) of the TwoD field (vehicle.py:1625) for a pair formed from the precise records: is the receiver within rounding
+// of the line AHEAD of the source (behind it the field does not jump)?  rho sin(phi) against the band of tracked_precise's side
+// test - the same arithmetic: offsets, and a heading known to 2^-24.
+__device__ __forceinline__ bool side_undecided(const PairConsts &k, const float4 q, float dx, float dy, float r2) {
+    const float rho = fast_sqrt(r2);
+    return (dx * q.z + dy * q.w >= 0.0f) & (fabsf(dy * q.z - dx * q.w) < k.sideP0 + k.sideP1 * rho) & (r2 > 0.0f);
+}
+
 // One undecidable pair -> the ring the per-agent kernel reads (csf_dev.h: EdgeRec; csf_agent.hip: COMBINE): the source's
 // fp64 position as it is now, its field of view, the pair's force (fx, fy) and whether the caller has added it (seen).
 // The source's position: its fp64 state where this device holds it, else (a rank of a sharded run) rebuilt from the record.
-__device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int32_t a_src, double hfov, float fx, float fy, bool seen) {
+// side: np.sign(phi) of the pair is undecided as well - (fx, fy) was evaluated with +1, (fx2, fy2) with -1.
+__device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int32_t a_src, double hfov, float fx, float fy, bool seen,
+                                              bool side = false, float fx2 = 0.0f, float fy2 = 0.0f) {
     EdgeRec er;
     if (d.state_current) {
         er.xi = d.s[a_src];
         er.yi = d.s[d.cap + a_src];
+        er.psi = d.s[2 * d.cap + a_src];
     } else {   // a rank of a sharded run: origin + record + what the record left over = the owner's fp64 position to ~1e-14 m
         const float4 q = d.rec[a_src];
         const float2 o = d.rorg[a_src], lo = d.reclo[a_src];
         er.xi = (d.ox + (double)o.x) + ((double)q.x + (double)lo.x);
         er.yi = (d.oy + (double)o.y) + ((double)q.y + (double)lo.y);
+        // (a foreign heading is known as the fp32 pair of its record only; the per-agent kernel - the home of fp64 - turns it into
+        // an angle: EDGE_HEADING_REC)
+        er.psi = __hiloint2double(__float_as_int(q.w), __float_as_int(q.z));
     }
     er.hfov = hfov;
     er.fx = fx;
     er.fy = fy;
+    er.fx2 = fx2;
+    er.fy2 = fy2;
     er.recv = a_recv;
     er.next = 0;
     er.stamp = d.edge_stamp;
-    er.seen = seen ? 1 : 0;
+    er.flags = (seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC);
     const unsigned at = atomicAdd(d.edge_n, 1u) % EDGE_CAP;
     er.next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
     d.edge[at] = er;
@@ -123,8 +139,12 @@ __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int3
 
 // vehicle.py:1560-1648: force of source (record q) on receiver r, returned as magnitude F and an
 // unnormalised direction (gx, gy) with F already holding 1/|g|.  (dx, dy) = receiver - source.
+// SGN0: np.sign(phi) with sign(0) = 0, as the reference has it; false: the sign bit of sin(phi), bit for bit what the packed
+// field (field_twod_x2) computes - for the caller that takes a fast-path evaluation back.
+// sgf: +1 / -1 puts that in place of np.sign(phi) (0: the pair's own) - for a pair whose sign is decided elsewhere.
+template <bool SGN0 = true>
 __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, const float4 q, float dx,
-                                           float dy, float r2, float &F, float &gx, float &gy) {
+                                           float dy, float r2, float &F, float &gx, float &gy, float sgf = 0.0f) {
     float inv = fast_rsq(r2), rho = r2 * inv;
     float srel = q.w * r.c - q.z * r.s;               // sin(psi0 - psi)            :1595
     float s2 = srel * srel;
@@ -138,8 +158,9 @@ __device__ __forceinline__ void field_twod(const PairConsts &k, const Recv &r, c
     float rs = fast_rsq(a);
     float big = a * rs, small = 0.5f * fabsf(sphi) * rs;
     float sg = __builtin_amdgcn_fmed3f(sphi * 1e38f, -1.0f, 1.0f);  // np.sign(phi), 0 at phi = 0 :1625
+    if (sgf != 0.0f) sg = sgf;
     bool pos = cphi >= 0.0f;
-    float bs = big * sg, al = 0.5f * sphi * rs;
+    float bs = (SGN0 || sgf != 0.0f) ? big * sg : __builtin_copysignf(big, sphi), al = 0.5f * sphi * rs;
     float h1 = pos ? small : big;                     // sqrt((1 - cos phi)/2)       :1624
     float h2s = pos ? bs : al;                        // sqrt((1 + cos phi)/2) * sign(phi)
     float sigma = sga - sgb * h1;                     // :1624
@@ -184,11 +205,19 @@ __device__ __forceinline__ void field_twod_x2(const PairConsts &k, const Recv &r
     v2f rs = rsq2(a);
     v2f big = a * rs, hrs = 0.5f * rs;
     v2f al = sphi * hrs;
-    const v2f blown = sphi * 1e38f;                   // one packed multiply, then clamp to -1, 0, +1
-    v2f sg{__builtin_amdgcn_fmed3f(blown.x, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(blown.y, -1.0f, 1.0f)};
-    v2f small = al * sg, bs = big * sg;                // |sphi| hrs and sign(phi) big          :1624-1625
+    // np.sign(phi) (:1625) as the sign BIT of sin(phi) (two v_bfi; sign(0) = 0 does not come out of it).  A pair within fp32
+    // rounding of phi = 0 - |sin(phi)| below the band of the sine of a bearing at a metre (csf_engine.hip: set_fov_band), which
+    // holds phi = 0 itself - is noted like a near pair (NEARFLAG) and decided where those are corrected (csf_pair.hip: near_drain)
+    if (NEARFLAG) {
+        const float Ts = k.fovT0 + k.fovT1;           // (|al| <= 0.71 |sin phi|: nothing inside the band is missed)
+        unsigned long long s0 = __builtin_amdgcn_ballot_w64(__builtin_fabsf(al.x) <= Ts), s1 = __builtin_amdgcn_ballot_w64(__builtin_fabsf(al.y) <= Ts);   // (<=: phi = 0 itself with the band switched off)
+        if (!FULL) s0 &= __builtin_amdgcn_ballot_w64(valid0), s1 &= __builtin_amdgcn_ballot_w64(valid1);
+        *near0 |= s0;
+        *near1 |= s1;
+    }
+    v2f bs{__builtin_copysignf(big.x, sphi.x), __builtin_copysignf(big.y, sphi.y)};    // sign(phi) big          :1625
     const bool p0 = cphi.x >= 0.0f, p1 = cphi.y >= 0.0f;
-    v2f h1{p0 ? small.x : big.x, p1 ? small.y : big.y};
+    v2f h1{p0 ? __builtin_fabsf(al.x) : big.x, p1 ? __builtin_fabsf(al.y) : big.y};   // |sin phi| hrs      :1624
     v2f h2s{p0 ? bs.x : al.x, p1 ? bs.y : al.y};
     v2f sigma = sga - sgb * h1;
     v2f hd = 0.5f * sgb * h2s;                        // = -dsig

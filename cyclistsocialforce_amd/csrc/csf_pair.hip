@@ -348,9 +348,12 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                                      *(const float *)((const char *)tc + o), *(const float *)((const char *)ts + o));
         const float dx = ru.x - q.x, dy = ru.y - q.y, r2 = dx * dx + dy * dy;
         float F, gx, gy;
-        field_twod(k, ru, q, dx, dy, fmaxf(r2, 1e-30f), F, gx, gy);
+        field_twod<false>(k, ru, q, dx, dy, fmaxf(r2, 1e-30f), F, gx, gy);
         {   // (the wave mask of ONE compare, masked as a scalar: ballot1)
-            const unsigned long long nm = ballot1(r2 < k.rnear2) & (qlen >= WAVE ? ~0ull : ((1ull << qlen) - 1ull));
+            // (+ np.sign(phi) within rounding of phi = 0: csf_field.h field_twod_x2)
+            const float inv1 = fast_rsq(fmaxf(r2, 1e-30f));
+            const unsigned long long nm = (ballot1(r2 < k.rnear2) | ballot1(__builtin_fabsf((dy * q.z - dx * q.w) * inv1) <= k.fovT0 + k.fovT1)) &
+                                          (qlen >= WAVE ? ~0ull : ((1ull << qlen) - 1ull));
             if (__builtin_expect(nm != 0ull, 0)) near_note(((nm >> lane) & 1ull) != 0ull, o >> 2);
         }
         F = v ? F : 0.0f;
@@ -562,15 +565,21 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
             bool edge;
             bool seen = tracked_precise<P2R>(kc, k.chs, rr, dx, dy, r2p, edge) & act & (as != arc);
             edge = edge & act & (as != arc);
-            field_twod(k, rr, qs, dx, dy, fmaxf(r2p, 1e-30f), F, hx, hy);
-            if (__builtin_expect(ballot1(edge) != 0ull, 0)) {
-                if (edge && dc.edge != nullptr) edge_handover(dc, arc, as, SEG ? seg_hfov : dc.p.hfov, F * hx, F * hy, seen);
+            // np.sign(phi) undecided even here: evaluated with +1, and with -1 for the per-agent kernel to choose from
+            const bool side = side_undecided(kc, qs, dx, dy, r2p) & act & (as != arc) & (dc.edge != nullptr);   // (nobody to hand it to: the pair's own sign)
+            field_twod(k, rr, qs, dx, dy, fmaxf(r2p, 1e-30f), F, hx, hy, side ? 1.0f : 0.0f);
+            if (__builtin_expect((ballot1(edge) | ballot1(side)) != 0ull, 0)) {
+                if ((edge | (side & seen)) && dc.edge != nullptr) {
+                    float F2 = 0.0f, h2x = 0.0f, h2y = 0.0f;
+                    if (side) field_twod(k, rr, qs, dx, dy, fmaxf(r2p, 1e-30f), F2, h2x, h2y, -1.0f);
+                    edge_handover(dc, arc, as, SEG ? seg_hfov : dc.p.hfov, F * hx, F * hy, seen, side, F2 * h2x, F2 * h2y);
+                }
             }
             F = seen ? F : 0.0f;
             float fx = F * hx, fy = F * hy;
             {   // ... minus what the fast path added for it (every noted pair was kept and evaluated there)
                 const float sx = rr.x - tx[idx], sy = rr.y - ty[idx];
-                field_twod(k, rr, make_float4(0.f, 0.f, tc[idx], ts[idx]), sx, sy, fmaxf(sx * sx + sy * sy, 1e-30f), F, hx, hy);
+                field_twod<false>(k, rr, make_float4(0.f, 0.f, tc[idx], ts[idx]), sx, sy, fmaxf(sx * sx + sy * sy, 1e-30f), F, hx, hy);
                 F = act ? F : 0.0f;
                 fx -= F * hx;
                 fy -= F * hy;
@@ -864,9 +873,13 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
                 bool mg, lt, edge = false;
                 bool in = tracked_m<P2R>(d.pc, ks.chs, r[u], dx, dy, r2, mg, lt);
                 mg = mg & lt;
-                {   // near sources, and sources within rounding of a field-of-view edge (both rare): (dx, dy) from the precise
-                    // records (precise_delta) and the decision on them; this kernel's sources sit in slot order
-                    const bool fix = (r2 < d.pc.rnear2) | mg;
+                const bool twod = !(FIELD == 1 || (FIELD == 2 && ks.ipd != 0.0f));   // (ipd: Bicycle sets only)
+                bool side = false;
+                {   // near sources, sources within rounding of a field-of-view edge and - TwoD field - receivers within rounding of
+                    // the line ahead of the source, where np.sign(phi) turns (all rare): (dx, dy) from the precise records
+                    // (precise_delta) and the decisions on them; this kernel's sources sit in slot order
+                    const bool sd = twod & (fabsf(dy * q.z - dx * q.w) < d.pc.fovT1 + d.pc.fovT0 * (0.0625f * r2 + 4.0f));   // (rho <= r2 / 16 + 4)
+                    const bool fix = (r2 < d.pc.rnear2) | mg | sd;
                     const int64_t jr = j0 + u;
                     if (ballot1(fix) != 0ull && jr < d.hi) {
                         float px, py;
@@ -878,14 +891,20 @@ __global__ __launch_bounds__(BLOCK) void pair_kernel(const Dev d) {
                         r2 = dx * dx + dy * dy;
                         if (fix) in = tracked_precise<P2R>(d.pc, ks.chs, r[u], dx, dy, r2, edge) & (as != (int32_t)jr);
                         edge = edge & fix & (as != (int32_t)jr);
+                        side = fix & twod & (as != (int32_t)jr) & side_undecided(d.pc, q, dx, dy, r2) & (d.edge != nullptr);   // (nobody to hand it to: the pair's own sign)
                     }
                 }
                 r2 = fmaxf(r2, 1e-30f);  // self / coincident pair: keep every intermediate finite (F is masked)
                 float F, gx, gy;
-                if (FIELD == 1 || (FIELD == 2 && ks.ipd != 0.0f)) field_bicycle(ks, q, qb, dx, dy, r2, F, gx, gy);   // (ipd: Bicycle sets only)
-                else field_twod(ks, r[u], q, dx, dy, r2, F, gx, gy);
-                if (d.edge != nullptr && ballot1(edge) != 0ull) {   // undecidable even on the precise records: the per-agent kernel decides
-                    if (edge) edge_handover(d, (int32_t)(j0 + u), (int32_t)(base + t), HET ? d.ptab[tcls[t]].hfov : d.p.hfov, F * gx, F * gy, in);
+                if (!twod) field_bicycle(ks, q, qb, dx, dy, r2, F, gx, gy);
+                else field_twod(ks, r[u], q, dx, dy, r2, F, gx, gy, side ? 1.0f : 0.0f);
+                if (d.edge != nullptr && (ballot1(edge) | ballot1(side)) != 0ull) {   // undecidable even on the precise records: the per-agent kernel decides
+                    if (edge | (side & in)) {
+                        float F2 = 0.0f, h2x = 0.0f, h2y = 0.0f;
+                        if (side) field_twod(ks, r[u], q, dx, dy, r2, F2, h2x, h2y, -1.0f);
+                        edge_handover(d, (int32_t)(j0 + u), (int32_t)(base + t), HET ? d.ptab[tcls[t]].hfov : d.p.hfov, F * gx, F * gy, in, side,
+                                      F2 * h2x, F2 * h2y);
+                    }
                 }
                 F = in ? F : 0.0f;
                 ax[u] += F * gx;
@@ -1119,11 +1138,20 @@ __global__ void pair_kat_kernel(const Dev d, const float4 *src, const float2 *sr
         fx = F * gx;
         fy = F * gy;
     } else if (t & 1) {
+        // the packed field as the cull-first kernel uses it: a pair it flags (near, or np.sign(phi) within rounding of phi = 0)
+        // is evaluated once more by the unpacked field - there from the precise records - and that result counts
         float px = 0.f, py = 0.f;
-        if (t & 2) field_twod_x2<true>(k, r, v2f{q.x, q.x}, v2f{q.y, q.y}, v2f{q.z, q.z}, v2f{q.w, q.w}, true, true, px, py);
-        else field_twod_x2<false>(k, r, v2f{r.x, q.x}, v2f{r.y, q.y}, v2f{1.f, q.z}, v2f{0.f, q.w}, false, true, px, py);
+        unsigned long long n0 = 0ull, n1 = 0ull;
+        if (t & 2) field_twod_x2<true, true>(k, r, v2f{q.x, q.x}, v2f{q.y, q.y}, v2f{q.z, q.z}, v2f{q.w, q.w}, true, true, px, py, &n0, &n1);
+        else field_twod_x2<false, true>(k, r, v2f{r.x, q.x}, v2f{r.y, q.y}, v2f{1.f, q.z}, v2f{0.f, q.w}, false, true, px, py, &n0, &n1);
         fx = (t & 2) ? 0.5f * px : px;
         fy = (t & 2) ? 0.5f * py : py;
+        if ((n1 >> (threadIdx.x & 63)) & 1ull) {
+            float F, gx, gy;
+            field_twod(k, r, q, dx, dy, r2, F, gx, gy);
+            fx = F * gx;
+            fy = F * gy;
+        }
     } else {
         float F, gx, gy;
         field_twod(k, r, q, dx, dy, r2, F, gx, gy);

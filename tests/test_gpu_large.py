@@ -83,14 +83,13 @@ def test_config4_262144_twod_column_sums(amd, monkeypatch):
     _, x3, y3, _, _ = rep()
     # (c) the same terms: in slot order the pairs are formed in scene coordinates (3e-5 m at 400 m from the origin; + the
     # near-pair correction), in binned order relative to the receiver group's origin; sources within rounding of a
-    # field-of-view edge are decided in fp64 by both.  Rounding apart, the same sums - but for a receiver that sits within
-    # (3e-5 m / distance) rad of a source's heading line, ahead of it: the tangential part of the field jumps there
-    # (np.sign(phi), vehicle.py:1625; DESIGN D11), and the variant forced here - not the engine's choice at this size, which
-    # (a) pins to the oracle - resolves that line 30 times coarser.  Three of 262 144 receivers in this population.
+    # field-of-view edge, and receivers within rounding of the line ahead of a source (np.sign(phi), vehicle.py:1625: the
+    # tangential part of the field jumps there - until round 4 three receivers of this population took the other side in the
+    # variant forced here), are decided in fp64 by both.  Rounding apart, the same sums for every one of the 262 144 receivers.
     sc = max(np.hypot(x1, y1).max(), 1.0)
     dd = np.maximum(np.abs(x1 - x3), np.abs(y1 - y3))
-    print(f"   binned vs slot order: median {np.median(dd) / sc:.1e}, 99.9 % {np.percentile(dd, 99.9) / sc:.1e}, {(dd > 1e-4 * sc).sum()} receivers beyond 1e-4")
-    assert np.median(dd) < 1e-6 * sc and np.percentile(dd, 99.9) < 1e-4 * sc and (dd > 1e-4 * sc).sum() <= 8
+    print(f"   binned vs slot order: median {np.median(dd) / sc:.1e}, 99.9 % {np.percentile(dd, 99.9) / sc:.1e}, max {dd.max() / sc:.1e}")
+    assert np.median(dd) < 1e-6 * sc and dd.max() < 1e-4 * sc
 
 
 # --------------------------------------------------------------------------- BASELINE config 5

@@ -657,6 +657,60 @@ def test_no_receiver_leaves_the_band_at_a_field_of_view_edge(amd, monkeypatch):
     assert w0 > 1e-3, "the edge case this run is known for has disappeared: choose another seed"
 
 
+@pytest.mark.auto_variant
+@pytest.mark.parametrize("n,kernel", [(1500, "pair_kernel"), (4096, "pair_cull_kernel")])
+def test_sign_of_phi_where_the_receiver_sits_on_the_line_ahead_of_a_source(amd, monkeypatch, n, kernel):
+    """vehicle.py:1625 takes np.sign(phi): the tangential part of the TwoD field jumps (its direction by up to 25 degrees) where
+    the receiver sits exactly ahead of the source.  300 receivers of this crowd are put 3 - 40 m ahead of a source, off its
+    heading line by +-1e-9 ... +-1e-6 m - far below what fp32 resolves at coordinates of ~300 m (1.5e-5 m) - and every
+    force must still be the oracle's: such a pair is flagged by the fast path (|sin phi| within its rounding band), taken from the
+    precise records, and where even they cannot tell (a heading is known to 2^-24 there) the per-agent kernel decides by the
+    reference's own chain - acos, limitAngle, sign - on the fp64 states (csf_dev.h: sign_phi_exact).  With the bands switched off
+    (CSF_FOV_BAND=0) the fp32 sign is back, and about half of the planted receivers are off."""
+    rng = np.random.default_rng(77)
+    box, base = 150.0, 220.0                                       # coordinates 220 ... 370 m
+    x = base + rng.uniform(0, box, n); y = base + rng.uniform(0, box, n)
+    psi = rng.uniform(-np.pi, np.pi, n); v = rng.uniform(3, 6, n)
+    m = 300
+    src = rng.choice(n // 2, m, replace=False)                     # sources among the first half, receivers among the second
+    rcv = n // 2 + rng.choice(n - n // 2, m, replace=False)
+    dist = rng.uniform(3.0, 40.0, m)
+    offs = np.r_[1e-9, -1e-9, 1e-8, -1e-8, 1e-7, -1e-7, 1e-6, -1e-6][np.arange(m) % 8]     # (phi >= 2.5e-11: far above the reference's own rounding)
+    x[rcv] = x[src] + dist * np.cos(psi[src]) - offs * np.sin(psi[src])
+    y[rcv] = y[src] + dist * np.sin(psi[src]) + offs * np.cos(psi[src])
+    psi[rcv] = psi[src] + np.pi + rng.uniform(-1.0, 1.0, m)        # (facing the source, more or less: it is inside their field of view)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    dq = np.zeros((n, 2, 3)); dq[:, 0, 0] = x; dq[:, 0, 1] = y
+    dq[:, 1, 0] = x + 60 * np.cos(psi); dq[:, 1, 1] = y + 60 * np.sin(psi)
+    off = np.arange(n + 1, dtype=np.int64) * 2
+    p = orc.default_params("twod")
+    ox, oy = orc.column_sums(p, x, y, psi, v, np.arange(n))
+
+    def planted_off(band):
+        if band is None:
+            monkeypatch.delenv("CSF_FOV_BAND", raising=False)
+        else:
+            monkeypatch.setenv("CSF_FOV_BAND", band)
+        e = make_engine(amd, "twod", s0, 5.0, off, dq.reshape(-1, 3))
+        assert e.count_pairs()[1] == kernel
+        e.calc_forces()
+        fdx, fdy, rx, ry = e.force_parts()
+        lim, mag = np.hypot(fdx, fdy), np.maximum(np.hypot(ox, oy), 1e-300)
+        sc = np.minimum(1.0, lim / mag)
+        scale = max(np.hypot(ox * sc, oy * sc).max(), 1.0)
+        err = np.maximum(np.abs(rx - ox * sc), np.abs(ry - oy * sc)) / scale
+        assert e.near_dropped() == 0
+        e.close()
+        return err
+
+    err = planted_off(None)
+    print(f"  {kernel}: worst of all {n} receivers {err.max():.1e}, of the {m} planted ones {err[rcv].max():.1e}")
+    assert err.max() < 1e-4
+    err0 = planted_off("0")
+    print(f"  fp32 sign (CSF_FOV_BAND=0): {(err0[rcv] > 1e-4).sum()} of the {m} planted receivers beyond 1e-4, worst {err0[rcv].max():.1e}")
+    assert (err0[rcv] > 1e-4).sum() > m // 10, "the planted pairs no longer show the jump: the test has lost its teeth"
+
+
 @pytest.mark.parametrize("model,hfov,rule", [("twod", 2 * np.pi / 3, 0), ("twod", 2 * np.pi / 3, 1), ("bicycle", 4.0, 0),
                                              ("twod", np.pi, 0)])
 def test_untracked_matrix_is_the_oracles_at_4096(amd, model, hfov, rule):
