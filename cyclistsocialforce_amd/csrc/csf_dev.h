@@ -19,6 +19,7 @@ struct PairConsts {
     float kexp;                        // log2(e)
     float chs;                         // -cos^2(hfov/2) for hfov <= pi, +cos^2 beyond (intersection.py:733-736)
     float ch;                          // cos(hfov/2) (batch classification)
+    float chm, chp;                    // ch -+ 1e-4: the margins of that classification (kernel arguments, not registers: csf_pair.hip classify_batch)
     float ipd;                         // Bicycle field: 1 / p_decay (vehicle.py:1095-1099)
     int32_t p2r;                       // intersection.py:739-741
     int32_t f0_zero;                   // vehicle.py:1592-1593

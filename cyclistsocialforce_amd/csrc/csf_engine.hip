@@ -589,6 +589,8 @@ void derive_pair_consts(const csf_params &p, PairConsts &k, double rnear) {
     k.chs = (float)(p.hfov <= PI_ ? -ch * ch : ch * ch);
     if (p.hfov >= 2 * PI_) k.chs = 4.0f;  // full circle: every bearing is inside (t|t| + 4 rho^2 > 0)
     k.ch = (float)ch;
+    k.chm = k.ch - 1e-4f;
+    k.chp = k.ch + 1e-4f;
     k.chk = p.hfov >= 2 * PI_ ? -2.0f : (float)ch;      // (keep_x2: cos(bearing) > chk)
     k.p2r = p.priority_rule == CSF_P2R;
     if (p.model == CSF_BICYCLE) {

@@ -108,32 +108,34 @@ __device__ __forceinline__ bool side_undecided(const PairConsts &k, const float4
 // side: np.sign(phi) of the pair is undecided as well - (fx, fy) was evaluated with +1, (fx2, fy2) with -1.
 __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int32_t a_src, double hfov, float fx, float fy, bool seen,
                                               bool side = false, float fx2 = 0.0f, float fy2 = 0.0f) {
-    EdgeRec er;
+    double xi, yi, psi;
     if (d.state_current) {
-        er.xi = d.s[a_src];
-        er.yi = d.s[d.cap + a_src];
-        er.psi = d.s[2 * d.cap + a_src];
+        xi = d.s[a_src];
+        yi = d.s[d.cap + a_src];
+        psi = d.s[2 * d.cap + a_src];
     } else {   // a rank of a sharded run: origin + record + what the record left over = the owner's fp64 position to ~1e-14 m
         const float4 q = d.rec[a_src];
         const float2 o = d.rorg[a_src], lo = d.reclo[a_src];
-        er.xi = (d.ox + (double)o.x) + ((double)q.x + (double)lo.x);
-        er.yi = (d.oy + (double)o.y) + ((double)q.y + (double)lo.y);
+        xi = (d.ox + (double)o.x) + ((double)q.x + (double)lo.x);
+        yi = (d.oy + (double)o.y) + ((double)q.y + (double)lo.y);
         // (a foreign heading is known as the fp32 pair of its record only; the per-agent kernel - the home of fp64 - turns it into
         // an angle: EDGE_HEADING_REC)
-        er.psi = __hiloint2double(__float_as_int(q.w), __float_as_int(q.z));
+        psi = __hiloint2double(__float_as_int(q.w), __float_as_int(q.z));
     }
-    er.hfov = hfov;
-    er.fx = fx;
-    er.fy = fy;
-    er.fx2 = fx2;
-    er.fy2 = fy2;
-    er.recv = a_recv;
-    er.next = 0;
-    er.stamp = d.edge_stamp;
-    er.flags = (seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC);
     const unsigned at = atomicAdd(d.edge_n, 1u) % EDGE_CAP;
-    er.next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
-    d.edge[at] = er;
+    EdgeRec *const o = d.edge + at;          // (member by member: a local EdgeRec went through scratch memory)
+    o->xi = xi;
+    o->yi = yi;
+    o->psi = psi;
+    o->hfov = hfov;
+    o->fx = fx;
+    o->fy = fy;
+    o->fx2 = fx2;
+    o->fy2 = fy2;
+    o->recv = a_recv;
+    o->stamp = d.edge_stamp;
+    o->flags = (seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC);
+    o->next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
     atomicOr(&d.status[a_recv], CSF_ST_EDGE);
 }
 

@@ -186,8 +186,9 @@ __device__ __forceinline__ void classify_batch(const PairConsts &k, const float4
     const bool fov = apart & (k.fov_classify != 0);
     const float reach = k.rfar + bb.z;
     const bool far = D2 > reach * reach;
-    out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.ch - 1e-4f));
-    in = fov & !far & ((((cb * ca - sb * sa) > k.ch + 1e-4f) & ((sb * ca + cb * sa) > 1e-4f)) | (k.full_circle != 0));
+    // (k.chm, k.chp = k.ch -+ 1e-4 from the host: computed here they were loop invariants in vector registers, spilled to scratch)
+    out = far | (fov & (cb < ca) & ((cb * ca + sb * sa) < k.chm));
+    in = fov & !far & ((((cb * ca - sb * sa) > k.chp) & ((sb * ca + cb * sa) > 1e-4f)) | (k.full_circle != 0));
     if (P2R) {
         const float clear = bb.z * 1.0001f + 1e-4f;
         out = out | (off > clear);
@@ -481,8 +482,12 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         const int nb = cnt >> 6;
         // the LDS and global addresses of the fill and the classification are formed HERE, once per tile: hoisted out of the
         // tile loop (they only depend on the thread's number) they cost six registers, which were spilled to scratch memory
-        int tid = (int)threadIdx.x, ln = lane;
-        asm volatile("" : "+v"(tid), "+v"(ln));
+        // (the thread's number put together again from the wave's and the lane's: kept from the start of the kernel it was the one
+        // register spilled to scratch memory, and reloaded - with a wait - in front of every tile)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        int tid = (wave << 6) | ln;
+        asm volatile("" : "+v"(tid));
         if (BINR) {
             // is any batch of this tile within the far-field radius of any receiver of the group?  (every wave
             // evaluates the same 16 circles, so the answer - and the barriers below - are uniform in the workgroup)
@@ -791,9 +796,10 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     }
     if (DYN) {
         __syncthreads();
-        if (threadIdx.x < RPB) {
-            const int64_t a = ragent[threadIdx.x];
-            if (a >= 0) d.part[(int64_t)(d.part_base + by) * d.cap + a] = make_float2(racc[0][threadIdx.x], racc[1][threadIdx.x]);
+        const int te = (wave << 6) | lane;     // (threadIdx.x, not kept alive across the kernel)
+        if (te < RPB) {
+            const int64_t a = ragent[te];
+            if (a >= 0) d.part[(int64_t)(d.part_base + by) * d.cap + a] = make_float2(racc[0][te], racc[1][te]);
         }
     } else {
         reduce_store(d, j0, lane, ax, ay, &ragent[wave * RPW]);
