@@ -225,7 +225,7 @@ def main():
                 "pairs_evaluated": None if w_ is None else int(w_["evaluated"]), "sources_tested": None if w_ is None else int(w_["tested"])}
 
     # the kernels' own start / end time stamps (hipExtLaunchKernelGGL events on the engine's stream).  A launch that carries
-    # events costs the tick ~5 us (profiles/r4_v4_tick_sequence.json: 120.1 us per tick with every launch sampled, 114.6 with
+    # events costs the tick ~5 us (profiles/r4_v5_tick_sequence.json: 120.1 us per tick with every launch sampled, 114.6 with
     # none), so not every launch is sampled: every 8th tick in long runs, every other tick of the driver's 20-step command.
     # (The event pool is created here, not in front of the timed region.)
     every = max(1, min(8, args.steps // 8))
