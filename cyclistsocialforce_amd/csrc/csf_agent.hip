@@ -146,10 +146,11 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
                 rx += cx;
                 ry += cy;
             }
-            double rin = sqrt(rx * rx + ry * ry), lim = sqrt(fdx * fdx + fdy * fdy);
+            double rin = qsqrt(rx * rx + ry * ry), lim = qsqrt(fdx * fdx + fdy * fdy);
             if (rin > lim) {                                  // utils.py:79-84
-                rx = rx * lim / rin;
-                ry = ry * lim / rin;
+                const double irin = rcp_nr(rin);
+                rx = rx * lim * irin;
+                ry = ry * lim * irin;
             }
             Fx = rx + fdx;                                    // :847-848
             Fy = ry + fdy;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     if (phases & PH_INTEGRATE) {
         const bool frozen = d.replay_len != nullptr && d.replay_tick >= d.replay_len[a];  // replay sequence ended
         if (!frozen) {
-            if (phases & PH_FIXSPEED) g.v = sqrt(Fx * Fx + Fy * Fy);   // calibration.py:454-458
+            if (phases & PH_FIXSPEED) g.v = qsqrt(Fx * Fx + Fy * Fy);  // calibration.py:454-458
             integrate<MODEL>(d, g, Fx, Fy);
         }
         stamp(5);

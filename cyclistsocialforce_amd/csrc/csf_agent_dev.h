@@ -4,21 +4,45 @@
 // function.
 #pragma once
 #include "csf_dev.h"
+#define CSF_HD __device__ __forceinline__
+#include "csf_math64.h"
 
 namespace csf {
 
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmax(fmin(x, hi), lo); }
 
-// 1 / b for the planner's well-scaled operands (chord lengths, knot spans, pivots of a totally positive system: 1e-6 .. 1e6):
-// v_rcp_f64 and two Newton steps - five dependent instructions where the IEEE division (v_div_scale, v_rcp, four fma,
-// v_div_fmas, v_div_fixup) takes ten, and a reciprocal is shared by everything that is divided by the same number.  Within
-// an ulp or two of the quotient; the planner's results are pinned at 2e-7 (the reference runs FITPACK through lm).
-__device__ __forceinline__ double rcp_nr(double b) {
-    double x = __builtin_amdgcn_rcp(b);
-    x = fma(fma(-b, x, 1.0), x, x);
-    x = fma(fma(-b, x, 1.0), x, x);
-    return x;
+// The kernel's elementary functions (csf_math64.h: why, and how exact): lengths, quotients with a divisor that is not zero,
+// sin / cos / tan / atan2 of angles that are wrapped or small.  The field-of-view chain keeps the library's (csf_dev.h).
+struct HwDev {
+    static __device__ __forceinline__ double rcp(double b) { return __builtin_amdgcn_rcp(b); }
+    static __device__ __forceinline__ double rsq(double x) { return __builtin_amdgcn_rsq(x); }
+};
+__device__ __forceinline__ double rcp_nr(double b) { return m64::rcp_s<HwDev>(b); }
+__device__ __forceinline__ double qdiv(double a, double b) { return m64::div_s<HwDev>(a, b); }
+__device__ __forceinline__ double qsqrt(double x) { return m64::sqrt_s<HwDev>(x); }
+__device__ __forceinline__ double qrsqrt(double x) { return m64::rsqrt_s<HwDev>(x); }
+__device__ __forceinline__ double qtan(double x) { return m64::tan_s<HwDev>(x); }
+__device__ __forceinline__ double qatan2(double y, double x) { return m64::atan2_s<HwDev>(y, x); }
+__device__ __forceinline__ void qsincos(double x, double *s, double *c) { m64::sincos_s(x, s, c); }   // a wrapped or clamped angle
+__device__ __forceinline__ void qsincos_any(double x, double *s, double *c) {
+    if (fabs(x) < 1e5) m64::sincos_s(x, s, c);
+    else sincos(x, s, c);                                     // (an unwrapped yaw after 16 000 turns)
+}
+
+// utils.py:124-139 / 167-182 with the quotient th / 2 pi as a product: the same integer wherever th is not within an ulp of a
+// multiple of 2 pi, and there both wrap to the same angle
+__device__ __forceinline__ double limit_angle_m(double th) {
+    th = fma(floor(th * 0.15915494309189533577), -2 * PI, th);
+    if (th > PI) th -= 2 * PI;
+    else if (th < -PI) th += 2 * PI;
+    return th;
+}
+__device__ __forceinline__ double angle_diff_m(double a1, double a2) {
+    double da = fabs(a1 - a2);
+    if (da > PI) da = 2 * PI - da;
+    double t1 = fabs(limit_angle_m(a1 - da) - a2), t2 = fabs(limit_angle_m(a1 + da) - a2);
+    return t1 < t2 ? -da : da;
 }
 
 // Registers of one agent while it is being ticked.
@@ -63,7 +87,7 @@ __device__ __forceinline__ bool qstop(const Dev &d, const Agent &g, int k) {
 // vehicle.py:596-604
 __device__ __forceinline__ double dest_dist(const Dev &d, const Agent &g) {
     double ex = qx(d, g, g.ptr) - g.x, ey = qy(d, g, g.ptr) - g.y;
-    return sqrt(ex * ex + ey * ey);
+    return qsqrt(ex * ex + ey * ey);
 }
 
 // vehicle.py:545-594
@@ -73,7 +97,7 @@ __device__ __forceinline__ void update_destination(const Dev &d, Agent &g) {
     if (dnext <= g.p->d_arrived_inter) g.ptr = min(g.ptr + 1, g.K - 1);   // :571-574
     if (g.ptr < g.K - 1) {                                    // :577-583
         double ex = qx(d, g, g.ptr + 1) - g.x, ey = qy(d, g, g.ptr + 1) - g.y;
-        if (sqrt(ex * ex + ey * ey) < dnext) g.ptr += 1;
+        if (qsqrt(ex * ex + ey * ey) < dnext) g.ptr += 1;
     }
 }
 
@@ -83,8 +107,8 @@ __device__ __forceinline__ double update_nav(const Dev &d, Agent &g, double &dde
     const double k = 1.5;                                     // :377
     double d0, d1;
     if (g.zn == 0) {                                          // :379-386
-        d0 = 0.5 * (p.v_max_harddecel * p.v_max_harddecel - g.v * g.v) / p.a_desired_default[0];
-        d1 = 0.5 * -(p.v_max_harddecel * p.v_max_harddecel) / p.a_max[0];
+        d0 = qdiv(0.5 * (p.v_max_harddecel * p.v_max_harddecel - g.v * g.v), p.a_desired_default[0]);
+        d1 = qdiv(0.5 * -(p.v_max_harddecel * p.v_max_harddecel), p.a_max[0]);
     } else {
         d0 = g.zd0;
         d1 = g.zd1;
@@ -105,7 +129,7 @@ __device__ __forceinline__ double update_nav(const Dev &d, Agent &g, double &dde
     g.zn = n0 ? 0 : (n1 ? 1 : 2);
     if (n0) return g.vdes;                                    // :434-435
     if (n1) {                                                 // :436-450
-        if (ddest < k * g.zd1) return p.v_max_harddecel / g.zd1 * ddest * 1 / k;
+        if (ddest < k * g.zd1) return qdiv(qdiv(p.v_max_harddecel, g.zd1) * ddest, k);
         return (g.zv0 - p.v_max_harddecel) / g.zd0 * (ddest - g.zd1) * 1 / k + p.v_max_harddecel;
     }
     return 0.0;                                               // :452-453
@@ -116,8 +140,8 @@ __device__ __forceinline__ void direct_approach(const Dev &d, Agent &g, double &
     update_destination(d, g);
     double ddest, vd = update_nav(d, g, ddest);
     if (ddest > 0) {
-        fx = -vd * (g.x - qx(d, g, g.ptr)) / ddest;
-        fy = -vd * (g.y - qy(d, g, g.ptr)) / ddest;
+        fx = qdiv(-vd * (g.x - qx(d, g, g.ptr)), ddest);
+        fy = qdiv(-vd * (g.y - qy(d, g, g.ptr)), ddest);
     } else {
         fx = 0;
         fy = 0;
@@ -195,7 +219,7 @@ __device__ __forceinline__ bool spline_fit(Spline<M> &s, const double (&px)[M], 
 #pragma unroll
     for (int r = 1; r < M; r++) {
         const double ex = px[r] - px[r - 1], ey = py[r] - py[r - 1];
-        const double dd = sqrt(ex * ex + ey * ey);
+        const double dd = qsqrt(ex * ex + ey * ey);
         ok = ok && (dd > 0.0);  // splprep raises ValueError on duplicate consecutive points
         u[r] = u[r - 1] + dd;
     }
@@ -351,13 +375,13 @@ __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const doubl
         double X0, Y0, X1, Y1, dX, dY, ddX, ddY;
         spline_all(s, ui, X0, Y0, dX, dY, ddX, ddY);
         spline_pos(s, up, X1, Y1);
-        const double sp = sqrt(dX * dX + dY * dY);
+        const double sp = qsqrt(dX * dX + dY * dY);
         const double R = sp * sp * sp / fabs(dX * ddY - dY * ddX);  // :1532-1537
         const double thetacomf = 10 * (2 * PI / 360);         // :1541
         double v = fmax(2.5, sqrt(thetacomf * g.p->g * R));    // :1542-1544
         v = fmin(v, vd);                                      // :1545
         const double ex = X1 - X0, ey = Y1 - Y0;
-        const double tmp = v / sqrt(ex * ex + ey * ey);       // :1548-1553
+        const double tmp = v * qrsqrt(ex * ex + ey * ey);     // :1548-1553
         fx = tmp * ex;
         fy = tmp * ey;
     } else {
@@ -370,8 +394,10 @@ __device__ __forceinline__ void twod_dest(const Dev &d, Agent &g, double &fx, do
     update_destination(d, g);                                 // :1451
     double ddest, vd = update_nav(d, g, ddest);               // :1452
     if (g.ti == 0) {                                          // :1455-1458
-        fx = vd * cos(g.psi);
-        fy = vd * sin(g.psi);
+        double sp, cp;
+        qsincos(g.psi, &sp, &cp);
+        fx = vd * cp;
+        fy = vd * sp;
         return;
     }
     if (g.zn == 2) {                                          // :1461-1462
@@ -419,20 +445,22 @@ __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, d
 // vehicle.py:1218-1272 (Bicycle.control + Bicycle.move; PIDcontroller with ki = kd = 0, dynamics.py:33-54)
 __device__ __forceinline__ void bike_control_move(const Dev &d, Agent &g, double Fx, double Fy) {
     const csf_params &p = *g.p;
-    double theta = atan2(Fy, Fx);                             // :1223
-    double vd = sqrt(Fx * Fx + Fy * Fy);                      // :1224
+    double theta = qatan2(Fy, Fx);                            // :1223
+    double vd = qsqrt(Fx * Fx + Fy * Fy);                     // :1224
     double ddest = dest_dist(d, g);                           // :1226-1229
-    if (ddest < 3 && g.ptr + 1 >= g.K) vd = (vd / 3) * ddest; // :1231-1232
-    double target = angle_diff(g.psi, theta);                 // :1235
-    double om = p.k_p_delta * angle_diff(g.delta, target);    // :1239-1242
+    if (ddest < 3 && g.ptr + 1 >= g.K) vd = (vd * (1.0 / 3)) * ddest; // :1231-1232
+    double target = angle_diff_m(g.psi, theta);               // :1235
+    double om = p.k_p_delta * angle_diff_m(g.delta, target);  // :1239-1242
     double acc = p.k_p_v * (vd - g.v);                        // :1240-1243
     acc = clampd(acc, p.a_max[0], p.a_max[1]);                // :1249
-    double delta = limit_angle(g.delta + p.t_s * om);         // :1254
+    double delta = limit_angle_m(g.delta + p.t_s * om);       // :1254
     double v = g.v + p.t_s * acc;                             // :1255
     delta = clampd(delta, -p.delta_max, p.delta_max);         // :1257
     v = clampd(v, p.v_max_riding[0], p.v_max_riding[1]);      // :1258
-    double psi = limit_angle(g.psi + p.t_s * v * tan(delta) / p.l);  // :1260-1262
-    sincos(psi, &g.spsi, &g.cpsi);                            // once: the next tick's record needs the same two
+    double sd, cd;                                            // tan(delta) / l as one quotient
+    qsincos(delta, &sd, &cd);
+    double psi = limit_angle_m(g.psi + qdiv(p.t_s * v * sd, cd * p.l));  // :1260-1262
+    qsincos(psi, &g.spsi, &g.cpsi);                           // once: the next tick's record needs the same two
     g.cs_fresh = true;
     g.y += p.t_s * v * g.spsi;                                // :1264
     g.x += p.t_s * v * g.cpsi;                                // :1265
@@ -448,16 +476,17 @@ __device__ __forceinline__ void bike_control_move(const Dev &d, Agent &g, double
 __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double *xl, double Fx, double Fy) {
     const csf_params &p = *g.p;
     const double v = g.v;
-    const double iv = 1.0 / v, iv2 = iv * iv, iv3 = iv2 * iv;
+    const double iv = rcp_nr(v), iv2 = iv * iv, iv3 = iv2 * iv;
     const double kx0 = 3.48203226e02 - 5.12057324e03 * iv + 1.58364873e04 * iv2 - 1.98073306e04 * iv3;
     const double kx1 = -4.51700000e01;
     const double kx2 = -9.16379250e02 + 1.31769807e04 * iv - 6.57341643e04 * iv2 + 8.22163589e04 * iv3;
     const double kx3 = 3.20214069e02 - 4.69953797e03 * iv + 1.66378680e04 * iv2 - 2.43114309e04 * iv3;
     const double kx4 = 2.87549256e-08 - 2.27913445e03 * iv;
     const double ku = -3.38638984e-09 - 2.27913445e+03 * iv;
-    const double Ktau2 = (v * p.l_2) / (p.g * p.l), K = (v * v) / (p.g * p.l), tau3 = p.l / v;
-    const double tau1sq = (p.i_bike_longlong + p.m * p.h * p.h) / (p.m * p.g * p.h);
-    const double bI = 1.0 / p.i_steer_vertvert, h = p.t_s;
+    const double igl = rcp_nr(p.g * p.l);
+    const double Ktau2 = (v * p.l_2) * igl, K = (v * v) * igl;
+    const double itau1sq = qdiv(p.m * p.g * p.h, p.i_bike_longlong + p.m * p.h * p.h);
+    const double bI = rcp_nr(p.i_steer_vertvert), h = p.t_s;
     double M[5][6];
 #pragma unroll
     for (int r = 0; r < 5; r++)
@@ -471,10 +500,10 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
     M[1][4] = -bI * kx4 * h;
     M[1][5] = ku * bI * h;
     M[2][3] = h;
-    M[3][0] = -K / tau1sq * h;
-    M[3][1] = -Ktau2 / tau1sq * h;
-    M[3][2] = 1 / tau1sq * h;
-    M[4][0] = 1 / tau3 * h;
+    M[3][0] = -K * itau1sq * h;
+    M[3][1] = -Ktau2 * itau1sq * h;
+    M[3][2] = itau1sq * h;
+    M[4][0] = v * rcp_nr(p.l) * h;
     double nrm = 0;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
@@ -503,7 +532,7 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
     const double m01 = M[0][1], m23 = M[2][3], m40 = M[4][0], m30 = M[3][0], m31 = M[3][1], m32 = M[3][2];
     for (int k = 11; k >= 1; k--) {
         double T[5][6];
-        const double ik = 1.0 / k;
+        const double ik = rcp_nr((double)k);
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             double r1 = (c == 5) ? M[1][5] : 0.0;  // M[:,5] * E[5][c], E row 5 = e5
@@ -536,7 +565,7 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
 #pragma unroll
             for (int c = 0; c < 6; c++) E[r][c] = T[r][c];
     }
-    const double psi_d = atan2(Fy, Fx);                       // :1832
+    const double psi_d = qatan2(Fy, Fx);                      // :1832
     double xn[5];
 #pragma unroll
     for (int r = 0; r < 5; r++) {
@@ -547,9 +576,9 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
     }
 #pragma unroll
     for (int r = 0; r < 5; r++) xl[r] = xn[r];                // :1843
-    g.psi = limit_angle(xn[4]);                               // :1844
-    g.delta = limit_angle(xn[0]);                             // :1845
-    g.theta = limit_angle(xn[2]);                             // :1846
+    g.psi = limit_angle_m(xn[4]);                             // :1844
+    g.delta = limit_angle_m(xn[0]);                           // :1845
+    g.theta = limit_angle_m(xn[2]);                           // :1846
 }
 
 __device__ __forceinline__ int64_t a_idx(int c, int64_t cap, int64_t a) { return (int64_t)c * cap + a; }
@@ -595,11 +624,13 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
             g.delta = 0;
             g.theta = 0;
         } else if (riding) {
-            double vd = sqrt(Fx * Fx + Fy * Fy);              // step_pos :1850-1881 (old psi)
+            double vd = qsqrt(Fx * Fx + Fy * Fy);             // step_pos :1850-1881 (old psi)
             double acc = clampd(p.k_p_v * (vd - g.v), p.a_max[0], p.a_max[1]);
             double v = clampd(g.v + p.t_s * acc, p.v_max_riding[0], p.v_max_riding[1]);
-            g.y += p.t_s * v * sin(g.psi);
-            g.x += p.t_s * v * cos(g.psi);
+            double so, co;
+            qsincos(g.psi, &so, &co);
+            g.y += p.t_s * v * so;
+            g.x += p.t_s * v * co;
             g.v = v;
             invpend_step_yaw(d, g, xl, Fx, Fy);               // uses the new speed (:1902-1903)
         } else {                                              // walking :1905-1916
@@ -621,35 +652,39 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
         // (csf_engine.hip: derive_planarbike), so one precomputed exact step does it.
         const double a = g.v / p.l;                           // the speed BEFORE the speed update (:228)
         double del = d.lti[a_idx(0, cap, g.a)], psu = d.ppsi[g.a];   // unwrapped (dynamics.py:195-197, 244)
-        const double psi_d = atan2(Fy, Fx), v_d = sqrt(Fy * Fy + Fx * Fx);   // :231-232
+        const double psi_d = qatan2(Fy, Fx), v_d = qsqrt(Fy * Fy + Fx * Fx);   // :231-232
         if (a > 0.0) {
             const double z0 = a * del, z1 = psu;
-            del = (g.pb[0] * z0 + g.pb[1] * z1 + g.pb[4] * psi_d) / a;   // :235-244
+            del = qdiv(g.pb[0] * z0 + g.pb[1] * z1 + g.pb[4] * psi_d, a);   // :235-244
             psu = g.pb[2] * z0 + g.pb[3] * z1 + g.pb[5] * psi_d;
         } else {
             g.st |= CSF_ST_UNCONTROLLABLE;                    // dynamics.py:1212-1214 asserts; here the yaw loop holds still
         }
         d.lti[a_idx(0, cap, g.a)] = del;
         d.ppsi[g.a] = psu;
-        g.psi = limit_angle(psu);                             // :246-247
-        g.delta = limit_angle(del);
+        g.psi = limit_angle_m(psu);                           // :246-247
+        g.delta = limit_angle_m(del);
         g.v = v_d + (g.v - v_d) * g.pb[6];                    // PPointSpeedDynamics: dynamics.py:156, 175
-        g.y += p.t_s * g.v * sin(g.psi);                      // :251-258
-        g.x += p.t_s * g.v * cos(g.psi);
+        qsincos(g.psi, &g.spsi, &g.cpsi);
+        g.cs_fresh = true;
+        g.y += p.t_s * g.v * g.spsi;                          // :251-258
+        g.x += p.t_s * g.v * g.cpsi;
     } else {                                                  // PlanarPoint: dynamics.py:996-1079
-        double vd = sqrt(Fx * Fx + Fy * Fy);                  // :1018
+        double vd = qsqrt(Fx * Fx + Fy * Fy);                 // :1018
         double acc = clampd(p.k_p_v * (vd - g.v), p.a_max[0], p.a_max[1]);
         double v = clampd(g.v + p.t_s * acc, p.v_max_riding[0], p.v_max_riding[1]);
-        double psi_c = limit_angle(atan2(Fy, Fx));            // dynamics.py:112-121
+        double psi_c = limit_angle_m(qatan2(Fy, Fx));         // dynamics.py:112-121
         double vbar = 0.5 * (v + g.v);                        // :1065
         // implicit midpoint of psi' = -k (psi - psi_c), x' = v cos psi, y' = v sin psi in closed form
         double hk = p.t_s * p.k_psi, pu = d.ppsi[a];
-        double pn = (pu * (1 - 0.5 * hk) + hk * psi_c) / (1 + 0.5 * hk);
+        double pn = qdiv(pu * (1 - 0.5 * hk) + hk * psi_c, 1 + 0.5 * hk);
         double pm = 0.5 * (pu + pn);
-        g.x += p.t_s * vbar * cos(pm);
-        g.y += p.t_s * vbar * sin(pm);
+        double sm, cm;
+        qsincos_any(pm, &sm, &cm);
+        g.x += p.t_s * vbar * cm;
+        g.y += p.t_s * vbar * sm;
         d.ppsi[a] = pn;
-        g.psi = limit_angle(pn);                              // :959-964
+        g.psi = limit_angle_m(pn);                            // :959-964
         g.v = v;
     }
     // ring-buffer bookkeeping — vehicle.py:1279-1282, 1407-1410, 1923-1926
@@ -668,7 +703,7 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
 // an offset from `o`, the road user's own origin (csf_dev.h: rorg), formed in fp64: one rounding, of a few metres.
 __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, int64_t a, const float2 o, double x, double y,
                                              double psi, double v, bool cs_fresh = false, double c = 0.0, double s = 0.0) {
-    if (!cs_fresh) sincos(psi, &s, &c);
+    if (!cs_fresh) qsincos(psi, &s, &c);
     const double px = (x - d.ox) - (double)o.x, py = (y - d.oy) - (double)o.y;
     const float4 q = make_float4((float)px, (float)py, (float)c, (float)s);
     d.rec[a] = q;
@@ -689,7 +724,7 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
         double e = 0.0;
         if (p.model == CSF_BICYCLE && v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
-        const float2 q2 = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
+        const float2 q2 = make_float2((float)e, (float)qrsqrt(1.0 - e * e));
         d.rec2[a] = q2;
         if (d.recs_valid) d.recs2[d.pos[a]] = q2;
     }
