@@ -14,8 +14,23 @@
 
 namespace csf {
 
+// The kernel's arguments (csf_dev.h: Dev, 1.3 KB with the parameter set) live in the kernarg segment, which the host has just
+// written: the first scalar load from each of its 64-byte lines goes to memory (~0.4 us), and the compiler loads a member where
+// it is first used - a dozen such round trips along the dependent chain of a kernel that is ONE wave per CU (58 % of a wave's
+// life was spent parked at s_waitcnt: profiles/r4_agent_kernel_pmc.json).  One word of every line is asked for at entry, all
+// at once: one round trip, and every later scalar load hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ uint32_t kernarg_touch() {
+    const __attribute__((address_space(4))) uint32_t *ka = (const __attribute__((address_space(4))) uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; i++) acc |= ka[16 * i];
+    return acc;
+}
+
 template <int MODEL, bool HET = false>
 __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
+    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();
     const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // CSF_TRACE_AGENT (measurement aid, tools/agent_timeline.py): where does a wave's time go?  Every stamp waits for what
     // was issued before it, so the traced kernel is a little slower than the product's.
@@ -51,8 +66,11 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     g.ti = d.ti[a];
     g.st = d.status[a];
     g.cs_fresh = false;
+    asm volatile("" ::"s"(ka_lines));                       // (kernarg_touch: the lines have been asked for by now)
+    const int32_t place = d.recs_valid ? d.pos[a] : -1;        // (for the record written at the end)
     agent_params<HET>(d, a, g);
     if (HET && g.p->model != MODEL) return;                    // a mixed population: one launch per vehicle class
+    constexpr bool PLANNER = MODEL != CSF_BICYCLE && MODEL != CSF_UNCONTROLLED;   // (the models whose planner reads the ring)
     // The partial sums of the pair kernel (the first 16 chunks: the usual split) and the road term are requested here, with
     // the agent's own scalars, so that their round trip runs beside the destination-force phase.  Unconditional loads from
     // clamped addresses: a guarded load is a branch with its own wait.
@@ -62,6 +80,8 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     for (int c = 0; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
     const float2 froad = d.froad[a];
     const float2 rorg = d.rorg[a];                             // (for the record written at the end)
+    load_rows(d, g);                                           // the second and last round trip of the common path
+    if (PLANNER && (phases & PH_DEST)) load_ring(d, g);
     // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge wait in a ring
     // (csf_dev.h: EdgeRec): bit 31 of the status word says so - a few dozen road users of a large population, per tick
     const bool edge_pending = (phases & PH_COMBINE) && (g.st & CSF_ST_EDGE) != 0u;
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
         d.s[4 * cap + a] = g.delta;
         d.s[5 * cap + a] = g.theta;
         d.ti[a] = g.ti;
-        write_record(d, *g.p, a, rorg, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi);
+        write_record(d, *g.p, a, rorg, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi, place);
         if (d.hist != nullptr) {
             int64_t t1 = d.tick + 1;
             if (t1 % d.hist_stride == 0) {
@@ -265,18 +285,16 @@ __global__ void nav_kat_kernel(const Dev d, const int32_t *idx, int64_t m, int w
     g.zd1 = d.znp[2 * cap + a];
     g.st = d.status[a];
     agent_params<true>(d, a, g);                             // (the class table is there for one parameter set as well)
+    load_rows(d, g);
     if (what & 1) {
         update_destination(d, g);
         d.ptr[a] = g.ptr;
     }
     if (what & 2) {
-        const int64_t row = 3 * (g.qb + g.ptr) + 2;
-        const double flag = d.q[row];
         const bool forced = stop != nullptr && stop[k] >= 0;
-        if (forced) d.q[row] = stop[k] ? 1.0 : 0.0;          // this thread is the only reader of its agent's rows
+        if (forced) g.rs[0] = stop[k] ? 1.0 : 0.0;           // (the row in registers; the slab keeps its flag)
         double ddest;
         const double vd = update_nav(d, g, ddest);
-        if (forced) d.q[row] = flag;
         d.znav[a] = (uint8_t)g.zn;
         d.znp[a] = g.zv0;
         d.znp[cap + a] = g.zd0;

@@ -59,6 +59,12 @@ struct Agent {
     uint32_t st;
     double cpsi, spsi;  // cos / sin of psi when the integrator has just computed them (cs_fresh), for the fp32 record
     bool cs_fresh;
+    // The destination rows ptr .. ptr + 3 (beyond the queue's end: its last row) and the ring's last two positions, asked for
+    // in ONE batch as soon as queue pointer and ring column are known (load_rows, load_ring): every later look at a row is a
+    // register, where the reference's call tree (updateDestination -> updateNavState -> planner -> control) would be five
+    // dependent round trips.  The rows are asked for again when the pointer moves - once per leg of a route.
+    double rx[4], ry[4], rs[4];
+    double h0x, h0y, h1x, h1y;   // ring[ti], ring[ti - 1]
     // the parameter set of this road user (vehicle.py:64-204: every vehicle owns one): the engine's only one in the kernel
     // arguments, or its row of the class table; pb: the PlanarBicycle step matrices that belong to it (Dev::pb)
     const csf_params *p;
@@ -78,26 +84,45 @@ __device__ __forceinline__ void agent_params(const Dev &d, int64_t a, Agent &g) 
     }
 }
 
-__device__ __forceinline__ double qx(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k)]; }
-__device__ __forceinline__ double qy(const Dev &d, const Agent &g, int k) { return d.q[3 * (g.qb + k) + 1]; }
-__device__ __forceinline__ bool qstop(const Dev &d, const Agent &g, int k) {
-    return d.q[3 * (g.qb + k) + 2] != 0.0;
+// the rows ptr .. ptr + 3 of the destination queue (vehicle.py:183-185, 606-647) into the registers
+__device__ __forceinline__ void load_rows(const Dev &d, Agent &g) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t r = 3 * (g.qb + max(min(g.ptr + k, g.K - 1), 0));
+        g.rx[k] = d.q[r];
+        g.ry[k] = d.q[r + 1];
+        g.rs[k] = d.q[r + 2];
+    }
 }
 
+// the ring's last two positions (vehicle.py:1474-1491 reads them from traj)
+__device__ __forceinline__ void load_ring(const Dev &d, Agent &g) {
+    const int hm = d.hist_len - 1;
+    g.h1x = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a], g.h1y = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
+    g.h0x = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a], g.h0y = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
+}
+
+__device__ __forceinline__ bool qstop(const Agent &g) { return g.rs[0] != 0.0; }   // stop flag of the current destination
+
 // vehicle.py:596-604
-__device__ __forceinline__ double dest_dist(const Dev &d, const Agent &g) {
-    double ex = qx(d, g, g.ptr) - g.x, ey = qy(d, g, g.ptr) - g.y;
+__device__ __forceinline__ double dest_dist(const Agent &g) {
+    double ex = g.rx[0] - g.x, ey = g.ry[0] - g.y;
     return qsqrt(ex * ex + ey * ey);
 }
 
 // vehicle.py:545-594
 __device__ __forceinline__ void update_destination(const Dev &d, Agent &g) {
     if (g.zn != 0) return;                                    // :567-568
-    double dnext = dest_dist(d, g);
-    if (dnext <= g.p->d_arrived_inter) g.ptr = min(g.ptr + 1, g.K - 1);   // :571-574
-    if (g.ptr < g.K - 1) {                                    // :577-583
-        double ex = qx(d, g, g.ptr + 1) - g.x, ey = qy(d, g, g.ptr + 1) - g.y;
-        if (qsqrt(ex * ex + ey * ey) < dnext) g.ptr += 1;
+    double dnext = dest_dist(g);
+    int adv = 0;                                              // rows the pointer moves: 0, 1 or 2
+    if (dnext <= g.p->d_arrived_inter) adv = min(g.ptr + 1, g.K - 1) - g.ptr;   // :571-574
+    if (g.ptr + adv < g.K - 1) {                              // :577-583
+        double ex = (adv ? g.rx[2] : g.rx[1]) - g.x, ey = (adv ? g.ry[2] : g.ry[1]) - g.y;
+        if (qsqrt(ex * ex + ey * ey) < dnext) adv += 1;
+    }
+    if (adv) {                                                // (once per leg of a road user's route)
+        g.ptr += adv;
+        load_rows(d, g);
     }
 }
 
@@ -113,8 +138,8 @@ __device__ __forceinline__ double update_nav(const Dev &d, Agent &g, double &dde
         d0 = g.zd0;
         d1 = g.zd1;
     }
-    ddest = dest_dist(d, g);
-    bool x0 = qstop(d, g, g.ptr);                             // :397-400
+    ddest = dest_dist(g);
+    bool x0 = qstop(g);                                       // :397-400
     bool x1 = ddest <= k * (d0 + d1), x2 = ddest <= p.d_arrived_stop, x3 = g.v <= p.v_max_stop;
     bool z0 = g.zn == 0, z1 = g.zn == 1, z2 = g.zn == 2;
     bool n0 = !x0 || (x0 && !x1 && ((z0 && !x2) || z1));      // :404-406
@@ -140,8 +165,8 @@ __device__ __forceinline__ void direct_approach(const Dev &d, Agent &g, double &
     update_destination(d, g);
     double ddest, vd = update_nav(d, g, ddest);
     if (ddest > 0) {
-        fx = qdiv(-vd * (g.x - qx(d, g, g.ptr)), ddest);
-        fy = qdiv(-vd * (g.y - qy(d, g, g.ptr)), ddest);
+        fx = qdiv(-vd * (g.x - g.rx[0]), ddest);
+        fy = qdiv(-vd * (g.y - g.ry[0]), ddest);
     } else {
         fx = 0;
         fy = 0;
@@ -368,7 +393,7 @@ __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const doubl
             }
         }
     }
-    const int iprev = i + (qstop(d, g, g.ptr) ? ipredlast : ipred);  // :1523-1526
+    const int iprev = i + (qstop(g) ? ipredlast : ipred);     // :1523-1526
     if (iprev < nS) {                                         // :1529-1553
         const double ui = i == nS - 1 ? 1.0 : (double)i / (nS - 1);
         const double up = iprev == nS - 1 ? 1.0 : (double)iprev / (nS - 1);
@@ -405,29 +430,28 @@ __device__ __forceinline__ void twod_dest(const Dev &d, Agent &g, double &fx, do
         fy = 0;
         return;
     }
-    const int hm = d.hist_len - 1;
-    const double h1x = d.hx[(int64_t)((g.ti - 1) & hm) * d.cap + g.a], h1y = d.hy[(int64_t)((g.ti - 1) & hm) * d.cap + g.a];
-    const double h0x = d.hx[(int64_t)(g.ti & hm) * d.cap + g.a], h0y = d.hy[(int64_t)(g.ti & hm) * d.cap + g.a];
+    const double h1x = g.h1x, h1y = g.h1y, h0x = g.h0x, h0y = g.h0y;
     const bool last = g.ptr + 1 >= g.K;                       // :537-543
     if (!last) {                                              // :1465-1479: two trajectory points + up to 4 destinations
         const int cnt = min(g.ptr + 4, g.K) - g.ptr;          // >= 2
         if (cnt == 2) {
-            const double px[4] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1)};
-            const double py[4] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1)};
+            const double px[4] = {h1x, h0x, g.rx[0], g.rx[1]};
+            const double py[4] = {h1y, h0y, g.ry[0], g.ry[1]};
             spline_force<4>(d, g, px, py, false, vd, fx, fy);
         } else if (cnt == 3) {
-            const double px[5] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1), qx(d, g, g.ptr + 2)};
-            const double py[5] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1), qy(d, g, g.ptr + 2)};
+            const double px[5] = {h1x, h0x, g.rx[0], g.rx[1], g.rx[2]};
+            const double py[5] = {h1y, h0y, g.ry[0], g.ry[1], g.ry[2]};
             spline_force<5>(d, g, px, py, false, vd, fx, fy);
         } else {
-            const double px[6] = {h1x, h0x, qx(d, g, g.ptr), qx(d, g, g.ptr + 1), qx(d, g, g.ptr + 2), qx(d, g, g.ptr + 3)};
-            const double py[6] = {h1y, h0y, qy(d, g, g.ptr), qy(d, g, g.ptr + 1), qy(d, g, g.ptr + 2), qy(d, g, g.ptr + 3)};
+            const double px[6] = {h1x, h0x, g.rx[0], g.rx[1], g.rx[2], g.rx[3]};
+            const double py[6] = {h1y, h0y, g.ry[0], g.ry[1], g.ry[2], g.ry[3]};
             spline_force<6>(d, g, px, py, false, vd, fx, fy);
         }
     } else {                                                  // :1486-1492: last leg, three trajectory points
+        const int hm = d.hist_len - 1;
         const int back = max(0, g.ti - d.back);
-        const double px[4] = {d.hx[(int64_t)(back & hm) * d.cap + g.a], h1x, h0x, qx(d, g, g.ptr)};
-        const double py[4] = {d.hy[(int64_t)(back & hm) * d.cap + g.a], h1y, h0y, qy(d, g, g.ptr)};
+        const double px[4] = {d.hx[(int64_t)(back & hm) * d.cap + g.a], h1x, h0x, g.rx[0]};
+        const double py[4] = {d.hy[(int64_t)(back & hm) * d.cap + g.a], h1y, h0y, g.ry[0]};
         spline_force<4>(d, g, px, py, true, vd, fx, fy);
     }
 }
@@ -447,7 +471,7 @@ __device__ __forceinline__ void bike_control_move(const Dev &d, Agent &g, double
     const csf_params &p = *g.p;
     double theta = qatan2(Fy, Fx);                            // :1223
     double vd = qsqrt(Fx * Fx + Fy * Fy);                     // :1224
-    double ddest = dest_dist(d, g);                           // :1226-1229
+    double ddest = dest_dist(g);                              // :1226-1229
     if (ddest < 3 && g.ptr + 1 >= g.K) vd = (vd * (1.0 / 3)) * ddest; // :1231-1232
     double target = angle_diff_m(g.psi, theta);               // :1235
     double om = p.k_p_delta * angle_diff_m(g.delta, target);  // :1239-1242
@@ -702,7 +726,8 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
 // fp32 source record of the next tick — the (x, y, psi) snapshot of intersection.py:660-677.  The position is stored as
 // an offset from `o`, the road user's own origin (csf_dev.h: rorg), formed in fp64: one rounding, of a few metres.
 __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, int64_t a, const float2 o, double x, double y,
-                                             double psi, double v, bool cs_fresh = false, double c = 0.0, double s = 0.0) {
+                                             double psi, double v, bool cs_fresh = false, double c = 0.0, double s = 0.0,
+                                             int32_t place = -1) {
     if (!cs_fresh) qsincos(psi, &s, &c);
     const double px = (x - d.ox) - (double)o.x, py = (y - d.oy) - (double)o.y;
     const float4 q = make_float4((float)px, (float)py, (float)c, (float)s);
@@ -714,7 +739,7 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     const float4 g = make_float4(q.x + o.x, q.y + o.y, q.z, q.w);
     d.recg[a] = g;
     if (d.recs_valid) {
-        const int32_t p = d.pos[a];
+        const int32_t p = place >= 0 ? place : d.pos[a];      // (the per-agent kernel asks for it with its first loads)
         d.recs[p] = g;
         if (d.recv_binned) {                                   // (large populations only: csf_dev.h recb)
             const float2 bo = d.borg[p >> 6];
