@@ -14,23 +14,9 @@
 
 namespace csf {
 
-// The kernel's arguments (csf_dev.h: Dev, 1.3 KB with the parameter set) live in the kernarg segment, which the host has just
-// written: the first scalar load from each of its 64-byte lines goes to memory (~0.4 us), and the compiler loads a member where
-// it is first used - a dozen such round trips along the dependent chain of a kernel that is ONE wave per CU (58 % of a wave's
-// life was spent parked at s_waitcnt: profiles/r4_agent_kernel_pmc.json).  One word of every line is asked for at entry, all
-// at once: one round trip, and every later scalar load hits the scalar cache.
-template <int BYTES>
-__device__ __forceinline__ uint32_t kernarg_touch() {
-    const __attribute__((address_space(4))) uint32_t *ka = (const __attribute__((address_space(4))) uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t acc = 0;
-#pragma unroll
-    for (int i = 0; i < (BYTES + 63) / 64; i++) acc |= ka[16 * i];
-    return acc;
-}
-
 template <int MODEL, bool HET = false>
 __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
-    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();
+    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();   // (csf_dev.h)
     const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // CSF_TRACE_AGENT (measurement aid, tools/agent_timeline.py): where does a wave's time go?  Every stamp waits for what
     // was issued before it, so the traced kernel is a little slower than the product's.
@@ -66,7 +52,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     g.ti = d.ti[a];
     g.st = d.status[a];
     g.cs_fresh = false;
-    asm volatile("" ::"s"(ka_lines));                       // (kernarg_touch: the lines have been asked for by now)
+    kernarg_touched(ka_lines);
     const int32_t place = d.recs_valid ? d.pos[a] : -1;        // (for the record written at the end)
     agent_params<HET>(d, a, g);
     if (HET && g.p->model != MODEL) return;                    // a mixed population: one launch per vehicle class

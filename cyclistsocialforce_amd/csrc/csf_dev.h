@@ -300,6 +300,23 @@ void launch_nav_kat(const Dev &d, const int32_t *idx, int64_t m, int what, const
 void launch_pair_kat(const Dev &d, const float4 *src, const float2 *src2, const float4 *recv, int64_t m,
                      int apply_fov, float2 *out, hipStream_t st);
 
+// The kernel's arguments (csf_dev.h: Dev, 1.3 KB with the parameter set) live in the kernarg segment, which the host has just
+// written: the first scalar load from each of its 64-byte lines goes to memory (~0.4 us), and the compiler loads a member where
+// it is first used - a dozen such round trips along the dependent chain of the per-agent kernel, which is ONE wave per CU (58 % of a wave's
+// life was spent parked at s_waitcnt: profiles/r4_agent_kernel_pmc.json), seven at the start of the plain pair kernel.  One word of every line is asked for at entry, all
+// at once: one round trip, and every later scalar load hits the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ uint32_t kernarg_touch() {
+    const __attribute__((address_space(4))) uint32_t *ka = (const __attribute__((address_space(4))) uint32_t *)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; i++) acc |= ka[16 * i];
+    return acc;
+}
+
+// ... and the value has to be used: `kernarg_touched(x)` behind the kernel's first own loads costs nothing.
+__device__ __forceinline__ void kernarg_touched(uint32_t lines) { asm volatile("" ::"s"(lines)); }
+
 constexpr double PI = 3.141592653589793238462643383279502884;
 
 // utils.py:124-139
