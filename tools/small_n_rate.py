@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Resident tick time of small populations (GPU box): csf_step(K) of N road users at the headline's density, three models,
-with the per-launch times of the pair and the per-agent kernel.  One JSON line per (model, N)."""
+with the host's time to enqueue a tick and the per-launch times of the pair and the per-agent kernel.  One JSON line per (model, N)."""
 import json
 import os
 import sys
@@ -28,11 +28,13 @@ for model in ("bicycle", "twod", "invpend", "planarpoint"):
         e.set_dest_queue(np.arange(n), off, dq, reset=True)
         e.step(300, sync=True)
         t0 = time.perf_counter()
-        e.step(K, sync=True)
+        e.step(K)                                             # returns when the ticks are enqueued
+        t_enq = time.perf_counter() - t0
+        e.sync()
         dt = time.perf_counter() - t0
         e.profile(8)
         e.step(256, sync=True)
         prof = {k: ms * 1e3 / max(c, 1) for k, (ms, c) in e.profile_kernels().items()}
-        print(json.dumps({"model": model, "agents": n, "us_per_tick": dt / K * 1e6, "pair_us": prof["pair"], "agent_us": prof["agent"],
+        print(json.dumps({"model": model, "agents": n, "us_per_tick": dt / K * 1e6, "host_enqueue_us_per_tick": t_enq / K * 1e6, "pair_us": prof["pair"], "agent_us": prof["agent"],
                           "healthy": bool(np.isfinite(e.state()).all())}), flush=True)
         e.close()
