@@ -231,9 +231,19 @@ def test_untracked_foes_and_queue_methods(golden):
     a.setDestinations((1.5, 30.0, 31.0, 90.0), (0.0, 0.0, 0.0, 0.0), reset=True)
     a.updateDestination()
     assert a.destpointer == 1
-    a.s[0] = 29.5                                         # within d_arrived_inter of (30, 0) and closer to (31, 0) than to it
-    a.updateDestination()
-    assert a.destpointer == 3 or a.destpointer == 2
+    a.s[0] = 29.5                                         # within d_arrived_inter of (30, 0): advances once - (90, 0) is not
+    a.updateDestination()                                 # closer than the destination just left was (vehicle.py:577-583)
+    assert a.destpointer == 2
+    # ... and twice in one call when the destination behind the next one is closer than the one just reached
+    a2 = TwoDBicycle((0, 0, 0, 5, 0), id="a2")
+    a2.setDestinations((1.5, 30.0, 31.0, 29.6, 90.0), (0.0, 0.0, 0.0, 0.0, 0.0), reset=True)
+    a2.updateDestination()
+    assert a2.destpointer == 1
+    a2.s[0] = 29.5
+    a2.updateDestination()
+    assert a2.destpointer == 3
+    a2.updateDestination()                                # (29.6, 0) is within reach as well; (90, 0) is the last row
+    assert a2.destpointer == 4
     # navigation state machine through its three states with an explicit stop argument
     b = TwoDBicycle((0, 0, 0, 5, 0), id="b")
     b.setDestinations((40.0,), (0.0,), reset=True)
