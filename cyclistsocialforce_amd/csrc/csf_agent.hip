@@ -66,6 +66,14 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     for (int c = 0; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
     const float2 froad = d.froad[a];
     const float2 rorg = d.rorg[a];                             // (for the record written at the end)
+    if (MODEL == CSF_INVPEND) {                                // (side-state of the model: with the first round trip, not the fourth)
+#pragma unroll
+        for (int k = 0; k < 5; k++) g.xl[k] = d.lti[(int64_t)k * cap + a];
+        g.riding = d.zrid[a] != 0;
+        g.dgood = d.dgood[a];
+    }
+    if (MODEL == CSF_PLANARBIKE) g.xl[0] = d.lti[a];
+    if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) g.ppsi = d.ppsi[a];
     load_rows(d, g);                                           // the second and last round trip of the common path
     if (PLANNER && (phases & PH_DEST)) load_ring(d, g);
     // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge wait in a ring

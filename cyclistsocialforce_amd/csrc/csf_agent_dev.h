@@ -65,6 +65,12 @@ struct Agent {
     // dependent round trips.  The rows are asked for again when the pointer moves - once per leg of a route.
     double rx[4], ry[4], rs[4];
     double h0x, h0y, h1x, h1y;   // ring[ti], ring[ti - 1]
+    // InvPendulum / PlanarPoint / PlanarBicycle side-state, asked for with the agent's own scalars (agent_kernel): the LTI state
+    // (vehicle.py:1728), the riding flag, the run of small steering angles; the unwrapped yaw (dynamics.py:943-966)
+    double xl[5];
+    int32_t dgood;
+    bool riding;
+    double ppsi;
     // the parameter set of this road user (vehicle.py:64-204: every vehicle owns one): the engine's only one in the kernel
     // arguments, or its row of the class table; pb: the PlanarBicycle step matrices that belong to it (Dev::pb)
     const csf_params *p;
@@ -528,6 +534,22 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
     M[3][1] = -Ktau2 * itau1sq * h;
     M[3][2] = itau1sq * h;
     M[4][0] = v * rcp_nr(p.l) * h;
+    // Balancing: the steer-rate row holds entries of 20 .. 70 (gains over the steering inertia), its column 0.01 .. 0.03, and
+    // the 1-norm of M - the number of squarings below - follows the row.  With x1 scaled by a power of two (exact: M' =
+    // D^-1 M D, exp(M) = D exp(M') D^-1, D = diag(1, dd, 1, 1, 1, 1)) row and column meet in the middle: three or four
+    // squarings instead of seven.  The state goes through as x' = D^-1 x and comes back as D x'.
+    double dd = 1.0, idd = 1.0;
+    {
+        const double r1 = fabs(M[1][0]) + fabs(M[1][2]) + fabs(M[1][3]) + fabs(M[1][4]) + fabs(M[1][5]);
+        const double c1 = fabs(M[0][1]) + fabs(M[3][1]);
+        if (r1 > 0.0 && c1 > 0.0 && isfinite(r1) && isfinite(c1)) {
+            const int eb = max(-20, min(20, (ilogb(r1) - ilogb(c1)) / 2));
+            dd = ldexp(1.0, eb);
+            idd = ldexp(1.0, -eb);
+        }
+        M[1][0] *= idd, M[1][2] *= idd, M[1][3] *= idd, M[1][4] *= idd, M[1][5] *= idd;
+        M[0][1] *= dd, M[3][1] *= dd;
+    }
     double nrm = 0;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
@@ -554,9 +576,10 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
         for (int c = 0; c < 6; c++) E[r][c] = (r == c ? 1.0 : 0.0) + M[r][c] * (1.0 / 12);
     // M has 12 non-zero entries (rows 0, 2, 4 one each, row 3 three, row 1 six): the products M E are written out
     const double m01 = M[0][1], m23 = M[2][3], m40 = M[4][0], m30 = M[3][0], m31 = M[3][1], m32 = M[3][2];
+#pragma unroll
     for (int k = 11; k >= 1; k--) {
         double T[5][6];
-        const double ik = rcp_nr((double)k);
+        const double ik = 1.0 / k;                            // (unrolled: a constant)
 #pragma unroll
         for (int c = 0; c < 6; c++) {
             double r1 = (c == 5) ? M[1][5] : 0.0;  // M[:,5] * E[5][c], E row 5 = e5
@@ -591,6 +614,7 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
     }
     const double psi_d = qatan2(Fy, Fx);                      // :1832
     double xn[5];
+    xl[1] *= idd;                                             // x' = D^-1 x (the balancing above)
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         double acc = E[r][5] * psi_d;
@@ -598,6 +622,7 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
         for (int c = 0; c < 5; c++) acc += E[r][c] * xl[c];
         xn[r] = acc;
     }
+    xn[1] *= dd;
 #pragma unroll
     for (int r = 0; r < 5; r++) xl[r] = xn[r];                // :1843
     g.psi = limit_angle_m(xn[4]);                             // :1844
@@ -632,17 +657,17 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
             g.delta = 0;
         } else bike_control_move(d, g, Fx, Fy);
     } else if (MODEL == CSF_INVPEND) {                        // vehicle.py:1883-1950
-        bool riding = d.zrid[a] != 0;
+        bool riding = g.riding;
         // updateRidingState (:1932-1950): the slice traj[4, imin:i+1] is all inside +-delta_max_walk iff the
         // run of good samples ending at column i is at least as long as the slice
         bool cvwalk = g.v < p.v_max_walk;
         int imin = max(0, (int)((double)g.ti - 1.0 / p.t_s));
-        bool cdelta = d.dgood[a] >= (g.ti - imin + 1);
+        bool cdelta = g.dgood >= (g.ti - imin + 1);
         riding = !cvwalk && ((!riding && cdelta) || riding);
         d.zrid[a] = riding ? 1 : 0;
         double xl[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) xl[k] = d.lti[k * cap + a];
+        for (int k = 0; k < 5; k++) xl[k] = g.xl[k];
         if (g.zn == 2) {                                      // :1898-1899
             g.v = 0;
             g.delta = 0;
@@ -675,7 +700,7 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
         // step (dynamics.py:203-223, 1167-1226).  In z = (v delta / l, psi) the closed loop is the same for every speed
         // (csf_engine.hip: derive_planarbike), so one precomputed exact step does it.
         const double a = g.v / p.l;                           // the speed BEFORE the speed update (:228)
-        double del = d.lti[a_idx(0, cap, g.a)], psu = d.ppsi[g.a];   // unwrapped (dynamics.py:195-197, 244)
+        double del = g.xl[0], psu = g.ppsi;                   // unwrapped (dynamics.py:195-197, 244)
         const double psi_d = qatan2(Fy, Fx), v_d = qsqrt(Fy * Fy + Fx * Fx);   // :231-232
         if (a > 0.0) {
             const double z0 = a * del, z1 = psu;
@@ -700,7 +725,7 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
         double psi_c = limit_angle_m(qatan2(Fy, Fx));         // dynamics.py:112-121
         double vbar = 0.5 * (v + g.v);                        // :1065
         // implicit midpoint of psi' = -k (psi - psi_c), x' = v cos psi, y' = v sin psi in closed form
-        double hk = p.t_s * p.k_psi, pu = d.ppsi[a];
+        double hk = p.t_s * p.k_psi, pu = g.ppsi;
         double pn = qdiv(pu * (1 - 0.5 * hk) + hk * psi_c, 1 + 0.5 * hk);
         double pm = 0.5 * (pu + pn);
         double sm, cm;
@@ -718,7 +743,7 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
     d.hy[(int64_t)slot * cap + a] = g.y;
     if (MODEL == CSF_INVPEND) {
         bool good = (-p.delta_max_walk < g.delta) && (p.delta_max_walk > g.delta);
-        int run = d.dgood[a];
+        int run = g.dgood;
         d.dgood[a] = good ? min(run + 1, 1 << 30) : 0;
     }
 }
