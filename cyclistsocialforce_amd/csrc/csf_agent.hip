@@ -11,23 +11,21 @@
 //                 (intersection.py:660-677) written as the fp32 source record of the next tick.
 // The O(N) work is done in fp64 so that the only fp32 rounding in a tick is the pair sum.
 #include "csf_agent_dev.h"
+#include "csf_field.h"
 
 namespace csf {
 
-template <int MODEL, bool HET = false>
-__global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
-    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();   // (csf_dev.h)
-    const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // CSF_TRACE_AGENT (measurement aid, tools/agent_timeline.py): where does a wave's time go?  Every stamp waits for what
-    // was issued before it, so the traced kernel is a little slower than the product's.
-    uint64_t *const tr = d.atrace ? d.atrace + 8 * ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+// One road user's tick.  FUSED (small_tick_kernel, below): the repulsive sum (frx, fry) comes from the caller - no pair kernel
+// has run, so there are no partial sums to read and no pairs handed over.
+template <int MODEL, bool HET, bool FUSED>
+__device__ __forceinline__ void agent_body(const Dev &d, const int phases, const int64_t a, uint64_t *const tr, const uint32_t ka_lines,
+                                           const double frx, const double fry) {
     auto stamp = [&](int k) {
         if (tr != nullptr) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if ((threadIdx.x & 63) == 0) tr[k] = wall_clock64();
         }
     };
-    if (tr != nullptr && (threadIdx.x & 63) == 0) tr[0] = wall_clock64();
     if (a >= d.hi) return;
     // a slot left behind by csf_remove_agents; asked only when there is one (n_live != n, uniform): the answer is a round
     // trip to memory that every other load of the kernel would wait behind
@@ -63,7 +61,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     constexpr int PRE = 16;
     float2 pp[PRE];
 #pragma unroll
-    for (int c = 0; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
+    for (int c = 0; c < PRE; c++) pp[c] = FUSED ? make_float2(0.f, 0.f) : d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
     const float2 froad = d.froad[a];
     const float2 rorg = d.rorg[a];                             // (for the record written at the end)
     if (MODEL == CSF_INVPEND) {                                // (side-state of the model: with the first round trip, not the fourth)
@@ -78,7 +76,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     if (PLANNER && (phases & PH_DEST)) load_ring(d, g);
     // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge wait in a ring
     // (csf_dev.h: EdgeRec): bit 31 of the status word says so - a few dozen road users of a large population, per tick
-    const bool edge_pending = (phases & PH_COMBINE) && (g.st & CSF_ST_EDGE) != 0u;
+    const bool edge_pending = !FUSED && (phases & PH_COMBINE) && (g.st & CSF_ST_EDGE) != 0u;
     if (edge_pending) g.st &= ~CSF_ST_EDGE;
     stamp(1);
     double fdx, fdy;
@@ -107,16 +105,17 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
             int c = 0;
 #pragma unroll
             for (; c < PRE; c++) {
-                if (c < d.n_split) {
+                if (!FUSED && c < d.n_split) {
                     rx += (double)pp[c].x;
                     ry += (double)pp[c].y;
                 }
             }
-            for (; c < d.n_split; c++) {
+            for (; !FUSED && c < d.n_split; c++) {
                 const float2 pr = d.part[(int64_t)c * cap + a];
                 rx += (double)pr.x;
                 ry += (double)pr.y;
             }
+            if (FUSED) rx = frx, ry = fry;
             if (edge_pending) {     // rare: decide those pairs as the reference does (intersection.py:711-741) and put the sum right
                 double cx = 0, cy = 0;   // (fp64: the order in which the entries were appended does not show)
                 int32_t at = d.edge_head[a];
@@ -215,6 +214,86 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     d.status[a] = g.st;
     if (tr != nullptr && (threadIdx.x & 63) == 0) tr[6] = wall_clock64();
     stamp(7);
+}
+
+template <int MODEL, bool HET = false>
+__global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phases) {
+    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();   // (csf_dev.h)
+    const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // CSF_TRACE_AGENT (measurement aid, tools/agent_timeline.py): where does a wave's time go?  Every stamp waits for what
+    // was issued before it, so the traced kernel is a little slower than the product's.
+    uint64_t *const tr = d.atrace ? d.atrace + 8 * ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+    if (tr != nullptr && (threadIdx.x & 63) == 0) tr[0] = wall_clock64();
+    agent_body<MODEL, HET, false>(d, phases, a, tr, ka_lines, 0.0, 0.0);
+}
+
+// ---- a handful of road users: the whole tick in one wave, any number of ticks in one launch ---------------------------------
+// The reference's own scenarios (three cyclists at a crossing, scenarios/*.py; BASELINE config 1) are latency, not work: a pair
+// launch and a per-agent launch of 5 - 6 us each, nearly all of it launch, teardown and first round trips.  Up to
+// SMALL_MAX road users of one TwoD-field class are ticked by ONE wave instead - lane = road user - with nothing between the
+// phases but the wave's own program order, and csf_step(n) is one launch for all n ticks:
+//   snapshot (x, y, psi) of every lane                                    intersection.py:660-677
+//   every source j in turn (its numbers broadcast from lane j): the receiver's field of view decided as the reference
+//   decides it - fp64 atan2 -> limitAngle -> angleDifference (csf_dev.h: untracked_exact_xy) -, np.sign(phi) by the
+//   reference's chain (sign_phi_exact), the field in fp32 on the fp64 difference, summed in fp64 in source order
+//                                                                         intersection.py:690-745, 814-843; vehicle.py:1560-1648
+//   the per-agent tick with that sum (agent_body<FUSED>)                  see the head of this file
+// No records are binned, nothing is noted or handed over: every yes / no is taken in fp64 on the spot.
+__device__ __forceinline__ double readlane_f64(double v, int j) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(64) void small_tick_kernel(const Dev d, const int n_ticks) {
+    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();
+    const int lane = (int)threadIdx.x;
+    const int n = (int)d.n;
+    const int64_t cap = d.cap;
+    const bool live = lane < n;
+    const int64_t a = live ? lane : 0;
+    const PairConsts k = d.pc;
+    const bool p2r = d.p.priority_rule == CSF_P2R;
+    for (int t = 0; t < n_ticks; t++) {
+        // (own stores of the previous tick: the same thread reads them back in program order)
+        const double x = d.s[a], y = d.s[cap + a], psi = d.s[2 * cap + a];
+        double sp, cp;
+        sincos(psi, &sp, &cp);
+        const Recv r{0.f, 0.f, (float)cp, (float)sp};
+        double rx = 0.0, ry = 0.0;
+        for (int j = 0; j < n; j++) {
+            const double xs = readlane_f64(x, j), ys = readlane_f64(y, j), ps = readlane_f64(psi, j);
+            const double cs = readlane_f64(cp, j), ss = readlane_f64(sp, j);
+            const double ex = x - xs, ey = y - ys;                 // vehicle.py:1615-1616
+            // the receiver itself and a road user on the very same spot (D2) add nothing
+            if (!live || j == lane || (ex == 0.0 && ey == 0.0)) continue;
+            if (untracked_exact_xy(xs, ys, x, y, psi, d.p.hfov, p2r)) continue;
+            const int sg = sign_phi_exact(xs, ys, ps, x, y);
+            const float dx = (float)ex, dy = (float)ey;
+            float F, gx, gy;
+            field_twod(k, r, make_float4(0.f, 0.f, (float)cs, (float)ss), dx, dy, fmaxf(dx * dx + dy * dy, 1e-30f), F, gx, gy, sg < 0 ? -1.0f : 1.0f);
+            double wx = (double)(F * gx), wy = (double)(F * gy);
+            if (sg == 0) {                                          // phi = 0 exactly: no tangential part, |F| = P along the line
+                const double P = sqrt(wx * wx + wy * wy), il = 1.0 / sqrt(ex * ex + ey * ey);
+                wx = P * ex * il;
+                wy = P * ey * il;
+            }
+            rx += wx;
+            ry += wy;
+        }
+        if (live) agent_body<MODEL, false, true>(d, PH_DEST | PH_COMBINE | PH_INTEGRATE, a, nullptr, ka_lines, rx, ry);
+    }
+}
+
+void launch_small_tick(const Dev &d, int n_ticks, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
+    if (n_ticks <= 0 || d.n <= 0) return;
+#define CSF_SMALL(MODEL) hipExtLaunchKernelGGL((small_tick_kernel<MODEL>), dim3(1), dim3(64), 0, st, t0, t1, 0, d, n_ticks)
+    switch (d.p.model) {
+    case CSF_TWOD: CSF_SMALL(CSF_TWOD); break;
+    case CSF_INVPEND: CSF_SMALL(CSF_INVPEND); break;
+    case CSF_PLANARBIKE: CSF_SMALL(CSF_PLANARBIKE); break;
+    default: CSF_SMALL(CSF_PLANARPOINT); break;
+    }
+#undef CSF_SMALL
 }
 
 // (re)build the fp32 records, the short position ring and the model side-state from the fp64 state:

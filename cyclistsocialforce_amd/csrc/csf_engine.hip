@@ -100,6 +100,7 @@ struct Knobs {
     int dyn_recv = -1, rpb = 0;               // CSF_DYN_RECV, CSF_RPB
     int wide = -1;                            // CSF_WIDE: workgroups of 8 waves on tiles of 2048 sources (-1: the engine's choice)
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
+    int fused_small = 1;                      // CSF_FUSED_SMALL=0: a handful of road users take the general path too (csf_agent.hip: small_tick_kernel)
     int segments = -1;                        // CSF_SEGMENTS
     int seg_grid = 1;                         // CSF_SEG_GRID=0: one launch per parameter set (class-segmented order) instead of one grid
     int clist = 1;                            // CSF_CLIST=0: receivers in binned order walk every tile of their chunk (no candidate lists)
@@ -129,6 +130,7 @@ struct Knobs {
         rpb = geti("CSF_RPB", 0);
         wide = geti("CSF_WIDE", -1);
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
+        fused_small = geti("CSF_FUSED_SMALL", 1);
         segments = geti("CSF_SEGMENTS", -1);
         recv_binned = geti("CSF_RECV_BINNED", -1);
         clist = geti("CSF_CLIST", 1);
@@ -272,6 +274,7 @@ struct csf_engine {
     // since), and the integration steps since - nobody moves farther than t_s * v_max per step
     double coord_bound0 = 0.0;
     int64_t moves = 0;
+    int64_t small_ticks = 0;         // ticks run by the one-wave kernel (csf_small_ticks)
     bool bound_stale = false;        // positions moved without a speed clamp (csf_replay_forces with fix_speed): measure them
     uint32_t edge_stamp = 0;
     DevBuf<EdgeRec> edge;
@@ -2352,6 +2355,18 @@ static int loopback_exchange(csf_engine *const *g, int world) {
     return CSF_OK;
 }
 
+// A handful of road users of one TwoD-field class on one device, nothing sampled or recorded per tick: the whole tick in one
+// wave, all ticks of the call in one launch (csf_agent.hip: small_tick_kernel).  A pinned pair-kernel variant (the test suite's
+// CSF_PAIR_VARIANT) keeps the general path.
+static bool small_fused_ok(const csf_engine *e) {
+    const Dev &d = e->d;
+    const int m = d.p.model;
+    return e->knobs.fused_small != 0 && e->knobs.pair_variant < 0 && d.n >= 1 && d.n <= SMALL_MAX && d.n_live == d.n &&
+           e->classes.size() == 1 && (m == CSF_TWOD || m == CSF_INVPEND || m == CSF_PLANARPOINT || m == CSF_PLANARBIKE) && d.nv == 0 &&
+           e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && d.hist == nullptr && e->profile <= 0 &&
+           d.atrace == nullptr && d.lo == 0 && d.hi == d.n && e->pend.empty() && !e->dirty;
+}
+
 int csf_step(csf_engine *e, int64_t n_ticks) {
     if (!e) return CSF_E_ARG;
     if (n_ticks < 0) return fail(e, CSF_E_ARG, "n_ticks must be >= 0");
@@ -2365,6 +2380,19 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
         return CSF_OK;
     }
     if (n_ticks > 0 && !e->comm_calibrated && (rc = calibrate_comm_stream(e))) return rc;
+    if (n_ticks > 0 && small_fused_ok(e)) {
+        for (int64_t t = 0; t < n_ticks;) {                    // (launches of at most 2^16 ticks: a second or less each)
+            const int k = (int)std::min<int64_t>(n_ticks - t, 65536);
+            launch_small_tick(e->d, k, e->main);
+            HIPCHK(e, hipGetLastError());
+            e->d.tick += k;
+            e->moves += k;
+            e->small_ticks += k;
+            t += k;
+        }
+        e->device_ahead = true;
+        return CSF_OK;
+    }
     for (int64_t t = 0; t < n_ticks; t++) {
         rc = enqueue_tick(e);
         if (rc) return rc;
@@ -2977,6 +3005,12 @@ int csf_comm_stream_order(const csf_engine *e, int32_t *second_stream, double us
     if (!e || !second_stream) return CSF_E_ARG;
     *second_stream = e->comm_second ? 1 : 0;
     if (us_per_tick) us_per_tick[0] = e->comm_cal_us[0], us_per_tick[1] = e->comm_cal_us[1];
+    return CSF_OK;
+}
+
+int csf_small_ticks(const csf_engine *e, int64_t *n_ticks) {
+    if (!e || !n_ticks) return CSF_E_ARG;
+    *n_ticks = e->small_ticks;
     return CSF_OK;
 }
 

@@ -373,6 +373,12 @@ class Engine:
         self._ck(self._lib.csf_near_dropped(self._h, C.byref(n)))
         return n.value
 
+    def small_ticks(self):
+        """ticks run by the one-wave kernel of small populations (csf.h: csf_small_ticks)"""
+        n = C.c_int64(0)
+        self._ck(self._lib.csf_small_ticks(self._h, C.byref(n)))
+        return n.value
+
     def comm_stream_order(self):
         """('main' | 'second', [us per tick in stream order, on the second stream]) - where a sharded engine issues its
         all-gather, and what its communicator measured when it chose (zeros: CSF_COMM_STREAM decided, or not sharded)"""

@@ -1,0 +1,114 @@
+"""The one-wave tick of small populations (csf_agent.hip: small_tick_kernel; include/csf.h: csf_small_ticks): up to 8 road
+users of one TwoD-field class are ticked by ONE wave, every tick of a csf_step call in one launch, with every field-of-view
+decision and np.sign(phi) taken in fp64 as the reference takes them.  Against the golden trajectories of the literal
+reference, against the oracle on random small crowds, against the general path (pair launch + per-agent launch), and the
+conditions under which the engine leaves the path."""
+import numpy as np
+import pytest
+
+from oracle import csf_oracle as orc
+from test_gpu_parity import MODELS, amd, make_engine  # noqa: F401  (amd: fixture)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.auto_variant]
+
+
+@pytest.mark.parametrize("prefix,model", [("demo_twod", "twod"), ("demo_planarpoint", "planarpoint"), ("demo_invpend", "invpend")])
+@pytest.mark.parametrize("per_call", [10, 1])
+def test_demo_trajectories_golden_through_the_one_wave_kernel(amd, golden, prefix, model, per_call):
+    """intersection.py:866-896 for the reference's three-cyclist demo: 1e-4 of the scene extent, as everywhere"""
+    g = golden("trajectories")
+    e = make_engine(amd, model, g[f"{prefix}_s0"], g[f"{prefix}_vdes"], g[f"{prefix}_off"], g[f"{prefix}_dq"], 0)
+    S = g[f"{prefix}_S"]
+    assert g[f"{prefix}_s0"].shape[0] <= 8
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    ticks = 0
+    for k in range(1, S.shape[0]):
+        for _ in range(10 // per_call):
+            e.step(per_call)
+        ticks += 10
+        got = e.state()
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"{prefix} sample {k}")
+        np.testing.assert_allclose(got[:, 3], S[k][:, 3], rtol=0, atol=2e-3, err_msg=f"{prefix} speed sample {k}")
+    assert (e.status() == 0).all() and e.small_ticks() == ticks
+
+
+def crowd(n, seed, box=14.0):
+    rng = np.random.default_rng(seed)
+    x, y = rng.uniform(0, box, n), rng.uniform(0, box, n)
+    psi, v = rng.uniform(-np.pi, np.pi, n), rng.uniform(3, 6, n)
+    reach = np.array([8.0, 25.0, 60.0, 61.0])
+    dq = np.zeros((n, 5, 3))
+    dq[:, 0, 0], dq[:, 0, 1] = x, y
+    dq[:, 1:, 0] = x[:, None] + reach[None, :] * np.cos(psi)[:, None]
+    dq[:, 1:, 1] = y[:, None] + reach[None, :] * np.sin(psi)[:, None]
+    dq[:, 4, 2] = 1.0                                      # the last destination is a stop
+    return x, y, psi, v, np.arange(n + 1) * 5, dq.reshape(-1, 3)
+
+
+@pytest.mark.parametrize("model,n,rule,hfov", [("twod", 8, 0, None), ("twod", 5, 1, None), ("twod", 2, 0, 4.0), ("twod", 1, 0, None),
+                                               ("invpend", 6, 0, None), ("planarpoint", 8, 1, 2.0), ("planarpoint", 3, 0, None)])
+def test_small_crowds_vs_oracle(amd, model, n, rule, hfov):
+    """a dense handful (14 m box: every pair matters, fields of view cut through the crowd), forces every tick for 30 ticks,
+    trajectories over 400 - against the oracle, and against the engine's general path"""
+    x, y, psi, v, off, dq = crowd(n, seed=10 * n + rule)
+    s0 = np.zeros((n, orc.N_STATES[MODELS[model]])); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
+    over = {} if hfov is None else {"hfov": hfov}
+    e = make_engine(amd, model, s0, 5.0, off, dq, rule, **over)
+    pop = orc.Population(orc.default_params(model, priority_rule=rule, **over), s0, 5.0, off, dq)
+    for t in range(30):
+        e.step(1); pop.step(1)
+        fx, fy = e.forces(); ofx, ofy = pop.forces()
+        scale = max(np.hypot(ofx, ofy).max(), 1e-3)
+        assert max(np.abs(fx - ofx).max(), np.abs(fy - ofy).max()) < 1e-4 * scale, (t, n)
+    e.step(370); pop.step(370)
+    assert e.small_ticks() == 400 and (e.status() == 0).all()
+    got, ref = e.state(), pop.state()
+    extent = max(np.ptp(ref[:, 0]), np.ptp(ref[:, 1]), 14.0)
+    assert np.abs(got[:, :2] - ref[:, :2]).max() < 1e-4 * extent
+    _, ptr, zn, _ = e.state(with_nav=True)
+    optr, ozn, _, _ = pop.nav()
+    np.testing.assert_array_equal(ptr, optr)                  # destination pointers and navigation states: the same decisions
+    np.testing.assert_array_equal(np.asarray(zn).reshape(n, 3).astype(bool), ozn)    # (one-hot, as the reference keeps it)
+
+
+def test_general_path_agrees_and_is_taken_when_asked(amd, monkeypatch):
+    x, y, psi, v, off, dq = crowd(7, seed=3)
+    s0 = np.c_[x, y, psi, v, np.zeros(7)]
+    a = make_engine(amd, "twod", s0, 5.0, off, dq)
+    monkeypatch.setenv("CSF_FUSED_SMALL", "0")
+    b = make_engine(amd, "twod", s0, 5.0, off, dq)
+    monkeypatch.delenv("CSF_FUSED_SMALL")
+    a.step(300); b.step(300)
+    assert a.small_ticks() == 300 and b.small_ticks() == 0
+    assert np.abs(a.state()[:, :2] - b.state()[:, :2]).max() < 2e-5      # (fp32 pair sums on fp32 records against fp64 differences)
+
+
+def test_the_engine_leaves_the_path_when_it_does_not_apply(amd):
+    """a ninth road user, a road, a Bicycle-field class, profiling: the general path - and back"""
+    x, y, psi, v, off, dq = crowd(8, seed=4)
+    s0 = np.c_[x, y, psi, v, np.zeros(8)]
+    e = make_engine(amd, "twod", s0, 5.0, off, dq, capacity=16)
+    e.step(5)
+    assert e.small_ticks() == 5
+    e.add_agents(np.array([[30.0, 30.0, 0.0, 4.0, 0.0]]), 5.0)
+    e.set_dest_queue(np.array([8]), np.array([0, 2]), np.array([[30.0, 30.0, 0.0], [90.0, 30.0, 0.0]]), reset=True)
+    e.step(5)
+    assert e.small_ticks() == 5 and e.n == 9 and np.isfinite(e.state()).all()
+    e.remove_agents(np.array([8], dtype=np.int32))
+    e.step(5)
+    assert e.small_ticks() == 5 and e.n == 8 and (e.status() == 0).all()   # (its slot stays behind, dead: the general path skips it)
+    f = make_engine(amd, "twod", s0, 5.0, off, dq)
+    f.profile(1)
+    f.step(3)
+    assert f.small_ticks() == 0 and f.profile_kernels()["pair"][1] == 3     # sampled launches are the general path's
+    f.profile(0)
+    f.step(2)
+    assert f.small_ticks() == 2 and (f.status() == 0).all()
+    g = make_engine(amd, "twod", s0, 5.0, off, dq)
+    g.set_road(np.array([0, 2]), np.array([[-5.0, -5.0], [-5.0, 20.0]]), np.array([0.15]), np.array([2.0]))
+    g.step(4)
+    assert g.small_ticks() == 0 and np.isfinite(g.state()).all()
+    bx, by, bpsi, bv, boff, bdq = crowd(4, seed=5)
+    bike = make_engine(amd, "bicycle", np.c_[bx, by, bpsi, bv, np.zeros(4)], 5.0, boff, bdq)
+    bike.step(4)
+    assert bike.small_ticks() == 0
