@@ -61,7 +61,15 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     constexpr int PRE = 16;
     float2 pp[PRE];
 #pragma unroll
-    for (int c = 0; c < PRE; c++) pp[c] = FUSED ? make_float2(0.f, 0.f) : d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
+    for (int c = 0; c < PRE; c++) pp[c] = make_float2(0.f, 0.f);
+    if (!FUSED) {                                              // (eight chunks is the single-device split: the other eight loads
+#pragma unroll                                                 //  would only queue in front of everything asked for after them)
+        for (int c = 0; c < PRE / 2; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
+        if (d.n_split > PRE / 2) {
+#pragma unroll
+            for (int c = PRE / 2; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
+        }
+    }
     const float2 froad = d.froad[a];
     const float2 rorg = d.rorg[a];                             // (for the record written at the end)
     if (MODEL == CSF_INVPEND) {                                // (side-state of the model: with the first round trip, not the fourth)
