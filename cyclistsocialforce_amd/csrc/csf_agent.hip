@@ -240,55 +240,77 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
 // launch and a per-agent launch of 5 - 6 us each, nearly all of it launch, teardown and first round trips.  Up to
 // SMALL_MAX road users of one TwoD-field class are ticked by ONE wave instead - lane = road user - with nothing between the
 // phases but the wave's own program order, and csf_step(n) is one launch for all n ticks:
-//   snapshot (x, y, psi) of every lane                                    intersection.py:660-677
-//   every source j in turn (its numbers broadcast from lane j): the receiver's field of view decided as the reference
-//   decides it - fp64 atan2 -> limitAngle -> angleDifference (csf_dev.h: untracked_exact_xy) -, np.sign(phi) by the
-//   reference's chain (sign_phi_exact), the field in fp32 on the fp64 difference, summed in fp64 in source order
+//   snapshot (x, y, psi) of every road user, staged in LDS                intersection.py:660-677
+//   every source j of the lane's group in turn: receiver - source formed in fp64; the field of view and
+//   np.sign(phi) decided in fp32 on that difference with the band of ITS rounding (csf_field.h: tracked_precise,
+//   side_undecided - the predicates of the pair kernels' exact path) and, inside the band, as the reference decides them -
+//   fp64 atan2 -> limitAngle -> angleDifference (csf_dev.h: untracked_exact_xy), acos -> limitAngle -> sign
+//   (sign_phi_exact); the field in fp32, summed in fp64 (per group in source order, the groups pairwise)
 //                                                                         intersection.py:690-745, 814-843; vehicle.py:1560-1648
 //   the per-agent tick with that sum (agent_body<FUSED>)                  see the head of this file
-// No records are binned, nothing is noted or handed over: every yes / no is taken in fp64 on the spot.
-__device__ __forceinline__ double readlane_f64(double v, int j) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
-}
-
+// No records are binned, nothing is noted or handed over: every yes / no is settled on the spot.
 template <int MODEL>
 __global__ __launch_bounds__(64) void small_tick_kernel(const Dev d, const int n_ticks) {
     const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();
+    // Lane = (receiver, source group): with P the power of two that holds the road users, lane % P is the receiver and lane / P
+    // one of 64 / P groups that share the sources between them (source j belongs to group j % G) - all 64 lanes work on the
+    // pair term whatever the population, and the groups' sums meet in lanes 0 .. n - 1, which then tick their road user.
+    __shared__ double sx[SMALL_MAX], sy[SMALL_MAX], spsi[SMALL_MAX], scs[SMALL_MAX], ssn[SMALL_MAX];
     const int lane = (int)threadIdx.x;
     const int n = (int)d.n;
+    int P = 1;
+    while (P < n) P <<= 1;
+    const int G = WAVE / P, i = lane & (P - 1), grp = lane / P;
     const int64_t cap = d.cap;
-    const bool live = lane < n;
-    const int64_t a = live ? lane : 0;
+    const bool live = i < n;
+    const int64_t a = live ? i : 0;
     const PairConsts k = d.pc;
     const bool p2r = d.p.priority_rule == CSF_P2R;
     for (int t = 0; t < n_ticks; t++) {
-        // (own stores of the previous tick: the same thread reads them back in program order)
+        // (own stores of the previous tick: the lanes of the first group wrote them, in this wave: program order)
         const double x = d.s[a], y = d.s[cap + a], psi = d.s[2 * cap + a];
         double sp, cp;
         sincos(psi, &sp, &cp);
+        if (lane < n) sx[lane] = x, sy[lane] = y, spsi[lane] = psi, scs[lane] = cp, ssn[lane] = sp;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const Recv r{0.f, 0.f, (float)cp, (float)sp};
         double rx = 0.0, ry = 0.0;
-        for (int j = 0; j < n; j++) {
-            const double xs = readlane_f64(x, j), ys = readlane_f64(y, j), ps = readlane_f64(psi, j);
-            const double cs = readlane_f64(cp, j), ss = readlane_f64(sp, j);
+        for (int j = grp; j < n; j += G) {                         // (lanes of one group: the same j)
+            const double xs = sx[j], ys = sy[j], ps = spsi[j];
             const double ex = x - xs, ey = y - ys;                 // vehicle.py:1615-1616
             // the receiver itself and a road user on the very same spot (D2) add nothing
-            if (!live || j == lane || (ex == 0.0 && ey == 0.0)) continue;
-            if (untracked_exact_xy(xs, ys, x, y, psi, d.p.hfov, p2r)) continue;
-            const int sg = sign_phi_exact(xs, ys, ps, x, y);
-            const float dx = (float)ex, dy = (float)ey;
+            if (!live || j == i || (ex == 0.0 && ey == 0.0)) continue;
+            const float dx = (float)ex, dy = (float)ey, r2 = fmaxf(dx * dx + dy * dy, 1e-30f);
+            const float4 q = make_float4(0.f, 0.f, (float)scs[j], (float)ssn[j]);
+            bool edge;
+            bool seen = p2r ? tracked_precise<true>(k, k.chs, r, dx, dy, r2, edge) : tracked_precise<false>(k, k.chs, r, dx, dy, r2, edge);
+            if (edge) seen = !untracked_exact_xy(xs, ys, x, y, psi, d.p.hfov, p2r);   // (one pair in a million)
+            if (!seen) continue;
+            int sg = 1;
+            float sgf = 0.0f;                                       // 0: the sign of the fp32 sine
+            if (side_undecided(k, q, dx, dy, r2)) {
+                sg = sign_phi_exact(xs, ys, ps, x, y);
+                sgf = sg < 0 ? -1.0f : 1.0f;
+            }
             float F, gx, gy;
-            field_twod(k, r, make_float4(0.f, 0.f, (float)cs, (float)ss), dx, dy, fmaxf(dx * dx + dy * dy, 1e-30f), F, gx, gy, sg < 0 ? -1.0f : 1.0f);
+            field_twod(k, r, q, dx, dy, r2, F, gx, gy, sgf);
             double wx = (double)(F * gx), wy = (double)(F * gy);
             if (sg == 0) {                                          // phi = 0 exactly: no tangential part, |F| = P along the line
-                const double P = sqrt(wx * wx + wy * wy), il = 1.0 / sqrt(ex * ex + ey * ey);
-                wx = P * ex * il;
-                wy = P * ey * il;
+                const double Pm = sqrt(wx * wx + wy * wy), il = 1.0 / sqrt(ex * ex + ey * ey);
+                wx = Pm * ex * il;
+                wy = Pm * ey * il;
             }
             rx += wx;
             ry += wy;
         }
-        if (live) agent_body<MODEL, false, true>(d, PH_DEST | PH_COMBINE | PH_INTEGRATE, a, nullptr, ka_lines, rx, ry);
+        // the groups' sums of a receiver, added pairwise in a fixed order: every lane of it ends with the total
+        for (int o = P; o < WAVE; o <<= 1) {
+            rx += __shfl_xor(rx, o, WAVE);
+            ry += __shfl_xor(ry, o, WAVE);
+        }
+        __builtin_amdgcn_wave_barrier();                          // (the staged snapshot is read by every lane before it is renewed)
+        if (lane < n) agent_body<MODEL, false, true>(d, PH_DEST | PH_COMBINE | PH_INTEGRATE, lane, nullptr, ka_lines, rx, ry);
     }
 }
 

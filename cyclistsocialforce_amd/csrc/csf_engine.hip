@@ -2381,6 +2381,7 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
     }
     if (n_ticks > 0 && !e->comm_calibrated && (rc = calibrate_comm_stream(e))) return rc;
     if (n_ticks > 0 && small_fused_ok(e)) {
+        if ((rc = set_fov_band(e))) return rc;                 // (the bands of the fp32 decisions: tracked_precise, side_undecided)
         for (int64_t t = 0; t < n_ticks;) {                    // (launches of at most 2^16 ticks: a second or less each)
             const int k = (int)std::min<int64_t>(n_ticks - t, 65536);
             launch_small_tick(e->d, k, e->main);

@@ -1,12 +1,14 @@
-"""The one-wave tick of small populations (csf_agent.hip: small_tick_kernel; include/csf.h: csf_small_ticks): up to 8 road
-users of one TwoD-field class are ticked by ONE wave, every tick of a csf_step call in one launch, with every field-of-view
-decision and np.sign(phi) taken in fp64 as the reference takes them.  Against the golden trajectories of the literal
+"""The one-wave tick of small populations (csf_agent.hip: small_tick_kernel; include/csf.h: csf_small_ticks): up to 32 road
+users of one TwoD-field class are ticked by ONE wave, every tick of a csf_step call in one launch; field-of-view decisions
+and np.sign(phi) are taken on the fp64 difference of the two positions - in fp32 with the band of its rounding, and inside
+the band by the reference's own fp64 chain.  Against the golden trajectories of the literal
 reference, against the oracle on random small crowds, against the general path (pair launch + per-agent launch), and the
 conditions under which the engine leaves the path."""
 import numpy as np
 import pytest
 
 from oracle import csf_oracle as orc
+from conftest import shadow_run
 from test_gpu_parity import MODELS, amd, make_engine  # noqa: F401  (amd: fixture)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.auto_variant]
@@ -19,7 +21,7 @@ def test_demo_trajectories_golden_through_the_one_wave_kernel(amd, golden, prefi
     g = golden("trajectories")
     e = make_engine(amd, model, g[f"{prefix}_s0"], g[f"{prefix}_vdes"], g[f"{prefix}_off"], g[f"{prefix}_dq"], 0)
     S = g[f"{prefix}_S"]
-    assert g[f"{prefix}_s0"].shape[0] <= 8
+    assert g[f"{prefix}_s0"].shape[0] <= 32
     extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
     ticks = 0
     for k in range(1, S.shape[0]):
@@ -46,11 +48,13 @@ def crowd(n, seed, box=14.0):
 
 
 @pytest.mark.parametrize("model,n,rule,hfov", [("twod", 8, 0, None), ("twod", 5, 1, None), ("twod", 2, 0, 4.0), ("twod", 1, 0, None),
-                                               ("invpend", 6, 0, None), ("planarpoint", 8, 1, 2.0), ("planarpoint", 3, 0, None)])
+                                               ("invpend", 6, 0, None), ("planarpoint", 8, 1, 2.0), ("planarpoint", 3, 0, None),
+                                               ("twod", 16, 0, None), ("twod", 13, 1, 2.0), ("invpend", 16, 0, 4.0), ("planarpoint", 11, 0, None), ("twod", 16, 0, 4.0),
+                                               ("twod", 32, 0, None), ("planarpoint", 27, 1, 2.0), ("invpend", 32, 0, None), ("twod", 19, 0, 4.0)])
 def test_small_crowds_vs_oracle(amd, model, n, rule, hfov):
     """a dense handful (14 m box: every pair matters, fields of view cut through the crowd), forces every tick for 30 ticks,
     trajectories over 400 - against the oracle, and against the engine's general path"""
-    x, y, psi, v, off, dq = crowd(n, seed=10 * n + rule)
+    x, y, psi, v, off, dq = crowd(n, seed=10 * n + rule, box=14.0 if n <= 8 else (22.0 if n <= 16 else 30.0))
     s0 = np.zeros((n, orc.N_STATES[MODELS[model]])); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
     over = {} if hfov is None else {"hfov": hfov}
     e = make_engine(amd, model, s0, 5.0, off, dq, rule, **over)
@@ -60,13 +64,19 @@ def test_small_crowds_vs_oracle(amd, model, n, rule, hfov):
         fx, fy = e.forces(); ofx, ofy = pop.forces()
         scale = max(np.hypot(ofx, ofy).max(), 1e-3)
         assert max(np.abs(fx - ofx).max(), np.abs(fy - ofy).max()) < 1e-4 * scale, (t, n)
-    e.step(370); pop.step(370)
-    assert e.small_ticks() == 400 and (e.status() == 0).all()
-    got, ref = e.state(), pop.state()
+    # trajectories: a handful runs free for 400 ticks; a dense crowd of up to 32 is chaotic on that horizon (conftest.shadow_run:
+    # the oracle shadows the uninterrupted engine in windows of 10 ticks)
+    e2 = make_engine(amd, model, s0, 5.0, off, dq, rule, **over)
+    pop2 = orc.Population(orc.default_params(model, priority_rule=rule, **over), s0, 5.0, off, dq)
+    # (InvPendulum's yaw loop takes atan2(Fy, Fx) as it comes, vehicle.py:1832: where a crowd pushes a rider's force through the
+    # cut at +-pi, rounding decides which way the steering swings - in the reference as here; the dense crowds stop before that)
+    ticks = 400 if n <= 8 else 100
+    worst, _, got, ref = shadow_run(e2, pop2, ticks, 400 if n <= 8 else 10)
+    assert e2.small_ticks() == ticks and (e2.status() == 0).all()
     extent = max(np.ptp(ref[:, 0]), np.ptp(ref[:, 1]), 14.0)
-    assert np.abs(got[:, :2] - ref[:, :2]).max() < 1e-4 * extent
-    _, ptr, zn, _ = e.state(with_nav=True)
-    optr, ozn, _, _ = pop.nav()
+    assert worst < 1e-4 * extent
+    _, ptr, zn, _ = e2.state(with_nav=True)
+    optr, ozn, _, _ = pop2.nav()
     np.testing.assert_array_equal(ptr, optr)                  # destination pointers and navigation states: the same decisions
     np.testing.assert_array_equal(np.asarray(zn).reshape(n, 3).astype(bool), ozn)    # (one-hot, as the reference keeps it)
 
@@ -84,19 +94,21 @@ def test_general_path_agrees_and_is_taken_when_asked(amd, monkeypatch):
 
 
 def test_the_engine_leaves_the_path_when_it_does_not_apply(amd):
-    """a ninth road user, a road, a Bicycle-field class, profiling: the general path - and back"""
-    x, y, psi, v, off, dq = crowd(8, seed=4)
-    s0 = np.c_[x, y, psi, v, np.zeros(8)]
-    e = make_engine(amd, "twod", s0, 5.0, off, dq, capacity=16)
+    """a thirty-third road user, a road, a Bicycle-field class, profiling: the general path"""
+    x, y, psi, v, off, dq = crowd(32, seed=4, box=30.0)
+    s0 = np.c_[x, y, psi, v, np.zeros(32)]
+    e = make_engine(amd, "twod", s0, 5.0, off, dq, capacity=48)
     e.step(5)
     assert e.small_ticks() == 5
-    e.add_agents(np.array([[30.0, 30.0, 0.0, 4.0, 0.0]]), 5.0)
-    e.set_dest_queue(np.array([8]), np.array([0, 2]), np.array([[30.0, 30.0, 0.0], [90.0, 30.0, 0.0]]), reset=True)
+    e.add_agents(np.array([[40.0, 40.0, 0.0, 4.0, 0.0]]), 5.0)
+    e.set_dest_queue(np.array([32]), np.array([0, 2]), np.array([[40.0, 40.0, 0.0], [90.0, 40.0, 0.0]]), reset=True)
     e.step(5)
-    assert e.small_ticks() == 5 and e.n == 9 and np.isfinite(e.state()).all()
-    e.remove_agents(np.array([8], dtype=np.int32))
+    assert e.small_ticks() == 5 and e.n == 33 and np.isfinite(e.state()).all()
+    e.remove_agents(np.array([32], dtype=np.int32))
     e.step(5)
-    assert e.small_ticks() == 5 and e.n == 8 and (e.status() == 0).all()   # (its slot stays behind, dead: the general path skips it)
+    assert e.small_ticks() == 5 and e.n == 32 and (e.status() == 0).all()   # (its slot stays behind, dead: the general path skips it)
+    x, y, psi, v, off, dq = crowd(8, seed=4)
+    s0 = np.c_[x, y, psi, v, np.zeros(8)]
     f = make_engine(amd, "twod", s0, 5.0, off, dq)
     f.profile(1)
     f.step(3)
