@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
 // ---- a handful of road users: the whole tick in one wave, any number of ticks in one launch ---------------------------------
 // The reference's own scenarios (three cyclists at a crossing, scenarios/*.py; BASELINE config 1) are latency, not work: a pair
 // launch and a per-agent launch of 5 - 6 us each, nearly all of it launch, teardown and first round trips.  Up to
-// SMALL_MAX road users of one TwoD-field class are ticked by ONE wave instead - lane = road user - with nothing between the
+// SMALL_MAX road users of one class (not the UncontrolledVehicle's) are ticked by ONE wave instead - lane = road user - with nothing between the
 // phases but the wave's own program order, and csf_step(n) is one launch for all n ticks:
 //   snapshot (x, y, psi) of every road user, staged in LDS                intersection.py:660-677
 //   every source j of the lane's group in turn: receiver - source formed in fp64; the field of view and
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(64) void small_tick_kernel(const Dev d, const int n
     // one of 64 / P groups that share the sources between them (source j belongs to group j % G) - all 64 lanes work on the
     // pair term whatever the population, and the groups' sums meet in lanes 0 .. n - 1, which then tick their road user.
     __shared__ double sx[SMALL_MAX], sy[SMALL_MAX], spsi[SMALL_MAX], scs[SMALL_MAX], ssn[SMALL_MAX];
+    __shared__ float2 se[MODEL == CSF_BICYCLE ? SMALL_MAX : 1];   // Bicycle field: (e, 1 / sqrt(1 - e^2)) of every source (vehicle.py:1062-1064)
     const int lane = (int)threadIdx.x;
     const int n = (int)d.n;
     int P = 1;
@@ -266,12 +267,21 @@ __global__ __launch_bounds__(64) void small_tick_kernel(const Dev d, const int n
     const int64_t a = live ? i : 0;
     const PairConsts k = d.pc;
     const bool p2r = d.p.priority_rule == CSF_P2R;
+    // road elements (intersection.py:226-242; the curve scenario's ~1 500 vertices): staged once per launch - they are static
+    __shared__ float4 srv[SMALL_ROAD_MAX];
+    const int nvp = (int)d.nv_pad;
+    for (int v = lane; v < nvp; v += WAVE) srv[v] = d.rv[v];
     for (int t = 0; t < n_ticks; t++) {
         // (own stores of the previous tick: the lanes of the first group wrote them, in this wave: program order)
         const double x = d.s[a], y = d.s[cap + a], psi = d.s[2 * cap + a];
         double sp, cp;
         sincos(psi, &sp, &cp);
         if (lane < n) sx[lane] = x, sy[lane] = y, spsi[lane] = psi, scs[lane] = cp, ssn[lane] = sp;
+        if (MODEL == CSF_BICYCLE && lane < n) {                    // (what write_record keeps in rec2 for the pair kernels)
+            const double v = d.s[3 * cap + a];
+            const double e = v > 0.0 ? fmin(pow(v / d.p.v_max_riding[1], 0.1), 0.7) : 0.0;
+            se[lane] = make_float2((float)e, (float)(1.0 / sqrt(1.0 - e * e)));
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const Recv r{0.f, 0.f, (float)cp, (float)sp};
@@ -288,13 +298,17 @@ __global__ __launch_bounds__(64) void small_tick_kernel(const Dev d, const int n
             if (edge) seen = !untracked_exact_xy(xs, ys, x, y, psi, d.p.hfov, p2r);   // (one pair in a million)
             if (!seen) continue;
             int sg = 1;
-            float sgf = 0.0f;                                       // 0: the sign of the fp32 sine
-            if (side_undecided(k, q, dx, dy, r2)) {
-                sg = sign_phi_exact(xs, ys, ps, x, y);
-                sgf = sg < 0 ? -1.0f : 1.0f;
-            }
             float F, gx, gy;
-            field_twod(k, r, q, dx, dy, r2, F, gx, gy, sgf);
+            if (MODEL == CSF_BICYCLE) {                             // vehicle.py:1054-1147: no jump at phi = 0
+                field_bicycle(k, q, se[j], dx, dy, r2, F, gx, gy);
+            } else {
+                float sgf = 0.0f;                                   // 0: the sign of the fp32 sine
+                if (side_undecided(k, q, dx, dy, r2)) {
+                    sg = sign_phi_exact(xs, ys, ps, x, y);
+                    sgf = sg < 0 ? -1.0f : 1.0f;
+                }
+                field_twod(k, r, q, dx, dy, r2, F, gx, gy, sgf);
+            }
             double wx = (double)(F * gx), wy = (double)(F * gy);
             if (sg == 0) {                                          // phi = 0 exactly: no tangential part, |F| = P along the line
                 const double Pm = sqrt(wx * wx + wy * wy), il = 1.0 / sqrt(ex * ex + ey * ey);
@@ -309,6 +323,36 @@ __global__ __launch_bounds__(64) void small_tick_kernel(const Dev d, const int n
             rx += __shfl_xor(rx, o, WAVE);
             ry += __shfl_xor(ry, o, WAVE);
         }
+        if (nvp > 0) {
+            // vertices as offsets from the origin of their tile of 1 024 (csf_dev.h: rv, rvo): the receiver's offset from it is formed
+            // in fp64; the sum as road_kernel forms it (fp32, r^-(sigma+1) as a power of rsq(r^2) where every edge shares an integer sigma)
+            float qx = 0.f, qy = 0.f;
+            const double bx = x - d.ox, by = y - d.oy;
+            for (int base = 0; base < nvp; base += 1024) {
+                const float2 ot = d.rvo[base >> 10];
+                const float rxo = (float)(bx - (double)ot.x), ryo = (float)(by - (double)ot.y);
+                const int cnt = nvp - base < 1024 ? nvp - base : 1024;
+                for (int u = grp; u < cnt; u += G) {
+                    const float4 v = srv[base + u];                // (x, y, -F0, -(sigma + 1) / 2); padding has F0 = 0
+                    const float ex = v.x - rxo, ey = v.y - ryo, r2 = ex * ex + ey * ey;
+                    float m;
+                    if (d.road_np) {
+                        const float inv = fminf(fast_rsq(r2), 1e6f), i2 = inv * inv;   // r = 0: finite, times ex = ey = 0
+                        m = d.road_np == 2 ? i2 : d.road_np == 3 ? i2 * inv : d.road_np == 4 ? i2 * i2 : d.road_np == 5 ? i2 * i2 * inv : i2 * i2 * i2;
+                    } else {
+                        m = fast_exp2(fminf(v.w * fast_log2(r2), 120.f));
+                    }
+                    m *= v.z;
+                    qx = m * ex + qx;
+                    qy = m * ey + qy;
+                }
+            }
+            for (int o = P; o < WAVE; o <<= 1) {
+                qx += __shfl_xor(qx, o, WAVE);
+                qy += __shfl_xor(qy, o, WAVE);
+            }
+            if (lane < n) d.froad[lane] = make_float2(qx, qy);    // (agent_body reads it back: the same lane, program order)
+        }
         __builtin_amdgcn_wave_barrier();                          // (the staged snapshot is read by every lane before it is renewed)
         if (lane < n) agent_body<MODEL, false, true>(d, PH_DEST | PH_COMBINE | PH_INTEGRATE, lane, nullptr, ka_lines, rx, ry);
     }
@@ -318,6 +362,7 @@ void launch_small_tick(const Dev &d, int n_ticks, hipStream_t st, hipEvent_t t0,
     if (n_ticks <= 0 || d.n <= 0) return;
 #define CSF_SMALL(MODEL) hipExtLaunchKernelGGL((small_tick_kernel<MODEL>), dim3(1), dim3(64), 0, st, t0, t1, 0, d, n_ticks)
     switch (d.p.model) {
+    case CSF_BICYCLE: CSF_SMALL(CSF_BICYCLE); break;
     case CSF_TWOD: CSF_SMALL(CSF_TWOD); break;
     case CSF_INVPEND: CSF_SMALL(CSF_INVPEND); break;
     case CSF_PLANARBIKE: CSF_SMALL(CSF_PLANARBIKE); break;

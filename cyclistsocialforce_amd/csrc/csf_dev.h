@@ -247,6 +247,7 @@ void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0 = null
 // csf_agent.hip: up to SMALL_MAX road users of one TwoD-field class, n_ticks whole ticks in one launch of one wave (the rounding
 // bands of the launch: csf_engine.hip set_fov_band)
 constexpr int SMALL_MAX = 32;
+constexpr int SMALL_ROAD_MAX = 2048;   // road vertices (padded) the one-wave kernel stages; and at most 256 of them per lane and tick
 void launch_small_tick(const Dev &d, int n_ticks, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 const char *pair_kernel_name(const Dev &d);           // the kernel launch_pair() takes for this engine
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state

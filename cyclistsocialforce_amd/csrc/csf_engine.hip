@@ -2355,14 +2355,21 @@ static int loopback_exchange(csf_engine *const *g, int world) {
     return CSF_OK;
 }
 
-// A handful of road users of one TwoD-field class on one device, nothing sampled or recorded per tick: the whole tick in one
+// A handful of road users of one class (not the UncontrolledVehicle's) on one device, nothing sampled or recorded per tick: the whole tick in one
 // wave, all ticks of the call in one launch (csf_agent.hip: small_tick_kernel).  A pinned pair-kernel variant (the test suite's
 // CSF_PAIR_VARIANT) keeps the general path.
+static bool small_road_ok(const Dev &d) {   // no road, or a small one: staged in LDS, at most 256 vertices per lane and tick
+    if (d.nv == 0) return true;
+    int64_t P = 1;
+    while (P < d.n) P <<= 1;
+    return d.rg_nx == 0 && d.nv_pad <= SMALL_ROAD_MAX && d.nv_pad * P <= 256 * WAVE;
+}
+
 static bool small_fused_ok(const csf_engine *e) {
     const Dev &d = e->d;
     const int m = d.p.model;
     return e->knobs.fused_small != 0 && e->knobs.pair_variant < 0 && d.n >= 1 && d.n <= SMALL_MAX && d.n_live == d.n &&
-           e->classes.size() == 1 && (m == CSF_TWOD || m == CSF_INVPEND || m == CSF_PLANARPOINT || m == CSF_PLANARBIKE) && d.nv == 0 &&
+           e->classes.size() == 1 && m != CSF_UNCONTROLLED && small_road_ok(d) &&
            e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && d.hist == nullptr && e->profile <= 0 &&
            d.atrace == nullptr && d.lo == 0 && d.hi == d.n && e->pend.empty() && !e->dirty;
 }

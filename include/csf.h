@@ -285,9 +285,8 @@ int csf_comm_stream_order(const csf_engine *e, int32_t *second_stream, double us
 /* milliseconds between the end of the agent kernel and the end of the RCCL all-gather, accumulated over the launches
  * of the last csf_profile_read (0 for an unsharded engine) */
 int csf_profile_gather(const csf_engine *e, double *gather_ms);
-/* Ticks this engine has run in its one-wave kernel (ABI 6).  Up to 32 road users of one parameter set whose field is the
- * TwoD one (TwoDBicycle, InvPendulumBicycle, PlanarPointBicycle, PlanarBicycle) - the reference's own scenarios, e.g. the
- * three cyclists of scenarios/ - on one device, without road elements, history ring or profiling: csf_step(e, n) is then ONE
+/* Ticks this engine has run in its one-wave kernel (ABI 6).  Up to 32 road users of one parameter set (any rider class; not
+ * UncontrolledVehicle) - the reference's own scenarios, e.g. the three cyclists of scenarios/ - on one device, with no road or a small one (at most 2048 vertices), without history ring or profiling: csf_step(e, n) is then ONE
  * launch of one wave for all n ticks (lane = road user; field-of-view decisions and np.sign(phi) on the fp64 difference of
  * the two positions, inside the band of fp32 rounding by the reference's own fp64 chain, intersection.py:690-745,
  * vehicle.py:1617-1625), instead of a pair launch and a per-agent launch per tick.  CSF_FUSED_SMALL=0 or a pinned CSF_PAIR_VARIANT keep the general path. */

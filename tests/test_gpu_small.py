@@ -1,5 +1,5 @@
 """The one-wave tick of small populations (csf_agent.hip: small_tick_kernel; include/csf.h: csf_small_ticks): up to 32 road
-users of one TwoD-field class are ticked by ONE wave, every tick of a csf_step call in one launch; field-of-view decisions
+users of one parameter set are ticked by ONE wave, every tick of a csf_step call in one launch; field-of-view decisions
 and np.sign(phi) are taken on the fp64 difference of the two positions - in fp32 with the band of its rounding, and inside
 the band by the reference's own fp64 chain.  Against the golden trajectories of the literal
 reference, against the oracle on random small crowds, against the general path (pair launch + per-agent launch), and the
@@ -14,12 +14,15 @@ from test_gpu_parity import MODELS, amd, make_engine  # noqa: F401  (amd: fixtur
 pytestmark = [pytest.mark.gpu, pytest.mark.auto_variant]
 
 
-@pytest.mark.parametrize("prefix,model", [("demo_twod", "twod"), ("demo_planarpoint", "planarpoint"), ("demo_invpend", "invpend")])
+@pytest.mark.parametrize("prefix,model", [("demo_twod", "twod"), ("demo_planarpoint", "planarpoint"), ("demo_invpend", "invpend"), ("demo_bicycle", "bicycle"),
+                                          ("road_pp", "planarpoint")])
 @pytest.mark.parametrize("per_call", [10, 1])
 def test_demo_trajectories_golden_through_the_one_wave_kernel(amd, golden, prefix, model, per_call):
     """intersection.py:866-896 for the reference's three-cyclist demo: 1e-4 of the scene extent, as everywhere"""
     g = golden("trajectories")
     e = make_engine(amd, model, g[f"{prefix}_s0"], g[f"{prefix}_vdes"], g[f"{prefix}_off"], g[f"{prefix}_dq"], 0)
+    if f"{prefix}_verts" in g.files:                          # the curve scenario's road edges (scenarios/curve-scenario.py): 1 530 vertices
+        e.set_road(g[f"{prefix}_roff"], g[f"{prefix}_verts"], g[f"{prefix}_F0"], g[f"{prefix}_sigma"])
     S = g[f"{prefix}_S"]
     assert g[f"{prefix}_s0"].shape[0] <= 32
     extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
@@ -50,7 +53,8 @@ def crowd(n, seed, box=14.0):
 @pytest.mark.parametrize("model,n,rule,hfov", [("twod", 8, 0, None), ("twod", 5, 1, None), ("twod", 2, 0, 4.0), ("twod", 1, 0, None),
                                                ("invpend", 6, 0, None), ("planarpoint", 8, 1, 2.0), ("planarpoint", 3, 0, None),
                                                ("twod", 16, 0, None), ("twod", 13, 1, 2.0), ("invpend", 16, 0, 4.0), ("planarpoint", 11, 0, None), ("twod", 16, 0, 4.0),
-                                               ("twod", 32, 0, None), ("planarpoint", 27, 1, 2.0), ("invpend", 32, 0, None), ("twod", 19, 0, 4.0)])
+                                               ("twod", 32, 0, None), ("planarpoint", 27, 1, 2.0), ("invpend", 32, 0, None), ("twod", 19, 0, 4.0),
+                                               ("bicycle", 7, 0, None), ("bicycle", 32, 1, None), ("bicycle", 12, 0, 4.0)])
 def test_small_crowds_vs_oracle(amd, model, n, rule, hfov):
     """a dense handful (14 m box: every pair matters, fields of view cut through the crowd), forces every tick for 30 ticks,
     trajectories over 400 - against the oracle, and against the engine's general path"""
@@ -94,7 +98,7 @@ def test_general_path_agrees_and_is_taken_when_asked(amd, monkeypatch):
 
 
 def test_the_engine_leaves_the_path_when_it_does_not_apply(amd):
-    """a thirty-third road user, a road, a Bicycle-field class, profiling: the general path"""
+    """a thirty-third road user, a road, profiling: the general path"""
     x, y, psi, v, off, dq = crowd(32, seed=4, box=30.0)
     s0 = np.c_[x, y, psi, v, np.zeros(32)]
     e = make_engine(amd, "twod", s0, 5.0, off, dq, capacity=48)
@@ -116,11 +120,30 @@ def test_the_engine_leaves_the_path_when_it_does_not_apply(amd):
     f.profile(0)
     f.step(2)
     assert f.small_ticks() == 2 and (f.status() == 0).all()
-    g = make_engine(amd, "twod", s0, 5.0, off, dq)
-    g.set_road(np.array([0, 2]), np.array([[-5.0, -5.0], [-5.0, 20.0]]), np.array([0.15]), np.array([2.0]))
+    g = make_engine(amd, "twod", s0, 5.0, off, dq)                           # a road the wave cannot stage (> 2 048 vertices)
+    big = np.c_[np.linspace(-5.0, 300.0, 3000), np.full(3000, -6.0)]
+    g.set_road(np.array([0, 3000]), big, np.array([0.15]), np.array([2.0]))
     g.step(4)
     assert g.small_ticks() == 0 and np.isfinite(g.state()).all()
-    bx, by, bpsi, bv, boff, bdq = crowd(4, seed=5)
-    bike = make_engine(amd, "bicycle", np.c_[bx, by, bpsi, bv, np.zeros(4)], 5.0, boff, bdq)
-    bike.step(4)
-    assert bike.small_ticks() == 0
+
+
+@pytest.mark.parametrize("model,n,sigma", [("twod", 5, 2.0), ("planarpoint", 1, 3.0), ("invpend", 3, 2.5), ("bicycle", 8, 2.0)])
+def test_small_crowds_between_road_edges_vs_oracle(amd, model, n, sigma):
+    """intersection.py:226-242 in the one-wave kernel: two edges of 700 vertices each beside the crowd (integer and fractional
+    sigma: the power of rsq and the exp2 / log2 form), total forces against the oracle every tick for 60 ticks"""
+    x, y, psi, v, off, dq = crowd(n, seed=40 + n)
+    s0 = np.zeros((n, orc.N_STATES[MODELS[model]])); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
+    xs = np.linspace(-20.0, 50.0, 700)
+    verts = np.r_[np.c_[xs, np.full(700, -3.0)], np.c_[xs, np.full(700, 17.0)]]
+    roff, F0, sg = np.array([0, 700, 1400]), np.array([0.15, 0.2]), np.array([sigma, sigma])
+    e = make_engine(amd, model, s0, 5.0, off, dq)
+    e.set_road(roff, verts, F0, sg)
+    pop = orc.Population(orc.default_params(model), s0, 5.0, off, dq)
+    pop.set_road(roff, verts, F0, sg)
+    for t in range(60):
+        e.step(1); pop.step(1)
+        fx, fy = e.forces(); ofx, ofy = pop.forces()
+        scale = max(np.hypot(ofx, ofy).max(), 1e-3)
+        assert max(np.abs(fx - ofx).max(), np.abs(fy - ofy).max()) < 1e-4 * scale, (t, n)
+    assert e.small_ticks() == 60 and (e.status() == 0).all()
+    assert np.abs(e.state()[:, :2] - pop.state()[:, :2]).max() < 1e-4 * 70.0
