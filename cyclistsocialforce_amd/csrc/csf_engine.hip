@@ -100,6 +100,7 @@ struct Knobs {
     int dyn_recv = -1, rpb = 0;               // CSF_DYN_RECV, CSF_RPB
     int wide = -1;                            // CSF_WIDE: workgroups of 8 waves on tiles of 2048 sources (-1: the engine's choice)
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
+    int64_t rebin_ticks = 64;                 // CSF_REBIN_TICKS: ticks between two re-binnings (1 .. 120; the tests that step 40 - 48 ticks "across a re-binning" pin 32)
     int fused_small = 1;                      // CSF_FUSED_SMALL=0: a handful of road users take the general path too (csf_agent.hip: small_tick_kernel)
     int segments = -1;                        // CSF_SEGMENTS
     int seg_grid = 1;                         // CSF_SEG_GRID=0: one launch per parameter set (class-segmented order) instead of one grid
@@ -131,6 +132,7 @@ struct Knobs {
         wide = geti("CSF_WIDE", -1);
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
         fused_small = geti("CSF_FUSED_SMALL", 1);
+        rebin_ticks = std::max(1, std::min(120, geti("CSF_REBIN_TICKS", 64)));
         segments = geti("CSF_SEGMENTS", -1);
         recv_binned = geti("CSF_RECV_BINNED", -1);
         clist = geti("CSF_CLIST", 1);
@@ -350,6 +352,11 @@ int fail(csf_engine *e, int code, const char *fmt, ...) {
     } while (0)
 
 const int NS_OF[6] = {5, 5, 6, 4, 5, 4};
+// Ticks between two re-binnings.  The circles of the batches are renewed EVERY tick from the positions as they are (the pair
+// kernel emits them), so a stale order costs only what the batches' members drift apart: the pair kernel takes the same
+// 105 us with 32, 48 and 64 ticks and 0.3 - 0.5 us more with 96 / 128, while the re-binning itself (~40 us of sort, rebase
+// and launch gaps) is paid half as often: 64 (round 4: +0.5 % over 32; profiles/r4_rebin_period_ab.txt).
+constexpr int64_t REBIN_TICKS = 64;     // (default of Knobs::rebin_ticks)
 int32_t pair_variant_for(const csf_engine *e, int64_t n);   // (with rebin, below)
 
 double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, vehicle.py:154-155)
@@ -492,9 +499,9 @@ int set_fov_band(csf_engine *e) {
     // classify_batch): the bearing of a source nearer than 2.9 u (coordinates) / 5e-5 is not known that well in fp32, so a
     // batch whose circle comes closer goes to the per-lane test
     k.clsk = (float)(2.9 * u * 1.01 / 5e-5);
-    // offsets: a quarter-metre grid of origins + what a road user covers between two re-binnings (REBIN_TICKS = 32 steps;
+    // offsets: a quarter-metre grid of origins + what a road user covers between two re-binnings (REBIN_TICKS steps + a few;
     // arrivals take their position as their origin)
-    const double off = 0.25 + step * 40.0;
+    const double off = 0.25 + step * (double)(e->knobs.rebin_ticks + 8);
     const double eps_o = u * off * 1.5;
     k.fovP1 = (float)(sc * 24 * eps_o);
     k.fovP2 = (float)(sc * 36 * u);
@@ -963,7 +970,6 @@ void set_chunks(csf_engine *e) {
     if (e->knobs.dyn_recv >= 0) d.dyn_recv = e->knobs.dyn_recv != 0;
 }
 
-constexpr int64_t REBIN_TICKS = 32;   // agents move <= 0.1 m per tick: the binned order stays useful for long
 constexpr int64_t BIN_MIN_AGENTS = 1024;
 
 // Which pair kernel (csf_pair.hip: launch_pair): 0 the cull-first kernel (binned records from BIN_MIN_AGENTS road users),
@@ -1138,7 +1144,7 @@ int rebin(csf_engine *e) {
             // (where arrivals appear) are always visited
             d.ctail = (int32_t)(e->tail_tracked ? d.n_live / d.clist_tile : ntiles);
             // both sides move until the lists are rebuilt (REBIN_TICKS ticks; a churn-triggered re-binning comes sooner)
-            const float reach = d.pc.rfar + 2.0f * (float)(REBIN_TICKS + 2) * d.bnd_margin + 1e-2f;
+            const float reach = d.pc.rfar + 2.0f * (float)(e->knobs.rebin_ticks + 2) * d.bnd_margin + 1e-2f;
             launch_candidate_lists(d, e->tcirc.p, e->clist.p, e->ccount.p, reach, e->main);
             d.clist = e->clist.p;
             d.ccount = e->ccount.p;
@@ -1159,7 +1165,7 @@ int bounds_before_pair(csf_engine *e) {
     // sqrt(2 * 35 * 64 / (1.3 r)) ticks, i.e. re-bin when ticks x arrivals since the last one reaches ~3500; 3000 to 6000
     // measured alike (profiles/r2_churn_rate.txt; CSF_REBIN_CHURN overrides the constant).
     const int64_t churn_k = e->knobs.rebin_churn;
-    if (e->ticks_since_rebin >= REBIN_TICKS || e->ticks_since_rebin * e->churn >= churn_k) {
+    if (e->ticks_since_rebin >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= churn_k) {
         int rc = rebin(e);
         if (rc) return rc;
     }
@@ -1534,7 +1540,7 @@ int flush_pending(csf_engine *e) {
     // The class-segmented order has no tail for arrivals: an arrival belongs into its set's run, which only a re-binning
     // can give it (the sort reads every slot's record and set) - so the order is renewed before the next pair launch
     // (~50 us, against 5 ms for the way through the host mirror).  Departures leave sentinel records in their runs.
-    if (!e->segs.empty() && h.n_spawn > 0) e->ticks_since_rebin = std::max<int64_t>(e->ticks_since_rebin, REBIN_TICKS);
+    if (!e->segs.empty() && h.n_spawn > 0) e->ticks_since_rebin = std::max<int64_t>(e->ticks_since_rebin, e->knobs.rebin_ticks);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(pin->done, e->main));
     pin->busy = true;
@@ -2979,7 +2985,7 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     for (int k = 0; k < 4; k++) counts[k] = 0;
     if (d.n_live <= 1 || d.hi <= d.lo) return CSF_OK;
     if ((rc = wait_gather(e))) return rc;
-    if (!e->segs.empty() && e->ticks_since_rebin >= REBIN_TICKS && (rc = rebin(e))) return rc;   // (arrivals since: flush_pending)
+    if (!e->segs.empty() && e->ticks_since_rebin >= e->knobs.rebin_ticks && (rc = rebin(e))) return rc;   // (arrivals since: flush_pending)
     if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
     if ((e->world > 1 || e->nccl != nullptr || e->loopback) && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
     DevBuf<unsigned long long> &cnt = e->scratch_cnt;

@@ -391,6 +391,7 @@ def test_sharded_engine_loopback(amd, monkeypatch, model, world, n, binned):
     (48 ticks: across the re-sort at tick 32), foreign fp64 state going stale - with the all-gather replaced by
     device-to-device copies between `world` engines of this process (csf_comm_init_loopback).  Against the unsharded
     engine (the same terms in another summation order) and against the oracle."""
+    monkeypatch.setenv("CSF_REBIN_TICKS", "32")             # (the engine re-bins every 64 ticks; this case is written around 32)
     monkeypatch.setenv("CSF_RECV_BINNED", binned)
     box, ticks = 110.0, 48
     s0, off, dq = population(n, box, seed=5)
@@ -500,12 +501,13 @@ def test_sharded_engine_with_parameter_sets(amd):
 
 
 @pytest.mark.parametrize("world,n", [(2, 8192), (3, 9000)])
-def test_sharded_engine_with_parameter_sets_in_the_class_segmented_order(amd, world, n):
+def test_sharded_engine_with_parameter_sets_in_the_class_segmented_order(amd, monkeypatch, world, n):
     """Ranks of a sharded run with several parameter sets take the class-segmented order too (csf_engine.hip: rebin - the order
     is one of the SOURCES, which every rank holds in full): four sets over two vehicle classes, N >= 8 192, a loopback group
     of `world` ranks; the culling kernel must be the one that runs.  41 ticks (across the re-binning from gathered records at
     tick 32) against the unsharded engine; the clamped repulsive sums of 200 receivers on the state the group is in
     against the oracle, every source with ITS set's field, field of view and far-field radius."""
+    monkeypatch.setenv("CSF_REBIN_TICKS", "32")             # (the engine re-bins every 64 ticks; this case is written around 32)
     box = 180.0
     s0, off, dq = population(n, box, seed=21)
     s = np.zeros((n, 6)); s[:, :4] = s0[:, :4]
@@ -715,11 +717,12 @@ def test_population_changes_on_the_device(amd, model):
     assert np.isfinite(e.state()).all() and e.n == m           # (the queues handed out here are other agents': no status check)
 
 
-def test_arrivals_in_the_sentinel_tail(amd):
+def test_arrivals_in_the_sentinel_tail(amd, monkeypatch):
     """N = 16 384 with arrivals and departures EVERY tick: the arrivals take the places of the sentinel tail of the binned
     order, which get source chunks of their own behind the sixteen full tiles, until the next re-binning sorts them in
     (csf_engine.hip: rebin, set_chunks).  The repulsive sums of old and new road users against the oracle's on the
     population as it is after 1, 5 and 14 such ticks."""
+    monkeypatch.setenv("CSF_REBIN_TICKS", "32")             # (the engine re-bins every 64 ticks; this case is written around 32)
     n, box = 16384, 200.0
     s0, off, dq = population(n + 4096, box, seed=21)
     dq3 = dq.reshape(-1, 4, 3)
@@ -1086,11 +1089,12 @@ def test_config3_16384_invpend_200_ticks(amd):
     e.close()
 
 
-def test_config4_262144_twod_40_ticks_and_two_shards(amd):
+def test_config4_262144_twod_40_ticks_and_two_shards(amd, monkeypatch):
     """BASELINE config 4 stepped on one device: 262 144 TwoDBicycle in 800 m, 40 ticks across a re-binning (the variant
     with receivers in binned order and far tiles skipped unloaded), the forces of 96 receivers against the oracle every 8
     ticks; and the same population as a 2-way loopback group (the sharded code path: receiver lists per rank, records
     exchanged every tick, re-binning from gathered records) against the unsharded engine."""
+    monkeypatch.setenv("CSF_REBIN_TICKS", "32")             # (the engine re-bins every 64 ticks; this case is written around 32)
     n, box = 262144, 800.0
     s0, off, dq = population(n, box, seed=1)
     p = orc.default_params("twod")
@@ -1139,11 +1143,12 @@ def test_config4_262144_twod_40_ticks_and_two_shards(amd):
 
 
 @pytest.mark.parametrize("world", [4, 8])
-def test_headline_population_as_loopback_ranks(amd, world):
+def test_headline_population_as_loopback_ranks(amd, monkeypatch, world):
     """What `bench.py --gpus 4 / 8` runs, rehearsed on one device: the headline population (16 384 TwoDBicycle in 200 m) as
     a 4- and an 8-way loopback group - receiver blocks of 4 096 and 2 048 slots, i.e. the kernel variants a rank of that run
     takes (workgroups of 8 waves with 32 and with 16 receivers) - 40 ticks across a re-binning.  Every rank's own forces
     against the oracle on the group's state, and the group against the unsharded engine."""
+    monkeypatch.setenv("CSF_REBIN_TICKS", "32")             # (the engine re-bins every 64 ticks; this case is written around 32)
     n, box = 16384, 200.0
     s0, off, dq = population(n, box, seed=6)
     p = orc.default_params("twod")

@@ -593,6 +593,7 @@ def test_binned_receivers_and_far_tile_skip_are_exact(amd, monkeypatch):
 def test_bicycle_field_on_binned_records_vs_oracle(amd, monkeypatch, hfov, rule, rpb):
     """The older elliptic field (vehicle.py:1054-1147) at N >= 1024: binned records, batches outside the field of view
     skipped whole (pair_bike_kernel); column sums of one evaluation and a short run against the oracle."""
+    monkeypatch.setenv("CSF_REBIN_TICKS", "32")             # (the engine re-bins every 64 ticks; this case is written around 32)
     monkeypatch.setenv("CSF_RPB", str(rpb))      # receivers per workgroup (32 is chosen from 8192 receivers up)
     n, box = 2048, 120.0
     x, y, psi, v, off, dq = synthetic_population(n, box, seed=3)
