@@ -226,9 +226,10 @@ def main():
 
     # the kernels' own start / end time stamps (hipExtLaunchKernelGGL events on the engine's stream).  A launch that carries
     # events costs the tick ~5 us (profiles/r4_v5_tick_sequence.json: 120.1 us per tick with every launch sampled, 114.6 with
-    # none), so not every launch is sampled: every 8th tick in long runs, every 4th tick of the driver's 20-step command (five
-    # launches: their spread is 2 %).  (The event pool is created here, not in front of the timed region.)
-    every = max(1, min(8, args.steps // 5))
+    # none), so not every launch is sampled: every 16th tick in long runs (62 launches of the default 1 000 steps), every 4th tick
+    # of the driver's 20-step command (five launches: their spread is 2 %).  (The event pool is created here, not in front of
+    # the timed region.)
+    every = max(1, min(16, args.steps // 5))
     eng.profile(every)
     eng.step(first)
     fence()
