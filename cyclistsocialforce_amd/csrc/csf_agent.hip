@@ -356,6 +356,21 @@ __global__ __launch_bounds__(64) void small_tick_kernel(const Dev d, const int n
         __builtin_amdgcn_wave_barrier();                          // (the staged snapshot is read by every lane before it is renewed)
         if (lane < n) agent_body<MODEL, false, true>(d, PH_DEST | PH_COMBINE | PH_INTEGRATE, lane, nullptr, ka_lines, rx, ry);
     }
+    // csf_step_get_tick: what snapshot_kernel would pack in a launch of its own (slots are the population order here)
+    if (d.snap != nullptr && lane < n) {
+        const int ns = d.ns;
+        for (int c = 0; c < ns; c++) d.snap[(int64_t)lane * ns + c] = d.s[(int64_t)c * cap + lane];
+        double *F = d.snap + (int64_t)n * ns;
+        F[lane] = d.F[lane];
+        F[n + lane] = d.F[cap + lane];
+        int32_t *ptr = (int32_t *)(F + 2 * n);
+        ptr[lane] = d.ptr[lane];
+        uint8_t *zn = (uint8_t *)(ptr + n);
+        const int z = d.znav[lane] & 3;
+        zn[3 * lane + 0] = z == 0;
+        zn[3 * lane + 1] = z == 1;
+        zn[3 * lane + 2] = z == 2;
+    }
 }
 
 void launch_small_tick(const Dev &d, int n_ticks, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {

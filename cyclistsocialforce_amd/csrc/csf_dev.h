@@ -222,6 +222,8 @@ struct Dev {
     double *hist;      // opt-in history [hist_cap][n][ns]
     int32_t hist_stride, hist_cap;
     unsigned long long *pair_count;  // csf_count_pairs: [4] pair evaluations, per-lane tests, full and partial evaluation passes of the launch (NULL: not counted)
+    double *snap;      // csf_step_get_tick on the one-wave path: the packed read-back of csf_get_tick, written by the kernel behind its last
+                       // tick (a mapped host buffer), else NULL
     uint64_t *atrace;  // CSF_TRACE_AGENT: eight time stamps (wall_clock64, 100 MHz) of every wave of the last per-agent launch, else NULL:
                        // entry, own scalars loaded, destination force done, partial sums loaded, combine done, integrate done, stores
                        // issued, stores done

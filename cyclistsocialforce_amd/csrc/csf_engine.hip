@@ -881,6 +881,7 @@ int alloc_all(csf_engine *e) {
     d.near_dropped = e->edge_n.p + 1;
     d.edge_head = e->edge_head.p;
     d.atrace = nullptr;
+    d.snap = nullptr;
     if (!e->knobs.trace_agent.empty()) {   // 8 words per wave of 64 road users
         HIPCHK(e, e->atrace.alloc(8 * ((size_t)cap / 64 + 2)));
         d.atrace = e->atrace.p;
@@ -2380,7 +2381,24 @@ static bool small_fused_ok(const csf_engine *e) {
            d.atrace == nullptr && d.lo == 0 && d.hi == d.n && e->pend.empty() && !e->dirty;
 }
 
-int csf_step(csf_engine *e, int64_t n_ticks) {
+// the mapped host buffer of the packed read-back (csf_get_tick, csf_step_get_tick), large enough for the population
+static int snap_reserve(csf_engine *e, size_t need) {
+    if (need <= e->snap_bytes) return CSF_OK;
+    if (e->snap_host) {
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        HIPCHK(e, hipHostFree(e->snap_host));
+        e->snap_host = nullptr;
+        e->snap_bytes = 0;
+    }
+    const size_t want = std::max<size_t>(need * 2, 4096);
+    HIPCHK(e, hipHostMalloc(&e->snap_host, want, hipHostMallocMapped));
+    HIPCHK(e, hipHostGetDevicePointer((void **)&e->snap_dev, e->snap_host, 0));
+    e->snap_bytes = want;
+    return CSF_OK;
+}
+
+static int step_impl(csf_engine *e, int64_t n_ticks, bool want_snap, bool *snapped) {
+    if (snapped) *snapped = false;
     if (!e) return CSF_E_ARG;
     if (n_ticks < 0) return fail(e, CSF_E_ARG, "n_ticks must be >= 0");
     HIPCHK(e, hipSetDevice(e->device));
@@ -2395,9 +2413,18 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
     if (n_ticks > 0 && !e->comm_calibrated && (rc = calibrate_comm_stream(e))) return rc;
     if (n_ticks > 0 && small_fused_ok(e)) {
         if ((rc = set_fov_band(e))) return rc;                 // (the bands of the fp32 decisions: tracked_precise, side_undecided)
+        // csf_step_get_tick: the kernel packs the read-back itself behind its last tick, when slots are the population order
+        bool snap = false;
+        if (want_snap) {
+            if ((rc = sync_order(e))) return rc;
+            const size_t n = e->order.size();
+            snap = e->d.order == nullptr && snap_reserve(e, n * ((size_t)(e->d.ns + 2) * sizeof(double) + sizeof(int32_t) + 3)) == CSF_OK;
+        }
         for (int64_t t = 0; t < n_ticks;) {                    // (launches of at most 2^16 ticks: a second or less each)
             const int k = (int)std::min<int64_t>(n_ticks - t, 65536);
-            launch_small_tick(e->d, k, e->main);
+            Dev dd = e->d;
+            dd.snap = (snap && t + k == n_ticks) ? e->snap_dev : nullptr;
+            launch_small_tick(dd, k, e->main);
             HIPCHK(e, hipGetLastError());
             e->d.tick += k;
             e->moves += k;
@@ -2405,6 +2432,7 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
             t += k;
         }
         e->device_ahead = true;
+        if (snapped) *snapped = snap;
         return CSF_OK;
     }
     for (int64_t t = 0; t < n_ticks; t++) {
@@ -2414,6 +2442,8 @@ int csf_step(csf_engine *e, int64_t n_ticks) {
     if (n_ticks > 0) e->device_ahead = true;
     return CSF_OK;
 }
+
+int csf_step(csf_engine *e, int64_t n_ticks) { return step_impl(e, n_ticks, false, nullptr); }
 
 int csf_sync(csf_engine *e) {
     if (!e) return CSF_E_ARG;
@@ -2577,6 +2607,8 @@ static int get_F(csf_engine *e, int comp, double *out) {
     return read_rows(e, e->F.p + (size_t)comp * e->cap, 1, out, false);
 }
 
+static int snap_unpack(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy);
+
 int csf_get_tick(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy, int64_t *tick) {
     if (!e) return CSF_E_ARG;
     HIPCHK(e, hipSetDevice(e->device));
@@ -2587,23 +2619,18 @@ int csf_get_tick(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav,
     if (tick) *tick = e->d.tick;
     if (n == 0) return csf_sync(e);
     if ((rc = sync_order(e))) return rc;
-    const size_t need = (size_t)n * ((size_t)(ns + 2) * sizeof(double) + sizeof(int32_t) + 3);
-    if (need > e->snap_bytes) {
-        if (e->snap_host) {
-            HIPCHK(e, hipStreamSynchronize(e->main));
-            HIPCHK(e, hipHostFree(e->snap_host));
-            e->snap_host = nullptr;
-            e->snap_bytes = 0;
-        }
-        const size_t want = std::max<size_t>(need * 2, 4096);
-        HIPCHK(e, hipHostMalloc(&e->snap_host, want, hipHostMallocMapped));
-        HIPCHK(e, hipHostGetDevicePointer((void **)&e->snap_dev, e->snap_host, 0));
-        e->snap_bytes = want;
-    }
+    if ((rc = snap_reserve(e, (size_t)n * ((size_t)(ns + 2) * sizeof(double) + sizeof(int32_t) + 3)))) return rc;
     launch_snapshot(e->d, e->snap_dev, e->main);
     HIPCHK(e, hipGetLastError());
     rc = csf_sync(e);
     if (rc) return rc;
+    return snap_unpack(e, s_out, dest_ptr, znav, Fx, Fy);
+}
+
+// the packed read-back in the mapped host buffer -> the caller's arrays
+static int snap_unpack(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy) {
+    const int64_t n = (int64_t)e->order.size();
+    const int ns = e->d.ns;
     const double *S = (const double *)e->snap_host;
     const double *F = S + (size_t)n * ns;
     const int32_t *P = (const int32_t *)(F + 2 * (size_t)n);
@@ -2614,6 +2641,20 @@ int csf_get_tick(csf_engine *e, double *s_out, int32_t *dest_ptr, uint8_t *znav,
     if (dest_ptr) std::memcpy(dest_ptr, P, (size_t)n * sizeof(int32_t));
     if (znav) std::memcpy(znav, Z, (size_t)n * 3);
     return CSF_OK;
+}
+
+// csf_step(e, n_ticks) + csf_get_tick in one call: what a caller that looks at every tick does (SocialForceIntersection.step(),
+// intersection.py:866-896 - the host mirror refreshes vehicle.s, znav, force after each tick).  On the one-wave path the kernel
+// packs the read-back itself: one launch and one wait per call.
+int csf_step_get_tick(csf_engine *e, int64_t n_ticks, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy,
+                      int64_t *tick) {
+    bool snapped = false;
+    int rc = step_impl(e, n_ticks, true, &snapped);
+    if (rc) return rc;
+    if (!snapped) return csf_get_tick(e, s_out, dest_ptr, znav, Fx, Fy, tick);
+    if (tick) *tick = e->d.tick;
+    if ((rc = csf_sync(e))) return rc;
+    return snap_unpack(e, s_out, dest_ptr, znav, Fx, Fy);
 }
 
 int csf_get_forces(csf_engine *e, double *Fx, double *Fy) {

@@ -218,6 +218,20 @@ class Engine:
                                         None if fy is None else _ptr(fy), C.byref(tick)))
         return s, ptr, zn.astype(bool), fx, fy, tick.value
 
+    def step_snapshot(self, n_ticks=1, forces=True):
+        """step(n_ticks) and tick_snapshot() in one call (csf_step_get_tick): a handful of road users then cost one launch and
+        one wait per call"""
+        n = self.n
+        s = np.zeros((n, self.ns))
+        ptr = np.zeros(n, dtype=np.int32)
+        zn = np.zeros((n, 3), dtype=np.uint8)
+        fx = np.zeros(n) if forces else None
+        fy = np.zeros(n) if forces else None
+        tick = C.c_int64(0)
+        self._ck(self._lib.csf_step_get_tick(self._h, int(n_ticks), _ptr(s), _ptr(ptr), _ptr(zn), None if fx is None else _ptr(fx),
+                                             None if fy is None else _ptr(fy), C.byref(tick)))
+        return s, ptr, zn.astype(bool), fx, fy, tick.value
+
     @property
     def tick(self):
         t = C.c_int64(0)

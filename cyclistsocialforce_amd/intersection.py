@@ -612,11 +612,12 @@ class SocialForceIntersection:
             self._road_sig = sig
         return e
 
-    def _pull(self, forces=True, advance=1):
-        """One read-back of the device's view into the bulk mirror (vehicle.s, znav, traj are views of it)."""
+    def _pull(self, forces=True, advance=1, step=0):
+        """One read-back of the device's view into the bulk mirror (vehicle.s, znav, traj are views of it); step: that many
+        ticks first, in the same call (csf_step_get_tick)."""
         e = self._engine
         n = len(self.vehicles)
-        s, ptr, zn, fx, fy, _ = e.tick_snapshot(forces=forces)
+        s, ptr, zn, fx, fy, _ = e.step_snapshot(step, forces=forces) if step else e.tick_snapshot(forces=forces)
         self._S[:n, : s.shape[1]] = s
         self._shadow[:n, : s.shape[1]] = s
         self._ptr[:n] = ptr
@@ -710,9 +711,8 @@ class SocialForceIntersection:
                     v.add_drawing(self.ax, animated=True, **self.bicycle_drawing_kwargs)
         self.is_first_step = False
         if self.n_bikes > 0:
-            e = self._push_mutations()
-            e.step(1)
-            self._pull(forces=True, advance=1)
+            self._push_mutations()
+            self._pull(forces=True, advance=1, step=1)
         self.hist_n_vecs.append(self.n_bikes)
 
     def step_n(self, n_ticks, pull=True):

@@ -291,6 +291,12 @@ int csf_profile_gather(const csf_engine *e, double *gather_ms);
  * the two positions, inside the band of fp32 rounding by the reference's own fp64 chain, intersection.py:690-745,
  * vehicle.py:1617-1625), instead of a pair launch and a per-agent launch per tick.  CSF_FUSED_SMALL=0 or a pinned CSF_PAIR_VARIANT keep the general path. */
 int csf_small_ticks(const csf_engine *e, int64_t *n_ticks);
+/* csf_step(e, n_ticks) followed by csf_get_tick(...) in one call (ABI 6): what a caller that looks at every tick does -
+ * SocialForceIntersection.step() refreshes vehicle.s, znav and force after each tick (intersection.py:866-896).  On the
+ * one-wave path the kernel packs the read-back itself behind its last tick: one launch and one wait per call.  Arguments as
+ * csf_get_tick's (any output may be NULL). */
+int csf_step_get_tick(csf_engine *e, int64_t n_ticks, double *s_out, int32_t *dest_ptr, uint8_t *znav, double *Fx, double *Fy,
+                      int64_t *tick);
 
 /* Far-field radius of the pair kernel (metres; +inf when the cull is off).  The repulsive field of
  * vehicle.py:1560-1648 decays at least like f_0 exp(-kappa rho); sources beyond

@@ -147,3 +147,30 @@ def test_small_crowds_between_road_edges_vs_oracle(amd, model, n, sigma):
         assert max(np.abs(fx - ofx).max(), np.abs(fy - ofy).max()) < 1e-4 * scale, (t, n)
     assert e.small_ticks() == 60 and (e.status() == 0).all()
     assert np.abs(e.state()[:, :2] - pop.state()[:, :2]).max() < 1e-4 * 70.0
+
+
+@pytest.mark.parametrize("n,road", [(3, False), (16, False), (5, True), (40, False)])
+def test_step_and_read_back_in_one_call(amd, n, road):
+    """csf_step_get_tick = csf_step + csf_get_tick, tick for tick: on the one-wave path (the kernel packs the read-back itself)
+    and on the general path (40 road users), after single ticks and after several"""
+    x, y, psi, v, off, dq = crowd(n, seed=70 + n, box=14.0 if n <= 8 else 35.0)
+    s0 = np.c_[x, y, psi, v, np.zeros(n)]
+    a, b = make_engine(amd, "twod", s0, 5.0, off, dq), make_engine(amd, "twod", s0, 5.0, off, dq)
+    if road:
+        xs = np.linspace(-20.0, 40.0, 300)
+        for e in (a, b):
+            e.set_road(np.array([0, 300]), np.c_[xs, np.full(300, -3.0)], np.array([0.15]), np.array([2.0]))
+    for k in (1, 1, 1, 7, 1, 30):
+        sa, pa, za, fxa, fya, ta = a.step_snapshot(k)
+        b.step(k)
+        sb, pb, zb, fxb, fyb, tb = b.tick_snapshot()
+        assert ta == tb
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(pa, pb)
+        np.testing.assert_array_equal(za, zb)
+        np.testing.assert_array_equal(fxa, fxb)
+        np.testing.assert_array_equal(fya, fyb)
+    assert a.small_ticks() == (41 if n <= 32 else 0) and b.small_ticks() == a.small_ticks()
+    s2, _, _, _, _, _ = a.step_snapshot(2, forces=False)       # (outputs may be left out)
+    b.step(2)
+    np.testing.assert_array_equal(s2, b.state())
