@@ -218,10 +218,21 @@ class Engine:
                                         None if fy is None else _ptr(fy), C.byref(tick)))
         return s, ptr, zn.astype(bool), fx, fy, tick.value
 
-    def step_snapshot(self, n_ticks=1, forces=True):
+    def step_snapshot(self, n_ticks=1, forces=True, reuse=False):
         """step(n_ticks) and tick_snapshot() in one call (csf_step_get_tick): a handful of road users then cost one launch and
-        one wait per call"""
+        one wait per call.  reuse: the arrays returned are the engine's own buffers, overwritten by the next call (the host
+        mirror copies them into its bulk arrays at once) - at three road users the allocations are a fifth of the call."""
         n = self.n
+        if reuse:
+            key = (n, self.ns)
+            if getattr(self, "_snap_key", None) != key:
+                bufs = (np.zeros((n, self.ns)), np.zeros(n, dtype=np.int32), np.zeros((n, 3), dtype=np.uint8), np.zeros(n), np.zeros(n))
+                self._snap_key, self._snap_bufs, self._snap_ptrs, self._snap_tick = key, bufs, [_ptr(b) for b in bufs], C.c_int64(0)
+            s, ptr, zn, fx, fy = self._snap_bufs
+            p = self._snap_ptrs
+            self._ck(self._lib.csf_step_get_tick(self._h, int(n_ticks), p[0], p[1], p[2], p[3] if forces else None,
+                                                 p[4] if forces else None, C.byref(self._snap_tick)))
+            return s, ptr, zn, (fx if forces else None), (fy if forces else None), self._snap_tick.value
         s = np.zeros((n, self.ns))
         ptr = np.zeros(n, dtype=np.int32)
         zn = np.zeros((n, 3), dtype=np.uint8)

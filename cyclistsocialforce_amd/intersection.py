@@ -617,7 +617,7 @@ class SocialForceIntersection:
         ticks first, in the same call (csf_step_get_tick)."""
         e = self._engine
         n = len(self.vehicles)
-        s, ptr, zn, fx, fy, _ = e.step_snapshot(step, forces=forces) if step else e.tick_snapshot(forces=forces)
+        s, ptr, zn, fx, fy, _ = e.step_snapshot(step, forces=forces, reuse=True) if step else e.tick_snapshot(forces=forces)
         self._S[:n, : s.shape[1]] = s
         self._shadow[:n, : s.shape[1]] = s
         self._ptr[:n] = ptr
