@@ -255,7 +255,7 @@ def test_pair_kernel_chosen_by_population_size(amd, monkeypatch, model, n, kerne
     # a population that shrinks below the threshold changes kernel at the next re-binning
     if n == 3100:
         e.remove_agents(np.arange(0, 400))
-        e.step(40)
+        e.step(70)                                               # (past the next re-binning: the engine re-bins every 64 ticks)
         assert e.count_pairs()[1] == "pair_kernel" and np.isfinite(e.state()).all()
 
 
