@@ -127,7 +127,12 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
             if (edge_pending) {     // rare: decide those pairs as the reference does (intersection.py:711-741) and put the sum right
                 double cx = 0, cy = 0;   // (fp64: the order in which the entries were appended does not show)
                 int32_t at = d.edge_head[a];
-                for (int guard = 0; at != 0 && guard < 64; guard++) {
+                // (a receiver's chain is at most the ring; a walk that long without reaching its end is counted like an overflow)
+                for (int guard = 0; at != 0; guard++) {
+                    if (guard == (int)EDGE_CAP) {
+                        atomicAdd(d.near_dropped, 1u);
+                        break;
+                    }
                     const EdgeRec er = d.edge[(unsigned)(at - 1) % EDGE_CAP];
                     if (er.recv != (int32_t)a || er.stamp != d.edge_stamp) {   // left over from another launch, or a ring that overflowed
                         if (er.stamp == d.edge_stamp) atomicAdd(d.near_dropped, 1u);

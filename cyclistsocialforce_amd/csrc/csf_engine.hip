@@ -263,6 +263,11 @@ struct csf_engine {
     DevBuf<uint32_t> sort_keys, sort_keys_out;
     DevBuf<uint8_t> sort_tmp;
     int64_t ticks_since_rebin = 0;
+    // integration steps since the last re-binning that no pair launch went with (csf_apply_forces, csf_replay_forces on forces
+    // from elsewhere): the candidate tile lists and the stretch of the circles allow for rebin_ticks + 2 steps of motion, so
+    // these count towards the next re-binning like ticks do
+    int64_t moved_unbinned = 0;
+    bool pair_since_move = false;
     DevBuf<float2> rec2, recs2, part, froad, kat2;
     // candidate tiles of every receiver group (large populations, csf_dev.h: Dev::clist): rebuilt at every re-binning
     DevBuf<float4> tcirc;
@@ -1151,7 +1156,12 @@ int rebin(csf_engine *e) {
             d.ccount = e->ccount.p;
         }
     }
+    // set_fov_band bounds the coordinates by "where they were at the last upload + a speed clamp's worth per step since": over
+    // 1e5 ticks that bound - and with it every rounding band - grows far beyond the scene.  Measure again now and then
+    // (one read-back of the positions; where every slot's state is on this device).
+    if (e->moves >= 4096 && e->world <= 1 && !e->loopback) e->bound_stale = true;
     e->ticks_since_rebin = 0;
+    e->moved_unbinned = 0;
     e->churn = 0;
     e->bounds_fresh = true;                                          // (rebase_kernel wrote the circles of the records as they are)
     return CSF_OK;
@@ -1166,12 +1176,13 @@ int bounds_before_pair(csf_engine *e) {
     // sqrt(2 * 35 * 64 / (1.3 r)) ticks, i.e. re-bin when ticks x arrivals since the last one reaches ~3500; 3000 to 6000
     // measured alike (profiles/r2_churn_rate.txt; CSF_REBIN_CHURN overrides the constant).
     const int64_t churn_k = e->knobs.rebin_churn;
-    if (e->ticks_since_rebin >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= churn_k) {
+    if (e->ticks_since_rebin + e->moved_unbinned >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= churn_k) {
         int rc = rebin(e);
         if (rc) return rc;
     }
     if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
     e->ticks_since_rebin++;
+    e->pair_since_move = true;
     return CSF_OK;
 }
 
@@ -1891,6 +1902,11 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     }
     d.n_live = (int64_t)e->order.size();
     e->order_dirty = true;
+    // The candidate tile lists were built for the receiver groups and the tiles of the last re-binning: an arrival sits in the
+    // sentinel tail (or a fresh slot behind it) - its group had an empty circle then and lists nothing, and groups behind
+    // the old last one have no list at all.  Until the next re-binning every group walks every tile again.
+    d.clist = nullptr;
+    d.ccount = nullptr;
     if (!patch) {
         set_shard(e);
     } else {
@@ -2184,6 +2200,48 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
     return CSF_OK;
 }
 
+int csf_get_integrator_state(csf_engine *e, double *x, double *psi_unwrapped, uint8_t *zrid) {
+    if (!e) return CSF_E_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = upload_all(e);
+    if (rc) return rc;
+    rc = csf_sync(e);
+    if (rc) return rc;
+    const int64_t n = (int64_t)e->order.size();
+    if (n == 0) return CSF_OK;
+    if (x && (rc = read_rows(e, e->lti.p, 5, x, true))) return rc;
+    if (psi_unwrapped && (rc = read_rows(e, e->ppsi.p, 1, psi_unwrapped, false))) return rc;
+    if (zrid) {
+        std::vector<uint8_t> z((size_t)n);
+        if ((rc = read_rows(e, e->zrid.p, 1, z.data(), false))) return rc;
+        for (int64_t a = 0; a < n; a++) {
+            zrid[2 * a] = z[(size_t)a] != 0;                     // vehicle.py:1949-1950
+            zrid[2 * a + 1] = z[(size_t)a] == 0;
+        }
+    }
+    return CSF_OK;
+}
+
+int csf_set_integrator_state(csf_engine *e, int64_t n, const int32_t *idx, const double *x, const double *psi_unwrapped,
+                             const uint8_t *zrid) {
+    if (!e) return CSF_E_ARG;
+    if (n < 0 || (n > 0 && !idx)) return fail(e, CSF_E_ARG, "csf_set_integrator_state: bad arguments");
+    for (int64_t k = 0; k < n; k++)
+        if (idx[k] < 0 || idx[k] >= (int64_t)e->order.size()) return fail(e, CSF_E_ARG, "agent index %d out of range", idx[k]);
+    HIPCHK(e, hipSetDevice(e->device));
+    int rc = prepare_mutation(e);
+    if (rc) return rc;
+    const int64_t cap = e->cap;
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t a = e->order[(size_t)idx[k]];
+        if (x)
+            for (int c = 0; c < 5; c++) e->h_lti[c * cap + a] = x[k * 5 + c];
+        if (psi_unwrapped) e->h_ppsi[a] = psi_unwrapped[k];
+        if (zrid) e->h_zrid[a] = zrid[2 * k] ? 1 : 0;
+    }
+    return CSF_OK;
+}
+
 // One tick, all on the main stream (dependent launches in one stream cost ~2 us; a cross-stream event wait was
 // measured at ~11 us here, more than running the destination-force phase beside the pair kernel saves):
 //   main:  bounds - pair - road - agent(DEST|COMBINE|INTEGRATE) - [all-gather(records)]       (world > 1: RCCL)
@@ -2230,9 +2288,35 @@ static void launch_pair_all(csf_engine *e, const Dev &base, hipEvent_t t0 = null
 // all-gather of the records (in place: what arrives is what was there), 8 + 32 times in stream order and 8 + 32 times with
 // the collective on the second stream behind an event and a small kernel of the next tick in front of the wait.  The two
 // times are max-reduced over the ranks, so that every rank keeps the same order.
+static int calibrate_comm_stream_body(csf_engine *e);
+
+// (the flag is set only when the measurement went through: after an error the order is the plain one - collective in stream
+// order - and the next csf_step tries again)
 int calibrate_comm_stream(csf_engine *e) {
-    e->comm_calibrated = true;
-    if (e->knobs.comm_second >= 0 || !e->nccl || e->loopback) {
+    const int rc = calibrate_comm_stream_body(e);
+    if (rc) e->comm_second = false;
+    else e->comm_calibrated = true;
+    return rc;
+}
+
+static int calibrate_comm_stream_body(csf_engine *e) {
+    if (!e->nccl || e->loopback) {
+        e->comm_second = e->knobs.comm_second > 0;
+        return CSF_OK;
+    }
+    {   // CSF_COMM_STREAM decides which collectives a rank issues below: every rank must have read the same value, or the
+        // ranks that measure wait for the ones that do not.  Agree on it before branching (max and min over the ranks).
+        float v[2] = {(float)e->knobs.comm_second, -(float)e->knobs.comm_second};
+        DevBuf<float> t;
+        HIPCHK(e, t.alloc(2));
+        HIPCHK(e, hipMemcpy(t.p, v, sizeof v, hipMemcpyHostToDevice));
+        NCCLCHK(e, g_rccl.AllReduce(t.p, t.p, 2, ncclFloat32, ncclMax, e->nccl, e->main));
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        HIPCHK(e, hipMemcpy(v, t.p, sizeof v, hipMemcpyDeviceToHost));
+        t.release();
+        if (v[0] != -v[1]) return fail(e, CSF_E_STATE, "CSF_COMM_STREAM differs between the ranks of this communicator: set it on all of them or on none");
+    }
+    if (e->knobs.comm_second >= 0) {
         e->comm_second = e->knobs.comm_second > 0;
         return CSF_OK;
     }
@@ -2499,6 +2583,8 @@ int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy) {
     launch_agent(e->d, PH_INTEGRATE, e->main);
     HIPCHK(e, hipGetLastError());
     e->bounds_fresh = false;
+    if (!e->pair_since_move) e->moved_unbinned++;              // (csf_calc_forces before it has counted this tick already)
+    e->pair_since_move = false;
     e->moves++;
     e->d.tick++;
     e->device_ahead = true;
@@ -2520,7 +2606,10 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
     const int64_t chunk = std::min<int64_t>(n_ticks, 256);
     DevBuf<double> fbuf, hbuf;
     DevBuf<int32_t> lbuf;
-    HIPCHK(e, fbuf.alloc((size_t)chunk * 2 * (size_t)cap));
+    // (+ 4 rows: the per-agent kernel asks for the destination-force rows F[2], F[3] of its view unconditionally - a guarded
+    // load would be a branch with its own wait -, which for the last tick of a chunk lie behind the chunk's forces)
+    HIPCHK(e, fbuf.alloc(((size_t)chunk * 2 + 4) * (size_t)cap));
+    HIPCHK(e, hipMemsetAsync(fbuf.p + (size_t)chunk * 2 * (size_t)cap, 0, 4 * (size_t)cap * sizeof(double), e->main));
     const int64_t n_samples = n_ticks / stride;
     if (states_out && n_samples > 0) HIPCHK(e, hbuf.alloc((size_t)n_samples * (size_t)n * (size_t)e->d.ns));
     if (lengths) {
@@ -2551,7 +2640,12 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
     }
     e->d.tick += n_ticks;
     e->moves += n_ticks;
-    if (fix_speed) e->bound_stale = true;    // (calibration.py:454-458 sets the speed to |F|: no clamp bounds the step)
+    e->moved_unbinned += n_ticks;
+    e->pair_since_move = false;
+    if (fix_speed) {                         // (calibration.py:454-458 sets the speed to |F|: no clamp bounds the step)
+        e->bound_stale = true;
+        e->moved_unbinned = 1 << 20;         // (nor what the candidate lists and the circles allow for: re-bin before the next pair launch)
+    }
     e->device_ahead = true;
     e->bounds_fresh = false;
     if (dd.hist)

@@ -441,8 +441,12 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     __syncthreads();
     float gx = 0.f, gy = 0.f, gr = 0.f;   // BINR: bounding circle of the workgroup's receivers (the same in every wave)
     if (BINR) {
+        // (the places of road users that left since the last re-binning hold sentinel records, 1e15 m away: they take no part -
+        // a circle that reached out to them would pass every tile, and its extent would blow up the rounding band below
+        // until every pair of the group's receivers went down the exact path)
         const float4 q = rrec[lane & (RPB - 1)];
-        float x0 = q.x, x1 = q.x, y0 = q.y, y1 = q.y;
+        const bool real = rec_is_real(q);
+        float x0 = real ? q.x : 3e38f, x1 = real ? q.x : -3e38f, y0 = real ? q.y : 3e38f, y1 = real ? q.y : -3e38f;
 #pragma unroll
         for (int o = RPB / 2; o > 0; o >>= 1) {
             x0 = fminf(x0, __shfl_xor(x0, o, WAVE));
@@ -450,6 +454,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
             y0 = fminf(y0, __shfl_xor(y0, o, WAVE));
             y1 = fmaxf(y1, __shfl_xor(y1, o, WAVE));
         }
+        if (x1 < x0) x0 = x1 = y0 = y1 = 0.f;                     // nobody here: an empty circle at the group's origin
         const float w = x1 - x0, h = y1 - y0;
         gx = 0.5f * (x0 + x1), gy = 0.5f * (y0 + y1);
         gr = 0.5f * fast_sqrt(w * w + h * h) * 1.0001f + 1e-4f;   // rounded up: must contain

@@ -143,6 +143,21 @@ class Engine:
         s = _f64(s).reshape(idx.size, self.ns)
         self._ck(self._lib.csf_push_state(self._h, idx.size, _ptr(idx), _ptr(s)))
 
+    def integrator_state(self):
+        """(vehicle.x [n, 5] - InvPendulum: delta, ddelta, theta, dtheta, psi unwrapped, vehicle.py:1728-1733 -, the unwrapped
+        yaw of the PlanarPoint / PlanarBicycle integrators [n], vehicle.zrid [n, 2]): what vehicle.s does not carry"""
+        n = self.n
+        x = np.zeros((n, 5)); psi = np.zeros(n); z = np.zeros((n, 2), dtype=np.uint8)
+        self._ck(self._lib.csf_get_integrator_state(self._h, _ptr(x), _ptr(psi), _ptr(z)))
+        return x, psi, z.astype(bool)
+
+    def set_integrator_state(self, idx, x=None, psi_unwrapped=None, zrid=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        x = None if x is None else _f64(x).reshape(idx.size, 5)
+        psi = None if psi_unwrapped is None else _f64(psi_unwrapped).reshape(idx.size)
+        z = None if zrid is None else np.ascontiguousarray(zrid, dtype=np.uint8).reshape(idx.size, 2)
+        self._ck(self._lib.csf_set_integrator_state(self._h, idx.size, _ptr(idx), *[None if a is None else _ptr(a) for a in (x, psi, z)]))
+
     # -- hot path ---------------------------------------------------------------------------
     def step(self, n_ticks=1, sync=False):
         self._ck(self._lib.csf_step(self._h, int(n_ticks)))

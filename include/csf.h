@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSF_ABI_VERSION 6
+#define CSF_ABI_VERSION 7
 
 /* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
  * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle); :920 (UncontrolledVehicle: follows a prescribed trajectory
@@ -139,6 +139,17 @@ int csf_set_priority_rule(csf_engine *e, int32_t rule);                /* inters
 
 /* host-side mutation of vehicle.s between ticks (calibration.py:455-460): s is [n, n_states] */
 int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s);
+
+/* The hidden state of the rider models' integrators, which vehicle.s does not carry (ABI 7): x [n, 5] = vehicle.x of an
+ * InvPendulumBicycle (vehicle.py:1728-1733, 1843: delta, ddelta, theta, dtheta, psi - the yaw UNWRAPPED, which is what the
+ * commanded yaw arctan2(Fy, Fx) of vehicle.py:1832 is compared with), for PlanarBicycle x[., 0] = dynamics.x[0] (delta,
+ * dynamics.py:195-197); psi_unwrapped [n] = the yaw state of the PlanarPoint / PlanarBicycle integrators (dynamics.py:828,
+ * 943-966, 987-993); zrid [n, 2] = vehicle.zrid, one-hot riding / walking (vehicle.py:1735-1736, 1932-1950).  Any pointer
+ * may be NULL.  csf_push_state replaces vehicle.s only (calibration.py:455-460 does the same to the reference object); a
+ * caller that moves a population from one engine - or from the reference - to another needs these as well. */
+int csf_get_integrator_state(csf_engine *e, double *x, double *psi_unwrapped, uint8_t *zrid);
+int csf_set_integrator_state(csf_engine *e, int64_t n, const int32_t *idx, const double *x, const double *psi_unwrapped,
+                             const uint8_t *zrid);
 
 int64_t csf_num_agents(const csf_engine *e);
 int32_t csf_num_states(const csf_engine *e);

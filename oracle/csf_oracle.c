@@ -1296,6 +1296,17 @@ void csfo_apply_forces(csfo_t *o, const double *Fx, const double *Fy) {
     csfo_update_snapshot_range(o, 0, o->n);
     o->tick++;
 }
+/* Test aid (no reference counterpart): the hidden state of the InvPendulum integrator - vehicle.x (vehicle.py:1728-1733:
+ * delta, ddelta, theta, dtheta, psi UNWRAPPED) and the riding state vehicle.zrid (:1735-1736) - for studies that compare two
+ * runs state by state (tools/invpend_cut_study.py) and for anchors that carry the winding number over */
+void csfo_get_lti(const csfo_t *o, double *x_out, uint8_t *zrid_out) {
+    memcpy(x_out, o->xlti, sizeof(double) * 5 * (size_t)o->n);
+    memcpy(zrid_out, o->zrid, 2 * (size_t)o->n);
+}
+void csfo_set_lti(csfo_t *o, const double *x_in, const uint8_t *zrid_in) {
+    if (x_in) memcpy(o->xlti, x_in, sizeof(double) * 5 * (size_t)o->n);
+    if (zrid_in) memcpy(o->zrid, zrid_in, 2 * (size_t)o->n);
+}
 void csfo_set_num_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

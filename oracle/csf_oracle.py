@@ -155,6 +155,8 @@ def lib():
         L.csfo_push_state.argtypes = [C.c_void_p] * 5
         L.csfo_dest_force.argtypes = [C.c_void_p, C.c_int, dp, dp]
         L.csfo_apply_forces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_get_lti.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.csfo_set_lti.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_num_threads.restype = C.c_int
         L.csfo_set_num_threads.argtypes = [C.c_int]
         L.csfo_set_num_threads(want)
@@ -377,6 +379,17 @@ class Population:
         znav = None if znav is None else np.ascontiguousarray(znav, dtype=np.uint8).reshape(self.n, 3)
         col = None if col is None else np.ascontiguousarray(np.broadcast_to(np.asarray(col, dtype=np.int32), (self.n,)))
         lib().csfo_push_state(self.h, _p(s), *[None if a is None else _p(a) for a in (ptr, znav, col)])
+
+    def lti(self):
+        """(vehicle.x [n, 5] with psi unwrapped, vehicle.zrid [n, 2]) of InvPendulum riders (vehicle.py:1728-1736)"""
+        x = np.zeros((self.n, 5)); z = np.zeros((self.n, 2), dtype=np.uint8)
+        lib().csfo_get_lti(self.h, _p(x), _p(z))
+        return x, z.astype(bool)
+
+    def set_lti(self, x=None, zrid=None):
+        x = None if x is None else np.ascontiguousarray(x, dtype=np.float64).reshape(self.n, 5)
+        zrid = None if zrid is None else np.ascontiguousarray(zrid, dtype=np.uint8).reshape(self.n, 2)
+        lib().csfo_set_lti(self.h, None if x is None else _p(x), None if zrid is None else _p(zrid))
 
     def dest_force(self, a):
         fx, fy = C.c_double(), C.c_double()

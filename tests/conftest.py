@@ -72,20 +72,28 @@ def shadow_run(e, pop, ticks, window, traj_len=3000):
     by side compares the two programs only until the first such event.  Here the oracle is re-anchored on the engine's
     state of two consecutive ticks at every window boundary (two: the planner reads the previous position from the
     trajectory ring, tests/test_gpu_large.py::test_config2), and every window compares `window` ticks of both programs
-    from a common state.  Returns (largest position deviation at a window end, per-road-user deviation at the last one,
-    the engine's and the oracle's final state)."""
+    from a common state.  The common state includes what vehicle.s does not carry - vehicle.x of an InvPendulumBicycle
+    (steer and lean RATES, the unwrapped yaw) and vehicle.zrid: without them the oracle keeps its own rates behind the
+    engine's angles, and the stiff roll loop of a slow rider (gains ~ v^-3, parameters.py:1832-1892) turns that mismatch
+    into decimetres within one window (tools/invpend_cut_study.py shows it with the oracle alone).
+    Returns (largest position deviation at a window end, per-road-user deviation at the last one, the engine's and the
+    oracle's final state)."""
     import numpy as np
+
+    def anchor():
+        s, ptr, zn, t = e.state(with_nav=True)
+        pop.push_state(s, ptr, zn, col=t % traj_len)
+        x, _, zrid = e.integrator_state()                      # include/csf.h: csf_get_integrator_state
+        pop.set_lti(x, zrid)
+        return t
 
     tick, worst, dev, ref = 0, 0.0, None, None
     while tick < ticks:
         end = min(tick + window, ticks)
         if tick > 0:                                          # anchor on the engine's states of ticks `tick - 1` (where it is) and `tick`
-            a, aptr, azn, t = e.state(with_nav=True)
-            assert t == tick - 1
-            pop.push_state(a, aptr, azn, col=t % traj_len)
+            assert anchor() == tick - 1
             e.step(1); pop.step(1)
-            b, bptr, bzn, t = e.state(with_nav=True)
-            pop.push_state(b, bptr, bzn, col=t % traj_len)
+            anchor()
         last = end == ticks
         k = end - tick - (0 if last else 1)                   # stop one tick short of the next boundary
         e.step(k); pop.step(k)

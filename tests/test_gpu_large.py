@@ -757,6 +757,83 @@ def test_arrivals_in_the_sentinel_tail(amd, monkeypatch):
     e.close()
 
 
+def _sums_vs_oracle(e, p, recv):
+    e.calc_forces()                                              # of the state as it is now
+    fdx, fdy, frx, fry = e.force_parts()
+    st = e.state()
+    ox, oy = orc.column_sums(p, st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv)
+    cx, cy = clamped(ox, oy, fdx[recv], fdy[recv])
+    return max(np.abs(frx[recv] - cx).max(), np.abs(fry[recv] - cy).max()) / max(np.hypot(cx, cy).max(), 1.0)
+
+
+def test_arrivals_with_receivers_in_binned_order_and_candidate_lists(amd, monkeypatch):
+    """Receivers in binned order with candidate tile lists (csf_engine.hip: rebin; what configs 4 / 5 run) while road users
+    leave, arrive in the sentinel tail AND the population grows into fresh slots: the lists were built for the groups and
+    tiles of the last re-binning, an arrival's group listed nothing then and a group behind the old last one has no list
+    (round-4 advisor finding: the arrivals missed every listed tile until the next re-binning).  Repulsive sums of old road
+    users, of arrivals in retired slots and of arrivals in fresh slots against the oracle, between two re-binnings."""
+    monkeypatch.setenv("CSF_RECV_BINNED", "1")
+    monkeypatch.setenv("CSF_REBIN_CHURN", "1000000000")         # (no churn-triggered re-binning: the lists stay in use)
+    n, box, grow = 24576, 1500.0, 700
+    s0, off, dq = population(n + 2048, box, seed=33)
+    dq3 = dq.reshape(-1, 4, 3)
+    p = orc.default_params("twod")
+    e = amd.Engine(amd.pod("twod"), n + grow)
+    e.set_incremental(True)
+    e.add_agents(s0[:n, :5], 5.0)
+    e.set_dest_queue(np.arange(n), np.arange(n + 1) * 4, dq3[:n].reshape(-1, 3), reset=True)
+    e.step(3)
+    assert np.isfinite(e.far_radius()) and e.far_radius() < 0.2 * box
+    rng = np.random.default_rng(9)
+    k = 300
+    kill = np.sort(rng.choice(n, k, replace=False))
+    e.remove_agents(kill)
+    new = np.arange(n, n + k + grow)                            # k of them take retired slots, `grow` fresh ones
+    e.add_agents(s0[new, :5], 5.0)
+    e.set_dest_queue(np.arange(n - k, n + grow), np.arange(k + grow + 1) * 4, dq3[new].reshape(-1, 3), reset=True)
+    assert e.n == n + grow
+    for tick in range(3):
+        e.step(1)
+        recv = np.concatenate([np.arange(0, n - k, 307), np.arange(n - k, n + grow, 5)])
+        err = _sums_vs_oracle(e, p, recv)
+        print(f"  tick {tick}: clamped repulsive sums vs oracle {err:.1e}")
+        assert err < 1e-4
+    assert (e.status() == 0).all() and e.near_dropped() == 0
+    e.close()
+
+
+def test_forces_from_elsewhere_move_a_binned_population_past_its_candidate_lists(amd, monkeypatch):
+    """csf_replay_forces / csf_apply_forces move the road users without a pair launch (calibration.py:438-460); with
+    fix_speed the speed is set to |F| before every step (:454-458).  The candidate tile lists and the circles' stretch allow for
+    rebin_ticks + 2 ticks of motion: the next evaluation has to re-bin first (round-4 advisor finding).  A quarter of the crowd
+    is driven 20 m at the speed clamp while the rest crawls, then the sums of movers and bystanders against the oracle; then
+    single csf_apply_forces ticks past the re-binning period."""
+    monkeypatch.setenv("CSF_RECV_BINNED", "1")
+    n, box = 24576, 1500.0
+    s0, off, dq = population(n, box, seed=34)
+    p = orc.default_params("twod")
+    e = make_engine(amd, "twod", s0[:, :5], 5.0, off, dq)
+    e.step(2)
+    st = e.state()
+    T = 300
+    mover = np.arange(n) % 4 == 0
+    Fx = np.where(mover, 150.0 * np.cos(st[:, 2]), 0.5 * np.cos(st[:, 2]))[None, :].repeat(T, 0)
+    Fy = np.where(mover, 150.0 * np.sin(st[:, 2]), 0.5 * np.sin(st[:, 2]))[None, :].repeat(T, 0)
+    e.replay_forces(Fx, Fy, fix_speed=True, return_states=False)
+    moved = np.hypot(*(e.state()[:, :2] - st[:, :2]).T)
+    assert moved[mover].min() > 15.0 and moved[~mover].max() < 3.0
+    recv = np.arange(0, n, 97)
+    err = _sums_vs_oracle(e, p, recv)
+    print(f"  after the replay: {err:.1e}")
+    assert err < 1e-4
+    for t in range(70):                                         # (past a re-binning period of ticks without a pair launch)
+        e.apply_forces(Fx[0] * 0.04, Fy[0] * 0.04)
+    err = _sums_vs_oracle(e, p, recv)
+    print(f"  after 70 ticks on supplied forces: {err:.1e}")
+    assert err < 1e-4
+    e.close()
+
+
 @pytest.mark.parametrize("seed,n0,box,sets,every", [(1, 1300, 420.0, 1, 1), (2, 3300, 700.0, 1, 1), (3, 1100, 400.0, 3, 1), (18, 1100, 400.0, 3, 1),
                                                     (17, 3300, 700.0, 1, 1), (30, 1100, 400.0, 3, 1), (5, 1200, 420.0, -3, 1), (6, 1200, 420.0, -3, 1),
                                                     (101, 1400, 420.0, 3, 1), (102, 2600, 600.0, -3, 1),
