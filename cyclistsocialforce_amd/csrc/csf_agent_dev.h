@@ -756,13 +756,13 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     if (!cs_fresh) qsincos(psi, &s, &c);
     const double px = (x - d.ox) - (double)o.x, py = (y - d.oy) - (double)o.y;
     const float4 q = make_float4((float)px, (float)py, (float)c, (float)s);
-    d.rec[a] = q;
+    d.rec_w[a] = q;
     if (d.keep_lo) d.reclo[a] = make_float2((float)(px - (double)q.x), (float)(py - (double)q.y));   // (what fp32 left over: csf_dev.h reclo)
     // scene coordinates = offset + origin, in fp32 (the same sum a rank forms from the records it has gathered, so that
     // every path sees the same numbers): by slot (the receivers), and the copy in binned order (csf_bin.hip) that the
     // pair kernel's tiles are filled with
     const float4 g = make_float4(q.x + o.x, q.y + o.y, q.z, q.w);
-    d.recg[a] = g;
+    d.recg_w[a] = g;
     if (d.recs_valid) {
         const int32_t p = place >= 0 ? place : d.pos[a];      // (the per-agent kernel asks for it with its first loads)
         d.recs[p] = g;
@@ -775,10 +775,250 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
         double e = 0.0;
         if (p.model == CSF_BICYCLE && v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
         const float2 q2 = make_float2((float)e, (float)qrsqrt(1.0 - e * e));
-        d.rec2[a] = q2;
+        d.rec2_w[a] = q2;
         if (d.recs_valid) d.recs2[d.pos[a]] = q2;
     }
 }
 
+
+// One road user's tick.  FUSED (small_tick_kernel, below): the repulsive sum (frx, fry) comes from the caller - no pair kernel
+// has run, so there are no partial sums to read and no pairs handed over.
+// MID (csf_mid.hip: the tick of a mid-size population in one launch, one workgroup per receiver group): 1 - this call is the
+// destination-force phase, run by the group's first wave WHILE the other waves form the pair sums (they may be setting
+// CSF_ST_EDGE in the status word: its bits go in with an atomic OR); 2 - this call is the rest, by the same wave behind the
+// workgroup's barrier: the repulsive sum comes from the caller (frx, fry) and what the other waves left in memory - status bits,
+// hand-overs - comes in through agent-scope loads, which bypass this CU's L1 (csf_dev.h: ld_pub).
+template <bool PUB>
+__device__ __forceinline__ EdgeRec load_edge(const EdgeRec *p) {
+    if (!PUB) return *p;
+    EdgeRec r;
+    r.xi = ld_pub<true>(&p->xi); r.yi = ld_pub<true>(&p->yi); r.psi = ld_pub<true>(&p->psi); r.hfov = ld_pub<true>(&p->hfov);
+    r.fx = ld_pub<true>(&p->fx); r.fy = ld_pub<true>(&p->fy); r.fx2 = ld_pub<true>(&p->fx2); r.fy2 = ld_pub<true>(&p->fy2);
+    r.recv = ld_pub<true>(&p->recv); r.next = ld_pub<true>(&p->next); r.stamp = ld_pub<true>(&p->stamp); r.flags = ld_pub<true>(&p->flags);
+    return r;
+}
+
+template <int MODEL, bool HET, bool FUSED, int MID = 0>
+__device__ __forceinline__ void agent_body(const Dev &d, const int phases, const int64_t a, uint64_t *const tr, const uint32_t ka_lines,
+                                           const double frx, const double fry) {
+    auto stamp = [&](int k) {
+        if (tr != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if ((threadIdx.x & 63) == 0) tr[k] = wall_clock64();
+        }
+    };
+    if (a >= d.hi) return;
+    // a slot left behind by csf_remove_agents; asked only when there is one (n_live != n, uniform): the answer is a round
+    // trip to memory that every other load of the kernel would wait behind
+    if (d.n_live != d.n && !d.alive[a]) return;
+    const int64_t cap = d.cap;
+    constexpr bool IN = MID == 2, OUT = MID == 1, SUMS_GIVEN = FUSED || MID == 2;
+    constexpr bool PLANNER = MODEL != CSF_BICYCLE && MODEL != CSF_UNCONTROLLED;   // (the models whose planner reads the ring)
+    constexpr int PRE = 16;
+    Agent g;
+    float2 pp[PRE];
+    g.a = a;
+    g.x = d.s[a];
+    g.y = d.s[cap + a];
+    g.psi = d.s[2 * cap + a];
+    g.v = d.s[3 * cap + a];
+    g.delta = d.s[4 * cap + a];
+    g.theta = d.s[5 * cap + a];
+    g.vdes = d.vdes[a];
+    g.qb = d.qbeg[a];
+    g.K = d.qlen[a];
+    g.ptr = d.ptr[a];
+    g.zn = d.znav[a] & 3;
+    g.zv0 = d.znp[a];
+    g.zd0 = d.znp[cap + a];
+    g.zd1 = d.znp[2 * cap + a];
+    g.ti = d.ti[a];
+    g.st = ld_pub<IN>(&d.status[a]);
+    g.cs_fresh = false;
+    kernarg_touched(ka_lines);
+    const int32_t place = d.recs_valid ? d.pos[a] : -1;        // (for the record written at the end)
+    agent_params<HET>(d, a, g);
+    if (HET && g.p->model != MODEL) return;                    // a mixed population: one launch per vehicle class
+    // The partial sums of the pair kernel (the first 16 chunks: the usual split) and the road term are requested here, with
+    // the agent's own scalars, so that their round trip runs beside the destination-force phase.  Unconditional loads from
+    // clamped addresses: a guarded load is a branch with its own wait.
+#pragma unroll
+    for (int c = 0; c < PRE; c++) pp[c] = make_float2(0.f, 0.f);
+    if (!SUMS_GIVEN) {                                         // (eight chunks is the single-device split: the other eight loads
+#pragma unroll                                                 //  would only queue in front of everything asked for after them)
+        for (int c = 0; c < PRE / 2; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
+        if (d.n_split > PRE / 2) {
+#pragma unroll
+            for (int c = PRE / 2; c < PRE; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
+        }
+    }
+    const float2 froad = d.froad[a];
+    const float2 rorg = d.rorg[a];                             // (for the record written at the end)
+    if (MODEL == CSF_INVPEND) {                                // (side-state of the model: with the first round trip, not the fourth)
+#pragma unroll
+        for (int k = 0; k < 5; k++) g.xl[k] = d.lti[(int64_t)k * cap + a];
+        g.riding = d.zrid[a] != 0;
+        g.dgood = d.dgood[a];
+    }
+    if (MODEL == CSF_PLANARBIKE) g.xl[0] = d.lti[a];
+    if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) g.ppsi = d.ppsi[a];
+    load_rows(d, g);                                           // the second and last round trip of the common path
+    if (PLANNER && (phases & PH_DEST)) load_ring(d, g);
+    // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge wait in a ring
+    // (csf_dev.h: EdgeRec): bit 31 of the status word says so - a few dozen road users of a large population, per tick
+    const bool edge_pending = !FUSED && (phases & PH_COMBINE) && (g.st & CSF_ST_EDGE) != 0u;
+    if (edge_pending) g.st &= ~CSF_ST_EDGE;
+    stamp(1);
+    double fdx, fdy;
+    if (phases & PH_DEST) {
+        dest_force<MODEL>(d, g, fdx, fdy);
+        d.F[2 * cap + a] = fdx;
+        d.F[3 * cap + a] = fdy;
+        d.ptr[a] = g.ptr;
+        d.znav[a] = (uint8_t)g.zn;
+        d.znp[a] = g.zv0;
+        d.znp[cap + a] = g.zd0;
+        d.znp[2 * cap + a] = g.zd1;
+    } else {
+        fdx = d.F[2 * cap + a];
+        fdy = d.F[3 * cap + a];
+    }
+    stamp(2);
+    double Fx, Fy;
+    if (phases & PH_COMBINE) {
+        double rx = 0, ry = 0;
+        Fx = fdx;
+        Fy = fdy;
+        if (d.n_live > 1) {                                   // intersection.py:813, 825, 849-851
+            // the first 16 chunks (the usual split) requested together: one round trip, not one per group of four.  Added
+            // in chunk order: reproducible
+            int c = 0;
+#pragma unroll
+            for (; c < PRE; c++) {
+                if (!SUMS_GIVEN && c < d.n_split) {
+                    rx += (double)pp[c].x;
+                    ry += (double)pp[c].y;
+                }
+            }
+            for (; !SUMS_GIVEN && c < d.n_split; c++) {
+                const float2 pr = d.part[(int64_t)c * cap + a];
+                rx += (double)pr.x;
+                ry += (double)pr.y;
+            }
+            if (SUMS_GIVEN) rx = frx, ry = fry;
+            if (edge_pending) {     // rare: decide those pairs as the reference does (intersection.py:711-741) and put the sum right
+                double cx = 0, cy = 0;   // (fp64: the order in which the entries were appended does not show)
+                int32_t at = ld_pub<IN>(&d.edge_head[a]);
+                // (a receiver's chain is at most the ring; a walk that long without reaching its end is counted like an overflow)
+                for (int guard = 0; at != 0; guard++) {
+                    if (guard == (int)EDGE_CAP) {
+                        atomicAdd(d.near_dropped, 1u);
+                        break;
+                    }
+                    const EdgeRec er = load_edge<IN>(&d.edge[(unsigned)(at - 1) % EDGE_CAP]);
+                    if (er.recv != (int32_t)a || er.stamp != d.edge_stamp) {   // left over from another launch, or a ring that overflowed
+                        if (er.stamp == d.edge_stamp) atomicAdd(d.near_dropped, 1u);
+                        break;
+                    }
+                    const bool seen = !untracked_exact_xy(er.xi, er.yi, g.x, g.y, g.psi, er.hfov, d.p.priority_rule == CSF_P2R);
+                    double wx = 0, wy = 0;                       // what the reference adds for this pair ...
+                    // (road users that coincide in fp64 contribute nothing - deviation D2 - though their records may be an ulp apart)
+                    if (seen && (g.x != er.xi || g.y != er.yi)) {
+                        wx = (double)er.fx;
+                        wy = (double)er.fy;
+                        if (er.flags & EDGE_SIDE) {              // np.sign(phi) by the reference's own chain (vehicle.py:1617-1625)
+                            double psii = er.psi;
+                            if (er.flags & EDGE_HEADING_REC)
+                                psii = atan2((double)__int_as_float(__double2hiint(er.psi)), (double)__int_as_float(__double2loint(er.psi)));
+                            const int sg = sign_phi_exact(er.xi, er.yi, psii, g.x, g.y);
+                            if (sg < 0) {
+                                wx = (double)er.fx2;
+                                wy = (double)er.fy2;
+                            } else if (sg == 0) {                // phi = 0 exactly: no tangential part, |F| = P along the line
+                                const double ex = g.x - er.xi, ey = g.y - er.yi, P = sqrt(wx * wx + wy * wy);
+                                const double il = 1.0 / sqrt(ex * ex + ey * ey);
+                                wx = P * ex * il;
+                                wy = P * ey * il;
+                            }
+                        }
+                    }
+                    if (er.flags & EDGE_SEEN) {                  // ... minus what the pair kernel added
+                        wx -= (double)er.fx;
+                        wy -= (double)er.fy;
+                    }
+                    cx += wx;
+                    cy += wy;
+                    at = er.next;
+                }
+                d.edge_head[a] = 0;
+                rx += cx;
+                ry += cy;
+            }
+            double rin = qsqrt(rx * rx + ry * ry), lim = qsqrt(fdx * fdx + fdy * fdy);
+            if (rin > lim) {                                  // utils.py:79-84
+                const double irin = rcp_nr(rin);
+                rx = rx * lim * irin;
+                ry = ry * lim * irin;
+            }
+            Fx = rx + fdx;                                    // :847-848
+            Fy = ry + fdy;
+        }
+        if (d.nv > 0) {                                       // :854-857
+            Fx += (double)froad.x;
+            Fy += (double)froad.y;
+        }
+        d.F[a] = Fx;                                          // :860-861
+        d.F[cap + a] = Fy;
+        d.F[4 * cap + a] = rx;
+        d.F[5 * cap + a] = ry;
+        if (!(isfinite(Fx) && isfinite(Fy))) g.st |= CSF_ST_NAN;
+    } else {
+        Fx = d.F[a];
+        Fy = d.F[cap + a];
+    }
+    stamp(4);
+    if (phases & PH_INTEGRATE) {
+        const bool frozen = d.replay_len != nullptr && d.replay_tick >= d.replay_len[a];  // replay sequence ended
+        if (!frozen) {
+            if (phases & PH_FIXSPEED) g.v = qsqrt(Fx * Fx + Fy * Fy);  // calibration.py:454-458
+            integrate<MODEL>(d, g, Fx, Fy);
+        }
+        stamp(5);
+        d.s[a] = g.x;
+        d.s[cap + a] = g.y;
+        d.s[2 * cap + a] = g.psi;
+        d.s[3 * cap + a] = g.v;
+        d.s[4 * cap + a] = g.delta;
+        d.s[5 * cap + a] = g.theta;
+        d.ti[a] = g.ti;
+        write_record(d, *g.p, a, rorg, g.x, g.y, g.psi, g.v, g.cs_fresh, g.cpsi, g.spsi, place);
+        if (d.src64_w != nullptr) {                           // (fused tick, csf_mid.hip: the next tick's snapshot)
+            d.src64_w[a] = g.x;
+            d.src64_w[cap + a] = g.y;
+            d.src64_w[2 * cap + a] = g.psi;
+        }
+        if (d.hist != nullptr) {
+            int64_t t1 = d.tick + 1;
+            if (t1 % d.hist_stride == 0) {
+                int64_t smp = (t1 / d.hist_stride - 1) % d.hist_cap;
+                double *o = d.hist + (smp * d.n + a) * d.ns;
+                o[0] = g.x;
+                o[1] = g.y;
+                o[2] = g.psi;
+                o[3] = g.v;
+                if (d.ns > 4) o[4] = g.delta;
+                if (d.ns > 5) o[5] = g.theta;
+            }
+        }
+    }
+    if (OUT) {
+        // (fused tick, csf_mid.hip: the pair workgroups of this group may be setting CSF_ST_EDGE in the same word right now)
+        if ((g.st & ~CSF_ST_EDGE) != 0u) atomicOr(&d.status[a], g.st & ~CSF_ST_EDGE);
+    } else {
+        d.status[a] = g.st;
+    }
+    if (tr != nullptr && (threadIdx.x & 63) == 0) tr[6] = wall_clock64();
+    stamp(7);
+}
 
 }  // namespace csf

@@ -217,6 +217,16 @@ struct Dev {
     double *F;         // [6][cap] Fx, Fy, Fdest_x, Fdest_y, Frep_x, Frep_y
     uint32_t *status;
 
+    // The fused tick of mid-size populations (csf_mid.hip: one launch = pair sums + per-agent tick): a receiver group's per-agent
+    // phase runs as soon as ITS sums are complete, while other groups still read this tick's records - so the next tick's records
+    // go to the other half of a double buffer, and the fp64 positions an undecidable pair is handed over with (csf_field.h:
+    // edge_handover) come from a snapshot of the tick's start instead of the state that is being overwritten.
+    float4 *rec_w, *recg_w;   // where write_record puts the record: rec, recg themselves, or the other half
+    float2 *rec2_w;
+    const double *src64;      // [3][cap] (x, y, psi) of every slot as the pair kernels' hand-overs read them: s itself, or the snapshot
+    double *src64_w;          // fused tick: the snapshot the per-agent phase leaves for the next tick (NULL otherwise)
+    int32_t mid_group;        // fused tick: road users (slots) per workgroup: 4, 8, 16 or 32
+
     const int32_t *replay_len;  // csf_replay_forces: per-agent number of ticks (NULL = all), and the tick within
     int64_t replay_tick;        // the replay
     double *hist;      // opt-in history [hist_cap][n][ns]
@@ -251,6 +261,9 @@ void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0 = null
 constexpr int SMALL_MAX = 32;
 constexpr int SMALL_ROAD_MAX = 2048;   // road vertices (padded) the one-wave kernel stages; and at most 256 of them per lane and tick
 void launch_small_tick(const Dev &d, int n_ticks, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// csf_mid.hip: one tick of a mid-size population (plain pair sums + per-agent tick) in one launch; d.rec_w / recg_w / rec2_w /
+// src64_w point at the halves of the double buffers this tick does not read, d.mid_group = slots per workgroup
+void launch_mid_tick(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 const char *pair_kernel_name(const Dev &d);           // the kernel launch_pair() takes for this engine
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state
 // csf_get_tick: row-major state [n, ns], Fx [n], Fy [n] (doubles), destination pointers [n] (int32), navigation state
@@ -325,6 +338,16 @@ __device__ __forceinline__ uint32_t kernarg_touch() {
 __device__ __forceinline__ void kernarg_touched(uint32_t lines) { asm volatile("" ::"s"(lines)); }
 
 constexpr double PI = 3.141592653589793238462643383279502884;
+
+// Data that WAVES of one workgroup hand to each other through memory (csf_mid.hip: status bits and hand-over entries that the
+// pair waves leave for the wave that runs the per-agent tick): a CU's vector L1 may hold an older copy of the line, and it does
+// not see atomics, so the consumer's loads are agent-scope loads (`sc1`: they bypass the L1 and are served by the XCD's L2,
+// where the producers' stores and atomics have landed once their `s_waitcnt vmcnt(0)` has passed).  PUB = false: plain accesses.
+template <bool PUB, class T>
+__device__ __forceinline__ T ld_pub(const T *p) {
+    if (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
 
 // utils.py:124-139
 __device__ __forceinline__ double limit_angle(double th) {

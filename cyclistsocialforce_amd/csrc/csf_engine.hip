@@ -101,6 +101,9 @@ struct Knobs {
     int wide = -1;                            // CSF_WIDE: workgroups of 8 waves on tiles of 2048 sources (-1: the engine's choice)
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
     int64_t rebin_ticks = 64;                 // CSF_REBIN_TICKS: ticks between two re-binnings (1 .. 120; the tests that step 40 - 48 ticks "across a re-binning" pin 32)
+    int fused_mid = 1;                        // CSF_FUSED_MID=0: mid-size populations take a pair launch and a per-agent launch per tick (csf_mid.hip: one launch)
+    int mid_below = 1280;                     // CSF_MID_BELOW: ... for populations smaller than this
+    int mid_group = 0;                        // CSF_MID_GROUP: road users per workgroup of it, 4 / 8 / 16 / 32 (0: about one workgroup per CU)
     int fused_small = 1;                      // CSF_FUSED_SMALL=0: a handful of road users take the general path too (csf_agent.hip: small_tick_kernel)
     int segments = -1;                        // CSF_SEGMENTS
     int seg_grid = 1;                         // CSF_SEG_GRID=0: one launch per parameter set (class-segmented order) instead of one grid
@@ -132,6 +135,9 @@ struct Knobs {
         wide = geti("CSF_WIDE", -1);
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
         fused_small = geti("CSF_FUSED_SMALL", 1);
+        fused_mid = geti("CSF_FUSED_MID", 1);
+        mid_below = geti("CSF_MID_BELOW", 1280);
+        mid_group = geti("CSF_MID_GROUP", 0);
         rebin_ticks = std::max(1, std::min(120, geti("CSF_REBIN_TICKS", 64)));
         segments = geti("CSF_SEGMENTS", -1);
         recv_binned = geti("CSF_RECV_BINNED", -1);
@@ -255,6 +261,14 @@ struct csf_engine {
     int pinned_next = 0;
     DevBuf<uint32_t> status;
     DevBuf<float4> rec, recs, recg, recb, rv, kat4, bnd, bnd2;
+    // the fused tick of mid-size populations (csf_mid.hip): the other halves of the record double buffers, the two snapshots of
+    // (x, y, psi), the arrival counters; mid_synced: the other halves hold this tick's sentinels and the current snapshot holds
+    // this tick's state (any other path that writes records or state clears it)
+    DevBuf<float4> rec_alt, recg_alt;
+    DevBuf<float2> rec2_alt;
+    DevBuf<double> src64_a, src64_b;
+    bool mid_synced = false, mid_cur_is_a = true;
+    int64_t mid_ticks = 0;
     DevBuf<float2> borg;
     DevBuf<float2> rvo;          // origins of the road-vertex tiles
     DevBuf<int32_t> pos;
@@ -875,6 +889,12 @@ int alloc_all(csf_engine *e) {
     d.pos = e->pos.p;
     d.recs = e->recs.p;
     d.recg = e->recg.p;
+    d.rec_w = d.rec;
+    d.recg_w = d.recg;
+    d.rec2_w = d.rec2;
+    d.src64 = e->s.p;
+    d.src64_w = nullptr;
+    d.mid_group = 0;
     d.recb = e->recb.p;
     d.borg = e->borg.p;
     d.bnd = e->bnd.p;
@@ -888,7 +908,7 @@ int alloc_all(csf_engine *e) {
     d.atrace = nullptr;
     d.snap = nullptr;
     if (!e->knobs.trace_agent.empty()) {   // 8 words per wave of 64 road users
-        HIPCHK(e, e->atrace.alloc(8 * ((size_t)cap / 64 + 2)));
+        HIPCHK(e, e->atrace.alloc(8 * ((size_t)cap / 64 + 2) + 16 * ((size_t)cap / 4 + 2)));   // (csf_mid.hip: 16 words per workgroup)
         d.atrace = e->atrace.p;
     }
     d.trace = nullptr;
@@ -991,6 +1011,7 @@ int32_t pair_variant_for(const csf_engine *e, int64_t n) {
 // (re)build the spatially binned order of the records; decides whether batches are classified this tick
 int rebin(csf_engine *e) {
     Dev &d = e->d;
+    e->mid_synced = false;     // (records re-expressed, perhaps a new sentinel tail: csf_mid.hip's other halves are stale)
     if (e->world <= 1 && !e->loopback && d.n_pad < e->cap && d.n + TAIL_SLOTS / 2 > d.n_pad) {   // fresh slots are running out
         set_shard(e);
         launch_records(d, e->main);     // sentinels in the new tail (the records of the road users are rewritten as they are)
@@ -1336,6 +1357,7 @@ int upload_all(csf_engine *e) {
     }
     if (!e->dirty) return flush_pending(e);
     Dev &d = e->d;
+    e->mid_synced = false;
     compact_host(e);
     if (e->classes.size() > 1) HIPCHK(e, hipMemcpy(e->cls.p, e->h_cls.data(), e->h_cls.size(), hipMemcpyHostToDevice));   // (slots moved)
     const int64_t n = d.n;
@@ -1512,6 +1534,7 @@ int flush_pending(csf_engine *e) {
     csf_engine::Pending &pd = e->pend;
     if (pd.empty()) return CSF_OK;
     Dev &d = e->d;
+    e->mid_synced = false;
     const size_t b_ret = pd.retire.size() * sizeof(int32_t), b_sp = pd.spawn.size() * sizeof(SpawnRec),
                  b_rq = pd.requeue.size() * sizeof(QueueRec), b_rows = pd.rows.size() * sizeof(double);
     auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
@@ -1784,6 +1807,7 @@ int csf_destroy(csf_engine *e) {
     if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
+    e->rec_alt.release(); e->recg_alt.release(); e->rec2_alt.release(); e->src64_a.release(); e->src64_b.release();
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
@@ -2376,10 +2400,82 @@ static int calibrate_comm_stream_body(csf_engine *e) {
     return CSF_OK;
 }
 
+// ---- mid-size populations: the whole tick in one launch (csf_mid.hip) --------------------------------------------------
+// One device, one parameter set, the plain all-pairs kernel's range (below PLAIN_BELOW road users; up to SMALL_MAX the one-wave
+// kernel is faster still), nothing that wants the two kernels apart (time stamps per kernel, wave traces, pair counters).
+static bool mid_fused_ok(const csf_engine *e) {
+    const Dev &d = e->d;
+    return e->knobs.fused_mid != 0 && e->knobs.pair_variant < 0 && d.pair_variant == 1 && d.n_live > 1 && d.n_live < e->knobs.mid_below && e->classes.size() == 1 &&
+           d.p.model != CSF_UNCONTROLLED && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && e->profile <= 0 &&
+           d.trace == nullptr && d.pair_count == nullptr && d.lo == 0 && d.hi == d.n && e->segs.empty() && e->state_all_current &&
+           d.src_beg == 0 && d.n_src / 64 * 8 <= 384;                  // (csf_mid.hip: MID_ITEMS_MAX items of the largest group)
+}
+
+// the other halves of the double buffers <- this tick's records (sentinels of free and padding slots included) and state
+static int mid_sync(csf_engine *e) {
+    Dev &d = e->d;
+    const size_t nrec = e->rec.n;
+    if (e->rec_alt.n < nrec) {
+        HIPCHK(e, e->rec_alt.alloc(nrec));
+        HIPCHK(e, e->recg_alt.alloc(e->recg.n));
+        HIPCHK(e, e->rec2_alt.alloc(e->rec2.n));
+        HIPCHK(e, e->src64_a.alloc(3 * (size_t)e->cap));
+        HIPCHK(e, e->src64_b.alloc(3 * (size_t)e->cap));
+    }
+    float4 *rec_o = d.rec == e->rec.p ? e->rec_alt.p : e->rec.p, *recg_o = d.recg == e->recg.p ? e->recg_alt.p : e->recg.p;
+    float2 *rec2_o = d.rec2 == e->rec2.p ? e->rec2_alt.p : e->rec2.p;
+    HIPCHK(e, hipMemcpyAsync(rec_o, d.rec, (size_t)d.n_pad * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
+    HIPCHK(e, hipMemcpyAsync(recg_o, d.recg, std::min((size_t)d.n_pad, e->recg.n) * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
+    if (d.has_bike) HIPCHK(e, hipMemcpyAsync(rec2_o, d.rec2, (size_t)d.n_pad * sizeof(float2), hipMemcpyDeviceToDevice, e->main));
+    double *cur = e->mid_cur_is_a ? e->src64_a.p : e->src64_b.p;
+    HIPCHK(e, hipMemcpyAsync(cur, e->s.p, 3 * (size_t)e->cap * sizeof(double), hipMemcpyDeviceToDevice, e->main));
+    e->mid_synced = true;
+    return CSF_OK;
+}
+
+static int enqueue_mid_tick(csf_engine *e) {
+    Dev &d = e->d;
+    int rc;
+    if ((rc = bounds_before_pair(e))) return rc;              // (the re-binning: new origins of the precise records)
+    if ((rc = set_fov_band(e))) return rc;
+    if (!e->mid_synced && (rc = mid_sync(e))) return rc;
+    if (d.nv > 0) launch_road(d, e->main);
+    float4 *rec_o = d.rec == e->rec.p ? e->rec_alt.p : e->rec.p, *recg_o = d.recg == e->recg.p ? e->recg_alt.p : e->recg.p;
+    float2 *rec2_o = d.rec2 == e->rec2.p ? e->rec2_alt.p : e->rec2.p;
+    double *cur = e->mid_cur_is_a ? e->src64_a.p : e->src64_b.p, *nxt = e->mid_cur_is_a ? e->src64_b.p : e->src64_a.p;
+    Dev dd = d;
+    dd.rec_w = rec_o;
+    dd.recg_w = recg_o;
+    dd.rec2_w = rec2_o;
+    dd.src64 = cur;
+    dd.src64_w = nxt;
+    // road users per workgroup: about one workgroup (of eight waves, at the per-agent code's 255 registers a CU holds one) per CU
+    int G = e->knobs.mid_group;
+    if (G != 4 && G != 8 && G != 16 && G != 32) {
+        G = 4;
+        while (G < 32 && (d.hi - d.lo + G - 1) / G > 256) G *= 2;
+    }
+    dd.mid_group = G;
+    launch_mid_tick(dd, e->main);
+    HIPCHK(e, hipGetLastError());
+    // the halves trade places: what the launch wrote is what every later launch reads
+    d.rec = d.rec_w = rec_o;
+    d.recg = d.recg_w = recg_o;
+    d.rec2 = d.rec2_w = rec2_o;
+    e->mid_cur_is_a = !e->mid_cur_is_a;
+    bounds_after_pair(e, true);
+    e->moves++;
+    e->mid_ticks++;
+    d.tick++;
+    return CSF_OK;
+}
+
 //   main:  agent(DEST) - wait(ev_gather) - bounds - pair - road - agent(COMBINE|INTEGRATE) - record(ev_integ)
 //   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)
 static int enqueue_tick(csf_engine *e) {
     Dev &d = e->d;
+    if (mid_fused_ok(e)) return enqueue_mid_tick(e);
+    e->mid_synced = false;
     const bool sharded = e->world > 1 || e->nccl != nullptr || e->loopback;  // a 1-rank communicator rehearses the sharded path
     int rc = CSF_OK;
     csf_engine::ProfSlot *ps = prof_slot(e, &rc);
@@ -2509,6 +2605,7 @@ static int step_impl(csf_engine *e, int64_t n_ticks, bool want_snap, bool *snapp
             Dev dd = e->d;
             dd.snap = (snap && t + k == n_ticks) ? e->snap_dev : nullptr;
             launch_small_tick(dd, k, e->main);
+            e->mid_synced = false;
             HIPCHK(e, hipGetLastError());
             e->d.tick += k;
             e->moves += k;
@@ -2582,6 +2679,7 @@ int csf_apply_forces(csf_engine *e, const double *Fx, const double *Fy) {
     }
     launch_agent(e->d, PH_INTEGRATE, e->main);
     HIPCHK(e, hipGetLastError());
+    e->mid_synced = false;
     e->bounds_fresh = false;
     if (!e->pair_since_move) e->moved_unbinned++;              // (csf_calc_forces before it has counted this tick already)
     e->pair_since_move = false;
@@ -2640,6 +2738,7 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
     }
     e->d.tick += n_ticks;
     e->moves += n_ticks;
+    e->mid_synced = false;
     e->moved_unbinned += n_ticks;
     e->pair_since_move = false;
     if (fix_speed) {                         // (calibration.py:454-458 sets the speed to |F|: no clamp bounds the step)
@@ -3160,6 +3259,12 @@ int csf_comm_stream_order(const csf_engine *e, int32_t *second_stream, double us
 int csf_small_ticks(const csf_engine *e, int64_t *n_ticks) {
     if (!e || !n_ticks) return CSF_E_ARG;
     *n_ticks = e->small_ticks;
+    return CSF_OK;
+}
+
+int csf_mid_ticks(const csf_engine *e, int64_t *n_ticks) {
+    if (!e || !n_ticks) return CSF_E_ARG;
+    *n_ticks = e->mid_ticks;
     return CSF_OK;
 }
 

@@ -110,9 +110,9 @@ __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int3
                                               bool side = false, float fx2 = 0.0f, float fy2 = 0.0f) {
     double xi, yi, psi;
     if (d.state_current) {
-        xi = d.s[a_src];
-        yi = d.s[d.cap + a_src];
-        psi = d.s[2 * d.cap + a_src];
+        xi = d.src64[a_src];
+        yi = d.src64[d.cap + a_src];
+        psi = d.src64[2 * d.cap + a_src];
     } else {   // a rank of a sharded run: origin + record + what the record left over = the owner's fp64 position to ~1e-14 m
         const float4 q = d.rec[a_src];
         const float2 o = d.rorg[a_src], lo = d.reclo[a_src];
@@ -134,7 +134,7 @@ __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int3
     o->fy2 = fy2;
     o->recv = a_recv;
     o->stamp = d.edge_stamp;
-    o->flags = (seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC);
+    o->flags = (int32_t)((seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC));
     o->next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
     atomicOr(&d.status[a_recv], CSF_ST_EDGE);
 }

@@ -419,6 +419,12 @@ class Engine:
         self._ck(self._lib.csf_small_ticks(self._h, C.byref(n)))
         return n.value
 
+    def mid_ticks(self):
+        """ticks run as one launch each (csf_mid.hip: mid-size populations)"""
+        v = C.c_int64()
+        self._ck(self._lib.csf_mid_ticks(self._h, C.byref(v)))
+        return v.value
+
     def comm_stream_order(self):
         """('main' | 'second', [us per tick in stream order, on the second stream]) - where a sharded engine issues its
         all-gather, and what its communicator measured when it chose (zeros: CSF_COMM_STREAM decided, or not sharded)"""

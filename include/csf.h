@@ -302,6 +302,12 @@ int csf_profile_gather(const csf_engine *e, double *gather_ms);
  * the two positions, inside the band of fp32 rounding by the reference's own fp64 chain, intersection.py:690-745,
  * vehicle.py:1617-1625), instead of a pair launch and a per-agent launch per tick.  CSF_FUSED_SMALL=0 or a pinned CSF_PAIR_VARIANT keep the general path. */
 int csf_small_ticks(const csf_engine *e, int64_t *n_ticks);
+/* Ticks this engine has run as ONE launch each (ABI 7; csf_mid.hip).  Between 33 and ~3 000 road users of one parameter set on
+ * one device - BASELINE config 2, and what the reference runs under SUMO - a tick is launch latency, not work: the pair sums
+ * of a receiver group (intersection.py:690-745, 814-843) and the per-agent tick of its road users (:841-862, 891-892) share
+ * one grid, the group's last workgroup to finish its sums carrying on with the road users; the next tick's records go to the
+ * other half of a double buffer.  CSF_FUSED_MID=0, a pinned CSF_PAIR_VARIANT or per-kernel profiling keep the two launches. */
+int csf_mid_ticks(const csf_engine *e, int64_t *n_ticks);
 /* csf_step(e, n_ticks) followed by csf_get_tick(...) in one call (ABI 6): what a caller that looks at every tick does -
  * SocialForceIntersection.step() refreshes vehicle.s, znav and force after each tick (intersection.py:866-896).  On the
  * one-wave path the kernel packs the read-back itself behind its last tick: one launch and one wait per call.  Arguments as

@@ -269,7 +269,8 @@ def test_road_lattice_with_arrivals_and_departures(amd, monkeypatch):
 
 # --------------------------------------------------------------------------- BASELINE config 2, full length
 
-def test_config2_1024_twod_10000_ticks(amd):
+@pytest.mark.parametrize("kernel", ["cull-first (the suite's pin)", pytest.param("the engine's own choice: one launch per tick", marks=pytest.mark.auto_variant)])
+def test_config2_1024_twod_10000_ticks(amd, kernel):
     """1 024 TwoDBicycle in 200 m x 200 m for the full 10 000 ticks (three laps of the 3000-column trajectory ring),
     destinations every 50 m out to 650 m so that the route outlasts the run (SURVEY.md §8(d) generator, longer reach).
 
@@ -314,6 +315,7 @@ def test_config2_1024_twod_10000_ticks(amd):
         assert np.array_equal(gzn, ozn) and (ost == 0).all()
     e.step(ticks - tick)
     assert e.state(with_nav=True)[3] == ticks and (e.status() == 0).all()   # nobody ran out of route (no CSF_ST_SPLINE)
+    assert e.mid_ticks() == (ticks if "own choice" in kernel else 0)         # (csf_mid.hip: BASELINE config 2 is its case)
     assert worst_v < 1e-2                 # (m/s, over windows of 100 ticks)
     # a destination is passed one tick apart at most a handful of times (the 2 m arrival test on positions 1e-5 m apart)
     assert ptr_mismatch <= 5
