@@ -258,6 +258,25 @@ class Engine:
                                              None if fy is None else _ptr(fy), C.byref(tick)))
         return s, ptr, zn.astype(bool), fx, fy, tick.value
 
+    def step_into(self, n_ticks, s, ptr, zn, fx=None, fy=None):
+        """step_snapshot straight into the caller's arrays: s [n, n_states] float64, ptr [n] int32, zn [n, 3] bool or uint8
+        (one-hot), fx / fy [n] float64 or None - all C-contiguous (the host mirror's own bulk arrays: no copy in between)"""
+        n = self.n
+        key = (s.ctypes.data, ptr.ctypes.data, zn.ctypes.data, 0 if fx is None else fx.ctypes.data, 0 if fy is None else fy.ctypes.data, n)
+        if getattr(self, "_into_key", None) != key:
+            if not (s.flags.c_contiguous and ptr.flags.c_contiguous and zn.flags.c_contiguous and s.shape == (n, self.ns) and s.dtype == np.float64
+                    and ptr.shape == (n,) and ptr.dtype == np.int32 and zn.shape == (n, 3) and zn.dtype.itemsize == 1):
+                raise ValueError("step_into: s [n, n_states] float64, ptr [n] int32, zn [n, 3] of one byte each, C-contiguous")
+            for f in (fx, fy):
+                if f is not None and not (f.flags.c_contiguous and f.shape == (n,) and f.dtype == np.float64):
+                    raise ValueError("step_into: fx, fy [n] float64, C-contiguous")
+            self._into_key = key
+            self._into_ptrs = [_ptr(s), _ptr(ptr), _ptr(zn), None if fx is None else _ptr(fx), None if fy is None else _ptr(fy)]
+            self._into_tick = C.c_int64(0)
+        p = self._into_ptrs
+        self._ck(self._lib.csf_step_get_tick(self._h, int(n_ticks), p[0], p[1], p[2], p[3], p[4], C.byref(self._into_tick)))
+        return self._into_tick.value
+
     @property
     def tick(self):
         t = C.c_int64(0)

@@ -160,15 +160,18 @@ class SocialForceIntersection:
         self.hist_n_vecs = []
         self.vehicles = []
         self.n_bikes = 0
-        self.vehicleX = np.zeros((0, 1))
-        self.vehicleY = np.zeros((0, 1))
-        self.vehicleTheta = np.zeros((0, 1))
+        self._vx = np.zeros((0, 1))       # vehicleX / vehicleY / vehicleTheta (intersection.py:660-677): refreshed when read
+        self._vy = np.zeros((0, 1))
+        self._vth = np.zeros((0, 1))
+        self._pos_stale = False
         self._device = device
         self._capacity = capacity
         self._track_params = track_params
         self._engine = None
         self._S = None            # host mirror [capacity, n_states]; vehicle.s are row views
-        self._shadow = None       # device's view of the mirror after the last pull / push
+        self._shadow = None       # device's view of the mirror after the last pull / push, kept once a vehicle.s has been handed out
+        self._s_watched = False   # some vehicle.s has been handed out: the mirror is compared with the shadow before every tick
+        self._scripted = []       # live UncontrolledVehicles (their traj may be rewritten while they run)
         self._vd = None
         self._rule_on_device = None
         self._pod_bytes = None
@@ -262,11 +265,11 @@ class SocialForceIntersection:
         if len(lanes_in) > 1:                                  # the closer of the first two approach lanes
             xs = np.concatenate((lanes_in[0][0], lanes_in[1][0]))
             ys = np.concatenate((lanes_in[0][1], lanes_in[1][1]))
-            lane_in = int(np.argmin(np.hypot(xs - user.s[0], ys - user.s[1])) / 2)
+            lane_in = int(np.argmin(np.hypot(xs - user._s[0], ys - user._s[1])) / 2)
         lane_out = np.random.randint(0, len(self.outEdges[enext]))
         pts = np.vstack((np.array(lanes_in[lane_in]).T, np.array(self.outEdges[enext][lane_out]).T))
         xp, yp = generateSplinePrototype(pts[:, 0], pts[:, 1], 5)
-        ahead = np.hypot(xp - xp[-1], yp - yp[-1]) < np.hypot(user.s[0] - xp[-1], user.s[1] - yp[-1])
+        ahead = np.hypot(xp - xp[-1], yp - yp[-1]) < np.hypot(user._s[0] - xp[-1], user._s[1] - yp[-1])
         user.setDestinations(xp[ahead], yp[ahead], reset=True)  # only the points still in front of the road user
 
     # ------------------------------------------------------------------ population management
@@ -290,9 +293,7 @@ class SocialForceIntersection:
         self.vehicles.append(v)
         self._pending.append(v)
         self.n_bikes = len(self.vehicles)
-        self.vehicleX = np.vstack((self.vehicleX, [[v.s[0]]]))         # intersection.py:531-538
-        self.vehicleY = np.vstack((self.vehicleY, [[v.s[1]]]))
-        self.vehicleTheta = np.vstack((self.vehicleTheta, [[v.s[2]]]))
+        self._pos_stale = True                                         # intersection.py:531-538: vehicleX ... grow by a row
 
     def _param_classes(self, vehicles=None):
         """The parameter sets of the population.  Every reference vehicle owns its params object: the field vehicle i
@@ -402,15 +403,14 @@ class SocialForceIntersection:
             if v._live:
                 self._bind(v)
         self._drawn_stale = True
+        self._scripted = [v for v in self._scripted if v._owner is self]
         self.n_bikes = len(self.vehicles)
-        self.vehicleX = np.delete(self.vehicleX, idx, 0)
-        self.vehicleY = np.delete(self.vehicleY, idx, 0)
-        self.vehicleTheta = np.delete(self.vehicleTheta, idx, 0)
+        self._pos_stale = True
 
     def _bind(self, v):
         """vehicle attributes that are views of the bulk mirror"""
         k, w = v._index, type(v).N_STATES       # (a mixed population: the bulk rows are as wide as the widest class)
-        v.s = self._S[k, :w]
+        v._s = self._S[k, :w]
         v.znav = self._zn[k]
         if not getattr(v, "uncontrolled", False):             # (an UncontrolledVehicle's traj is its prescription: vehicle.py:958-960)
             v.traj = self._traj[:, k, :w].T
@@ -419,7 +419,7 @@ class SocialForceIntersection:
         """the vehicle leaves with private copies of everything it saw through the mirror"""
         if v._live:
             st = dict(i=v.i, destpointer=v.destpointer, force=v.force)
-            v.s, v.znav, v.traj = v.s.copy(), v.znav.copy(), v.traj.copy()
+            v._s, v.znav, v.traj = v._s.copy(), v.znav.copy(), v.traj.copy()
             v._live = False
             v.i, v.destpointer, v.force = st["i"], st["destpointer"], st["force"]
         v._owner, v._index = None, -1
@@ -440,7 +440,7 @@ class SocialForceIntersection:
             self._S = np.zeros((cap, ns))
             self._shadow = np.zeros((cap, ns))
             self._vd = np.zeros(cap)
-            self._ptr = np.zeros(cap, dtype=np.int64)
+            self._ptr = np.zeros(cap, dtype=np.int32)
             self._zn = np.zeros((cap, 3), dtype=bool)
             self._fx = np.zeros(cap)
             self._fy = np.zeros(cap)
@@ -467,7 +467,7 @@ class SocialForceIntersection:
         self._sync_param_table(pods, cls, len(self.vehicles) - len(new))   # first: it decides the engine's state layout
         s0 = np.zeros((len(new), ns))
         for k, v in enumerate(new):
-            s0[k, : v.s.size] = v.s
+            s0[k, : v._s.size] = v._s
         vd = np.array([float(getattr(v.params, "v_desired_default", 0.0)) for v in new])   # (CarParameters have none)
         first = new[0]._index
         e.add_agents(s0[:, : e.ns], vd)
@@ -488,6 +488,7 @@ class SocialForceIntersection:
             e.set_script([v._index for v in scripted], np.cumsum([0] + [r.shape[0] for r in rows]), np.vstack(rows))
             for v in scripted:                                # (what the engine holds: writes to car.traj are noticed, _push_mutations)
                 v._script_sent = np.ascontiguousarray(v.traj.T).copy()
+            self._scripted.extend(scripted)
         for v in new:
             if v.traj.shape[1] != T and not getattr(v, "uncontrolled", False):
                 raise NotImplementedError("all road users of one intersection share t_s (one engine per intersection)")
@@ -551,8 +552,8 @@ class SocialForceIntersection:
         # UncontrolledVehicle: the reference reads car.traj[:, i] on every step (vehicle.py:964-979), so a trajectory written
         # after the car joined - external control - has to reach the engine: compare with what was sent, send again on a change
         changed = []
-        for v in self.vehicles:
-            if getattr(v, "uncontrolled", False) and v._live and getattr(v, "_script_sent", None) is not None:
+        for v in self._scripted:
+            if v._live and getattr(v, "_script_sent", None) is not None:
                 cur = np.ascontiguousarray(v.traj.T)
                 if cur.shape != v._script_sent.shape or not np.array_equal(cur, v._script_sent):
                     v._script = cur
@@ -584,9 +585,9 @@ class SocialForceIntersection:
                 agents, blocks, off = groups[mode]
                 if agents:
                     e.set_dest_queue(agents, off, np.vstack(blocks), reset=mode)
-        # vehicle.s edited in place (calibration.py:455-460)
-        changed = np.where(np.any(self._S[:n] != self._shadow[:n], axis=1))[0]
-        if changed.size:
+        # vehicle.s edited in place (calibration.py:455-460): looked for once a vehicle.s has been handed out (Vehicle.s)
+        if self._s_watched and (self._S[:n] != self._shadow[:n]).any():
+            changed = np.where(np.any(self._S[:n] != self._shadow[:n], axis=1))[0]
             e.push_state(changed, self._S[changed][:, : e.ns])
             self._shadow[changed] = self._S[changed]
         if self._track_params:
@@ -617,14 +618,23 @@ class SocialForceIntersection:
         ticks first, in the same call (csf_step_get_tick)."""
         e = self._engine
         n = len(self.vehicles)
-        s, ptr, zn, fx, fy, _ = e.step_snapshot(step, forces=forces, reuse=True) if step else e.tick_snapshot(forces=forces)
-        self._S[:n, : s.shape[1]] = s
-        self._shadow[:n, : s.shape[1]] = s
-        self._ptr[:n] = ptr
-        self._zn[:n] = zn
+        if step and self._S.shape[1] == e.ns:
+            # straight into the bulk mirror: the rows of the live road users are one contiguous block of it
+            fx, fy = (self._fx[:n], self._fy[:n]) if forces else (None, None)
+            e.step_into(step, self._S[:n], self._ptr[:n], self._zn[:n], fx, fy)
+            if self._s_watched:
+                self._shadow[:n] = self._S[:n]
+        else:
+            s, ptr, zn, fx, fy, _ = e.step_snapshot(step, forces=forces, reuse=True) if step else e.tick_snapshot(forces=forces)
+            self._S[:n, : s.shape[1]] = s
+            if self._s_watched:
+                self._shadow[:n, : s.shape[1]] = s
+            self._ptr[:n] = ptr
+            self._zn[:n] = zn
+            if forces:
+                self._fx[:n] = fx                                     # intersection.py:860-862
+                self._fy[:n] = fy
         if forces:
-            self._fx[:n] = fx                                         # intersection.py:860-862
-            self._fy[:n] = fy
             self._have_force = True
         if advance:
             if forces:
@@ -645,12 +655,17 @@ class SocialForceIntersection:
                     v.trajF[0, self._ti[k]] = Fx
                     v.trajF[1, self._ti[k]] = Fy
                 v.update_drawing(Fres=(Fx, Fy))
-        self.update_road_user_positions()
+        if self.activate_sumo_cosimulation:
+            self.update_road_user_positions()                         # (SUMO is told every tick; else: when somebody reads them)
+        else:
+            self._pos_stale = True
         return fx, fy
 
     # vehicle.F: the per-tick magnitudes are logged as arrays and folded into a vehicle's list when it is read
     def _log_forces(self, fx, fy):
-        self._flog.append(np.hypot(fx, fy))
+        mag = fx * fx                                                 # (np.hypot is three times the time of this at N = 16 384)
+        mag += fy * fy
+        self._flog.append(np.sqrt(mag, out=mag))
         if len(self._flog) >= 4096:
             self._fold_all_force_logs()
 
@@ -670,16 +685,37 @@ class SocialForceIntersection:
         for v in self.vehicles:
             v._f_seen = self._flog_base
 
+    def _state_handed_out(self):
+        """a vehicle.s view goes to the caller, who may write through it: from now on the mirror is compared with what the
+        device holds (the shadow) before every tick"""
+        if not self._s_watched and self._S is not None:
+            self._shadow[:] = self._S                                 # (nobody has written yet: the getter runs before the write)
+            self._s_watched = True
+
+    # vehicleX / vehicleY / vehicleTheta (intersection.py:660-677) are refreshed when they are read: three column copies of the
+    # mirror per tick are a tenth of the tick's host time at N = 16 384, and most ticks nobody looks
+    def _positions(self):
+        if self._pos_stale:
+            self.update_road_user_positions()
+        return self._vx, self._vy, self._vth
+
+    vehicleX = property(lambda self: self._positions()[0], lambda self, a: setattr(self, "_vx", a))
+    vehicleY = property(lambda self: self._positions()[1], lambda self, a: setattr(self, "_vy", a))
+    vehicleTheta = property(lambda self: self._positions()[2], lambda self, a: setattr(self, "_vth", a))
+
     def update_road_user_positions(self):
         """intersection.py:660-677"""
         n = len(self.vehicles)
+        self._pos_stale = False
+        if self._vx.shape[0] != n:
+            self._vx, self._vy, self._vth = np.zeros((n, 1)), np.zeros((n, 1)), np.zeros((n, 1))
         if n and self._S is not None and not self._pending:
-            self.vehicleX[:, 0] = self._S[:n, 0]
-            self.vehicleY[:, 0] = self._S[:n, 1]
-            self.vehicleTheta[:, 0] = self._S[:n, 2]
+            self._vx[:, 0] = self._S[:n, 0]
+            self._vy[:, 0] = self._S[:n, 1]
+            self._vth[:, 0] = self._S[:n, 2]
         else:
             for k, v in enumerate(self.vehicles):
-                self.vehicleX[k, 0], self.vehicleY[k, 0], self.vehicleTheta[k, 0] = v.s[0], v.s[1], v.s[2]
+                self._vx[k, 0], self._vy[k, 0], self._vth[k, 0] = v._s[0], v._s[1], v._s[2]
         if self.activate_sumo_cosimulation and n:              # intersection.py:679-688: SUMO follows the social-force positions
             move = self._traci.vehicle.moveToXY
             angles = angleSFMtoSUMO(self.vehicleTheta[:, 0])

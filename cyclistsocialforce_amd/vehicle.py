@@ -85,6 +85,26 @@ class Vehicle:
     # Inside a SocialForceIntersection these live in the intersection's bulk arrays (one device read-back per tick
     # refreshes every vehicle at once); on its own the vehicle keeps them itself.
     @property
+    def s(self):
+        """the state vector (vehicle.py:154-156).  Inside an intersection it is a row view of the bulk mirror, and whoever
+        holds it may write through it (calibration.py:455-460 edits vehicle.s in place): the intersection is told, and
+        compares its mirror with what the device holds before the next tick - only from then on, not on every tick of a
+        population nobody looks at"""
+        if self._live:
+            self._owner._state_handed_out()
+        return self._s
+
+    @s.setter
+    def s(self, value):
+        if self._live:                                                 # rebinding vehicle.s: the mirror's row takes the values
+            row = self._s
+            if value is not row:
+                self._owner._state_handed_out()
+                row[:] = np.asarray(value, dtype=float)[: row.size]
+        else:
+            self._s = value
+
+    @property
     def i(self):
         """column of `traj` written last (vehicle.py:146, 1279-1282)"""
         return int(self._owner._ti[self._index]) if self._live else self._i
@@ -203,7 +223,7 @@ class Vehicle:
         y = np.atleast_1d(np.asarray(y, dtype=float)).ravel()
         psi = np.atleast_1d(np.asarray(psi, dtype=float)).ravel() if psi is not None else np.zeros_like(x)
         eng = self._owner._engine_ready() if self._owner is not None else self._solo_engine()
-        return eng.pair_force(np.r_[self.s[:3], self.s[3]], x, y, psi)
+        return eng.pair_force(np.r_[self._s[:3], self._s[3]], x, y, psi)
 
     def calcDestinationForce(self):
         """vehicle.py:281-299, 1189-1194, 1416-1558 (advances the destination queue / nav state)."""
@@ -254,7 +274,7 @@ class Vehicle:
     def getDestinationDistance(self):
         """vehicle.py:596-604"""
         dest = self.destqueue[self.destpointer, :]
-        return np.sqrt(np.power(dest[0] - self.s[0], 2) + np.power(dest[1] - self.s[1], 2))
+        return np.sqrt(np.power(dest[0] - self._s[0], 2) + np.power(dest[1] - self._s[1], 2))
 
     def isLastDest(self):
         """vehicle.py:537-543"""
@@ -321,8 +341,8 @@ class Vehicle:
         from scipy import interpolate
 
         assert len(x) >= 3, "Provide at least 3 points to calculate a cubic trajectory prototype"
-        x = np.insert(np.array(x, dtype=float), 0, self.s[0])
-        y = np.insert(np.array(y, dtype=float), 0, self.s[1])
+        x = np.insert(np.array(x, dtype=float), 0, self._s[0])
+        y = np.insert(np.array(y, dtype=float), 0, self._s[1])
         tck, _ = interpolate.splprep((x, y), s=0.0)
         x_i, y_i = interpolate.splev(np.linspace(0, 1, npoints), tck)
         if stop:

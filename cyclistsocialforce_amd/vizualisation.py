@@ -23,7 +23,7 @@ class VehicleDrawing:
         self.ax = ax
         self.force_scale = force_scale
         color = color or ax._get_lines.get_next_color()
-        self.body = Polygon(self._outline(vehicle.s), closed=True, facecolor=color, edgecolor="black", linewidth=0.5,
+        self.body = Polygon(self._outline(vehicle._s), closed=True, facecolor=color, edgecolor="black", linewidth=0.5,
                             animated=animated, zorder=3)
         ax.add_patch(self.body)
         self.trajectory = self.destinations = self.force = None
@@ -51,7 +51,7 @@ class VehicleDrawing:
 
     def update(self, vehicle, Fdest=None, Frep=None, Fres=None):
         """the hook of vehicle.py:722-732"""
-        s = vehicle.s
+        s = vehicle._s
         self.body.set_xy(self._outline(s))
         if self.trajectory is not None:
             i = int(vehicle.i)

@@ -120,6 +120,42 @@ def test_mutation_between_ticks_and_population_changes(golden):
     assert not np.array_equal(before, lone.s) and np.isfinite(lone.s).all()
 
 
+def test_vehicle_state_written_through_a_view_a_rebinding_or_an_old_reference(golden):
+    """vehicle.s inside an intersection is a row of the bulk mirror.  The intersection compares the mirror with the device's
+    state only once a vehicle.s has been handed out (Vehicle.s); from then on every way the reference object can be edited
+    reaches the engine before the next tick: a write through the view (calibration.py:455-460), a rebinding
+    (`vehicle.s = array`), and a write through a reference taken many ticks ago."""
+    rng = np.random.default_rng(8)
+    vs = []
+    for k in range(40):
+        x, y, psi = rng.uniform(0, 40), rng.uniform(0, 40), rng.uniform(-np.pi, np.pi)
+        v = TwoDBicycle((x, y, psi, 4.0, 0.0), id=f"v{k}")
+        v.setDestinations(x + np.array([30, 60, 90]) * np.cos(psi), y + np.array([30, 60, 90]) * np.sin(psi))
+        vs.append(v)
+    ins = SocialForceIntersection(vs)
+    for _ in range(3):
+        ins.step()
+    assert not ins._s_watched                                  # nobody has looked: no compare, no shadow copy per tick
+    old_ref = vs[7].s                                          # handed out now ...
+    assert ins._s_watched
+    for _ in range(3):
+        ins.step()
+    x_before = float(ins.vehicleX[7, 0])
+    old_ref[0] += 5.0                                          # ... written three ticks later
+    vs[8].s = np.array([1.0, 2.0, 0.5, 3.0, 0.0])              # rebinding
+    vs[9].s[1] -= 4.0                                          # through a fresh view
+    y9 = float(vs[9].s[1])
+    ins.step()
+    e = ins.engine
+    dev = e.state()
+    assert abs(dev[7, 0] - (x_before + 5.0)) < 0.1             # (+ one tick of motion)
+    assert np.hypot(dev[8, 0] - 1.0, dev[8, 1] - 2.0) < 0.1 and vs[8].s is not None and vs[8]._s.base is not None
+    assert abs(dev[9, 1] - y9) < 0.1
+    np.testing.assert_array_equal(dev, np.array([v.s for v in ins.vehicles]))      # mirror == device after the pull
+    np.testing.assert_array_equal(ins.vehicleX[:, 0], dev[:, 0])                   # refreshed when read
+    np.testing.assert_array_equal(ins.vehicleTheta[:, 0], dev[:, 2])
+
+
 def test_vehicle_hooks_against_golden(golden):
     """calcRepulsiveForce / calcDestinationForce / step on single vehicles (vehicle.py:250-328)."""
     g = golden("pair_fields")
