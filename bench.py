@@ -130,6 +130,11 @@ def cpu_baseline(n, box, ticks):
     return {
         "value": n * ticks / dt, "unit": "agent-steps/s", "cores": orc.num_threads(), "kind": "port",
         "sample": f"{ticks} ticks of the same N={n} population, oracle/csf_oracle.c (fp64, OpenMP), {dt:.1f} s",
+        # the literal reference itself, which cannot run this N (memory ~ N^4; NaN beyond 101.6 m) - the
+        # figures of BASELINE.md §2, measured in the survey container, not on this box (the reference never travels here)
+        "literal_reference": {"kind": "literal-reference, survey container, 1 core (BASELINE.md §2; not measured in this run)",
+                              "unit": "agent-steps/s", "twod_random": {"4": 1.3e3, "16": 1.0e3, "32": 5.7e2, "64": 57, "128": 2},
+                              "demo_3_twod_700_ticks": 3.1e3},
     }
 
 
@@ -328,7 +333,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{n} {args.model} agents, uniform random in {box:g} m x {box:g} m, "
-                                   f"all pairs, t_s=0.01" + (", curve-scenario road tiled on a 100 m grid" if road else ""),
+                                   + ("every tracked pair evaluated" if not np.isfinite(rfar) else "all pairs within the 2^-24 far-field bound (every_pair: the literal sum)")
+                                   + ", t_s=0.01" + (", curve-scenario road tiled on a 100 m grid" if road else ""),
                        "agents": n, "rider_model": args.model, "far_field": far_note,
                        "road_vertices": 0 if road is None else int(road[1].shape[0]),
                        "parallelism": f"index-sharded x{world}, RCCL all-gather of fp32 records per tick"
