@@ -180,7 +180,13 @@ __global__ __launch_bounds__(256) void tile_circle_kernel(const Dev d, float4 *t
 
 // one wave per group of clist_rpb receivers (places of the binned order; a rank's own receivers through rlist): the tiles
 // whose circle comes within `reach` of the group's circle, in ascending order
-__global__ __launch_bounds__(256) void clist_kernel(const Dev d, const float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach) {
+// far (optional, [2]): the largest number of sources any group can meet - the places of its listed tiles and of the tiles that
+// are always visited - and the largest sum, over the tiles a group does NOT list, of (places) x exp(-kappa x separation),
+// separation = the distance left between the two circles after `move` metres of motion on both sides: what those tiles can add
+// to a receiver of the group in units of f_0, whatever happens until the next re-binning (csf_engine.hip: tighten_far_bound).
+// Both as atomic maxima over the groups (the sum as the bits of a non-negative float).
+__global__ __launch_bounds__(256) void clist_kernel(const Dev d, const float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach,
+                                                    unsigned *far, float kappa, float move) {
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nloc = d.hi - d.lo, groups = (nloc + d.clist_rpb - 1) / d.clist_rpb;
     if (g >= groups) return;
@@ -201,13 +207,17 @@ __global__ __launch_bounds__(256) void clist_kernel(const Dev d, const float4 *t
     const float4 gc = box_circle(x0, x1, y0, y1, 0.0f);
     const int64_t ntiles = (int64_t)d.ctail;                         // (tiles from ctail on are always visited)
     int count = 0;
+    float tail = 0.0f;
     for (int64_t t0 = 0; t0 < ntiles; t0 += 64) {
         const int64_t t = t0 + lane;
         bool near = false;
         if (t < ntiles) {
             const float4 tc = tcirc[t];
             const float ex = tc.x - gc.x, ey = tc.y - gc.y, rr = reach + tc.z + gc.z;
-            near = ex * ex + ey * ey <= rr * rr;
+            const float d2 = ex * ex + ey * ey;
+            near = d2 <= rr * rr;
+            if (!near && far != nullptr && fabsf(tc.x) < 1e14f)     // (a tile of nothing but sentinels adds nothing)
+                tail += (float)d.clist_tile * __expf(-kappa * fmaxf(sqrtf(d2) * 0.9999f - tc.z - gc.z - move, 0.0f));
         }
         const unsigned long long m = __ballot(near);
         if (near) {
@@ -217,14 +227,25 @@ __global__ __launch_bounds__(256) void clist_kernel(const Dev d, const float4 *t
         count += __builtin_popcountll(m);
     }
     if (lane == 0) ccount[g] = count <= CLIST_MAX ? count : -1;
+    if (far != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tail += __shfl_xor(tail, o, 64);
+        if (lane == 0) {
+            const int64_t all = (d.n_src + d.clist_tile - 1) / d.clist_tile;
+            const int64_t met = count <= CLIST_MAX ? (int64_t)count + (all - ntiles) : all;   // (no list: the group walks every tile)
+            atomicMax(&far[0], (unsigned)min(met * d.clist_tile, (int64_t)0x7fffffff));
+            atomicMax(&far[1], __float_as_uint(count <= CLIST_MAX ? tail * 1.001f : 0.0f));
+        }
+    }
 }
 
-void launch_candidate_lists(const Dev &d, float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach, hipStream_t st) {
+void launch_candidate_lists(const Dev &d, float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach, hipStream_t st, unsigned *far, float kappa,
+                            float move) {
     const int64_t ntiles = (d.n_src + d.clist_tile - 1) / d.clist_tile;
     const int64_t nloc = d.hi - d.lo, groups = (nloc + d.clist_rpb - 1) / d.clist_rpb;
     if (ntiles <= 0 || groups <= 0) return;
     hipLaunchKernelGGL(tile_circle_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d, tcirc);
-    hipLaunchKernelGGL(clist_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st, d, tcirc, clist, ccount, reach);
+    hipLaunchKernelGGL(clist_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, st, d, tcirc, clist, ccount, reach, far, kappa, move);
 }
 
 size_t bin_temp_bytes(int64_t n_pad) {

@@ -289,7 +289,10 @@ void launch_rebase(const Dev &d, hipStream_t st);
 void launch_bounds(const Dev &d, hipStream_t st);
 // candidate tiles of every receiver group (Dev::clist): tile circles into tcirc [n_pad / tile], then the lists
 constexpr int CLIST_MAX = 128;
-void launch_candidate_lists(const Dev &d, float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach, hipStream_t st);
+// far (may be NULL): [2] zeroed words that receive the groups' maxima of (sources a group can meet, what the tiles it does not list
+// can add at most, in units of f_0, as float bits) for the decay rate kappa and `move` metres of motion on either side
+void launch_candidate_lists(const Dev &d, float4 *tcirc, uint16_t *clist, int32_t *ccount, float reach, hipStream_t st,
+                            unsigned *far = nullptr, float kappa = 0.0f, float move = 0.0f);
 // binned positions of the receivers [lo, hi) of this rank in ascending order (the rank's receivers as neighbours in space)
 int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void *tmp, size_t tmp_bytes, hipStream_t st);
 

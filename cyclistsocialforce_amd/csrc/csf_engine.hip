@@ -107,6 +107,7 @@ struct Knobs {
     int fused_small = 1;                      // CSF_FUSED_SMALL=0: a handful of road users take the general path too (csf_agent.hip: small_tick_kernel)
     int segments = -1;                        // CSF_SEGMENTS
     int seg_grid = 1;                         // CSF_SEG_GRID=0: one launch per parameter set (class-segmented order) instead of one grid
+    int far_tight = 1;                        // CSF_FAR_TIGHT=0: the far-field radius prices all n sources at the cut (ln(n / eps) / kappa) also where candidate lists say how many a receiver can meet
     int clist = 1;                            // CSF_CLIST=0: receivers in binned order walk every tile of their chunk (no candidate lists)
     int recv_binned = -1;                     // CSF_RECV_BINNED
     int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
@@ -142,6 +143,7 @@ struct Knobs {
         segments = geti("CSF_SEGMENTS", -1);
         recv_binned = geti("CSF_RECV_BINNED", -1);
         clist = geti("CSF_CLIST", 1);
+        far_tight = geti("CSF_FAR_TIGHT", 1);
         seg_grid = geti("CSF_SEG_GRID", 1);
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
@@ -287,6 +289,8 @@ struct csf_engine {
     DevBuf<float4> tcirc;
     DevBuf<uint16_t> clist;
     DevBuf<int32_t> ccount;
+    DevBuf<unsigned> far_stat;   // [2] what launch_candidate_lists found for the far-field bound (tighten_far_bound)
+    double far_met = 0.0, far_tail = 0.0, far_T = 0.0;   // ... and what became of it: sources met, tail (x f_0), T in use (0: the plain bound)
     DevBuf<float2> rorg;         // the origin every precise record is relative to, by slot
     DevBuf<float2> reclo;        // what the record's position left over in fp32 (csf_dev.h); all-gathered with the records
     bool state_all_current = true;   // every live slot's fp64 state on this device is current (false once a rank has ticked)
@@ -458,7 +462,20 @@ void set_far_consts(const Knobs &kn, const csf_params &p, double kappa, int64_t 
     }
 }
 
+// set_far_consts with ln(n / eps) replaced by T
+static void set_far_consts_T(const csf_params &p, double kappa, double T, PairConsts &k) {
+    k.rfar = (float)(T / kappa);
+    if (k.reach) {
+        const double Tm = T * 1.002;
+        k.tA0 = (float)(Tm * (p.sigma_0 - 0.5 * p.sigma_2));
+        k.tA1 = (float)(Tm * (p.sigma_1 - 0.5 * p.sigma_3));
+        k.tB0 = (float)(Tm * 0.5 * p.sigma_2);
+        k.tB1 = (float)(Tm * 0.5 * p.sigma_3);
+    }
+}
+
 void update_far_radius(csf_engine *e) {   // depends on the parameters and on the population size
+    e->far_T = 0.0;
     PairConsts &k = e->d.pc;
     if (e->classes.size() > 1) {          // several parameter sets: the plain kernel, or one launch per set with its own
         k.rfar = INFINITY;                // constants (Segment::pc)
@@ -1171,10 +1188,41 @@ int rebin(csf_engine *e) {
             // (where arrivals appear) are always visited
             d.ctail = (int32_t)(e->tail_tracked ? d.n_live / d.clist_tile : ntiles);
             // both sides move until the lists are rebuilt (REBIN_TICKS ticks; a churn-triggered re-binning comes sooner)
-            const float reach = d.pc.rfar + 2.0f * (float)(e->knobs.rebin_ticks + 2) * d.bnd_margin + 1e-2f;
-            launch_candidate_lists(d, e->tcirc.p, e->clist.p, e->ccount.p, reach, e->main);
+            const float move = (float)(e->knobs.rebin_ticks + 2) * d.bnd_margin + 5e-3f;   // what either side can move until then
+            const float reach = d.pc.rfar + 2.0f * move;
+            // The far-field bound from the tiles within reach (large populations): R = ln(n / eps) / kappa prices every one of
+            // the n sources at the cut - a million road users pay for a radius that holds a few ten thousand.  With the lists
+            // in hand: a receiver meets at most m sources (the places of its group's listed tiles and of the tiles always
+            // visited), and every source of a tile it does not list is at least the circles' separation away and adds at
+            // most f_0 exp(-kappa separation) - `tail` in all.  Leaving out the pairs with rho q / sigma > T among the m
+            // omits at most m exp(-T) f_0 more: T = ln(m / (eps - tail)) keeps the total below eps f_0, the same promise
+            // (include/csf.h: csf_far_radius) at a smaller radius.  m and tail are maxima over the groups of this device,
+            // measured at every re-binning; one read-back of two words, where a tick takes milliseconds.
+            const bool tighten = e->knobs.far_tight != 0 && d.pc.reach && e->classes.size() == 1 && e->far_kappa > 0;
+            if (tighten) {
+                HIPCHK(e, e->far_stat.reserve(2));
+                HIPCHK(e, hipMemsetAsync(e->far_stat.p, 0, 2 * sizeof(unsigned), e->main));
+            }
+            launch_candidate_lists(d, e->tcirc.p, e->clist.p, e->ccount.p, reach, e->main, tighten ? e->far_stat.p : nullptr, (float)e->far_kappa, move);
             d.clist = e->clist.p;
             d.ccount = e->ccount.p;
+            if (tighten) {
+                unsigned st[2] = {0u, 0u};
+                HIPCHK(e, hipMemcpyAsync(st, e->far_stat.p, sizeof st, hipMemcpyDeviceToHost, e->main));
+                HIPCHK(e, hipStreamSynchronize(e->main));
+                float tail;
+                std::memcpy(&tail, &st[1], sizeof tail);
+                const double eps = e->knobs.far_eps, met = std::min<double>((double)st[0], (double)d.n) + (double)TAIL_SLOTS;   // (+ arrivals until then)
+                e->far_met = met;
+                e->far_tail = tail;
+                if (st[0] > 0 && std::isfinite(tail) && tail < 0.5 * eps) {
+                    const double T = std::log(met / (eps - (double)tail)), T0 = std::log((double)d.n / eps);
+                    if (T < T0) {                                    // (the lists were built for the larger radius: still complete)
+                        set_far_consts_T(d.p, e->far_kappa, T, d.pc);
+                        e->far_T = T;
+                    }
+                }
+            }
         }
     }
     // set_fov_band bounds the coordinates by "where they were at the last upload + a speed clamp's worth per step since": over
@@ -1811,7 +1859,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->segtab.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->segtab.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->far_stat.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -3147,6 +3195,8 @@ int csf_far_radius(const csf_engine *e, double *radius_m) {
     const bool binned = e->d.pair_variant == 0 && e->d.p.model != CSF_BICYCLE && e->d.n >= BIN_MIN_AGENTS;
     // (computed here rather than read back: the kernel's copy is refreshed with the next upload of the population)
     *radius_m = binned ? (double)(float)far_radius(e->far_kappa, e->d.n, e->knobs.far_eps) : (double)INFINITY;  // no circles, no cull
+    // (large populations: the radius in use since the last re-binning, from the sources a receiver can meet - rebin)
+    if (binned && e->far_T > 0.0 && e->far_kappa > 0.0) *radius_m = (double)(float)(e->far_T / e->far_kappa);
     return CSF_OK;
 }
 

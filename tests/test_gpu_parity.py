@@ -425,12 +425,16 @@ def test_field_of_view_variants_vs_oracle(amd, monkeypatch, hfov, rule, rpb):
     assert err < 5e-5
 
 
-@pytest.mark.parametrize("n,box", [(4096, 500.0), (16384, 200.0)])
-def test_far_field_cull_bound(amd, monkeypatch, n, box):
+@pytest.mark.parametrize("n,box,binr", [(4096, 500.0, None), (16384, 200.0, None), (8192, 700.0, "1"), (65536, 400.0, None), (65536, 1600.0, None)])
+def test_far_field_cull_bound(amd, monkeypatch, n, box, binr):
     """Batches beyond the far-field radius are skipped (include/csf.h: csf_far_radius) and, inside it, the per-pair reach
     test drops every pair whose contribution is provably below eps * f_0 / n (csf_engine.hip: update_far_radius; at
     N = 16 384 in 200 m: four of five pairs inside the field of view).  What is left out of a receiver's column sum must
-    stay below eps * f_0; with eps = 0 every pair is evaluated."""
+    stay below eps * f_0; with eps = 0 every pair is evaluated.  With receivers in binned order and candidate tile lists (65 536
+    slots and more - the headline's density, and a sparse scene; 8 192 in 700 m by request) the radius comes from the sources
+    a receiver can meet instead of from all n (csf_engine.hip: rebin): smaller, the same promise."""
+    if binr is not None:
+        monkeypatch.setenv("CSF_RECV_BINNED", binr)
     x, y, psi, v, off, dq = synthetic_population(n, box)
     s0 = np.c_[x, y, psi, v, np.zeros(n)]
     f0 = amd.pod("twod").f_0
@@ -450,9 +454,31 @@ def test_far_field_cull_bound(amd, monkeypatch, n, box):
     assert np.isinf(r0)
     r1, x1, y1 = rep(None)                                    # default: eps = 2^-24
     assert 100.0 < r1 < box * 2 ** 0.5                        # the cull is active in this scene
+    r_plain = np.log(n * 2.0 ** 24) / (np.log(16384 * 2.0 ** 24) / 154.7)    # ln(n / eps) / kappa (kappa from the headline's 154.7 m)
+    if n >= 65536 or binr == "1":
+        monkeypatch.setenv("CSF_FAR_TIGHT", "0")
+        r1p, x1p, y1p = rep(None)
+        monkeypatch.delenv("CSF_FAR_TIGHT")
+        print(f"far radius from the sources within reach {r1:.1f} m, from all n {r1p:.1f} m")
+        # (a receiver of 8 192 in 700 m, or of the dense 400 m scene, can meet most of the population: nothing to gain there)
+        assert abs(r1p - r_plain) < 1.0 and (r1 < r1p - 4.0 if (n >= 65536 and box > 500.0) else r1 <= r1p + 1e-3)
+    else:
+        assert abs(r1 - r_plain) < 1.0
     scale = np.hypot(x0, y0).max()
     bound = 2.0 ** -24 * f0 + 8 * np.finfo(np.float32).eps * scale
+    if n >= 65536 or binr == "1":
+        # the engine without the cull takes its receivers in slot order (scene coordinates), the others in binned order
+        # (coordinates relative to their group): another arithmetic - both against the fp64 oracle on a sample of receivers,
+        # 1e-4 of the largest sum; the two radii share their arithmetic: the bound itself, for every receiver
+        recv = np.arange(0, n, max(1, n // 400))
+        ox, oy = orc.column_sums(orc.default_params("twod"), x, y, psi, v, recv)
+        assert max(np.abs(x1p[recv] - ox).max(), np.abs(y1p[recv] - oy).max()) <= 1e-4 * scale
+        assert max(np.abs(x1[recv] - ox).max(), np.abs(y1[recv] - oy).max()) <= 1e-4 * scale
+        assert np.abs(x1 - x1p).max() <= bound and np.abs(y1 - y1p).max() <= bound
+        x0, y0 = x1p, y1p
     assert np.abs(x1 - x0).max() <= bound and np.abs(y1 - y0).max() <= bound
+    if n >= 65536:
+        return
     r2, x2, y2 = rep(1e-3)                                    # a coarse eps: visibly different, still bounded
     assert r2 < r1
     d2 = np.hypot(x2 - x0, y2 - y0).max()
