@@ -186,6 +186,10 @@ __global__ void records_kernel(const Dev d) {
         d.rec[a] = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
         if (a < d.cap) d.recg[a] = d.rec[a];
         if (d.has_bike) d.rec2[a] = make_float2(0.0f, 1.0f);
+        if (d.xbuf != nullptr) {
+            d.xbuf[2 * a] = d.rec[a];
+            d.xbuf[2 * a + 1] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        }
         return;
     }
     write_record(d, d.ptab[d.cls[a]], a, d.rorg[a], d.s[a], d.s[d.cap + a], d.s[2 * d.cap + a], d.s[3 * d.cap + a]);

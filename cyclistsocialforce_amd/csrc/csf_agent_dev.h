@@ -757,7 +757,11 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     const double px = (x - d.ox) - (double)o.x, py = (y - d.oy) - (double)o.y;
     const float4 q = make_float4((float)px, (float)py, (float)c, (float)s);
     d.rec_w[a] = q;
-    if (d.keep_lo) d.reclo[a] = make_float2((float)(px - (double)q.x), (float)(py - (double)q.y));   // (what fp32 left over: csf_dev.h reclo)
+    float2 lo = make_float2(0.f, 0.f);
+    if (d.keep_lo) {
+        lo = make_float2((float)(px - (double)q.x), (float)(py - (double)q.y));   // (what fp32 left over: csf_dev.h reclo)
+        d.reclo[a] = lo;
+    }
     // scene coordinates = offset + origin, in fp32 (the same sum a rank forms from the records it has gathered, so that
     // every path sees the same numbers): by slot (the receivers), and the copy in binned order (csf_bin.hip) that the
     // pair kernel's tiles are filled with
@@ -771,12 +775,17 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
             d.recb[p] = make_float4(q.x + (o.x - bo.x), q.y + (o.y - bo.y), q.z, q.w);
         }
     }
+    float2 q2 = make_float2(0.0f, 1.0f);
     if (d.has_bike) {                                         // vehicle.py:1062-1064 (v <= 0: e := 0); other classes: unused
         double e = 0.0;
         if (p.model == CSF_BICYCLE && v > 0.0) e = fmin(pow(v / p.v_max_riding[1], 0.1), 0.7);
-        const float2 q2 = make_float2((float)e, (float)qrsqrt(1.0 - e * e));
+        q2 = make_float2((float)e, (float)qrsqrt(1.0 - e * e));
         d.rec2_w[a] = q2;
         if (d.recs_valid) d.recs2[d.pos[a]] = q2;
+    }
+    if (d.xbuf != nullptr) {                                  // the entry that travels to the other ranks (csf_dev.h: xbuf)
+        d.xbuf[2 * a] = q;
+        d.xbuf[2 * a + 1] = make_float4(lo.x, lo.y, q2.x, q2.y);
     }
 }
 

@@ -67,12 +67,28 @@ __global__ void identity_perm_kernel(const Dev d) {
     if (a < d.n_pad) d.perm[a] = (int32_t)a;
 }
 
+// the exchange record of a slot of another rank's block -> rec / reclo / rec2 (csf_dev.h: xbuf); returns the record
+__device__ __forceinline__ float4 unpack_exchange(const Dev &d, int32_t a) {
+    const float4 q = d.xbuf[2 * (int64_t)a], w = d.xbuf[2 * (int64_t)a + 1];
+    d.rec[a] = q;
+    d.reclo[a] = make_float2(w.x, w.y);
+    if (d.has_bike) d.rec2[a] = make_float2(w.z, w.w);
+    return q;
+}
+
+__global__ void unpack_exchange_kernel(const Dev d) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < d.n_pad && (a < d.lo || a >= d.hi)) (void)unpack_exchange(d, (int32_t)a);
+}
+
+template <bool UNPACK>
 __global__ void sorted_copy_kernel(const Dev d) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n_pad) return;
     const int32_t a = d.perm[p];
     if (a < d.n_pad) d.pos[a] = (int32_t)p;
-    float4 q = d.rec[a];
+    // (the padding slot of the class-segmented order sits in many places at once: it is unpacked as often, to the same effect)
+    float4 q = (UNPACK && a < d.n_pad && (a < d.lo || a >= d.hi)) ? unpack_exchange(d, a) : d.rec[a];
     if (rec_is_real(q)) {                                     // scene coordinates: offset + the slot's origin
         const float2 o = d.rorg[a];
         const float2 bo = d.borg[p >> 6];                     // (the batches keep their origins between re-binnings)
@@ -299,9 +315,15 @@ void launch_identity_perm(const Dev &d, hipStream_t st) {
     hipLaunchKernelGGL(identity_perm_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
 }
 
-void launch_sorted_copy(const Dev &d, hipStream_t st) {
+void launch_sorted_copy(const Dev &d, hipStream_t st, bool from_exchange) {
     if (d.n_pad <= 0) return;
-    hipLaunchKernelGGL(sorted_copy_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+    if (from_exchange && d.xbuf != nullptr) hipLaunchKernelGGL(sorted_copy_kernel<true>, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(sorted_copy_kernel<false>, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
+}
+
+void launch_unpack_exchange(const Dev &d, hipStream_t st) {
+    if (d.n_pad <= 0 || d.xbuf == nullptr) return;
+    hipLaunchKernelGGL(unpack_exchange_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
 }
 
 void launch_rebase(const Dev &d, hipStream_t st) {

@@ -156,6 +156,12 @@ struct Dev {
     float2 *reclo;     // [n_pad] by slot: what the record's position left over, (offset - fp32(offset)) in fp32: origin +
                        // record + this is the fp64 position to ~1e-14 m.  Exchanged with the records, so that a rank can
                        // hand a foreign source's position to the exact field-of-view decision (csf_field.h: edge_handover)
+    // A rank of a sharded run (or a member of a loopback group): what travels is ONE array of exchange records, 32 bytes per
+    // slot - (record) and (low part, second record) -, so that a tick is one collective on one contiguous block per rank
+    // instead of a group of two or three.  The per-agent kernel writes its road user's entry beside the arrays above
+    // (write_record); what arrives for the other ranks' blocks is spread to rec / reclo / rec2 by the copy into binned order
+    // that a rank runs anyway (csf_bin.hip: sorted_copy_kernel), or by a launch of its own where that does not run.
+    float4 *xbuf;      // [n_pad][2], NULL on an unsharded engine
     // Large populations (recv_binned; csf_pair.hip BINR works relative to the origin of its receiver group): the record by
     // place of the binned order, its position relative to the origin of its BATCH of 64 places - the own origin of the
     // batch's first road user at the last re-binning - formed as offset + (own origin - batch origin), the bracket exact:
@@ -282,7 +288,10 @@ void launch_segment_perm(const Dev &d, const int32_t *sorted_slots, const SegTab
 int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,
                  hipStream_t st);
 void launch_identity_perm(const Dev &d, hipStream_t st);
-void launch_sorted_copy(const Dev &d, hipStream_t st);  // pos[] and recs[] from perm[] and rec[]
+// pos[] and recs[] from perm[] and rec[]; from_exchange: the records of the other ranks' blocks are taken from the exchange
+// records that have just arrived (Dev::xbuf) and written to rec / reclo / rec2 on the way
+void launch_sorted_copy(const Dev &d, hipStream_t st, bool from_exchange = false);
+void launch_unpack_exchange(const Dev &d, hipStream_t st);   // ... that alone
 // after a re-sort: every record re-expressed relative to its new origin (from the fp64 state where
 // d.rebase_from_state), pos[] / recs[] and the bounding circles - one launch
 void launch_rebase(const Dev &d, hipStream_t st);

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -187,6 +188,17 @@ struct csf_engine {
     int64_t cap = 0;        // slots: the caller's capacity + head room for arrivals between two re-binnings (csf_create)
     int64_t cap_user = 0;   // road users the caller may have at once
     hipStream_t main = nullptr, comm = nullptr;
+    // The members of a loopback group share ONE main stream (ticks and exchanges in order).  It belongs to all of them: the
+    // handle lives as long as any member does, whichever is destroyed first (until round 5 it was the first member's, the
+    // others were told when that one went - unless another member had gone before and cleared the lists through which they
+    // would have been told: a dangling handle, which hipStreamSynchronize happened to tolerate and hipStreamQuery did not)
+    struct StreamHold {
+        hipStream_t s = nullptr;
+        ~StreamHold() {
+            if (s) (void)hipStreamDestroy(s);
+        }
+    };
+    std::shared_ptr<StreamHold> main_hold;
     hipEvent_t ev_integ = nullptr, ev_gather = nullptr;
     std::string err;
 
@@ -292,7 +304,9 @@ struct csf_engine {
     DevBuf<unsigned> far_stat;   // [2] what launch_candidate_lists found for the far-field bound (tighten_far_bound)
     double far_met = 0.0, far_tail = 0.0, far_T = 0.0;   // ... and what became of it: sources met, tail (x f_0), T in use (0: the plain bound)
     DevBuf<float2> rorg;         // the origin every precise record is relative to, by slot
-    DevBuf<float2> reclo;        // what the record's position left over in fp32 (csf_dev.h); all-gathered with the records
+    DevBuf<float2> reclo;        // what the record's position left over in fp32 (csf_dev.h); travels with the records
+    DevBuf<float4> xbuf;         // the exchange records of a sharded run (csf_dev.h: xbuf), allocated with the shard layout
+    bool xbuf_fresh = false;     // other ranks' exchange records have arrived and are not yet spread to rec / reclo / rec2
     bool state_all_current = true;   // every live slot's fp64 state on this device is current (false once a rank has ticked)
     // Field-of-view decisions within fp32 rounding of an edge (csf_dev.h: PairConsts::fovA, EdgeRec; set_fov_band): the
     // largest |coordinate| relative to the scene origin at the last upload (road users, prescribed trajectories, arrivals
@@ -330,7 +344,6 @@ struct csf_engine {
     // their record blocks with device-to-device copies where the ranks of a real run call ncclAllGather
     std::vector<csf_engine *> group;
     bool loopback = false;
-    bool owns_main = true;
 
     // profiling: a fixed pool of event slots, recycled in order (the oldest slot is resolved into the running sums
     // before it is reused, so stepping with profiling left on holds a bounded number of events)
@@ -944,6 +957,12 @@ void set_chunks(csf_engine *e);
 void set_shard(csf_engine *e) {
     Dev &d = e->d;
     d.keep_lo = (e->world > 1 || e->loopback || e->nccl != nullptr) ? 1 : 0;   // (csf_dev.h: reclo)
+    d.xbuf = nullptr;
+    if (d.keep_lo) {
+        // (set_shard has no error path: a failed allocation leaves the pointer NULL, and the exchange itself reports it)
+        if (e->xbuf.n < 2 * e->rec.n && e->xbuf.alloc(2 * e->rec.n) != hipSuccess) e->xbuf.release();
+        d.xbuf = e->xbuf.p;
+    }
     if (e->world <= 1) {
         d.lo = 0;
         d.hi = d.n;
@@ -1245,7 +1264,15 @@ int bounds_before_pair(csf_engine *e) {
     // sqrt(2 * 35 * 64 / (1.3 r)) ticks, i.e. re-bin when ticks x arrivals since the last one reaches ~3500; 3000 to 6000
     // measured alike (profiles/r2_churn_rate.txt; CSF_REBIN_CHURN overrides the constant).
     const int64_t churn_k = e->knobs.rebin_churn;
-    if (e->ticks_since_rebin + e->moved_unbinned >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= churn_k) {
+    const bool rebin_now = e->ticks_since_rebin + e->moved_unbinned >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= churn_k;
+    // Exchange records that arrived behind the last tick (a rank of a sharded run): spread to rec / reclo / rec2 by the copy into
+    // binned order that follows the circles - unless this call re-bins (the re-binning reads the records) or no such copy will
+    // run (records not binned; the first tick of a binned order, whose copy the re-binning made itself)
+    if (e->xbuf_fresh && (rebin_now || !d.recs_valid || e->ticks_since_rebin < 1)) {
+        launch_unpack_exchange(d, e->main);
+        e->xbuf_fresh = false;
+    }
+    if (rebin_now) {
         int rc = rebin(e);
         if (rc) return rc;
     }
@@ -1705,13 +1732,11 @@ int all_gather_records(csf_engine *e) {
     const bool second = comm_second_stream(e);
     hipStream_t cs = second ? e->comm : e->main;
     if (second) HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
-    // one group: the records (16 B), what their positions left over in fp32 (8 B: csf_dev.h reclo) and, for the Bicycle
-    // field, the second record (8 B)
-    NCCLCHK(e, g_rccl.GroupStart());
-    NCCLCHK(e, g_rccl.AllGather(d.rec + (size_t)e->rank * shard, d.rec, shard * 4, ncclFloat32, e->nccl, cs));
-    NCCLCHK(e, g_rccl.AllGather(d.reclo + (size_t)e->rank * shard, d.reclo, shard * 2, ncclFloat32, e->nccl, cs));
-    if (d.has_bike) NCCLCHK(e, g_rccl.AllGather(d.rec2 + (size_t)e->rank * shard, d.rec2, shard * 2, ncclFloat32, e->nccl, cs));
-    NCCLCHK(e, g_rccl.GroupEnd());
+    // ONE collective on the exchange records (csf_dev.h: xbuf; 32 B per slot: the record, what its position left over in
+    // fp32, the Bicycle field's second record) - until round 5 a group of two or three all-gathers on rec / reclo / rec2
+    if (d.xbuf == nullptr) return fail(e, CSF_E_DEVICE, "no exchange buffer (allocation failed when the shard layout was set)");
+    NCCLCHK(e, g_rccl.AllGather(d.xbuf + 2 * (size_t)e->rank * shard, d.xbuf, shard * 8, ncclFloat32, e->nccl, cs));
+    e->xbuf_fresh = true;
     if (second) {
         HIPCHK(e, hipEventRecord(e->ev_gather, e->comm));
         e->gather_pending = true;
@@ -1815,6 +1840,8 @@ csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t dev
         return (csf_engine *)nullptr;
     };
     if (hipStreamCreateWithFlags(&e->main, hipStreamNonBlocking) != hipSuccess) return bail("stream");
+    e->main_hold = std::make_shared<csf_engine::StreamHold>();
+    e->main_hold->s = e->main;
     if (hipStreamCreateWithFlags(&e->comm, hipStreamNonBlocking) != hipSuccess) return bail("stream");
     if (hipEventCreateWithFlags(&e->ev_integ, hipEventDisableTiming) != hipSuccess) return bail("event");
     if (hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming) != hipSuccess) return bail("event");
@@ -1859,7 +1886,7 @@ int csf_destroy(csf_engine *e) {
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
-    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->segtab.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->far_stat.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
+    e->part.release(); e->froad.release(); e->kat2.release(); e->bnd.release(); e->bnd2.release(); e->rorg.release(); e->reclo.release(); e->xbuf.release(); e->segtab.release(); e->tcirc.release(); e->clist.release(); e->ccount.release(); e->far_stat.release(); e->edge.release(); e->edge_n.release(); e->edge_head.release(); e->perm.release(); e->pos.release(); e->recs.release(); e->recg.release(); e->recb.release(); e->borg.release();
     e->ticket.release(); e->scratch_u8.release(); e->scratch_i32.release(); e->scratch_f64.release(); e->scratch_cnt.release();
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
@@ -1868,13 +1895,11 @@ int csf_destroy(csf_engine *e) {
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
-    if (e->main && e->owns_main) (void)hipStreamDestroy(e->main);
     if (e->comm) (void)hipStreamDestroy(e->comm);
-    for (csf_engine *m : e->group)          // the others of a loopback group lose this member (and its stream, if it was the owner)
-        if (m != e) {
-            m->group.clear();
-            if (e->owns_main && m->main == e->main) m->main = nullptr;
-        }
+    for (csf_engine *m : e->group)          // the others of a loopback group lose this member: no group any more (csf_step_group says so)
+        if (m != e) m->group.clear();
+    e->main = nullptr;
+    e->main_hold.reset();                   // (the stream itself goes with its last holder; this engine's events went above)
     delete e;
     return CSF_OK;
 }
@@ -2539,7 +2564,10 @@ static int enqueue_tick(csf_engine *e) {
     if ((rc = bounds_before_pair(e))) return rc;
     // sharded: the other ranks' records arrived in index order; a coalesced tile fill from the binned copy saves the
     // pair kernel 5 - 7 us at every shard size, the copy costs ~3 us
-    if (sharded && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
+    if (sharded && d.recs_valid && e->ticks_since_rebin > 1) {
+        launch_sorted_copy(d, e->main, e->xbuf_fresh);
+        e->xbuf_fresh = false;
+    }
     if ((rc = set_fov_band(e))) return rc;
     if (d.n_live > 1 && d.hi > d.lo) {
         launch_pair_all(e, d, ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr);
@@ -2578,13 +2606,11 @@ static int loopback_exchange(csf_engine *const *g, int world) {
         const size_t shard = (size_t)(src->d.n_pad / world);
         for (int p = 0; p < world; p++) {
             if (p == r) continue;
-            HIPCHK(g[p], hipMemcpyAsync(g[p]->rec.p + r * shard, src->rec.p + r * shard, shard * sizeof(float4),
+            // (one block of exchange records per peer, where a real run has one collective: csf_dev.h xbuf)
+            if (!g[p]->xbuf.p || !src->xbuf.p) return fail(g[p], CSF_E_DEVICE, "no exchange buffer (allocation failed when the shard layout was set)");
+            HIPCHK(g[p], hipMemcpyAsync(g[p]->xbuf.p + 2 * r * shard, src->xbuf.p + 2 * r * shard, 2 * shard * sizeof(float4),
                                         hipMemcpyDeviceToDevice, src->main));
-            HIPCHK(g[p], hipMemcpyAsync(g[p]->reclo.p + r * shard, src->reclo.p + r * shard, shard * sizeof(float2),
-                                        hipMemcpyDeviceToDevice, src->main));
-            if (src->d.has_bike)
-                HIPCHK(g[p], hipMemcpyAsync(g[p]->rec2.p + r * shard, src->rec2.p + r * shard, shard * sizeof(float2),
-                                            hipMemcpyDeviceToDevice, src->main));
+            g[p]->xbuf_fresh = true;
         }
     }
     return CSF_OK;
@@ -2681,6 +2707,8 @@ int csf_sync(csf_engine *e) {
         int rc = flush_pending(e);
         if (rc) return rc;
     }
+    // (polling hipStreamQuery before sleeping in the runtime was tried again in round 5, with the group's stream lifetime put
+    // right: no abort any more, and no gain - SocialForceIntersection.step() 37 / 54 us per tick at N = 3 / 1 024 against 32 / 48)
     HIPCHK(e, hipStreamSynchronize(e->main));
     HIPCHK(e, hipStreamSynchronize(e->comm));
     return CSF_OK;
@@ -2696,7 +2724,10 @@ int csf_calc_forces(csf_engine *e) {
     if (rc) return rc;
     rc = bounds_before_pair(e);
     if (rc) return rc;
-    if ((e->world > 1 || e->nccl != nullptr || e->loopback) && e->d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(e->d, e->main);
+    if ((e->world > 1 || e->nccl != nullptr || e->loopback) && e->d.recs_valid && e->ticks_since_rebin > 1) {
+        launch_sorted_copy(e->d, e->main, e->xbuf_fresh);
+        e->xbuf_fresh = false;
+    }
     if ((rc = set_fov_band(e))) return rc;
     if (e->d.n_live > 1) launch_pair_all(e, e->d);
     bounds_after_pair(e, false);                     // the records do not move: recompute next time
@@ -3146,9 +3177,8 @@ int csf_comm_init_loopback(csf_engine *const *engines, int32_t world) {
         e->group.assign(engines, engines + world);
         if (r > 0) {                                  // one stream for the whole group: ticks and exchanges in order
             HIPCHK(e, hipStreamSynchronize(e->main));
-            HIPCHK(e, hipStreamDestroy(e->main));
-            e->main = engines[0]->main;
-            e->owns_main = false;
+            e->main_hold = engines[0]->main_hold;     // (the member's own stream goes with its last holder: now)
+            e->main = e->main_hold->s;
         }
         set_shard(e);
     }
@@ -3164,7 +3194,6 @@ int csf_step_group(csf_engine *const *engines, int32_t world, int64_t n_ticks) {
         if (engines[r] != e0->group[(size_t)r]) return fail(e0, CSF_E_ARG, "members must be passed in rank order");
     HIPCHK(e0, hipSetDevice(e0->device));
     for (int r = 0; r < world; r++) {
-        if (!engines[r]->main) return fail(engines[r], CSF_E_STATE, "the group's stream owner was destroyed");
         int rc = upload_all(engines[r]);
         if (rc) return rc;
     }
@@ -3271,7 +3300,10 @@ int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) 
     if ((rc = wait_gather(e))) return rc;
     if (!e->segs.empty() && e->ticks_since_rebin >= e->knobs.rebin_ticks && (rc = rebin(e))) return rc;   // (arrivals since: flush_pending)
     if (d.classify && !e->bounds_fresh) launch_bounds(d, e->main);
-    if ((e->world > 1 || e->nccl != nullptr || e->loopback) && d.recs_valid && e->ticks_since_rebin > 1) launch_sorted_copy(d, e->main);
+    if ((e->world > 1 || e->nccl != nullptr || e->loopback) && d.recs_valid && e->ticks_since_rebin > 1) {
+        launch_sorted_copy(d, e->main, e->xbuf_fresh);
+        e->xbuf_fresh = false;
+    }
     DevBuf<unsigned long long> &cnt = e->scratch_cnt;
     HIPCHK(e, cnt.reserve(4));
     HIPCHK(e, hipMemsetAsync(cnt.p, 0, 4 * sizeof(unsigned long long), e->main));
