@@ -178,6 +178,10 @@ def main():
         os.dup2(2, 1)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse and world == 1:                              # (a plain `python bench.py`: no launcher has set these)
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from cyclistsocialforce_amd import parameters

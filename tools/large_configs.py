@@ -29,10 +29,19 @@ def run(name, model, n, box, ticks, road=None, warm=2, reach=(50.0, 99.0, 100.0)
     if road is not None:
         e.set_road(*road)
     e.step(warm, sync=True)
-    e.profile(max(1, ticks // 64))
-    t0 = time.perf_counter()
-    e.step(ticks, sync=True)
-    dt = time.perf_counter() - t0
+    if n < 2048:
+        # (populations that tick in one launch - csf_mid.hip - take the two launches when kernels are timed one by one: the
+        # rate first, without time stamps; then a short sampled stretch for the two kernels' own times)
+        t0 = time.perf_counter()
+        e.step(ticks, sync=True)
+        dt = time.perf_counter() - t0
+        e.profile(8)
+        e.step(512, sync=True)
+    else:
+        e.profile(max(1, ticks // 64))
+        t0 = time.perf_counter()
+        e.step(ticks, sync=True)
+        dt = time.perf_counter() - t0
     prof = {k: ms * 1e3 / max(c, 1) for k, (ms, c) in e.profile_kernels().items()}     # mean microseconds per launch
     e.profile(0)
     s = e.state()
@@ -43,7 +52,7 @@ def run(name, model, n, box, ticks, road=None, warm=2, reach=(50.0, 99.0, 100.0)
                       "finite": bool(np.isfinite(s).all()), "status_flags": int((st != 0).sum()),
                       "road_vertices": 0 if road is None else int(road[1].shape[0]),
                       "pair_kernel": kernel, "pair_us": prof["pair"], "road_us": prof["road"],
-                      "agent_us": prof["agent"], "pairs_evaluated": evaluated}), flush=True)
+                      "agent_us": prof["agent"], "pairs_evaluated": evaluated, "one_launch_ticks": e.mid_ticks()}), flush=True)
     e.close()
 
 
