@@ -314,6 +314,7 @@ struct csf_engine {
     double coord_bound0 = 0.0;
     int64_t moves = 0;
     int64_t small_ticks = 0;         // ticks run by the one-wave kernel (csf_small_ticks)
+    int64_t slab_rewrites = 0;       // compact_slab calls (upload_queues sizes the slab by them)
     bool bound_stale = false;        // positions moved without a speed clamp (csf_replay_forces with fix_speed): measure them
     uint32_t edge_stamp = 0;
     DevBuf<EdgeRec> edge;
@@ -1369,6 +1370,12 @@ int upload_queues(csf_engine *e, int64_t extra) {
         size_t want = (size_t)std::max<int64_t>(3 * (rows + extra) * 2, 3 * 4096);
         HIPCHK(e, e->q.alloc(want));
     }
+    // A slab that is rewritten often (compact_slab: arrivals and new routes every tick - each such rewrite waits for the ticks in
+    // flight and uploads every live queue, ~1 ms at N = 16 384, and at 5 % of the population replaced per tick it came every 17
+    // ticks: 59 us per tick, most of the host's time in csf_set_dest_queue) grows to eight times what is alive: a rewrite every
+    // ~140 such ticks.  (Up to 96 MB; beyond, twice the live rows as before.)
+    if (e->slab_rewrites >= 2 && (size_t)(3 * (rows + extra)) * 8 > e->q.n && (size_t)(3 * (rows + extra)) * 8 * sizeof(double) <= (96u << 20))
+        HIPCHK(e, e->q.alloc((size_t)(3 * (rows + extra)) * 8));
     d.q = e->q.p;
     d.qcap = (int64_t)(e->q.n / 3);
     e->q_top = rows;
@@ -1387,6 +1394,7 @@ int upload_queues(csf_engine *e, int64_t extra) {
 // The slab is full of queues that were replaced or whose road users left: write the live queues afresh (the host holds
 // every queue as it was last set; the pointers into them live on the device and stay as they are).
 int compact_slab(csf_engine *e, int64_t extra) {
+    e->slab_rewrites++;
     int rc = flush_pending(e);
     if (rc) return rc;
     HIPCHK(e, hipStreamSynchronize(e->main));                  // ticks in flight read the old slab
