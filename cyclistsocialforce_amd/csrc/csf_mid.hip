@@ -1,17 +1,18 @@
-// csf_mid.hip — the whole tick of a mid-size population (a few dozen to ~2 000 road users) in ONE launch.
+// csf_mid.hip — the whole tick of a mid-size population (a few dozen to ~1 300 road users) in ONE launch.
 //
 // Replaces, per tick, the same reference code as csf_pair.hip + csf_agent.hip together: get_untracked_foes
 // (intersection.py:690-745), the N calls of calcRepulsiveForce and the column sum (:814-843), the clamp and the road term
 // (:841-857), and vehicle.step for every road user (:891-892) - SocialForceIntersection.step (:866-896).
 //
-// Between 33 and ~2 000 road users - BASELINE config 2 (1 024 TwoDBicycle), and what the reference itself runs under SUMO -
+// Between 33 and ~1 300 road users - BASELINE config 2 (1 024 TwoDBicycle), and what the reference itself runs under SUMO -
 // the tick is latency, not work: the plain pair launch and the per-agent launch take 8 + 7 us at N = 1 024, of which ~9 us are
-// the two launches' fixed cost (dispatch, first round trips, teardown).  Here ONE WORKGROUP of eight waves owns a group of G
-// road users (4 ... 32 slots, so that the grid is about one workgroup per CU) for the whole tick:
+// the two launches' fixed cost (dispatch, first round trips, teardown).  Here ONE WORKGROUP of twelve waves (eight for the
+// InvPendulum's per-agent code) owns a group of G road users (4 ... 32 slots, so that the grid is about one workgroup per CU)
+// for the whole tick:
 //
 //   wave 0        the destination-force phase of the group's road users - queue, navigation state, planner: it needs no sums -
 //                 (csf_agent_dev.h: agent_body, lane = road user) ...
-//   waves 1 - 7   ... while they form the group's repulsive sums, item by item from an LDS counter: an item is one batch of 64 sources - sources in the lanes, straight from the records in memory, asked
+//   the others    ... while they form the group's repulsive sums, item by item from an LDS counter: an item is one batch of 64 sources - sources in the lanes, straight from the records in memory, asked
 //                 for one item ahead; no wave shares a source with another, so there is no tile to stage - against four
 //                 receivers (csf_pair_dev.h: plain_pair_eval - the very code of pair_kernel: mask, field, precise records for
 //                 near and marginal pairs, hand-overs of the undecidable ones), column sum by lane exchange, one partial per
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(mid_waves(MODEL) * WAVE) void mid_tick_kernel(const
     uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();   // (every wave: one workgroup per CU, and the pair waves' first
     kernarg_touched(ka_lines);                                   //  scalar loads sit in front of their first sources)
     // CSF_TRACE_AGENT (tools/mid_timeline.py): 16 stamps per workgroup - wave 0: entry, destination force done, its share of the
-    // sums done, behind the barrier, end; wave 1: entry, first sources loaded, sums done; wave 7: sums done
+    // sums done, behind the barrier, end; wave 1: entry, first sources loaded, sums done; the last wave: sums done
     uint64_t *const tr = d.atrace ? d.atrace + 16 * (int64_t)blockIdx.x : nullptr;
     auto stamp = [&](int k) {
         if (tr != nullptr) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(mid_waves(MODEL) * WAVE) void mid_tick_kernel(const
         stamp(0);
         if (lane < G) agent_body<MODEL, false, false, 1>(d, PH_DEST, a, nullptr, ka_lines, 0.0, 0.0);
         stamp(1);
-    } else {   // the pair sums: waves 1 .. 7 take items until there are none left
+    } else {   // the pair sums: the other waves take items until there are none left
         if (wave == 1) stamp(4);
         PairConsts k = d.pc;
         asm volatile("" : "+v"(k.sg0), "+v"(k.sg1), "+v"(k.sg2), "+v"(k.sg3), "+v"(k.e0), "+v"(k.e1), "+v"(k.lf0), "+v"(k.kexp), "+v"(k.chs));
