@@ -42,6 +42,8 @@
 #define CSFO_PLANARPOINT 3
 #define CSFO_PLANARBIKE 4
 #define CSFO_UNCONTROLLED 5   /* vehicle.py:920-988: follows a prescribed trajectory, exerts the TwoD field, feels nothing */
+#define CSFO_BALANCINGRIDER 6 /* vehicle.py:1953-1990; dynamics.py:261-705: Whipple-Carvallo bicycle under full-state feedback */
+#define CSFO_NS_MAX 8         /* columns of vehicle.s at most (BalancingRiderBicycle: + steer rate, roll rate) */
 
 #define CSFO_ST_SPLINE 1u
 #define CSFO_ST_NAN 2u
@@ -63,7 +65,13 @@ typedef struct csfo_params {
     double k_psi;
     /* PlanarBicycleParameters — parameters.py:1203-1211: the two desired poles (re, im, re, im) */
     double pb_poles[4];
-    int32_t model, priority_rule /* 0 unregulated, 1 p2r */, traj_len /* int(30/t_s) */, reserved;
+    /* BalancingRiderBicycleParameters — parameters.py:1214-1411; dynamics.py:261-705.  The linearised Whipple-Carvallo
+     * bicycle (Meijaard, Papadopoulos, Ruina & Schwab 2007: M q'' + v C1 q' + (g K0 + v^2 K2) q = f, q = (roll, steer)) as the
+     * 2 x 2 blocks of its state matrix (row-major), the steer-torque column of M^-1, the yaw row (dynamics.py:301-303), and
+     * the control model: desired poles as straight lines over speed (parameters.py:1400-1409; (intercept, slope) of p0_real,
+     * p1_real, p1_imag, p2_real, p2_imag), constant poles (slopes 0), or constant gains (br_mode 2, dynamics.py:604-605) */
+    double br_minv_k0g[4], br_minv_k2[4], br_minv_c1[4], br_minv_steer[2], br_yaw[2], br_pole_fun[10], br_gains[5];
+    int32_t model, priority_rule /* 0 unregulated, 1 p2r */, traj_len /* int(30/t_s) */, br_mode;
 } csfo_params;
 
 typedef struct csfo {
@@ -74,7 +82,7 @@ typedef struct csfo {
     csfo_params *ptab;
     uint8_t *pcls;
     int n, ns;
-    double *s;        /* [n][6] */
+    double *s;        /* [n][CSFO_NS_MAX] */
     double *vdes;     /* [n]  params.v_desired_default per agent (demoCSFstandalone.py:104-113) */
     int64_t *qoff;    /* [n+1] CSR offsets into dq */
     double *dq;       /* [sum][3] x, y, stop */
@@ -286,7 +294,7 @@ void csfo_road_forces(int64_t nv, const double *vx, const double *vy, const doub
 
 /* ----------------------------------------------- destination queue + nav state machine ---- */
 
-static inline double *S(csfo_t *o, int a) { return o->s + 6 * (size_t)a; }
+static inline double *S(csfo_t *o, int a) { return o->s + CSFO_NS_MAX * (size_t)a; }
 static inline const csfo_params *PA(const csfo_t *o, int a) { return o->pcls ? &o->ptab[o->pcls[a]] : &o->p; }
 static inline int qlen(csfo_t *o, int a) { return (int)(o->qoff[a + 1] - o->qoff[a]); }
 static inline double *qrow(csfo_t *o, int a, int k) { return o->dq + 3 * (o->qoff[a] + k); }
@@ -593,6 +601,10 @@ static void dest_force(csfo_t *o, int a, double *Fx, double *Fy) {
         break;
     case CSFO_BICYCLE:
         direct_approach(o, a, Fx, Fy);                             /* vehicle.py:1189-1194 */
+        break;
+    case CSFO_BALANCINGRIDER:
+        update_destination(o, a);                                  /* vehicle.py:295-297 */
+        direct_approach(o, a, Fx, Fy);                             /* vehicle.py:1987-1988, 2078-2108 */
         break;
     case CSFO_PLANARPOINT:
     case CSFO_PLANARBIKE:
@@ -911,6 +923,152 @@ static void planarbike_step(csfo_t *o, int a, double Fx, double Fy) {
     s[1] = y;
 }
 
+/* ---------------------------------------------------------- BalancingRiderBicycle (f)4 ---- */
+
+/* the bicycle-rider state matrix at speed v (dynamics.py:535-560; x = (roll, steer, roll rate, steer rate, yaw) in the bike
+ * model's frame) and the steer-torque input column */
+static void br_state_space(const csfo_params *p, double v, double A[25], double B[5]) {
+    memset(A, 0, 25 * sizeof(double));
+    A[0 * 5 + 2] = 1;
+    A[1 * 5 + 3] = 1;
+    for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 2; c++) {
+            A[(2 + r) * 5 + c] = -(p->br_minv_k0g[2 * r + c] + v * v * p->br_minv_k2[2 * r + c]);
+            A[(2 + r) * 5 + 2 + c] = -v * p->br_minv_c1[2 * r + c];
+        }
+    A[4 * 5 + 1] = p->br_yaw[0] * v;                               /* :549 */
+    A[4 * 5 + 3] = p->br_yaw[1];                                   /* :550 */
+    B[0] = B[1] = B[4] = 0;
+    B[2] = p->br_minv_steer[0];
+    B[3] = p->br_minv_steer[1];
+}
+
+/* solve M x = b for n <= 5 by elimination with partial pivoting (M row-major, destroyed) */
+static int solve_small(int n, double *M, double *b) {
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        for (int r = k + 1; r < n; r++)
+            if (fabs(M[r * n + k]) > fabs(M[piv * n + k])) piv = r;
+        if (M[piv * n + k] == 0) return -1;
+        if (piv != k) {
+            for (int c = 0; c < n; c++) {
+                double t = M[k * n + c];
+                M[k * n + c] = M[piv * n + c];
+                M[piv * n + c] = t;
+            }
+            double t = b[k];
+            b[k] = b[piv];
+            b[piv] = t;
+        }
+        for (int r = k + 1; r < n; r++) {
+            double f = M[r * n + k] / M[k * n + k];
+            for (int c = k; c < n; c++) M[r * n + c] -= f * M[k * n + c];
+            b[r] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double acc = b[k];
+        for (int c = k + 1; c < n; c++) acc -= M[k * n + c] * b[c];
+        b[k] = acc / M[k * n + k];
+    }
+    return 0;
+}
+
+/* dynamics.py:600-615: the gains that put the closed loop's poles where the control model wants them at speed v
+ * (from_pole_placement -> control.place, dynamics.py:1167-1209).  One input: the placement has exactly one solution,
+ * Ackermann's K = e_n^T W^-1 p(A), W = (B, A B, ..., A^4 B), p the polynomial of the desired poles - formed as products of
+ * (A - p0) and (A^2 - 2 Re p A + |p|^2) applied to the row e_n^T W^-1 from the left. */
+void csfo_balancingrider_gains(const csfo_params *p, double v, double K[5]) {
+    if (p->br_mode == 2) {                                         /* :604-605 */
+        memcpy(K, p->br_gains, 5 * sizeof(double));
+        return;
+    }
+    double f[5];
+    for (int i = 0; i < 5; i++) f[i] = p->br_pole_fun[2 * i] + p->br_pole_fun[2 * i + 1] * v;   /* parameters.py:1400-1409 */
+    double A[25], B[5], W[25], col[5], y[5];
+    br_state_space(p, v, A, B);
+    memcpy(col, B, sizeof col);
+    for (int k = 0; k < 5; k++) {                                  /* W^T, row k = (A^k B)^T */
+        for (int r = 0; r < 5; r++) W[k * 5 + r] = col[r];
+        double nxt[5];
+        for (int r = 0; r < 5; r++) {
+            double acc = 0;
+            for (int c = 0; c < 5; c++) acc += A[r * 5 + c] * col[c];
+            nxt[r] = acc;
+        }
+        memcpy(col, nxt, sizeof col);
+    }
+    for (int k = 0; k < 5; k++) y[k] = k == 4 ? 1.0 : 0.0;         /* W^T y = e_5 */
+    if (solve_small(5, W, y) != 0) {
+        for (int k = 0; k < 5; k++) K[k] = NAN;                    /* not controllable: the reference's assertion (:1205-1207) */
+        return;
+    }
+#define ROW_TIMES_A(out, in)                                   \
+    for (int c = 0; c < 5; c++) {                              \
+        double acc = 0;                                        \
+        for (int r = 0; r < 5; r++) acc += (in)[r] * A[r * 5 + c]; \
+        (out)[c] = acc;                                        \
+    }
+    double t1[5], t2[5];
+    ROW_TIMES_A(t1, y);                                            /* y (A - p0) */
+    for (int c = 0; c < 5; c++) y[c] = t1[c] - f[0] * y[c];
+    for (int pair = 0; pair < 2; pair++) {                         /* y (A^2 - 2 re A + (re^2 + im^2)) */
+        const double re = f[1 + 2 * pair], im = f[2 + 2 * pair];
+        ROW_TIMES_A(t1, y);
+        ROW_TIMES_A(t2, t1);
+        for (int c = 0; c < 5; c++) y[c] = t2[c] - 2 * re * t1[c] + (re * re + im * im) * y[c];
+    }
+#undef ROW_TIMES_A
+    memcpy(K, y, 5 * sizeof(double));
+}
+
+/* BalancingRiderDynamics.step (dynamics.py:664-705).  xlti = (roll, steer, roll rate, steer rate, yaw) in the bike model's
+ * frame (y to the right, z down: steer, yaw and y mirrored, :318-371), unwrapped; vdyn = the speed the gains in use were
+ * computed for (they are renewed only when the speed changes, :671-673).  The implicit midpoint rule (:497-513) on
+ * x' = (A - B K) x + B K_psi psi_c is a linear system in x+; the position follows from the yaw at both ends.  (The reference
+ * solves the same seven equations with MINPACK's lm to its default tolerance, ~1e-8.) */
+static void balancingrider_step(csfo_t *o, int a, double Fx, double Fy) {
+    const csfo_params *p = PA(o, a);
+    double *s = S(o, a), *x = o->xlti + 5 * a;
+    const double h = p->t_s, v_old = s[3];
+    double vd = sqrt(Fx * Fx + Fy * Fy);                           /* :640 */
+    double acc = thresh(p->k_p_v * (vd - v_old), p->a_max[0], p->a_max[1]);   /* :643-644 */
+    double v = thresh(v_old + h * acc, p->v_max_riding[0], p->v_max_riding[1]);   /* :647 */
+    if (v != v_old) o->vdyn[a] = (v + v_old) / 2;                  /* :671-673 */
+    double K[5];
+    csfo_balancingrider_gains(p, o->vdyn[a], K);
+    double psi_F = csfo_limit_angle(atan2(-Fy, Fx));               /* :656-658 (the lateral force mirrored) */
+    double psi_c = x[4] + csfo_angle_difference(x[4], psi_F);      /* :660-663 */
+    const double vbar = (v + v_old) / 2;                           /* :684, 687 */
+    double A[25], B[5], L[25], rhs[5];
+    br_state_space(p, vbar, A, B);
+    for (int r = 0; r < 5; r++)
+        for (int c = 0; c < 5; c++) A[r * 5 + c] -= B[r] * K[c];   /* :472 */
+    for (int r = 0; r < 5; r++) {
+        double accr = x[r] + h * B[r] * K[4] * psi_c;
+        for (int c = 0; c < 5; c++) {
+            L[r * 5 + c] = (r == c ? 1.0 : 0.0) - 0.5 * h * A[r * 5 + c];
+            accr += 0.5 * h * A[r * 5 + c] * x[c];
+        }
+        rhs[r] = accr;
+    }
+    if (solve_small(5, L, rhs) != 0) {
+        o->status[a] |= CSFO_ST_NAN;
+        return;
+    }
+    const double pm = 0.5 * (x[4] + rhs[4]);
+    const double px = s[0] + h * vbar * cos(pm), py = -s[1] + h * vbar * sin(pm);   /* :475-477 */
+    memcpy(x, rhs, 5 * sizeof(double));
+    s[0] = px;                                                     /* :337-348 */
+    s[1] = -py;
+    s[2] = -csfo_limit_angle(x[4]);
+    s[3] = v;
+    s[4] = -csfo_limit_angle(x[1]);
+    s[5] = csfo_limit_angle(x[0]);
+    s[6] = -x[3];
+    s[7] = x[2];
+}
+
 /* --------------------------------------------------------------- population tick ---- */
 
 /* intersection.py:747-864 for receivers [lo, hi) */
@@ -1017,6 +1175,9 @@ void csfo_integrate_range(csfo_t *o, int lo, int hi) {
         case CSFO_PLANARBIKE:
             planarbike_step(o, a, Fx, Fy);
             break;
+        case CSFO_BALANCINGRIDER:
+            balancingrider_step(o, a, Fx, Fy);
+            break;
         case CSFO_UNCONTROLLED: {                                  /* vehicle.py:964-979: the next prescribed state, if any */
             int64_t i = (int64_t)o->i[a] + 1;                      /* (:973: the counter never wraps) */
             if (i > 2000000000) i = 2000000000;
@@ -1062,7 +1223,7 @@ void csfo_step(csfo_t *o, int nticks) {
 
 /* ----------------------------------------------------------------- construction ---- */
 
-static const int NS[6] = {5, 5, 6, 4, 5, 4};
+static const int NS[7] = {5, 5, 6, 4, 5, 4, 8};
 
 /* what the constructors of the rider classes derive from the start state (vehicle.py:1728-1736; dynamics.py:195-197, 828,
  * 987-993), by the class of agent a */
@@ -1079,6 +1240,15 @@ static void init_side_state(csfo_t *o, int a) {
         x[4] = s[2];
         if (s[3] < p->v_max_walk) o->zrid[2 * a + 1] = 1;
         else o->zrid[2 * a] = 1;
+    }
+    if (p->model == CSFO_BALANCINGRIDER) {                         /* dynamics.py:306-307, 350-371 */
+        double *x = o->xlti + 5 * a;
+        x[0] = s[5];
+        x[1] = -s[4];
+        x[2] = s[7];
+        x[3] = -s[6];
+        x[4] = -s[2];
+        o->vdyn[a] = s[3];                                         /* :307: the gains of the start speed */
     }
     if (p->model == CSFO_PLANARBIKE) {                             /* dynamics.py:195-197 */
         o->xdyn[3 * a] = s[4];
@@ -1101,7 +1271,7 @@ csfo_t *csfo_create_ns(const csfo_params *p, int n, int ns, const double *s0, co
     o->n = n;
     o->ns = ns;
     size_t N = (size_t)(n > 0 ? n : 1), L = (size_t)p->traj_len;
-    o->s = (double *)calloc(N * 6, sizeof(double));
+    o->s = (double *)calloc(N * CSFO_NS_MAX, sizeof(double));
     o->vdes = (double *)calloc(N, sizeof(double));
     o->qoff = (int64_t *)calloc(N + 1, sizeof(int64_t));
     memcpy(o->qoff, qoff, sizeof(int64_t) * (size_t)(n + 1));
@@ -1170,6 +1340,14 @@ void csfo_push_state(csfo_t *o, const double *s_in, const int32_t *ptr, const ui
             x[0] = REWIND(x[0], s[4]);
             x[2] = REWIND(x[2], s[5]);
             x[4] = REWIND(x[4], s[2]);
+        }
+        if (PA(o, a)->model == CSFO_BALANCINGRIDER) {             /* (dynamics.py:350-371; the rates are states of vehicle.s here) */
+            double *x = o->xlti + 5 * a;
+            x[0] = REWIND(x[0], s[5]);
+            x[1] = REWIND(x[1], -s[4]);
+            x[2] = s[7];
+            x[3] = -s[6];
+            x[4] = REWIND(x[4], -s[2]);
         }
         if (PA(o, a)->model == CSFO_PLANARBIKE) {
             o->xdyn[3 * a] = REWIND(o->xdyn[3 * a], s[4]);

@@ -12,10 +12,10 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libcsf_oracle.so")
 
-BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE, UNCONTROLLED = 0, 1, 2, 3, 4, 5
+BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE, UNCONTROLLED, BALANCINGRIDER = 0, 1, 2, 3, 4, 5, 6
 MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE,
-             "uncontrolled": UNCONTROLLED}
-N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5, UNCONTROLLED: 4}
+             "uncontrolled": UNCONTROLLED, "balancingrider": BALANCINGRIDER}
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5, UNCONTROLLED: 4, BALANCINGRIDER: 8}
 
 ST_SPLINE, ST_NAN, ST_NAVSTATE = 1, 2, 4
 
@@ -34,7 +34,9 @@ class Params(C.Structure):
         ("i_steer_vertvert", C.c_double), ("c_steer", C.c_double),
         ("v_max_walk", C.c_double), ("delta_max_walk", C.c_double),
         ("k_psi", C.c_double), ("pb_poles", C.c_double * 4),
-        ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("reserved", C.c_int32),
+        ("br_minv_k0g", C.c_double * 4), ("br_minv_k2", C.c_double * 4), ("br_minv_c1", C.c_double * 4),
+        ("br_minv_steer", C.c_double * 2), ("br_yaw", C.c_double * 2), ("br_pole_fun", C.c_double * 10), ("br_gains", C.c_double * 5),
+        ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("br_mode", C.c_int32),
     ]
 
 
@@ -55,6 +57,64 @@ _INVPEND = dict(_BICYCLE, v_max_riding=(-1.0, 7.0), a_max=(-3.0, 1.0), a_desired
 _PLANARPOINT = dict(_BICYCLE, k_psi=2.0)
 _PLANARBIKE = dict(_BICYCLE, pb_poles=(-1.0141284591434665, 1.226826644413086, -1.0141284591434665, -1.226826644413086))
 _CAR = dict(_VEHICLE, i_steer_vertvert=1.0)       # CarParameters (parameters.py:752-764): VehicleParameters + a footprint
+
+
+def whipple_carvallo(p):
+    """(M, C1, K0, K2) of the linearised Whipple-Carvallo bicycle from a parameter dictionary: Meijaard, Papadopoulos, Ruina &
+    Schwab (2007), Appendix A - what bicycleparameters' Meijaard2007Model.form_reduced_canonical_matrices implements
+    (parameters.py:1284-1300).  Pinned to the paper's benchmark matrices and eigenvalues in tests/test_oracle_golden.py."""
+    w, c, lam = p["w"], p["c"], p["lam"]
+    mT = p["mR"] + p["mB"] + p["mH"] + p["mF"]
+    xT = (p["xB"] * p["mB"] + p["xH"] * p["mH"] + w * p["mF"]) / mT
+    zT = (-p["rR"] * p["mR"] + p["zB"] * p["mB"] + p["zH"] * p["mH"] - p["rF"] * p["mF"]) / mT
+    ITxx = p["IRxx"] + p["IBxx"] + p["IHxx"] + p["IFxx"] + p["mR"] * p["rR"]**2 + p["mB"] * p["zB"]**2 + p["mH"] * p["zH"]**2 + p["mF"] * p["rF"]**2
+    ITxz = p["IBxz"] + p["IHxz"] - p["mB"] * p["xB"] * p["zB"] - p["mH"] * p["xH"] * p["zH"] + p["mF"] * w * p["rF"]
+    ITzz = p["IRxx"] + p["IBzz"] + p["IHzz"] + p["IFxx"] + p["mB"] * p["xB"]**2 + p["mH"] * p["xH"]**2 + p["mF"] * w**2
+    mA = p["mH"] + p["mF"]
+    xA = (p["xH"] * p["mH"] + w * p["mF"]) / mA
+    zA = (p["zH"] * p["mH"] - p["rF"] * p["mF"]) / mA
+    IAxx = p["IHxx"] + p["IFxx"] + p["mH"] * (p["zH"] - zA)**2 + p["mF"] * (p["rF"] + zA)**2
+    IAxz = p["IHxz"] - p["mH"] * (p["xH"] - xA) * (p["zH"] - zA) + p["mF"] * (w - xA) * (p["rF"] + zA)
+    IAzz = p["IHzz"] + p["IFxx"] + p["mH"] * (p["xH"] - xA)**2 + p["mF"] * (w - xA)**2
+    sl, cl = np.sin(lam), np.cos(lam)
+    uA = (xA - w - c) * cl - zA * sl
+    IAll = mA * uA**2 + IAxx * sl**2 + 2 * IAxz * sl * cl + IAzz * cl**2
+    IAlx = -mA * uA * zA + IAxx * sl + IAxz * cl
+    IAlz = mA * uA * xA + IAxz * sl + IAzz * cl
+    mu = c / w * cl
+    SR, SF = p["IRyy"] / p["rR"], p["IFyy"] / p["rF"]
+    ST = SR + SF
+    SA = mA * uA + mu * mT * xT
+    M = np.array([[ITxx, IAlx + mu * ITxz], [IAlx + mu * ITxz, IAll + 2 * mu * IAlz + mu**2 * ITzz]])
+    K0 = np.array([[mT * zT, -SA], [-SA, -SA * sl]])
+    K2 = np.array([[0.0, (ST - mT * zT) / w * cl], [0.0, (SA + SF * sl) / w * cl]])
+    C1 = np.array([[0.0, mu * ST + SF * cl + ITxz / w * cl - mu * mT * zT], [-(mu * ST + SF * cl), IAlz / w * cl + mu * (SA + ITzz / w * cl)]])
+    return M, C1, K0, K2
+
+
+def balancingrider_fields(bike, pole_fun=None, gains=None):
+    """the br_* members of Params from a bicycle parameter dictionary and a control model: pole_fun [5, 2] ((intercept, slope) of
+    p0_real, p1_real, p1_imag, p2_real, p2_imag; constant poles: slopes 0) or fixed gains [5]"""
+    M, C1, K0, K2 = whipple_carvallo(bike)
+    Minv = np.linalg.inv(M)
+    d = dict(br_minv_k0g=tuple((Minv @ (bike["g"] * K0)).ravel()), br_minv_k2=tuple((Minv @ K2).ravel()), br_minv_c1=tuple((Minv @ C1).ravel()),
+             br_minv_steer=tuple(Minv[:, 1]), br_yaw=(np.cos(bike["lam"]) / bike["w"], np.cos(bike["lam"]) * bike["c"] / bike["w"]),
+             br_pole_fun=tuple(np.zeros(10)), br_gains=tuple(np.zeros(5)), br_mode=0)
+    if gains is not None:
+        d.update(br_gains=tuple(np.asarray(gains, dtype=float).ravel()), br_mode=2)
+    else:
+        d.update(br_pole_fun=tuple(np.asarray(pole_fun, dtype=float).ravel()))
+    return d
+
+
+def _balancingrider_defaults():
+    g = np.load(os.path.join(os.path.dirname(HERE), "tests", "golden", "balancingrider.npz"))
+    bike = dict(zip([str(k) for k in g["default_bike_names"]], [float(v) for v in g["default_bike_params"]]))
+    # BalancingRiderBicycleParameters() (parameters.py:1214-1320): BicycleParameters with the wheelbase of the bicycle, and the
+    # mean poles of component 0 of the model file BR1 (the reference's own PoleModel: tests/golden/make_golden_balancingrider.py)
+    return dict(_BICYCLE, l=bike["w"], g=bike["g"], **balancingrider_fields(bike, pole_fun=g["polefun_BR1"][0]))
+
+
 DEFAULTS = {BICYCLE: _BICYCLE, TWOD: _INVPEND, INVPEND: _INVPEND, PLANARPOINT: _PLANARPOINT, PLANARBIKE: _PLANARBIKE,
             UNCONTROLLED: _CAR}
 
@@ -62,6 +122,8 @@ DEFAULTS = {BICYCLE: _BICYCLE, TWOD: _INVPEND, INVPEND: _INVPEND, PLANARPOINT: _
 def default_params(model, priority_rule=0, **overrides):
     if isinstance(model, str):
         model = MODEL_IDS[model]
+    if model == BALANCINGRIDER and model not in DEFAULTS:
+        DEFAULTS[model] = _balancingrider_defaults()
     d = dict(DEFAULTS[model], **overrides)
     p = Params()
     for k, v in d.items():
@@ -135,6 +197,7 @@ def lib():
                                         C.c_double, C.c_void_p]
         L.csfo_expm.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.csfo_planarbike_gains.argtypes = [C.POINTER(Params), C.c_double, C.c_void_p, C.POINTER(C.c_double)]
+        L.csfo_balancingrider_gains.argtypes = [C.POINTER(Params), C.c_double, C.c_void_p]
         L.csfo_create.restype = C.c_void_p
         L.csfo_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.csfo_create_ns.restype = C.c_void_p
@@ -278,6 +341,13 @@ def planarbike_gains(params, v):
     ku = C.c_double()
     lib().csfo_planarbike_gains(C.byref(params), float(v), _p(kx), C.byref(ku))
     return kx, ku.value
+
+
+def balancingrider_gains(params, v):
+    """K [5] of BalancingRiderDynamics._get_gains at speed v (dynamics.py:600-615)"""
+    k = np.zeros(5)
+    lib().csfo_balancingrider_gains(C.byref(params), float(v), _p(k))
+    return k
 
 
 def expm(A):

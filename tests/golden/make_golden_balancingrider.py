@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Golden vectors for BalancingRiderBicycle (vehicle.py:1953-1990, dynamics.py:261-705, parameters.py:1214-1411), by RUNNING
+the reference where it can be run here.  Test infrastructure; build container only (the GPU box reads the .npz).
+
+What stands in for what (nothing of the reference is copied; it is imported from /root/reference/src by path):
+
+* `controlbehavior.py` (the pole model: a Gaussian mixture over (v, pole features) behind a log / Yeo-Johnson / scaler pipeline)
+  IS the reference's file: it only fails to compile on this container's Python 3.10 because four f-strings reuse their own
+  quote inside a replacement field (legal from 3.12).  `_load_controlbehavior` reads the file, swaps the inner quotes of
+  those lines and executes the result as `cyclistsocialforce.controlbehavior` - every statement that runs is the reference's.
+* `bicycleparameters` (Moore's toolbox: absent, no network) is replaced by a stand-in that forms the canonical matrices
+  M, C1, K0, K2 of the linearised Whipple-Carvallo bicycle from the parameter dictionary with the formulas of Meijaard,
+  Papadopoulos, Ruina & Schwab (2007), Appendix A - what the toolbox implements.  That part of the vectors is therefore
+  pinned to the PAPER, not to the toolbox: `wc_benchmark_*` below are the paper's published matrices (its eq. 5.3 / table 1
+  parameters) and eigenvalues (table 2), typed in from the paper; the stand-in reproduces them to 1e-13.
+* python-control (absent) is make_golden.py's shim: `place` = scipy.signal.place_poles (a single-input placement has one
+  solution), `ctrb`, `ss`, `forced_response`.
+* a no-op drawing, as in make_golden.py.
+
+Usage:  python tests/golden/make_golden_balancingrider.py        (writes tests/golden/balancingrider.npz)
+"""
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SRC = "/root/reference/src"
+sys.path.insert(0, HERE)
+
+
+# ---------------------------------------------------------------------------- Whipple-Carvallo stand-in
+def wc_canonical(p):
+    """Meijaard et al. (2007), Appendix A"""
+    w, c, lam = p["w"], p["c"], p["lam"]
+    rR, mR, IRxx, IRyy = p["rR"], p["mR"], p["IRxx"], p["IRyy"]
+    xB, zB, mB, IBxx, IBzz, IBxz = p["xB"], p["zB"], p["mB"], p["IBxx"], p["IBzz"], p["IBxz"]
+    xH, zH, mH, IHxx, IHzz, IHxz = p["xH"], p["zH"], p["mH"], p["IHxx"], p["IHzz"], p["IHxz"]
+    rF, mF, IFxx, IFyy = p["rF"], p["mF"], p["IFxx"], p["IFyy"]
+    mT = mR + mB + mH + mF
+    xT = (xB * mB + xH * mH + w * mF) / mT
+    zT = (-rR * mR + zB * mB + zH * mH - rF * mF) / mT
+    ITxx = IRxx + IBxx + IHxx + IFxx + mR * rR**2 + mB * zB**2 + mH * zH**2 + mF * rF**2
+    ITxz = IBxz + IHxz - mB * xB * zB - mH * xH * zH + mF * w * rF
+    ITzz = IRxx + IBzz + IHzz + IFxx + mB * xB**2 + mH * xH**2 + mF * w**2
+    mA = mH + mF
+    xA = (xH * mH + w * mF) / mA
+    zA = (zH * mH - rF * mF) / mA
+    IAxx = IHxx + IFxx + mH * (zH - zA)**2 + mF * (rF + zA)**2
+    IAxz = IHxz - mH * (xH - xA) * (zH - zA) + mF * (w - xA) * (rF + zA)
+    IAzz = IHzz + IFxx + mH * (xH - xA)**2 + mF * (w - xA)**2
+    sl, cl = np.sin(lam), np.cos(lam)
+    uA = (xA - w - c) * cl - zA * sl
+    IAll = mA * uA**2 + IAxx * sl**2 + 2 * IAxz * sl * cl + IAzz * cl**2
+    IAlx = -mA * uA * zA + IAxx * sl + IAxz * cl
+    IAlz = mA * uA * xA + IAxz * sl + IAzz * cl
+    mu = c / w * cl
+    SR, SF = IRyy / rR, IFyy / rF
+    ST = SR + SF
+    SA = mA * uA + mu * mT * xT
+    M = np.array([[ITxx, IAlx + mu * ITxz], [IAlx + mu * ITxz, IAll + 2 * mu * IAlz + mu**2 * ITzz]])
+    K0 = np.array([[mT * zT, -SA], [-SA, -SA * sl]])
+    K2 = np.array([[0.0, (ST - mT * zT) / w * cl], [0.0, (SA + SF * sl) / w * cl]])
+    C1 = np.array([[0.0, mu * ST + SF * cl + ITxz / w * cl - mu * mT * zT],
+                   [-(mu * ST + SF * cl), IAlz / w * cl + mu * (SA + ITzz / w * cl)]])
+    return M, C1, K0, K2
+
+
+class ParameterSetStandIn:
+    def __init__(self, par_dict, *a, **k):
+        self.parameters = dict(par_dict)
+
+
+class ModelStandIn:
+    def __init__(self, parameter_set):
+        self.parameter_set = parameter_set
+
+    def form_reduced_canonical_matrices(self, **over):
+        return wc_canonical(dict(self.parameter_set.parameters, **over))
+
+    def form_state_space_matrices(self, **over):
+        p = dict(self.parameter_set.parameters, **over)
+        M, C1, K0, K2 = wc_canonical(p)
+        Minv = np.linalg.inv(M)
+        A = np.zeros((4, 4))
+        A[0:2, 2:4] = np.eye(2)
+        A[2:4, 0:2] = -Minv @ (p["g"] * K0 + p["v"]**2 * K2)
+        A[2:4, 2:4] = -Minv @ (p["v"] * C1)
+        B = np.zeros((4, 2))
+        B[2:4, :] = Minv
+        return A, B
+
+
+# the benchmark of the paper: parameters (table 1), matrices (eq. 5.3) and eigenvalues (table 2), typed in from the paper
+BENCHMARK = dict(w=1.02, c=0.08, lam=np.pi / 10, g=9.81, v=1.0, rR=0.3, mR=2.0, IRxx=0.0603, IRyy=0.12, xB=0.3, zB=-0.9, mB=85.0,
+                 IBxx=9.2, IBxz=2.4, IByy=11.0, IBzz=2.8, xH=0.9, zH=-0.7, mH=4.0, IHxx=0.05892, IHxz=-0.00756, IHyy=0.06,
+                 IHzz=0.00708, rF=0.35, mF=3.0, IFxx=0.1405, IFyy=0.28)
+BENCHMARK_NAMES = sorted(BENCHMARK)
+PAPER_M = np.array([[80.81722, 2.31941332208709], [2.31941332208709, 0.29784188199686]])
+PAPER_K0 = np.array([[-80.95, -2.59951685249872], [-2.59951685249872, -0.80329488458618]])
+PAPER_K2 = np.array([[0.0, 76.59734589573222], [0.0, 2.65431523794604]])
+PAPER_C1 = np.array([[0.0, 33.86641391492494], [-0.85035641456978, 1.68540397397560]])
+PAPER_EIG = {0.0: [-5.53094371765393, -3.13164324790656, 3.13164324790656, 5.53094371765393],
+             5.0: [-14.07838969279822, -0.77534188219585 - 4.46486771378823j, -0.77534188219585 + 4.46486771378823j, -0.32286642900409],
+             10.0: [-24.62459635017404, -3.72016840437287 - 10.90681139476287j, -3.72016840437287 + 10.90681139476287j, 0.16105338653172]}
+
+
+def _install():
+    import make_golden  # noqa: F401  (its stand-ins for pypaperutils / mypyutils / control; imports the reference package)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("bicycleparameters")
+    mod("bicycleparameters.parameter_dicts", meijaard2007_browser_jason=dict(BENCHMARK))
+    mod("bicycleparameters.parameter_sets", Meijaard2007ParameterSet=ParameterSetStandIn)
+    mod("bicycleparameters.models", Meijaard2007Model=ModelStandIn)
+    import yaml
+
+    sys.modules["mypyutils.io"].read_yaml = lambda path, *a, **k: yaml.safe_load(open(path))
+    # the reference's own controlbehavior.py, made to compile on Python 3.10 (see the module docstring)
+    path = os.path.join(REF_SRC, "cyclistsocialforce", "controlbehavior.py")
+    lines = []
+    for line in open(path).read().split("\n"):
+        if re.search(r'f"[^"]*\{[^}"]*"[^"]*"[^}]*\}', line):
+            line = re.sub(r'\[\s*"([^"\]]*)"\s*\]', r"['\1']", line)
+        lines.append(line)
+    cb = types.ModuleType("cyclistsocialforce.controlbehavior")
+    cb.__file__ = path
+    exec(compile("\n".join(lines), path, "exec"), cb.__dict__)
+    sys.modules["cyclistsocialforce.controlbehavior"] = cb
+    # the modules make_golden imported with the empty stand-ins see the real ones from now on
+    import importlib
+
+    import cyclistsocialforce.parameters as rp
+
+    importlib.reload(rp)
+    import cyclistsocialforce.dynamics as rd
+
+    importlib.reload(rd)
+    import cyclistsocialforce.vehicle as rv
+
+    importlib.reload(rv)
+    import cyclistsocialforce.intersection as ri
+
+    importlib.reload(ri)
+    return rp, rd, rv, ri, make_golden
+
+
+def main():
+    rp, rd, rv, ri, mg = _install()
+    out = {}
+    # (1) canonical matrices: the paper's benchmark (typed in) and the reference's default bicycle
+    out["wc_benchmark_params"] = np.array([BENCHMARK[k] for k in BENCHMARK_NAMES])
+    out["wc_benchmark_names"] = np.array(BENCHMARK_NAMES)
+    for k, v in (("M", PAPER_M), ("K0", PAPER_K0), ("K2", PAPER_K2), ("C1", PAPER_C1)):
+        out[f"wc_benchmark_{k}"] = v
+    out["wc_benchmark_eig_v"] = np.array(sorted(PAPER_EIG))
+    out["wc_benchmark_eig"] = np.array([np.sort_complex(np.array(PAPER_EIG[v], dtype=complex)) for v in sorted(PAPER_EIG)])
+    M, C1, K0, K2 = wc_canonical(BENCHMARK)
+    for a, b in ((M, PAPER_M), (C1, PAPER_C1), (K0, PAPER_K0), (K2, PAPER_K2)):
+        assert np.abs(a - b).max() < 1e-12, (a, b)
+    from cyclistsocialforce.data.bicycleparams.balanceassist_bikeparams import balanceassistv1_with_averagerider as default_bike
+
+    names = sorted(default_bike)
+    out["default_bike_names"] = np.array(names)
+    out["default_bike_params"] = np.array([default_bike[k] for k in names])
+    # (2) the pole models: component mean functions, linear in speed (parameters.py:1352-1411; controlbehavior.py:1583-1650)
+    for fname in ("BR0_ImRe5GivenV_pole-model-params.yaml", "BR1_ImRe5GivenV_pole-model-params.yaml"):
+        p = rp.BalancingRiderBicycleParameters(controlparam_filename=fname)
+        coef = p.polemodel.get_component_mean_function_params()       # [components, features, (intercept, coefficient)]
+        tag = fname[:3]
+        out[f"polefun_{tag}"] = coef
+        vs = np.array([1.5, 2.5, 4.0, 5.5, 6.5])
+        poles = []
+        for v in vs:
+            p.update_control_params(v)
+            poles.append(np.array(p.poles, dtype=complex))
+        out[f"poles_{tag}_v"] = vs
+        out[f"poles_{tag}"] = np.array(poles)
+    # (3) gains by pole placement at a few speeds (dynamics.py:600-615), default parameters
+    s0 = np.array([0.0, 0.0, 0.3, 4.0, 0.0, 0.0, 0.0, 0.0])
+    bike = rv.BalancingRiderBicycle(tuple(s0))
+    bike.drawing = mg._NoDrawing()
+    dyn = bike.dynamics if hasattr(bike, "dynamics") else None
+    if dyn is None:
+        raise SystemExit("BalancingRiderBicycle has no dynamics attribute")
+    gv = np.array([2.0, 3.0, 4.0, 5.0, 6.0, 6.9])
+    out["gains_v"] = gv
+    out["gains"] = np.array([np.asarray(dyn._get_gains(v)).flatten() for v in gv])
+    A, B, _, _ = dyn.get_statespace_matrices(4.0)
+    out["ss_A_v4"] = A
+    out["ss_B_v4"] = B
+    # (4) closed loop on given forces, one vehicle: state after every step (dynamics.py:664-705)
+    rng = np.random.default_rng(11)
+    T = 120
+    F = np.c_[4.5 + rng.normal(0, 0.4, T), rng.normal(0, 1.2, T)]
+    bike = rv.BalancingRiderBicycle((1.0, 2.0, -0.4, 3.5, 0.02, -0.01, 0.05, 0.02))
+    bike.drawing = mg._NoDrawing()
+    S = [bike.s.copy()]
+    X = [bike.dynamics.x.copy()]
+    for t in range(T):
+        bike.step(F[t, 0], F[t, 1])
+        S.append(np.array(bike.s, dtype=float).copy())
+        X.append(np.array(bike.dynamics.x, dtype=float).copy())
+    out["steps_F"] = F
+    out["steps_S"] = np.array(S)
+    out["steps_X"] = np.array(X)
+    # (5) populations through the literal SocialForceIntersection.step: the demo geometry and a dense crowd
+    def run(vs, ticks, every=10):
+        for v in vs:
+            v.drawing = mg._NoDrawing()
+        ins = ri.SocialForceIntersection(vs)
+        n = len(vs)
+        S = np.zeros((ticks // every + 1, n, 8))
+        S[0] = np.array([v.s for v in vs])
+        for tk in range(ticks):
+            ins.step()
+            if (tk + 1) % every == 0:
+                S[(tk + 1) // every] = np.array([v.s for v in vs])
+        return S
+
+    def population(n, box, seed):
+        rng = np.random.default_rng(seed)
+        vs = []
+        for k in range(n):
+            x, y, psi, v = rng.uniform(0, box), rng.uniform(0, box), rng.uniform(-np.pi, np.pi), rng.uniform(3.5, 5.5)
+            b = rv.BalancingRiderBicycle((x, y, psi, v, 0.0, 0.0, 0.0, 0.0), id=f"b{k}")
+            d = np.array([12.0, 30.0, 60.0])
+            b.setDestinations(x + d * np.cos(psi), y + d * np.sin(psi))
+            vs.append(b)
+        return vs
+
+    vs = population(3, 12.0, 5)
+    out["demo_s0"] = np.array([v.s for v in vs])
+    out["demo_vdes"] = np.array([v.params.v_desired_default for v in vs])
+    out["demo_off"] = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
+    out["demo_dq"] = np.vstack([v.destqueue for v in vs])
+    out["demo_S"] = run(vs, 300)
+    vs = population(16, 30.0, 6)
+    out["dense_s0"] = np.array([v.s for v in vs])
+    out["dense_vdes"] = np.array([v.params.v_desired_default for v in vs])
+    out["dense_off"] = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
+    out["dense_dq"] = np.vstack([v.destqueue for v in vs])
+    out["dense_S"] = run(vs, 200)
+    np.savez(os.path.join(HERE, "balancingrider.npz"), **out)
+    print("wrote balancingrider.npz:", {k: np.shape(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -288,3 +288,71 @@ def test_uncontrolled_vehicle_among_cyclists_golden(golden):
         fx, fy = pop.forces()
         np.testing.assert_allclose(np.c_[fx, fy], F[k - 1], rtol=0, atol=1e-9, err_msg=f"forces of sample {k}")
     assert np.array_equal(S[-1, -1], np.zeros(6)) and abs(S[-1, -2, 1] - (-7.0 + 5.0 * 1.79)) < 1e-12
+
+
+# ------------------------------------------------------------------ BalancingRiderBicycle
+def test_whipple_carvallo_matrices_against_the_paper(golden):
+    """The canonical matrices of the linearised Whipple-Carvallo bicycle (parameters.py:1284-1300 takes them from
+    bicycleparameters, which is absent here): the formulas of Meijaard, Papadopoulos, Ruina & Schwab (2007), Appendix A, against
+    the paper's own benchmark - M, C1, K0, K2 of its table-1 bicycle and the eigenvalues of its table 2, typed in from the paper
+    (tests/golden/make_golden_balancingrider.py)."""
+    g = golden("balancingrider")
+    bench = dict(zip([str(k) for k in g["wc_benchmark_names"]], [float(v) for v in g["wc_benchmark_params"]]))
+    M, C1, K0, K2 = orc.whipple_carvallo(bench)
+    for got, name in ((M, "M"), (C1, "C1"), (K0, "K0"), (K2, "K2")):
+        np.testing.assert_allclose(got, g[f"wc_benchmark_{name}"], rtol=0, atol=2e-13, err_msg=name)
+    Minv = np.linalg.inv(M)
+    for v, want in zip(g["wc_benchmark_eig_v"], g["wc_benchmark_eig"]):
+        A = np.zeros((4, 4))
+        A[0:2, 2:4] = np.eye(2)
+        A[2:4, 0:2] = -Minv @ (bench["g"] * K0 + v * v * K2)
+        A[2:4, 2:4] = -Minv @ (v * C1)
+        np.testing.assert_allclose(np.sort_complex(np.linalg.eigvals(A)), want, rtol=0, atol=2e-12, err_msg=f"v = {v}")
+
+
+def test_balancingrider_pole_functions_against_the_reference_polemodel(golden):
+    """parameters.py:1352-1411 -> controlbehavior.py PoleModel.get_component_mean_function: the straight lines over speed that
+    give a rider's desired poles, computed by the host package's restatement (polemodel.py) from the reference's model files
+    where those are at hand (the build container), and its tabulated copy of them, against what the reference's own PoleModel
+    returned (make_golden_balancingrider.py executes the reference's controlbehavior.py)."""
+    import os
+
+    from cyclistsocialforce_amd import polemodel as pm
+
+    g = golden("balancingrider")
+    for tag in ("BR0", "BR1"):
+        name = f"{tag}_ImRe5GivenV_pole-model-params.yaml"
+        np.testing.assert_allclose(pm.MEAN_FUNCTIONS[name], g[f"polefun_{tag}"], rtol=0, atol=1e-13)
+        path = os.path.join("/root/reference/src/cyclistsocialforce/data/balancingriderparams", name)
+        if os.path.exists(path):
+            np.testing.assert_allclose(pm.component_mean_functions(path), g[f"polefun_{tag}"], rtol=0, atol=1e-13)
+        for v, want in zip(g[f"poles_{tag}_v"], g[f"poles_{tag}"]):
+            np.testing.assert_allclose(pm.poles_at(pm.MEAN_FUNCTIONS[name][0], v), want, rtol=0, atol=1e-12)
+
+
+def test_balancingrider_gains_and_steps_against_the_reference(golden):
+    """dynamics.py:600-615 (pole placement per speed: the reference calls control.place = scipy.signal.place_poles under the
+    golden script's shim; the oracle uses Ackermann's formula - one input, one solution) and :664-705 (the implicit midpoint
+    step, which the reference solves with MINPACK and the oracle as the linear system it is): gains at six speeds, and one
+    vehicle on 120 prescribed forces, state for state."""
+    g = golden("balancingrider")
+    P = orc.default_params("balancingrider")
+    for v, K in zip(g["gains_v"], g["gains"]):
+        np.testing.assert_allclose(orc.balancingrider_gains(P, v), K, rtol=1e-11, atol=1e-12, err_msg=f"v = {v}")
+    S, F = g["steps_S"], g["steps_F"]
+    pop = orc.Population(P, S[:1], 5.0, np.array([0, 1]), np.array([[S[0, 0], S[0, 1], 0.0]]))
+    for t in range(F.shape[0]):
+        pop.apply_forces(F[t:t + 1, 0], F[t:t + 1, 1])
+        np.testing.assert_allclose(pop.state()[0], S[t + 1], rtol=0, atol=1e-10, err_msg=f"step {t}")
+
+
+@pytest.mark.parametrize("tag", ["demo", "dense"])
+def test_balancingrider_population_trajectories(golden, tag):
+    """three and sixteen BalancingRiderBicycles through the literal SocialForceIntersection.step (TwoD field, direct-approach
+    destination force, vehicle.py:1953-1990): 300 / 200 ticks, every tenth state"""
+    g = golden("balancingrider")
+    pop = orc.Population(orc.default_params("balancingrider"), g[f"{tag}_s0"], g[f"{tag}_vdes"], g[f"{tag}_off"], g[f"{tag}_dq"])
+    S = g[f"{tag}_S"]
+    for k in range(1, S.shape[0]):
+        pop.step(10)
+        np.testing.assert_allclose(pop.state(), S[k], rtol=0, atol=1e-9, err_msg=f"sample {k}")
