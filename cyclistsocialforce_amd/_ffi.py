@@ -10,9 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # CSF_LIB selects another build of the same library (kernel A/B measurements, tools/ab.sh)
 LIB_PATH = os.environ.get("CSF_LIB") or os.path.join(HERE, "libcsf_hip.so")
 
-BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE, UNCONTROLLED = 0, 1, 2, 3, 4, 5
+BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE, UNCONTROLLED, BALANCINGRIDER = 0, 1, 2, 3, 4, 5, 6
 UNREGULATED, P2R = 0, 1
-N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5, UNCONTROLLED: 4}
+N_STATES = {BICYCLE: 5, TWOD: 5, INVPEND: 6, PLANARPOINT: 4, PLANARBIKE: 5, UNCONTROLLED: 4, BALANCINGRIDER: 8}
 UNIQUE_ID_BYTES = 128
 ST_SPLINE, ST_NAN, ST_NAVSTATE, ST_UNCONTROLLABLE = 1, 2, 4, 8
 
@@ -47,7 +47,9 @@ class Params(C.Structure):
         ("i_steer_vertvert", C.c_double), ("c_steer", C.c_double),
         ("v_max_walk", C.c_double), ("delta_max_walk", C.c_double),
         ("k_psi", C.c_double), ("pb_poles", C.c_double * 4),
-        ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("reserved", C.c_int32),
+        ("br_minv_k0g", C.c_double * 4), ("br_minv_k2", C.c_double * 4), ("br_minv_c1", C.c_double * 4),
+        ("br_minv_steer", C.c_double * 2), ("br_yaw", C.c_double * 2), ("br_pole_fun", C.c_double * 10), ("br_gains", C.c_double * 5),
+        ("model", C.c_int32), ("priority_rule", C.c_int32), ("traj_len", C.c_int32), ("br_mode", C.c_int32),
     ]
 
 
@@ -133,7 +135,7 @@ def load():
     L.csf_mid_ticks.argtypes = [vp, C.POINTER(i64)]
     L.csf_get_integrator_state.argtypes = [vp, dp, dp, vp]
     L.csf_set_integrator_state.argtypes = [vp, i64, vp, dp, dp, vp]
-    if L.csf_abi_version() != 7:
-        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 7")
+    if L.csf_abi_version() != 8:
+        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 8")
     _lib = L
     return L

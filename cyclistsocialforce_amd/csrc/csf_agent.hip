@@ -204,9 +204,10 @@ void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0, hipEv
     else hipExtLaunchKernelGGL((agent_kernel<MODEL, false>), g, b, 0, st, t0, t1, 0, d, phases)
     // every vehicle class of the population in turn (one, unless csf_set_param_classes installed sets of several classes;
     // the launches touch disjoint agents).  The time stamps bracket the first launch.
-    for (int m = 0; m < 6; m++) {
+    for (int m = 0; m < 7; m++) {
         if (!(d.model_mask >> m & 1)) continue;
         switch (m) {
+        case CSF_BALANCINGRIDER: CSF_AGENT(CSF_BALANCINGRIDER); break;
         case CSF_UNCONTROLLED: CSF_AGENT(CSF_UNCONTROLLED); break;
         case CSF_BICYCLE: CSF_AGENT(CSF_BICYCLE); break;
         case CSF_TWOD: CSF_AGENT(CSF_TWOD); break;
@@ -341,10 +342,10 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         const int64_t a = r.slot;
         const csf_params &p = d.ptab[r.cls];
         d.cls[a] = (uint8_t)r.cls;
-        double s[6];
-        for (int c = 0; c < 6; c++) s[c] = c < d.ns ? r.s[c] : 0.0;
+        double s[STATE_ROWS];
+        for (int c = 0; c < STATE_ROWS; c++) s[c] = c < d.ns ? r.s[c] : 0.0;
         s[2] = limit_angle(s[2]);                                  // vehicle.py:154-155
-        for (int c = 0; c < 6; c++) d.s[c * cap + a] = s[c];
+        for (int c = 0; c < STATE_ROWS; c++) d.s[c * cap + a] = s[c];
         d.vdes[a] = r.vdes;
         d.qbeg[a] = r.qbeg;
         d.qlen[a] = r.qlen;
@@ -363,6 +364,14 @@ __global__ __launch_bounds__(256) void patch_kernel(const Dev d, const PatchHead
         d.zrid[a] = s[3] < p.v_max_walk ? 0 : 1;                   // vehicle.py:1732-1736
         d.dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
         d.ppsi[a] = s[2];                                          // dynamics.py:828, 987-993
+        if (p.model == CSF_BALANCINGRIDER) {                       // dynamics.py:306-307, 350-371: (roll, steer, rates, yaw) mirrored
+            d.lti[0 * cap + a] = s[5];
+            d.lti[1 * cap + a] = -s[4];
+            d.lti[2 * cap + a] = s[7];
+            d.lti[3 * cap + a] = -s[6];
+            d.lti[4 * cap + a] = -s[2];
+            d.ppsi[a] = s[3];                                      // the speed its first gains belong to
+        }
         d.slen[a] = 0;                                             // (no prescribed trajectory until csf_set_script gives one)
         for (int c = 0; c < 6; c++) d.F[c * cap + a] = 0.0;
         d.status[a] = 0;

@@ -466,7 +466,10 @@ template <int MODEL>
 __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, double &fy) {
     if (MODEL == CSF_UNCONTROLLED) fx = 0, fy = 0;            // vehicle.py:987-988
     else if (MODEL == CSF_BICYCLE) direct_approach(d, g, fx, fy);  // vehicle.py:1189-1194
-    else {
+    else if (MODEL == CSF_BALANCINGRIDER) {                   // vehicle.py:295-297, then calc_direct_approach_dest_force (:1987-1988, 2078-2108)
+        update_destination(d, g);
+        direct_approach(d, g, fx, fy);
+    } else {
         if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) update_destination(d, g);  // Vehicle.calcDestinationForce :295-297
         twod_dest(d, g, fx, fy);
     }
@@ -630,6 +633,179 @@ __device__ __forceinline__ void invpend_step_yaw(const Dev &d, Agent &g, double 
     g.theta = limit_angle_m(xn[2]);                           // :1846
 }
 
+// ---- BalancingRiderBicycle: the Whipple-Carvallo bicycle under full-state feedback (dynamics.py:261-705) -----------------
+// x = (roll, steer, roll rate, steer rate, yaw) in the bike model's frame (y to the right, z down: steer, yaw and y mirrored
+// against the engine's, :318-371), unwrapped, in g.xl; the speed the gains in use belong to in g.ppsi.
+// the state matrix at speed v (:535-560) and the steer-torque input column
+__device__ __forceinline__ void br_state_space(const csf_params &p, double v, double (&A)[5][5], double (&B)[5]) {
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) A[r][c] = 0.0;
+    A[0][2] = 1.0;
+    A[1][3] = 1.0;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            A[2 + r][c] = -(p.br_minv_k0g[2 * r + c] + v * v * p.br_minv_k2[2 * r + c]);
+            A[2 + r][2 + c] = -v * p.br_minv_c1[2 * r + c];
+        }
+    A[4][1] = p.br_yaw[0] * v;                                // :549
+    A[4][3] = p.br_yaw[1];                                    // :550
+    B[0] = B[1] = B[4] = 0.0;
+    B[2] = p.br_minv_steer[0];
+    B[3] = p.br_minv_steer[1];
+}
+
+// M x = b for five unknowns, elimination with partial pivoting on registers (rows swapped by selects: an indexed per-lane array
+// would go to scratch memory); false: singular
+__device__ __forceinline__ bool solve5(double (&M)[5][5], double (&b)[5]) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+#pragma unroll
+        for (int r = k + 1; r < 5; r++) {                     // bring the larger of rows k and r to k
+            const bool sw = fabs(M[r][k]) > fabs(M[k][k]);
+#pragma unroll
+            for (int c = k; c < 5; c++) {
+                const double t = M[k][c];
+                M[k][c] = sw ? M[r][c] : t;
+                M[r][c] = sw ? t : M[r][c];
+            }
+            const double t = b[k];
+            b[k] = sw ? b[r] : t;
+            b[r] = sw ? t : b[r];
+        }
+        ok = ok && M[k][k] != 0.0;
+        const double ip = 1.0 / M[k][k];
+#pragma unroll
+        for (int r = k + 1; r < 5; r++) {
+            const double f = M[r][k] * ip;
+#pragma unroll
+            for (int c = k; c < 5; c++) M[r][c] -= f * M[k][c];
+            b[r] -= f * b[k];
+        }
+    }
+#pragma unroll
+    for (int k = 4; k >= 0; k--) {
+        double acc = b[k];
+#pragma unroll
+        for (int c = k + 1; c < 5; c++) acc -= M[k][c] * b[c];
+        b[k] = acc / M[k][k];
+    }
+    return ok;
+}
+
+// dynamics.py:600-615: the gains that put the closed loop's poles where the control model wants them at speed v - one input, so
+// the placement has one solution (the reference calls control.place): Ackermann's K = e_5^T W^-1 p(A), W = (B, A B, ..., A^4 B),
+// p the polynomial of the desired poles, applied to the row e_5^T W^-1 from the left as (A - p0) and (A^2 - 2 Re p A + |p|^2)
+__device__ __forceinline__ bool br_gains(const csf_params &p, double v, double (&K)[5]) {
+    if (p.br_mode == 2) {                                     // :604-605
+#pragma unroll
+        for (int k = 0; k < 5; k++) K[k] = p.br_gains[k];
+        return true;
+    }
+    double f[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) f[i] = p.br_pole_fun[2 * i] + p.br_pole_fun[2 * i + 1] * v;   // parameters.py:1400-1409
+    double A[5][5], B[5], W[5][5], col[5], y[5];
+    br_state_space(p, v, A, B);
+#pragma unroll
+    for (int r = 0; r < 5; r++) col[r] = B[r];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {                             // W^T: row k = (A^k B)^T
+        double nxt[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            W[k][r] = col[r];
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 5; c++) acc += A[r][c] * col[c];
+            nxt[r] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < 5; r++) col[r] = nxt[r];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) y[k] = k == 4 ? 1.0 : 0.0;    // W^T y = e_5
+    const bool ok = solve5(W, y);
+    auto row_times_A = [&](const double (&in)[5], double (&out)[5]) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < 5; r++) acc += in[r] * A[r][c];
+            out[c] = acc;
+        }
+    };
+    double t1[5], t2[5];
+    row_times_A(y, t1);
+#pragma unroll
+    for (int c = 0; c < 5; c++) y[c] = t1[c] - f[0] * y[c];
+#pragma unroll
+    for (int pair = 0; pair < 2; pair++) {
+        const double re = f[1 + 2 * pair], im = f[2 + 2 * pair];
+        row_times_A(y, t1);
+        row_times_A(t1, t2);
+#pragma unroll
+        for (int c = 0; c < 5; c++) y[c] = t2[c] - 2.0 * re * t1[c] + (re * re + im * im) * y[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) K[k] = y[k];
+    return ok;
+}
+
+// BalancingRiderDynamics.step (dynamics.py:664-705): speed, gains (renewed only when the speed has changed, :671-673), commanded
+// yaw, and the implicit midpoint rule (:497-513) on x' = (A - B K) x + B K_psi psi_c - a linear system in x+ (the reference
+// hands the seven equations to MINPACK); the position follows from the yaw at both ends of the step.  dr[2]: steer rate, roll rate
+// in the engine's frame.
+__device__ __forceinline__ void balancingrider_step(const Dev &d, Agent &g, double *xl, double Fx, double Fy, double (&dr)[2]) {
+    const csf_params &p = *g.p;
+    const double h = p.t_s, v_old = g.v;
+    const double vd = qsqrt(Fx * Fx + Fy * Fy);                                   // :640
+    const double acc = clampd(p.k_p_v * (vd - v_old), p.a_max[0], p.a_max[1]);   // :643-644
+    const double v = clampd(v_old + h * acc, p.v_max_riding[0], p.v_max_riding[1]);   // :647
+    if (v != v_old) g.ppsi = 0.5 * (v + v_old);                                   // :671-673
+    double K[5];
+    bool ok = br_gains(p, g.ppsi, K);
+    const double psi_F = limit_angle(atan2(-Fy, Fx));                             // :656-658 (the lateral force mirrored)
+    const double psi_c = xl[4] + angle_diff(xl[4], psi_F);                        // :660-663
+    const double vbar = 0.5 * (v + v_old);                                        // :684, 687
+    double A[5][5], B[5], L[5][5], rhs[5];
+    br_state_space(p, vbar, A, B);
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        double accr = xl[r] + h * B[r] * K[4] * psi_c;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const double acl = A[r][c] - B[r] * K[c];                             // :472
+            L[r][c] = (r == c ? 1.0 : 0.0) - 0.5 * h * acl;
+            accr += 0.5 * h * acl * xl[c];
+        }
+        rhs[r] = accr;
+    }
+    ok = solve5(L, rhs) && ok;
+    if (!ok) {
+        g.st |= CSF_ST_NAN;                                   // (the reference: "System not controllable!" / a failed root find)
+        dr[0] = -xl[3];
+        dr[1] = xl[2];
+        return;
+    }
+    double sm, cm;
+    qsincos_any(0.5 * (xl[4] + rhs[4]), &sm, &cm);
+    g.x += h * vbar * cm;                                     // :475-477; :337-348 back to the engine's frame
+    g.y -= h * vbar * sm;
+#pragma unroll
+    for (int k = 0; k < 5; k++) xl[k] = rhs[k];
+    g.psi = -limit_angle(xl[4]);
+    g.v = v;
+    g.delta = -limit_angle(xl[1]);
+    g.theta = limit_angle(xl[0]);
+    dr[0] = -xl[3];
+    dr[1] = xl[2];
+}
+
 __device__ __forceinline__ int64_t a_idx(int c, int64_t cap, int64_t a) { return (int64_t)c * cap + a; }
 
 template <int MODEL>
@@ -694,6 +870,16 @@ __device__ __forceinline__ void integrate(const Dev &d, Agent &g, double Fx, dou
         }
 #pragma unroll
         for (int k = 0; k < 5; k++) d.lti[k * cap + a] = xl[k];
+    } else if (MODEL == CSF_BALANCINGRIDER) {                 // vehicle.py:301-328 with BalancingRiderDynamics.step
+        double xl[5], dr[2];
+#pragma unroll
+        for (int k = 0; k < 5; k++) xl[k] = g.xl[k];
+        balancingrider_step(d, g, xl, Fx, Fy, dr);
+#pragma unroll
+        for (int k = 0; k < 5; k++) d.lti[k * cap + a] = xl[k];
+        d.ppsi[a] = g.ppsi;
+        d.s[6 * cap + a] = dr[0];                             // steer rate, roll rate: columns 6, 7 of vehicle.s (vehicle.py:1960)
+        d.s[7 * cap + a] = dr[1];
     } else if (MODEL == CSF_PLANARBIKE) {                     // PlanarTwoWheelerDynamics.step: dynamics.py:225-258
         // x = (delta, psi) follows x' = (A - B K_x) x + B K_u psi_d with A = [[0, 0], [v / l, 0]], B = (1, 0)^T, K_x placed
         // for the class's two poles and K_u from a simulated step response, both re-derived for the current speed every
@@ -863,14 +1049,16 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     }
     const float2 froad = d.froad[a];
     const float2 rorg = d.rorg[a];                             // (for the record written at the end)
-    if (MODEL == CSF_INVPEND) {                                // (side-state of the model: with the first round trip, not the fourth)
+    if (MODEL == CSF_INVPEND || MODEL == CSF_BALANCINGRIDER) {   // (side-state of the model: with the first round trip, not the fourth)
 #pragma unroll
         for (int k = 0; k < 5; k++) g.xl[k] = d.lti[(int64_t)k * cap + a];
+    }
+    if (MODEL == CSF_INVPEND) {
         g.riding = d.zrid[a] != 0;
         g.dgood = d.dgood[a];
     }
     if (MODEL == CSF_PLANARBIKE) g.xl[0] = d.lti[a];
-    if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) g.ppsi = d.ppsi[a];
+    if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE || MODEL == CSF_BALANCINGRIDER) g.ppsi = d.ppsi[a];
     load_rows(d, g);                                           // the second and last round trip of the common path
     if (PLANNER && (phases & PH_DEST)) load_ring(d, g);
     // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge wait in a ring

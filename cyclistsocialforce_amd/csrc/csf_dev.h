@@ -81,6 +81,8 @@ struct SegDev {
     int32_t first_by;        // its first source chunk in the grid's y dimension
 };
 
+constexpr int STATE_ROWS = 8;   // rows of the state array: the widest vehicle.s (BalancingRiderBicycle, vehicle.py:1959-1960)
+
 // All arrays have `cap` elements per component unless noted; component c of agent a is at [c*cap + a].
 struct Dev {
     csf_params p;
@@ -122,7 +124,7 @@ struct Dev {
     double ox, oy;     // origin of the scene: what the batch origins (org) and the bounding circles (bnd) are relative to
     int64_t tick;
 
-    double *s;         // [6][cap]  x, y, psi, v, delta, theta
+    double *s;         // [STATE_ROWS][cap]  x, y, psi, v, delta, theta (roll), + BalancingRider: steer rate, roll rate
     double *vdes;      // [cap]
     int64_t *qbeg;     // [cap] first row of the agent's destination queue in q
     int32_t *qlen;     // [cap] rows of it
@@ -310,7 +312,7 @@ int launch_receiver_list(const Dev &d, uint32_t *keys, int32_t *rlist_out, void 
 struct SpawnRec {      // one new road user (Vehicle.__init__, vehicle.py:64-204)
     int32_t slot, qlen;
     int64_t qbeg;
-    double s[6], vdes;
+    double s[STATE_ROWS], vdes;
     int32_t cls, pad;  // its parameter set (csf_set_agent_class before the batch reaches the device)
 };
 struct QueueRec {      // one replaced destination queue (Vehicle.setDestinations, vehicle.py:606-647)

@@ -388,7 +388,7 @@ int fail(csf_engine *e, int code, const char *fmt, ...) {
             return fail(e, CSF_E_COMM, "%s failed: %s", #call, g_rccl.GetErrorString(_r));        \
     } while (0)
 
-const int NS_OF[6] = {5, 5, 6, 4, 5, 4};
+const int NS_OF[7] = {5, 5, 6, 4, 5, 4, 8};
 // Ticks between two re-binnings.  The circles of the batches are renewed EVERY tick from the positions as they are (the pair
 // kernel emits them), so a stale order costs only what the batches' members drift apart: the pair kernel takes the same
 // 105 us with 32, 48 and 64 ticks and 0.3 - 0.5 us more with 96 / 128, while the re-binning itself (~40 us of sort, rebase
@@ -406,7 +406,7 @@ double limit_angle_h(double th) {  // utils.py:124-139 (host: Vehicle.__init__, 
 
 int check_params(csf_engine *e, const csf_params *p) {
     if (!p) return fail(e, CSF_E_ARG, "params is NULL");
-    if (p->model < 0 || p->model > 5) return fail(e, CSF_E_ARG, "unknown model %d", p->model);
+    if (p->model < 0 || p->model > 6) return fail(e, CSF_E_ARG, "unknown model %d", p->model);
     if (p->model == CSF_PLANARBIKE) {
         const double sum_im = p->pb_poles[1] + p->pb_poles[3], prod_im = p->pb_poles[0] * p->pb_poles[3] + p->pb_poles[1] * p->pb_poles[2];
         if (std::fabs(sum_im) > 1e-12 || std::fabs(prod_im) > 1e-12 || !(p->pb_poles[0] < 0) || !(p->pb_poles[2] < 0))
@@ -815,7 +815,7 @@ int build_road_grid(csf_engine *e, const double box[4]) {
 int alloc_all(csf_engine *e) {
     const size_t cap = (size_t)e->cap;
     const size_t hl = (size_t)e->d.hist_len;
-    HIPCHK(e, e->s.alloc(6 * cap));
+    HIPCHK(e, e->s.alloc(STATE_ROWS * cap));
     HIPCHK(e, e->vdes.alloc(cap));
     HIPCHK(e, e->qbeg.alloc(cap));
     HIPCHK(e, e->qlen.alloc(cap));
@@ -862,7 +862,7 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->sort_keys.alloc(nrec));
     HIPCHK(e, e->sort_keys_out.alloc(nrec));
     HIPCHK(e, e->sort_tmp.alloc(bin_temp_bytes((int64_t)nrec) + 256));
-    e->h_s.assign(6 * cap, 0.0);
+    e->h_s.assign(STATE_ROWS * cap, 0.0);
     e->h_vdes.assign(cap, 0.0);
     e->h_znp.assign(3 * cap, 0.0);
     e->h_hx.assign(hl * cap, 0.0);
@@ -1332,7 +1332,7 @@ void compact_host(csf_engine *e) {
             for (int64_t c = 0; c < comps; c++)
                 for (int64_t i = 0; i < n; i++) vec[(size_t)(c * cap + i)] = old[(size_t)(c * cap + e->order[(size_t)i])];
         };
-        gather(e->h_s, 6); gather(e->h_F, 6); gather(e->h_znp, 3); gather(e->h_lti, 5);
+        gather(e->h_s, STATE_ROWS); gather(e->h_F, 6); gather(e->h_znp, 3); gather(e->h_lti, 5);
         gather(e->h_hx, hl); gather(e->h_hy, hl);
         gather(e->h_vdes, 1); gather(e->h_ppsi, 1); gather(e->h_ptr, 1); gather(e->h_ti, 1); gather(e->h_dgood, 1);
         gather(e->h_znav, 1); gather(e->h_zrid, 1); gather(e->h_status, 1); gather(e->h_cls, 1);
@@ -1915,6 +1915,33 @@ int csf_destroy(csf_engine *e) {
 int64_t csf_num_agents(const csf_engine *e) { return e ? (int64_t)e->order.size() : 0; }
 int32_t csf_num_states(const csf_engine *e) { return e ? e->d.ns : 0; }
 
+// What a road user's constructor makes of vehicle.s beside it, with the limits of ITS parameter set: the state of the rider
+// model's integrator and the riding / walking state (vehicle.py:1728-1736; dynamics.py:195-197, 828, 987-993).  For a
+// BalancingRiderBicycle (dynamics.py:306-307, 350-371): roll, steer, their rates and the yaw in the bike model's frame
+// (steer, yaw mirrored), and the speed its first gains belong to.
+static void side_state(csf_engine *e, size_t a, const csf_params &p) {
+    const size_t cap = (size_t)e->cap;
+    const double *s = e->h_s.data() + a;
+    const double delta = s[4 * cap];
+    e->h_zrid[a] = s[3 * cap] < p.v_max_walk ? 0 : 1;            // vehicle.py:1732-1736
+    e->h_dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
+    if (p.model == CSF_BALANCINGRIDER) {
+        e->h_lti[0 * cap + a] = s[5 * cap];
+        e->h_lti[1 * cap + a] = -s[4 * cap];
+        e->h_lti[2 * cap + a] = s[7 * cap];
+        e->h_lti[3 * cap + a] = -s[6 * cap];
+        e->h_lti[4 * cap + a] = -s[2 * cap];
+        e->h_ppsi[a] = s[3 * cap];
+        return;
+    }
+    e->h_lti[0 * cap + a] = delta;                               // vehicle.py:1728
+    e->h_lti[1 * cap + a] = 0.0;
+    e->h_lti[2 * cap + a] = s[5 * cap];
+    e->h_lti[3 * cap + a] = 0.0;
+    e->h_lti[4 * cap + a] = s[2 * cap];
+    e->h_ppsi[a] = s[2 * cap];                                   // dynamics.py:828, 987-993
+}
+
 int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired) {
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!s0 || !v_desired))) return fail(e, CSF_E_ARG, "csf_add_agents: bad arguments");
@@ -1975,7 +2002,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             r.slot = (int32_t)a;
             r.qlen = 1;
             r.qbeg = (int64_t)(e->pend.rows.size() / 3);
-            for (int c = 0; c < 6; c++) r.s[c] = c < ns ? s[c] : 0.0;
+            for (int c = 0; c < STATE_ROWS; c++) r.s[c] = c < ns ? s[c] : 0.0;
             e->coord_bound0 = std::max({e->coord_bound0, std::fabs(s[0] - d.ox), std::fabs(s[1] - d.oy)});   // (set_fov_band)
             r.vdes = v_desired[k];
             r.cls = 0;
@@ -1985,7 +2012,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             e->pend.spawn.push_back(r);
             continue;
         }
-        for (int c = 0; c < 6; c++) e->h_s[c * cap + a] = c < ns ? s[c] : 0.0;
+        for (int c = 0; c < STATE_ROWS; c++) e->h_s[c * cap + a] = c < ns ? s[c] : 0.0;
         e->h_s[2 * cap + a] = limit_angle_h(s[2]);               // vehicle.py:154-155
         e->h_ptr[a] = 0;
         e->h_znav[a] = 0;                                        // vehicle.py:188
@@ -1993,15 +2020,7 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         e->h_ti[a] = 0;                                          // vehicle.py:146
         e->h_hx[a] = s[0];                                       // traj[:, 0] = s  (vehicle.py:159-160)
         e->h_hy[a] = s[1];
-        const double delta = ns > 4 ? s[4] : 0.0, theta = ns > 5 ? s[5] : 0.0;
-        e->h_lti[0 * cap + a] = delta;                           // vehicle.py:1728
-        e->h_lti[1 * cap + a] = 0.0;
-        e->h_lti[2 * cap + a] = theta;
-        e->h_lti[3 * cap + a] = 0.0;
-        e->h_lti[4 * cap + a] = e->h_s[2 * cap + a];
-        e->h_zrid[a] = s[3] < p.v_max_walk ? 0 : 1;              // vehicle.py:1732-1736
-        e->h_dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
-        e->h_ppsi[a] = e->h_s[2 * cap + a];                      // dynamics.py:828, 987-993
+        side_state(e, (size_t)a, p);
         for (int c = 0; c < 6; c++) e->h_F[c * cap + a] = 0.0;
         e->h_status[a] = 0;
     }
@@ -2228,7 +2247,6 @@ int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int3
         if (cls[k] < 0 || cls[k] >= (int32_t)e->classes.size())
             return fail(e, CSF_E_ARG, "parameter set %d of %d (csf_set_param_classes first)", cls[k], (int)e->classes.size());
     }
-    const int64_t cap = e->cap;
     bool device_rows_stale = false;
     for (int64_t k = 0; k < n; k++) {
         const size_t a = (size_t)e->order[(size_t)idx[k]];
@@ -2243,10 +2261,7 @@ int csf_set_agent_class(csf_engine *e, int64_t n, const int32_t *idx, const int3
         // (vehicle.py:1728-1736).  Only where the host mirror is the state of record: nothing collected for the device
         // (the mirror does not hold what a pending batch will write) and no tick since the last upload.
         if (!e->device_ahead && e->pend.empty() && e->h_ti[a] == 0) {
-            const csf_params &p = e->classes[(size_t)cls[k]];
-            const double delta = e->h_s[4 * cap + a];
-            e->h_zrid[a] = e->h_s[3 * cap + a] < p.v_max_walk ? 0 : 1;
-            e->h_dgood[a] = (-p.delta_max_walk < delta && p.delta_max_walk > delta) ? 1 : 0;
+            side_state(e, a, e->classes[(size_t)cls[k]]);
             e->dirty = true;
         }
     }
@@ -2296,8 +2311,24 @@ int csf_push_state(csf_engine *e, int64_t n, const int32_t *idx, const double *s
         const int64_t a = e->order[(size_t)idx[k]];
         for (int c = 0; c < ns; c++) e->h_s[c * cap + a] = s[k * ns + c];
         // keep the model side-state consistent with the pushed vehicle.s
-        e->h_ppsi[a] = e->h_s[2 * cap + a];
-        if (e->classes[e->h_cls[(size_t)a]].model == CSF_PLANARBIKE) e->h_lti[a] = e->h_s[4 * cap + a];   // dynamics.x[0] = delta
+        const int model = e->classes[e->h_cls[(size_t)a]].model;
+        if (model == CSF_BALANCINGRIDER) {
+            // The integrator restarts from the written vehicle.s (dynamics.py:350-371; roll, steer and yaw keep the winding
+            // number they have, the rates are states of vehicle.s); the speed its gains belong to stays (dynamics.py:671-673).
+            // (The reference object would ignore the write: BalancingRiderDynamics.step overwrites bicycle.s from its own
+            // x and v, dynamics.py:697-704.  Here a written state moves the rider, as for every other class.)
+            const double twopi = 6.283185307179586476925286766559;
+            auto rewind = [&](double own, double wrapped) { return wrapped + twopi * std::nearbyint((own - wrapped) / twopi); };
+            double *x = e->h_lti.data() + a;
+            x[0 * cap] = rewind(x[0 * cap], e->h_s[5 * cap + a]);
+            x[1 * cap] = rewind(x[1 * cap], -e->h_s[4 * cap + a]);
+            x[2 * cap] = e->h_s[7 * cap + a];
+            x[3 * cap] = -e->h_s[6 * cap + a];
+            x[4 * cap] = rewind(x[4 * cap], -e->h_s[2 * cap + a]);
+        } else {
+            e->h_ppsi[a] = e->h_s[2 * cap + a];
+        }
+        if (model == CSF_PLANARBIKE) e->h_lti[a] = e->h_s[4 * cap + a];   // dynamics.x[0] = delta
         const int slot = e->h_ti[a] & (e->d.hist_len - 1);
         e->h_hx[(size_t)slot * cap + a] = e->h_s[a];
         e->h_hy[(size_t)slot * cap + a] = e->h_s[cap + a];
@@ -2487,7 +2518,7 @@ static int calibrate_comm_stream_body(csf_engine *e) {
 static bool mid_fused_ok(const csf_engine *e) {
     const Dev &d = e->d;
     return e->knobs.fused_mid != 0 && e->knobs.pair_variant < 0 && d.pair_variant == 1 && d.n_live > 1 && d.n_live < e->knobs.mid_below && e->classes.size() == 1 &&
-           d.p.model != CSF_UNCONTROLLED && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && e->profile <= 0 &&
+           d.p.model != CSF_UNCONTROLLED && d.p.model != CSF_BALANCINGRIDER && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && e->profile <= 0 &&
            d.trace == nullptr && d.pair_count == nullptr && d.lo == 0 && d.hi == d.n && e->segs.empty() && e->state_all_current &&
            d.src_beg == 0 && d.n_src / 64 * 8 <= 384;                  // (csf_mid.hip: MID_ITEMS_MAX items of the largest group)
 }
@@ -2638,7 +2669,7 @@ static bool small_fused_ok(const csf_engine *e) {
     const Dev &d = e->d;
     const int m = d.p.model;
     return e->knobs.fused_small != 0 && e->knobs.pair_variant < 0 && d.n >= 1 && d.n <= SMALL_MAX && d.n_live == d.n &&
-           e->classes.size() == 1 && m != CSF_UNCONTROLLED && small_road_ok(d) &&
+           e->classes.size() == 1 && m != CSF_UNCONTROLLED && m != CSF_BALANCINGRIDER && small_road_ok(d) &&
            e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && d.hist == nullptr && e->profile <= 0 &&
            d.atrace == nullptr && d.lo == 0 && d.hi == d.n && e->pend.empty() && !e->dirty;
 }

@@ -11,7 +11,7 @@ from . import _ffi
 from ._ffi import BICYCLE, INVPEND, N_STATES, PLANARBIKE, PLANARPOINT, TWOD, UNCONTROLLED, EngineError, Params  # noqa: F401
 
 MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE,
-             "uncontrolled": UNCONTROLLED}
+             "uncontrolled": UNCONTROLLED, "balancingrider": _ffi.BALANCINGRIDER}
 
 
 def _f64(a, shape=None):

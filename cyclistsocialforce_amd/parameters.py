@@ -313,6 +313,151 @@ class PlanarBicycleParameters(BicycleParameters):
         self.poles = poles
 
 
+# The bicycle of BalancingRiderBicycleParameters' default (parameters.py:16, 1217): the Balance Assist v1 bicycle with an average
+# rider, as data/bicycleparams/balanceassist_bikeparams.py lists it (derived there from Moore's BicycleParameters data, BSD-2).
+balanceassistv1_with_averagerider = dict(
+    IBxx=16.136560964517308, IBxz=-2.5375819134691833, IByy=18.98228436804581, IBzz=4.308368614306412, IFxx=0.0995, IFyy=0.1902,
+    IHxx=0.2984, IHxz=-0.038, IHyy=0.257, IHzz=0.0566, IRxx=0.1023, IRyy=0.1887, c=0.042, g=9.81, lam=0.255,
+    mB=91.50000000000003, mF=2.235, mH=4.3, mR=4.085, rF=0.35231, rR=0.34895, v=1.0, w=1.113, xB=0.373106714751133, xH=0.921,
+    yB=0.0, zB=-0.9697039390081493, zH=-0.86)
+
+
+def whipple_carvallo_matrices(p):
+    """(M, C1, K0, K2) of the linearised Whipple-Carvallo bicycle, M q'' + v C1 q' + (g K0 + v^2 K2) q = f with q = (roll, steer),
+    from a parameter dictionary: Meijaard, Papadopoulos, Ruina & Schwab, Proc. R. Soc. A 463 (2007), Appendix A.  The reference
+    takes them from bicycleparameters' Meijaard2007Model (parameters.py:1284-1300, dynamics.py:570); the formulas are checked
+    against the paper's benchmark matrices and eigenvalues (tests/test_host_api.py)."""
+    w, c, lam = p["w"], p["c"], p["lam"]
+    mT = p["mR"] + p["mB"] + p["mH"] + p["mF"]
+    xT = (p["xB"] * p["mB"] + p["xH"] * p["mH"] + w * p["mF"]) / mT
+    zT = (-p["rR"] * p["mR"] + p["zB"] * p["mB"] + p["zH"] * p["mH"] - p["rF"] * p["mF"]) / mT
+    ITxx = (p["IRxx"] + p["IBxx"] + p["IHxx"] + p["IFxx"] + p["mR"] * p["rR"] ** 2 + p["mB"] * p["zB"] ** 2 + p["mH"] * p["zH"] ** 2
+            + p["mF"] * p["rF"] ** 2)
+    ITxz = p["IBxz"] + p["IHxz"] - p["mB"] * p["xB"] * p["zB"] - p["mH"] * p["xH"] * p["zH"] + p["mF"] * w * p["rF"]
+    ITzz = p["IRxx"] + p["IBzz"] + p["IHzz"] + p["IFxx"] + p["mB"] * p["xB"] ** 2 + p["mH"] * p["xH"] ** 2 + p["mF"] * w ** 2
+    mA = p["mH"] + p["mF"]                                   # the front assembly: handlebar + fork, front wheel
+    xA = (p["xH"] * p["mH"] + w * p["mF"]) / mA
+    zA = (p["zH"] * p["mH"] - p["rF"] * p["mF"]) / mA
+    IAxx = p["IHxx"] + p["IFxx"] + p["mH"] * (p["zH"] - zA) ** 2 + p["mF"] * (p["rF"] + zA) ** 2
+    IAxz = p["IHxz"] - p["mH"] * (p["xH"] - xA) * (p["zH"] - zA) + p["mF"] * (w - xA) * (p["rF"] + zA)
+    IAzz = p["IHzz"] + p["IFxx"] + p["mH"] * (p["xH"] - xA) ** 2 + p["mF"] * (w - xA) ** 2
+    sl, cl = np.sin(lam), np.cos(lam)
+    uA = (xA - w - c) * cl - zA * sl                         # the front assembly's centre of mass ahead of the steer axis
+    IAll = mA * uA ** 2 + IAxx * sl ** 2 + 2 * IAxz * sl * cl + IAzz * cl ** 2
+    IAlx = -mA * uA * zA + IAxx * sl + IAxz * cl
+    IAlz = mA * uA * xA + IAxz * sl + IAzz * cl
+    mu = c / w * cl
+    SR, SF = p["IRyy"] / p["rR"], p["IFyy"] / p["rF"]        # gyrostatic coefficients of the wheels
+    ST = SR + SF
+    SA = mA * uA + mu * mT * xT
+    M = np.array([[ITxx, IAlx + mu * ITxz], [IAlx + mu * ITxz, IAll + 2 * mu * IAlz + mu ** 2 * ITzz]])
+    K0 = np.array([[mT * zT, -SA], [-SA, -SA * sl]])
+    K2 = np.array([[0.0, (ST - mT * zT) / w * cl], [0.0, (SA + SF * sl) / w * cl]])
+    C1 = np.array([[0.0, mu * ST + SF * cl + ITxz / w * cl - mu * mT * zT], [-(mu * ST + SF * cl), IAlz / w * cl + mu * (SA + ITzz / w * cl)]])
+    return M, C1, K0, K2
+
+
+class BalancingRiderBicycleParameters(BicycleParameters):
+    """parameters.py:1214-1411: BicycleParameters + the Whipple-Carvallo bicycle (a parameter dictionary in the notation of
+    Meijaard et al. 2007) + the control model that says where the rider wants the closed loop's poles - fixed `poles`, fixed
+    `gains`, or a pole model file whose component mean over speed gives them (polemodel.py)."""
+
+    def __init__(self, bicycleParameterDict=balanceassistv1_with_averagerider, poles=None, gains=None,
+                 controlparam_filename="BR1_ImRe5GivenV_pole-model-params.yaml", stochastic_control_behavior=False,
+                 controlparam_resampling_speedthresh=0.8333, controlparam_polemodel_component=0, p_dist_roll=0.00, p_dist_steer=0.00,
+                 T_dist_roll=9000, T_dist_steer=1000, **kwargs):
+        from . import polemodel
+
+        bike = dict(bicycleParameterDict)
+        kwargs = dict(kwargs, l=bike["w"], l_1=bike["w"] / 2)          # parameters.py:1291-1293: the dictionary's wheelbase wins
+        BicycleParameters.__init__(self, **kwargs)
+        self.bp_params = bike
+        self.m = bike["mB"] + bike["mF"] + bike["mH"] + bike["mR"]     # :1300-1301
+        self.g = bike["g"]
+        self.stochastic_control_behavior = stochastic_control_behavior
+        self.controlparam_filename = controlparam_filename
+        self.controlparam_resampling_speedthresh = controlparam_resampling_speedthresh
+        self.controlparam_polemodel_component = controlparam_polemodel_component
+        self.polefuns = None
+        if poles is None and gains is None:                            # :1309-1316
+            if stochastic_control_behavior:
+                raise NotImplementedError("stochastic_control_behavior: poles sampled anew from the mixture as the speed changes "
+                                          "(parameters.py:1391-1396) - the engine takes the component mean over speed")
+            self.controlparam_fix = False
+            if controlparam_filename in polemodel.MEAN_FUNCTIONS:
+                self.polefuns = polemodel.MEAN_FUNCTIONS[controlparam_filename]
+            else:                                                      # a model file of the caller's: its path
+                import os
+
+                if not os.path.exists(controlparam_filename):
+                    raise FileNotFoundError(f"Couldn't find Balancing Rider Control Behavior model {controlparam_filename}. "
+                                            f"Available models are: {sorted(polemodel.MEAN_FUNCTIONS)} (or the path of a model file)")
+                self.polefuns = polemodel.component_mean_functions(controlparam_filename)
+            if controlparam_polemodel_component >= self.polefuns.shape[0]:
+                raise ValueError(f"Balancing Rider Control Behavior model {controlparam_filename} has only {self.polefuns.shape[0]} "
+                                 f"components but controlparam_polemodel_component is set to {controlparam_polemodel_component}!")
+            self.v_last_update = -10000
+            self.poles = None
+            self.gains = None
+        else:
+            self.controlparam_fix = True
+            self.poles = poles
+            self.gains = gains
+        if p_dist_roll > 0 or p_dist_steer:                            # dynamics.py:312-314
+            raise Warning("Support for steer and roll torque disturbance removed!")
+        self.p_dist_roll, self.p_dist_steer, self.T_dist_roll, self.T_dist_steer = p_dist_roll, p_dist_steer, T_dist_roll, T_dist_steer
+
+    def get_state_space_matrices(self, v):
+        """parameters.py:1324-1340: (A [4, 4], B [4, 2]) of the Whipple-Carvallo bicycle at speed v"""
+        M, C1, K0, K2 = whipple_carvallo_matrices(self.bp_params)
+        Minv = np.linalg.inv(M)
+        A = np.zeros((4, 4))
+        A[0:2, 2:4] = np.eye(2)
+        A[2:4, 0:2] = -Minv @ (self.bp_params["g"] * K0 + v ** 2 * K2)
+        A[2:4, 2:4] = -Minv @ (v * C1)
+        B = np.zeros((4, 2))
+        B[2:4, :] = Minv
+        return A, B
+
+    def update_control_params(self, v):
+        """parameters.py:1374-1411: the desired poles at speed v (component mean of the pole model; fixed ones stay)"""
+        if not self.controlparam_fix:
+            from . import polemodel
+
+            self.poles = polemodel.poles_at(self.polefuns[self.controlparam_polemodel_component], v)
+            self.v_last_update = v
+
+    def to_pod(self, model, priority_rule=0):
+        p = BicycleParameters.to_pod(self, model, priority_rule)
+        p.k_psi = 0.0
+        bike = self.bp_params
+        M, C1, K0, K2 = whipple_carvallo_matrices(bike)
+        Minv = np.linalg.inv(M)
+        d4 = _ffi.C.c_double * 4
+        p.br_minv_k0g = d4(*(Minv @ (bike["g"] * K0)).ravel())
+        p.br_minv_k2 = d4(*(Minv @ K2).ravel())
+        p.br_minv_c1 = d4(*(Minv @ C1).ravel())
+        p.br_minv_steer = (_ffi.C.c_double * 2)(*Minv[:, 1])
+        p.br_yaw = (_ffi.C.c_double * 2)(np.cos(bike["lam"]) / bike["w"], np.cos(bike["lam"]) * bike["c"] / bike["w"])   # dynamics.py:301-303
+        fun = np.zeros((5, 2))
+        p.br_mode = 0
+        if self.controlparam_fix and self.poles is not None:           # dynamics.py:382-391: desired poles overwrite desired gains
+            pl = np.asarray(self.poles, dtype=complex).flatten()
+            if pl.size != 5 or abs(pl[0].imag) > 1e-12 or abs((pl[1] - np.conj(pl[2])))  > 1e-12 or abs((pl[3] - np.conj(pl[4]))) > 1e-12:
+                raise ValueError("BalancingRider poles: one real pole and two conjugate pairs (p0, p1, conj(p1), p2, conj(p2))")
+            fun[:, 0] = [pl[0].real, pl[1].real, abs(pl[1].imag), pl[3].real, abs(pl[3].imag)]
+        elif self.controlparam_fix:
+            g = np.asarray(self.gains, dtype=float).flatten()
+            if g.size != 5:
+                raise ValueError("BalancingRider gains: five (k_phi, k_delta, k_phidot, k_deltadot, k_psi)")
+            p.br_gains = (_ffi.C.c_double * 5)(*g)
+            p.br_mode = 2
+        else:
+            fun = np.asarray(self.polefuns[self.controlparam_polemodel_component], dtype=float)
+        p.br_pole_fun = (_ffi.C.c_double * 10)(*fun.ravel())
+        return p
+
+
 class CarParameters(VehicleParameters):
     """parameters.py:752-764: VehicleParameters + the footprint of the car (UncontrolledVehicle, vehicle.py:920-988)."""
 
@@ -323,6 +468,7 @@ class CarParameters(VehicleParameters):
 
 
 PARAMS_OF_MODEL = {
+    _ffi.BALANCINGRIDER: BalancingRiderBicycleParameters,
     _ffi.UNCONTROLLED: CarParameters,
     _ffi.PLANARBIKE: PlanarBicycleParameters,
     _ffi.BICYCLE: BicycleParameters,
@@ -335,5 +481,5 @@ PARAMS_OF_MODEL = {
 def default_pod(model, priority_rule=0, **overrides):
     """csf_params of a vehicle class with the reference's defaults (keyword overrides allowed)."""
     if isinstance(model, str):
-        model = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3, "planarbike": 4, "uncontrolled": 5}[model]
+        model = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3, "planarbike": 4, "uncontrolled": 5, "balancingrider": 6}[model]
     return PARAMS_OF_MODEL[model](**overrides).to_pod(model, priority_rule)

@@ -16,8 +16,8 @@ import numpy as np
 
 from . import _ffi
 from .engine import Engine
-from .parameters import (BicycleParameters, CarParameters, InvPendulumBicycleParameters, PlanarBicycleParameters,
-                         PlanarPointBicycleParameters, VehicleParameters)
+from .parameters import (BalancingRiderBicycleParameters, BicycleParameters, CarParameters, InvPendulumBicycleParameters,
+                         PlanarBicycleParameters, PlanarPointBicycleParameters, VehicleParameters)
 from .utils import limitAngle
 
 
@@ -465,12 +465,15 @@ class UncontrolledVehicle(Vehicle):
 
 
 class BalancingRiderBicycle(Vehicle):
-    """vehicle.py:1953-1990 — NOT available: its Whipple-Carvallo model is assembled by the `bicycleparameters` package and
-    its feedback gains by `controlbehavior.py` (dynamics.py:261-705); neither can be imported where this engine was built,
-    so there is nothing to capture fixtures from and nothing to pin a restatement to.  The name
-    exists so that scripts importing it (demoCSFstandalone.py:23) load; constructing one says why it cannot run."""
+    """vehicle.py:1953-1990 — a bicycle with Whipple-Carvallo dynamics under the rider's full-state feedback
+    (dynamics.py:261-705): eight states (x, y, psi, v, delta, phi, deltadot, phidot), gains placed every step for the poles the
+    control model asks for at the current speed, implicit midpoint rule; the TwoDBicycle force field and the direct-approach
+    destination force."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("BalancingRiderBicycle is not part of the MI355X engine: its dynamics come from the "
-                                  "bicycleparameters / controlbehavior packages (DESIGN.md section 9); the other rider models "
-                                  "('invpendulum', 'planarpoint', 'planartwowheel', PlanarBicycle, TwoDBicycle) are")
+    PARAMS_TYPE = BalancingRiderBicycleParameters
+    MODEL = _ffi.BALANCINGRIDER
+    N_STATES = 8
+    STATE_NAMES = ["x[m]", "y[m]", "psi[rad]", "v[m/s]", "delta[rad]", "phi[rad]", "deltadot[rad/s]", "phidot[rad/s]"]
+
+    def __init__(self, s0, **kwargs):
+        Vehicle.__init__(self, s0, **kwargs)

@@ -25,12 +25,13 @@
 extern "C" {
 #endif
 
-#define CSF_ABI_VERSION 7
+#define CSF_ABI_VERSION 8
 
 /* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
  * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle); :920 (UncontrolledVehicle: follows a prescribed trajectory
  * - csf_set_script -, exerts the TwoDBicycle field with its own parameters, feels no force) */
-enum csf_model { CSF_BICYCLE = 0, CSF_TWOD = 1, CSF_INVPEND = 2, CSF_PLANARPOINT = 3, CSF_PLANARBIKE = 4, CSF_UNCONTROLLED = 5 };
+enum csf_model { CSF_BICYCLE = 0, CSF_TWOD = 1, CSF_INVPEND = 2, CSF_PLANARPOINT = 3, CSF_PLANARBIKE = 4, CSF_UNCONTROLLED = 5,
+                 CSF_BALANCINGRIDER = 6 /* vehicle.py:1953 (BalancingRiderBicycle: 8 states - x, y, psi, v, delta, phi, deltadot, phidot) */ };
 
 /* priority rule — intersection.py:263, 739-741 */
 enum csf_priority_rule { CSF_UNREGULATED = 0, CSF_P2R = 1 };
@@ -66,10 +67,17 @@ typedef struct csf_params {
     double k_psi;
     /* PlanarBicycleParameters — parameters.py:1203-1211: the two desired poles of the steer / yaw loop (re, im, re, im) */
     double pb_poles[4];
+    /* BalancingRiderBicycleParameters — parameters.py:1214-1411; dynamics.py:261-705 (ABI 8).  The linearised Whipple-Carvallo
+     * bicycle (Meijaard, Papadopoulos, Ruina & Schwab 2007: M q'' + v C1 q' + (g K0 + v^2 K2) q = f, q = (roll, steer)) as the
+     * 2 x 2 blocks of its state matrix (row-major: M^-1 g K0, M^-1 K2, M^-1 C1), the steer-torque column of M^-1, the yaw row
+     * (cos(lam) / w, cos(lam) c / w: dynamics.py:301-303), and the control model: the desired closed-loop poles as straight
+     * lines over speed - (intercept, slope) of p0_real, p1_real, p1_imag, p2_real, p2_imag (parameters.py:1400-1409; fixed
+     * poles: slopes 0) -, or fixed gains (br_mode 2: dynamics.py:604-605) */
+    double br_minv_k0g[4], br_minv_k2[4], br_minv_c1[4], br_minv_steer[2], br_yaw[2], br_pole_fun[10], br_gains[5];
     int32_t model;         /* enum csf_model */
     int32_t priority_rule; /* enum csf_priority_rule */
     int32_t traj_len;      /* columns of the reference's traj ring buffer, int(30 / t_s) — vehicle.py:159 */
-    int32_t reserved;
+    int32_t br_mode;       /* BalancingRider: 0 poles from br_pole_fun at the current speed, 2 the gains br_gains */
 } csf_params;
 
 typedef struct csf_engine csf_engine;

@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.csf_abi_version() == 7
-    assert ctypes.sizeof(_ffi.Params) == 328
+    assert lib.csf_abi_version() == 8
+    assert ctypes.sizeof(_ffi.Params) == 576
 
 
 def test_engine_fails_loudly_without_gpu():
@@ -387,7 +387,7 @@ def test_visual_hook_drawings():
 
 def test_reference_package_name_resolves_to_the_mirror():
     """compat/cyclistsocialforce: the import lines of the reference's scripts (demoCSFstandalone.py:23-25) load the mirror
-    classes; BalancingRiderBicycle exists as a name and refuses to be constructed."""
+    classes, BalancingRiderBicycle (vehicle.py:1953-1990) among them since round 5."""
     import importlib
     import os
     import sys
@@ -401,9 +401,43 @@ def test_reference_package_name_resolves_to_the_mirror():
             names = [k for k in vars(impl) if not k.startswith("_")]
             assert names and all(getattr(alias, k) is getattr(impl, k) for k in names), mod
         from cyclistsocialforce.vehicle import BalancingRiderBicycle, Bicycle, InvPendulumBicycle, PlanarPointBicycle  # noqa: F401
-        with pytest.raises(NotImplementedError, match="bicycleparameters"):
-            BalancingRiderBicycle((0, 0, 0, 5, 0, 0, 0, 0), id="a")
+        b = BalancingRiderBicycle((0, 0, 0, 5, 0, 0, 0, 0, 99), id="a")      # (longer start states are cut: vehicle.py:149-152)
+        assert b.N_STATES == 8 and b.s.shape == (8,) and b.params.l == b.params.bp_params["w"] and b.traj.shape == (8, 3000)
     finally:
         sys.path.remove(os.path.join(root, "compat"))
         for k in [k for k in sys.modules if k == "cyclistsocialforce" or k.startswith("cyclistsocialforce.")]:
             del sys.modules[k]
+
+
+def test_balancingrider_parameters_follow_the_reference(golden):
+    """parameters.py:1214-1411 in the host mirror: the Whipple-Carvallo matrices of the formulas of Meijaard et al. (2007)
+    against the paper's benchmark (typed in from the paper: tests/golden/make_golden_balancingrider.py), the state-space matrices
+    and the poles over speed against what the reference's objects returned there, and the POD the engine takes against the
+    oracle's (which reproduces the reference's trajectories to 1e-14, tests/test_oracle_golden.py)."""
+    from cyclistsocialforce_amd import parameters
+    from oracle import csf_oracle as orc
+
+    g = golden("balancingrider")
+    bench = dict(zip([str(k) for k in g["wc_benchmark_names"]], [float(v) for v in g["wc_benchmark_params"]]))
+    M, C1, K0, K2 = parameters.whipple_carvallo_matrices(bench)
+    for got, name in ((M, "M"), (C1, "C1"), (K0, "K0"), (K2, "K2")):
+        np.testing.assert_allclose(got, g[f"wc_benchmark_{name}"], rtol=0, atol=2e-13, err_msg=name)
+    p = parameters.BalancingRiderBicycleParameters()
+    assert dict(zip([str(k) for k in g["default_bike_names"]], g["default_bike_params"])) == p.bp_params
+    A, B = p.get_state_space_matrices(4.0)
+    np.testing.assert_allclose(A, g["ss_A_v4"][:4, :4], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(B, g["ss_B_v4"][:4], rtol=0, atol=1e-12)
+    for v, want in zip(g["poles_BR1_v"], g["poles_BR1"]):
+        p.update_control_params(v)
+        np.testing.assert_allclose(p.poles, want, rtol=0, atol=1e-12)
+    pod, ref = p.to_pod(6), orc.default_params("balancingrider")
+    for name in ("br_minv_k0g", "br_minv_k2", "br_minv_c1", "br_minv_steer", "br_yaw", "br_pole_fun", "v_max_riding", "a_max"):
+        np.testing.assert_allclose(list(getattr(pod, name)), list(getattr(ref, name)), rtol=1e-13, atol=1e-14, err_msg=name)
+    assert pod.l == ref.l == 1.113 and pod.k_p_v == ref.k_p_v and pod.br_mode == 0 and pod.model == 6
+    # fixed poles / fixed gains (parameters.py:1309-1316; dynamics.py:382-391, 604-605)
+    fixed = parameters.BalancingRiderBicycleParameters(poles=(-8.0, -1 + 2j, -1 - 2j, -2 + 6j, -2 - 6j)).to_pod(6)
+    assert list(fixed.br_pole_fun) == [-8.0, 0.0, -1.0, 0.0, 2.0, 0.0, -2.0, 0.0, 6.0, 0.0] and fixed.br_mode == 0
+    gained = parameters.BalancingRiderBicycleParameters(gains=(-10.0, 2.0, -7.0, -0.1, -7.0)).to_pod(6)
+    assert gained.br_mode == 2 and list(gained.br_gains) == [-10.0, 2.0, -7.0, -0.1, -7.0]
+    with pytest.raises(NotImplementedError):
+        parameters.BalancingRiderBicycleParameters(stochastic_control_behavior=True)
