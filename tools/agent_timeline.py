@@ -2,6 +2,7 @@
 """Where do the microseconds of the per-agent kernel go?  (GPU box; measurement aid)
 
     python3 tools/agent_timeline.py            # Bicycle, TwoDBicycle, InvPendulumBicycle at N = 3, 1 024, 16 384
+    python3 tools/agent_timeline.py balancingrider planarpoint 16384      # other classes / sizes
 
 CSF_TRACE_AGENT makes every wave of agent_kernel stamp wall_clock64() (100 MHz: 10 ns steps) at entry, when its own
 scalars, partial sums and road term have arrived, after the destination force, after the combine phase, after the
@@ -25,8 +26,9 @@ def child(model, n, path):
 
     box = max(10.0, (n / 0.41) ** 0.5)
     s0, off, dq = bench.synthetic_population(n, box)
-    if model == "invpend":
-        s0 = np.c_[s0, np.zeros(n)]
+    from cyclistsocialforce_amd import _ffi, engine
+    width = _ffi.N_STATES[engine.MODEL_IDS[model]]
+    s0 = np.c_[s0, np.zeros((n, max(0, width - s0.shape[1])))][:, :width]
     e = Engine(parameters.default_pod(model), n)
     e.add_agents(s0, 5.0)
     e.set_dest_queue(np.arange(n), off, dq, reset=True)
@@ -42,8 +44,10 @@ def child(model, n, path):
 def main():
     names = ["own scalars + partial sums arrive", "destination force", "combine", "controller + kinematics", "stores issued", "stores done"]
     print("per-agent kernel: mean over the waves of the last launch, microseconds (wall_clock64, 10 ns steps)")
-    for model in ("bicycle", "twod", "invpend"):
-        for n in (3, 1024, 16384):
+    models = [a for a in sys.argv[1:] if not a.isdigit()] or ["bicycle", "twod", "invpend"]
+    sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [3, 1024, 16384]
+    for model in models:
+        for n in sizes:
             path = f"/tmp/atrace_{model}_{n}.bin"
             out = {}
             for traced in (False, True):
