@@ -112,6 +112,8 @@ struct Knobs {
     int clist = 1;                            // CSF_CLIST=0: receivers in binned order walk every tile of their chunk (no candidate lists)
     int recv_binned = -1;                     // CSF_RECV_BINNED
     int64_t rebin_churn = 4000;               // CSF_REBIN_CHURN
+    int hole_reuse = 1;                       // CSF_HOLE_REUSE: an arrival takes the slot of a road user that left nearby (HoleIndex)
+    double hole_dist = 1.0;                   // CSF_HOLE_DIST: ... within this many median batch radii of the batch's centre
     bool incremental = true;                  // CSF_INCREMENTAL=0: population changes through the host mirror
     int comm_second = -1;                     // CSF_COMM_STREAM=second / main (-1: the communicator times both on its first tick and keeps the faster)
     double fov_band = 1.0;                    // CSF_FOV_BAND: scale of the rounding band of the field-of-view test (0: every pair decided in fp32, as in round 3)
@@ -147,6 +149,8 @@ struct Knobs {
         far_tight = geti("CSF_FAR_TIGHT", 1);
         seg_grid = geti("CSF_SEG_GRID", 1);
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
+        hole_reuse = geti("CSF_HOLE_REUSE", 1);
+        if (const char *v = getenv("CSF_HOLE_DIST")) hole_dist = atof(v);
         incremental = geti("CSF_INCREMENTAL", 1) != 0;
         if (const char *v = getenv("CSF_COMM_STREAM")) comm_second = std::string(v) == "second" ? 1 : 0;
         if (const char *v = getenv("CSF_RNEAR")) rnear = atof(v);
@@ -225,6 +229,25 @@ struct csf_engine {
     int64_t live_at_rebin = 0, tail_used = 0;       // road users at the last re-binning; sentinel places handed out since
     int64_t tail_flushed = 0;                       // ... of which the device has seen this many (flush_pending)
     bool pend_inplace = false;                      // an arrival of the pending batch took a slot inside a real batch
+    // HOLES (road users arriving and leaving every tick, SUMO co-simulation: intersection.py:458-634).  A road user that leaves
+    // leaves a hole in a real batch of the binned order; an arrival that starts within that batch's circle can have the hole -
+    // the circle does not grow, the sentinel tail does not fill up, and the order lasts its 64 ticks instead of three.  What the
+    // host needs for that it reads back once per re-binning, without waiting: the place of every slot and the circles (85 KB at
+    // N = 16 384).  The holes are kept in a lattice over the scene by the centre of their batch.
+    struct HoleIndex {
+        int32_t *pos = nullptr;                     // pinned: slot -> place at the last re-binning
+        float4 *bnd = nullptr;                      // pinned: circle of every batch then (scene coordinates)
+        size_t pos_n = 0, bnd_n = 0;
+        hipEvent_t ev = nullptr;
+        bool pending = false, ready = false;        // the read-back is under way / the lattice is built
+        int64_t places = 0;                         // places that held road users at the re-binning
+        double x0 = 0, y0 = 0, cell = 1, reach2 = 0, ox = 0, oy = 0;
+        int nx = 0, ny = 0;
+        std::vector<std::vector<int32_t>> cells;    // slots of free_recent by lattice cell
+        std::vector<int32_t> recent_at;             // slot -> index in free_recent (-1: not there)
+        int64_t taken = 0;
+    } holes;
+    int64_t pend_tail_spawns = 0;                   // arrivals of the pending batch that went to the sentinel tail
     DevBuf<unsigned> ticket;                        // patch_kernel: which workgroup finishes last
     // grow-only device scratch of the single-piece entry points (csf_untracked, csf_update_*, csf_count_pairs): no
     // hipMalloc / hipFree per call
@@ -888,6 +911,7 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->edge_n.alloc(2));
     HIPCHK(e, e->edge_head.alloc(cap));
     e->pend_spawn_at.assign(cap, -1);
+    e->holes.recent_at.assign(cap, -1);
     e->pend_requeue_at.assign(cap, -1);
     e->pend_retire_at.assign(cap, -1);
     e->dev_alive.assign(cap, 0);
@@ -1044,6 +1068,8 @@ constexpr int64_t PLAIN_BELOW = 3072;
 int32_t pair_variant_for(const csf_engine *e, int64_t n) {
     return e->knobs.pair_variant >= 0 ? e->knobs.pair_variant : (n < PLAIN_BELOW ? 1 : 0);
 }
+
+static int holes_request(csf_engine *e);
 
 // (re)build the spatially binned order of the records; decides whether batches are classified this tick
 int rebin(csf_engine *e) {
@@ -1253,7 +1279,7 @@ int rebin(csf_engine *e) {
     e->moved_unbinned = 0;
     e->churn = 0;
     e->bounds_fresh = true;                                          // (rebase_kernel wrote the circles of the records as they are)
-    return CSF_OK;
+    return holes_request(e);                                         // (places and circles of this order, for arrivals that take a leaver's slot)
 }
 
 // bounding circles for the pair launch that follows; afterwards the circles emitted by that launch become current
@@ -1344,6 +1370,7 @@ void compact_host(csf_engine *e) {
         for (int64_t i = 0; i < n; i++) e->order[(size_t)i] = (int32_t)i;
         e->free_tail.clear();
         e->free_recent.clear();
+        std::fill(e->holes.recent_at.begin(), e->holes.recent_at.end(), -1);
     }
     std::fill(e->h_alive.begin(), e->h_alive.end(), (uint8_t)0);
     std::fill(e->h_alive.begin(), e->h_alive.begin() + n, (uint8_t)1);
@@ -1666,7 +1693,8 @@ int flush_pending(csf_engine *e) {
     for (int32_t a : pd.retire) e->pend_retire_at[(size_t)a] = -1, e->dev_alive[(size_t)a] = 0;
     for (const SpawnRec &r : pd.spawn) e->pend_spawn_at[(size_t)r.slot] = -1, e->dev_alive[(size_t)r.slot] = 1;
     for (const QueueRec &r : pd.requeue) e->pend_requeue_at[(size_t)r.slot] = -1;
-    e->churn += h.n_spawn;
+    e->churn += e->pend_tail_spawns;                          // (an arrival in a leaver's slot adds nothing to the tail)
+    e->pend_tail_spawns = 0;
     pd.retire.clear();
     pd.spawn.clear();
     pd.requeue.clear();
@@ -1899,6 +1927,9 @@ int csf_destroy(csf_engine *e) {
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);
+    if (e->holes.pos) (void)hipHostFree(e->holes.pos);
+    if (e->holes.bnd) (void)hipHostFree(e->holes.bnd);
+    if (e->holes.ev) (void)hipEventDestroy(e->holes.ev);
     for (auto &sl : e->pinned) {
         if (sl.host) (void)hipHostFree(sl.host);
         if (sl.done) (void)hipEventDestroy(sl.done);
@@ -1942,6 +1973,120 @@ static void side_state(csf_engine *e, size_t a, const csf_params &p) {
     e->h_ppsi[a] = s[2 * cap];                                   // dynamics.py:828, 987-993
 }
 
+// ---- holes (csf_engine::HoleIndex) -----------------------------------------------------------------------------------
+// after a re-binning: ask for the places and the circles (two copies and an event behind the re-binning's launches)
+static int holes_request(csf_engine *e) {
+    csf_engine::HoleIndex &h = e->holes;
+    const Dev &d = e->d;
+    h.ready = h.pending = false;
+    for (auto &c : h.cells) c.clear();
+    h.recent_at.assign((size_t)e->cap, -1);
+    if (!e->knobs.hole_reuse || !e->tail_tracked || !d.classify || d.n_pad <= 0) return CSF_OK;
+    const size_t np = (size_t)d.n_pad, nb = np / 64;
+    if (h.pos_n < np) {
+        if (h.pos) HIPCHK(e, hipHostFree(h.pos));
+        h.pos = nullptr;
+        HIPCHK(e, hipHostMalloc((void **)&h.pos, np * sizeof(int32_t), hipHostMallocDefault));
+        h.pos_n = np;
+    }
+    if (h.bnd_n < nb) {
+        if (h.bnd) HIPCHK(e, hipHostFree(h.bnd));
+        h.bnd = nullptr;
+        HIPCHK(e, hipHostMalloc((void **)&h.bnd, nb * sizeof(float4), hipHostMallocDefault));
+        h.bnd_n = nb;
+    }
+    if (!h.ev) HIPCHK(e, hipEventCreateWithFlags(&h.ev, hipEventDisableTiming));
+    HIPCHK(e, hipMemcpyAsync(h.pos, d.pos, np * sizeof(int32_t), hipMemcpyDeviceToHost, e->main));
+    HIPCHK(e, hipMemcpyAsync(h.bnd, d.bnd, nb * sizeof(float4), hipMemcpyDeviceToHost, e->main));
+    HIPCHK(e, hipEventRecord(h.ev, e->main));
+    h.places = (e->live_at_rebin + 63) / 64 * 64;
+    h.ox = d.ox, h.oy = d.oy;
+    h.pending = true;
+    return CSF_OK;
+}
+
+// the lattice, once the read-back has landed (the first population call after a re-binning waits for it, if at all)
+static bool holes_ready(csf_engine *e) {
+    csf_engine::HoleIndex &h = e->holes;
+    if (h.ready) return true;
+    if (!h.pending) return false;
+    if (hipEventSynchronize(h.ev) != hipSuccess) return h.pending = false;
+    h.pending = false;
+    const int64_t nb = h.places / 64;
+    std::vector<float> radii;
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int64_t b = 0; b < nb; b++) {
+        const float4 c = h.bnd[b];
+        if (!(c.z < 1e6f) || !std::isfinite(c.x) || !std::isfinite(c.y)) continue;       // (a batch of sentinels)
+        radii.push_back(c.z);
+        x0 = std::min(x0, (double)c.x), x1 = std::max(x1, (double)c.x), y0 = std::min(y0, (double)c.y), y1 = std::max(y1, (double)c.y);
+    }
+    if (radii.size() < 4) return false;
+    std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+    const double reach = e->knobs.hole_dist * (double)radii[radii.size() / 2];
+    if (!(reach > 0.0)) return false;
+    h.reach2 = reach * reach;
+    h.cell = reach;
+    h.x0 = x0 - reach, h.y0 = y0 - reach;
+    h.nx = (int)std::min(512.0, std::ceil((x1 - x0 + 2 * reach) / h.cell) + 1);
+    h.ny = (int)std::min(512.0, std::ceil((y1 - y0 + 2 * reach) / h.cell) + 1);
+    h.cell = std::max({h.cell, (x1 - x0 + 2 * reach) / (h.nx - 1), (y1 - y0 + 2 * reach) / (h.ny - 1)});
+    h.cells.assign((size_t)h.nx * (size_t)h.ny, {});
+    return h.ready = true;
+}
+
+// a road user has left slot a: if the slot had a place in a real batch, its hole can be found by the batch's centre
+static void holes_add(csf_engine *e, int32_t a) {
+    csf_engine::HoleIndex &h = e->holes;
+    if (!holes_ready(e) || (size_t)a >= h.pos_n) return;
+    const int64_t place = h.pos[a];
+    if (place < 0 || place >= h.places) return;                    // (it arrived after the re-binning: a place of the tail)
+    const float4 c = h.bnd[place >> 6];
+    if (!(c.z < 1e6f)) return;
+    const int ix = (int)(((double)c.x - h.x0) / h.cell), iy = (int)(((double)c.y - h.y0) / h.cell);
+    if (ix < 0 || iy < 0 || ix >= h.nx || iy >= h.ny) return;
+    h.cells[(size_t)iy * h.nx + ix].push_back(a);
+}
+
+// the hole nearest to (x, y) whose batch's centre is within reach; -1: none
+static int32_t holes_take(csf_engine *e, double x, double y) {
+    csf_engine::HoleIndex &h = e->holes;
+    if (!h.ready || e->free_recent.empty()) return -1;
+    const double sx = x - h.ox, sy = y - h.oy;                     // scene coordinates, as the circles
+    const int ix = (int)std::floor((sx - h.x0) / h.cell), iy = (int)std::floor((sy - h.y0) / h.cell);
+    double best = h.reach2;
+    std::vector<int32_t> *bc = nullptr;
+    size_t bi = 0;
+    for (int jy = std::max(0, iy - 1); jy <= std::min(h.ny - 1, iy + 1); jy++)
+        for (int jx = std::max(0, ix - 1); jx <= std::min(h.nx - 1, ix + 1); jx++) {
+            std::vector<int32_t> &c = h.cells[(size_t)jy * h.nx + jx];
+            for (size_t i = 0; i < c.size();) {
+                const int32_t a = c[i];
+                if (h.recent_at[(size_t)a] < 0) {                   // (handed out some other way since)
+                    c[i] = c.back();
+                    c.pop_back();
+                    continue;
+                }
+                const float4 q = h.bnd[h.pos[a] >> 6];
+                const double dx = (double)q.x - sx, dy = (double)q.y - sy, d2 = dx * dx + dy * dy;
+                if (d2 < best) best = d2, bc = &c, bi = i;
+                i++;
+            }
+        }
+    if (!bc) return -1;
+    const int32_t a = (*bc)[bi];
+    (*bc)[bi] = bc->back();
+    bc->pop_back();
+    // out of free_recent as well
+    const int32_t at = h.recent_at[(size_t)a], last = e->free_recent.back();
+    e->free_recent[(size_t)at] = last;
+    h.recent_at[(size_t)last] = at;
+    e->free_recent.pop_back();
+    h.recent_at[(size_t)a] = -1;
+    h.taken++;
+    return a;
+}
+
 int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired) {
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!s0 || !v_desired))) return fail(e, CSF_E_ARG, "csf_add_agents: bad arguments");
@@ -1968,7 +2113,15 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     for (int64_t k = 0; k < n; k++) {
         int64_t a;
         bool tail = true;
-        if (!e->free_tail.empty()) {                             // the next place of the sentinel tail
+        int32_t hole = -1;
+        if (patch && e->tail_tracked && e->knobs.hole_reuse && !e->free_recent.empty() && holes_ready(e))
+            hole = holes_take(e, s0[k * ns], s0[k * ns + 1]);      // the slot of a road user that left from around here
+        if (hole >= 0) {
+            a = hole;
+            tail = false;
+            e->pend_inplace = true;                              // (the circles are renewed before the next pair launch)
+            d.clist = nullptr;
+        } else if (!e->free_tail.empty()) {                      // the next place of the sentinel tail
             a = e->free_tail.back();
             e->free_tail.pop_back();
         } else if (patch ? d.n < d.n_pad : e->free_recent.empty()) {   // a fresh slot: the tail continues there
@@ -1976,13 +2129,14 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         } else if (!e->free_recent.empty()) {                    // (inside a real batch: only when nothing else is left)
             a = e->free_recent.back();
             e->free_recent.pop_back();
+            e->holes.recent_at[(size_t)a] = -1;
             tail = false;
             e->pend_inplace = true;
             d.clist = nullptr;                                   // (a real batch's circle stretches: no candidate lists until the re-binning)
         } else {
             a = d.n++;
         }
-        if (tail) e->tail_used++;
+        if (tail) e->tail_used++, e->pend_tail_spawns += patch ? 1 : 0;
         const double *s = s0 + k * ns;
         e->h_vdes[a] = v_desired[k];
         e->h_q[a].assign({s[0], s[1], 0.0});                     // vehicle.py:183-185
@@ -2074,8 +2228,10 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         e->h_cls[(size_t)a] = 0;                                // (a dead slot's sentinel record is looked up in set 0: the table may shrink)
         e->h_q[(size_t)a].clear();
         e->h_script[(size_t)a].clear();
+        e->holes.recent_at[(size_t)a] = (int32_t)e->free_recent.size();
         e->free_recent.push_back(a);
         if (!patch) continue;
+        if (e->tail_tracked && e->knobs.hole_reuse) holes_add(e, a);
         drop_pending_requeue(e, (size_t)a);                      // a queue collected for the road user that leaves
         if (e->pend_spawn_at[(size_t)a] >= 0) {                  // added and removed within one batch: never reaches the device
             const int32_t at = e->pend_spawn_at[(size_t)a];
