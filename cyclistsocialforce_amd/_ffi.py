@@ -27,7 +27,7 @@ SYMBOLS = (
     "csf_far_radius", "csf_get_tick", "csf_profile_gather", "csf_profile_kernels", "csf_profile_samples",
     "csf_count_pairs", "csf_comm_init_loopback", "csf_step_group", "csf_untracked", "csf_update_destination",
     "csf_update_nav_state", "csf_set_dest_pointer", "csf_set_incremental", "csf_set_script", "csf_near_dropped", "csf_comm_stream_order", "csf_small_ticks", "csf_step_get_tick",
-    "csf_get_integrator_state", "csf_set_integrator_state", "csf_mid_ticks",
+    "csf_get_integrator_state", "csf_set_integrator_state", "csf_mid_ticks", "csf_holes_taken",
 )
 
 
@@ -133,6 +133,7 @@ def load():
     L.csf_small_ticks.argtypes = [vp, C.POINTER(i64)]
     L.csf_step_get_tick.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.csf_mid_ticks.argtypes = [vp, C.POINTER(i64)]
+    L.csf_holes_taken.argtypes = [vp, C.POINTER(i64)]
     L.csf_get_integrator_state.argtypes = [vp, dp, dp, vp]
     L.csf_set_integrator_state.argtypes = [vp, i64, vp, dp, dp, vp]
     if L.csf_abi_version() != 8:

@@ -444,6 +444,12 @@ class Engine:
         self._ck(self._lib.csf_mid_ticks(self._h, C.byref(v)))
         return v.value
 
+    def holes_taken(self):
+        """arrivals that took the slot of a road user who had left from nearby (include/csf.h: csf_holes_taken)"""
+        v = C.c_int64()
+        self._ck(self._lib.csf_holes_taken(self._h, C.byref(v)))
+        return v.value
+
     def comm_stream_order(self):
         """('main' | 'second', [us per tick in stream order, on the second stream]) - where a sharded engine issues its
         all-gather, and what its communicator measured when it chose (zeros: CSF_COMM_STREAM decided, or not sharded)"""

@@ -316,6 +316,12 @@ int csf_small_ticks(const csf_engine *e, int64_t *n_ticks);
  * one grid, the group's last workgroup to finish its sums carrying on with the road users; the next tick's records go to the
  * other half of a double buffer.  CSF_FUSED_MID=0, a pinned CSF_PAIR_VARIANT or per-kernel profiling keep the two launches. */
 int csf_mid_ticks(const csf_engine *e, int64_t *n_ticks);
+
+/* Arrivals that took the slot of a road user who had left from nearby (ABI 8).  Under traffic - road users arriving and leaving
+ * every tick, intersection.py:458-634 - a slot freed inside a batch of the binned order is handed to the next arrival that starts
+ * within that batch's bounding circle (up to CSF_HOLE_DIST median radii from its centre, [1.0]; CSF_HOLE_REUSE=0 switches it off):
+ * the circle does not grow and the sentinel tail of the order, which every receiver tests source by source, fills more slowly. */
+int csf_holes_taken(const csf_engine *e, int64_t *n);
 /* csf_step(e, n_ticks) followed by csf_get_tick(...) in one call (ABI 6): what a caller that looks at every tick does -
  * SocialForceIntersection.step() refreshes vehicle.s, znav and force after each tick (intersection.py:866-896).  On the
  * one-wave path the kernel packs the read-back itself behind its last tick: one launch and one wait per call.  Arguments as

@@ -744,12 +744,15 @@ def test_population_changes_on_the_device(amd, model):
     assert np.isfinite(e.state()).all() and e.n == m           # (the queues handed out here are other agents': no status check)
 
 
-def test_arrivals_in_the_sentinel_tail(amd, monkeypatch):
+@pytest.mark.parametrize("holes", ["0", "1"])
+def test_arrivals_in_the_sentinel_tail(amd, monkeypatch, holes):
     """N = 16 384 with arrivals and departures EVERY tick: the arrivals take the places of the sentinel tail of the binned
     order, which get source chunks of their own behind the sixteen full tiles, until the next re-binning sorts them in
-    (csf_engine.hip: rebin, set_chunks).  The repulsive sums of old and new road users against the oracle's on the
-    population as it is after 1, 5 and 14 such ticks."""
+    (csf_engine.hip: rebin, set_chunks) - or (holes = 1, the default) the slot of a road user who has just left from the
+    circle of a batch they start in (csf_engine.hip: HoleIndex), and only the others the tail.  The repulsive sums of old
+    and new road users against the oracle's on the population as it is after 1, 5 and 14 such ticks."""
     monkeypatch.setenv("CSF_REBIN_TICKS", "32")             # (the engine re-bins every 64 ticks; this case is written around 32)
+    monkeypatch.setenv("CSF_HOLE_REUSE", holes)
     n, box = 16384, 200.0
     s0, off, dq = population(n + 4096, box, seed=21)
     dq3 = dq.reshape(-1, 4, 3)
@@ -781,6 +784,8 @@ def test_arrivals_in_the_sentinel_tail(amd, monkeypatch):
             print(f"  tick {tick}: clamped repulsive sums vs oracle {err:.1e}")
             assert err < 1e-4
     assert (e.status() == 0).all() and np.isfinite(e.state()).all()
+    # 14 x 160 arrivals among 14 x 160 holes in 200 m x 200 m: most find one within a batch radius
+    assert e.holes_taken() == 0 if holes == "0" else e.holes_taken() > 700, e.holes_taken()
     e.close()
 
 
