@@ -103,7 +103,7 @@ struct Knobs {
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
     int64_t rebin_ticks = 64;                 // CSF_REBIN_TICKS: ticks between two re-binnings (1 .. 120; the tests that step 40 - 48 ticks "across a re-binning" pin 32)
     int fused_mid = 1;                        // CSF_FUSED_MID=0: mid-size populations take a pair launch and a per-agent launch per tick (csf_mid.hip: one launch)
-    int mid_below = 1280;                     // CSF_MID_BELOW: ... for populations smaller than this
+    int mid_below = 2176;                     // CSF_MID_BELOW: ... for populations smaller than this
     int mid_group = 0;                        // CSF_MID_GROUP: road users per workgroup of it, 4 / 8 / 16 / 32 (0: about one workgroup per CU)
     int fused_small = 1;                      // CSF_FUSED_SMALL=0: a handful of road users take the general path too (csf_agent.hip: small_tick_kernel)
     int segments = -1;                        // CSF_SEGMENTS
@@ -140,7 +140,7 @@ struct Knobs {
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
         fused_small = geti("CSF_FUSED_SMALL", 1);
         fused_mid = geti("CSF_FUSED_MID", 1);
-        mid_below = geti("CSF_MID_BELOW", 1280);
+        mid_below = geti("CSF_MID_BELOW", 2176);
         mid_group = geti("CSF_MID_GROUP", 0);
         rebin_ticks = std::max(1, std::min(120, geti("CSF_REBIN_TICKS", 64)));
         segments = geti("CSF_SEGMENTS", -1);

@@ -34,7 +34,7 @@ def start_state(model, x, y, psi, v):
                                                    ("planarpoint", 90, 0, None, 40.0), ("planarpoint", 500, 1, 2.0, 70.0),
                                                    ("bicycle", 48, 0, None, 35.0), ("bicycle", 300, 1, 4.0, 60.0),
                                                    ("planarbike", 70, 0, None, 40.0),
-                                                   ("twod", 1024, 0, None, 90.0), ("twod", 1279, 1, None, 100.0)])
+                                                   ("twod", 1024, 0, None, 90.0), ("twod", 1279, 1, None, 100.0), ("twod", 2100, 0, None, 130.0)])
 def test_mid_crowds_vs_oracle(amd, model, n, rule, hfov, box):
     """dense crowds: total forces against the oracle every tick for 20 ticks (every receiver, 1e-4 of the largest force; the
     oracle re-anchored on the engine's state before every tick where the crowd is large - with 3 000 road users some pair sits
