@@ -3440,7 +3440,9 @@ int csf_shard_range(const csf_engine *e, int64_t *lo, int64_t *hi) {
 
 int csf_far_radius(const csf_engine *e, double *radius_m) {
     if (!e || !radius_m) return CSF_E_ARG;
-    const bool binned = e->d.pair_variant == 0 && e->d.p.model != CSF_BICYCLE && e->d.n >= BIN_MIN_AGENTS;
+    // (a population that has not been uploaded yet: the kernel the upload's re-binning will choose)
+    const int32_t pv = e->dirty ? pair_variant_for(e, (int64_t)e->order.size()) : e->d.pair_variant;
+    const bool binned = pv == 0 && e->d.p.model != CSF_BICYCLE && e->d.n >= BIN_MIN_AGENTS;
     // (computed here rather than read back: the kernel's copy is refreshed with the next upload of the population)
     *radius_m = binned ? (double)(float)far_radius(e->far_kappa, e->d.n, e->knobs.far_eps) : (double)INFINITY;  // no circles, no cull
     // (large populations: the radius in use since the last re-binning, from the sources a receiver can meet - rebin)

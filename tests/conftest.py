@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "auto_variant: the engine chooses its pair kernel by population size")
+    config.addinivalue_line("markers", "cull_variant: written around the cull-first kernel (its counters, its name): pinned even with CSF_TEST_AUTO_VARIANT=1")
 
 
 @pytest.fixture(autouse=True)
@@ -21,7 +22,10 @@ def _cull_kernel_at_every_size(request, monkeypatch):
     (csf_engine.hip: pair_variant_for).  Most parity cases are small and exist to exercise the cull-first kernel - its
     classification, queue and far-field cull - so the suite pins that kernel; tests marked `auto_variant` (and every test
     that sets CSF_PAIR_VARIANT itself) run with the engine's own choice."""
-    if "auto_variant" not in request.keywords and "CSF_PAIR_VARIANT" not in os.environ:
+    if "auto_variant" in request.keywords or "CSF_PAIR_VARIANT" in os.environ:
+        return
+    # CSF_TEST_AUTO_VARIANT=1: the whole suite on the engine's own choice, but for the tests written around the cull-first kernel
+    if os.environ.get("CSF_TEST_AUTO_VARIANT") != "1" or "cull_variant" in request.keywords:
         monkeypatch.setenv("CSF_PAIR_VARIANT", "0")
 
 

@@ -71,6 +71,7 @@ def _on_the_edge(hfov, st, i, j):
     return abs(abs(rel) - hfov / 2) < 1e-5
 
 
+@pytest.mark.cull_variant
 @pytest.mark.parametrize("model,n,box,ticks,segments", [("twod", 1500, 150.0, 60, 0), ("bicycle", 700, 100.0, 60, 0), ("invpend", 600, 100.0, 60, 0),
                                                          ("planarpoint", 500, 100.0, 60, 0), ("planarbike", 500, 100.0, 60, 0),
                                                          ("twod", 1500, 150.0, 60, 1), ("twod", 5000, 260.0, 40, 1), ("bicycle", 2100, 160.0, 40, 1),

@@ -269,7 +269,7 @@ def test_road_lattice_with_arrivals_and_departures(amd, monkeypatch):
 
 # --------------------------------------------------------------------------- BASELINE config 2, full length
 
-@pytest.mark.parametrize("kernel", ["cull-first (the suite's pin)", pytest.param("the engine's own choice: one launch per tick", marks=pytest.mark.auto_variant)])
+@pytest.mark.parametrize("kernel", [pytest.param("cull-first (the suite's pin)", marks=pytest.mark.cull_variant), pytest.param("the engine's own choice: one launch per tick", marks=pytest.mark.auto_variant)])
 def test_config2_1024_twod_10000_ticks(amd, kernel):
     """1 024 TwoDBicycle in 200 m x 200 m for the full 10 000 ticks (three laps of the 3000-column trajectory ring),
     destinations every 50 m out to 650 m so that the route outlasts the run (SURVEY.md §8(d) generator, longer reach).
@@ -589,6 +589,7 @@ def test_sharded_engine_with_parameter_sets_in_the_class_segmented_order(amd, mo
 
 # --------------------------------------------------------------------------- measurement plumbing
 
+@pytest.mark.cull_variant
 def test_profiling_event_pool_is_bounded(amd):
     """csf_profile_enable left on for more ticks than the pool has slots (256): the slots are recycled, every sampled
     launch is accounted for, and the per-launch samples are available until the sums are read."""

@@ -386,6 +386,7 @@ def test_history_and_push_state(amd):
     np.testing.assert_array_equal(e.state()[0], s[0])
 
 
+@pytest.mark.cull_variant
 def test_single_rank_communicator_path(amd):
     """world = 1 with a real RCCL communicator: the sharded tick (split agent phases, all-gather on the comm
     stream, event choreography) must reproduce the unsharded engine bit for bit."""
