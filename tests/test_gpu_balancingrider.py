@@ -218,3 +218,54 @@ def test_through_the_mirror_classes(golden):
         ins.step()
     assert late.s.shape == (5,) and late.s[0] > 5.8 and all(np.isfinite(b.s).all() for b in bikes)
     assert abs(bikes[3].s[5]) < 0.05                                # (the rider has caught the roll)
+
+
+def test_arrivals_and_departures_on_the_device(amd):
+    """balancing riders arriving and leaving between ticks through the device-side path (the spawn record carries all eight states;
+    patch_kernel starts the integrator from them, dynamics.py:306-307, 350-371) against the same sequence through the host mirror
+    (csf_set_incremental(0): download, change, upload): states, integrator states and destination pointers after every call"""
+    n0, box = 3300, 420.0
+    pool, off, dq = crowd(n0 + 900, box, seed=77)
+    dq3 = dq.reshape(-1, 4, 3)
+    engines = []
+    for inc in (True, False):
+        e = amd.Engine(amd.pod("balancingrider"), n0 + 400)
+        e.set_incremental(inc)
+        e.add_agents(pool[:n0], 4.5)
+        e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, dq3[:n0].reshape(-1, 3), reset=True)
+        e.step(3)
+        engines.append(e)
+    rng = np.random.default_rng(5)
+    n, fresh = n0, n0
+    for it in range(24):
+        op = ("remove", "add", "step")[it % 3]
+        if op == "remove":
+            idx = np.sort(rng.choice(n, int(rng.integers(5, 40)), replace=False))
+            for e in engines:
+                e.remove_agents(idx)
+            n -= idx.size
+        elif op == "add":
+            k = int(rng.integers(5, 40))
+            new = np.arange(fresh, fresh + k); fresh += k
+            for e in engines:
+                e.add_agents(pool[new], 4.5)
+                e.set_dest_queue(np.arange(n, n + k), np.arange(k + 1) * 4, dq3[new].reshape(-1, 3), reset=True)
+            n += k
+        else:
+            k = int(rng.integers(1, 4))
+            for e in engines:
+                e.step(k)
+        a, b = engines[0].state(with_nav=True), engines[1].state(with_nav=True)
+        assert a[0].shape == (n, 8)
+        # (a sparse population: few pairs interact, the two engines' fp32 sums are cut at other places - rounding level, growing
+        # slowly over the calls: the two are never re-anchored)
+        # (... which the rider's feedback gains multiply on their way into the steer and roll rates)
+        tol = np.array([5e-5, 5e-5, 5e-5, 1e-3, 5e-4, 5e-5, 1e-2, 1e-3])     # (the speed follows |F| with gain k_p_v t_s = 0.1 per tick)
+        assert (np.abs(a[0] - b[0]) < tol).all(), (it, op, np.abs(a[0] - b[0]).max(axis=0))
+        np.testing.assert_array_equal(a[1], b[1])
+        xa, va, _ = engines[0].integrator_state(); xb, vb, _ = engines[1].integrator_state()
+        assert (np.abs(xa - xb) < np.array([5e-5, 5e-4, 1e-3, 1e-2, 5e-5])).all()
+        np.testing.assert_allclose(va, vb, rtol=0, atol=1e-3)
+    assert all((e.status() == 0).all() for e in engines)
+    for e in engines:
+        e.close()
