@@ -33,6 +33,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -58,6 +59,7 @@ struct Rccl {
         SYM(CommDestroy, "ncclCommDestroy")
         SYM(AllGather, "ncclAllGather")
         SYM(AllReduce, "ncclAllReduce")
+        SYM(Broadcast, "ncclBroadcast")
         SYM(GroupStart, "ncclGroupStart")
         SYM(GroupEnd, "ncclGroupEnd")
         SYM(GetErrorString, "ncclGetErrorString")
@@ -1712,6 +1714,7 @@ int upload_all(csf_engine *e) {
     // record its own origin and rewrites it from the fp64 state just uploaded
     HIPCHK(e, hipMemsetAsync(e->rorg.p, 0, e->rorg.n * sizeof(float2), e->main));
     e->state_all_current = true;
+    e->xbuf_fresh = false;                                       // (exchange records of the population as it was: every record is rewritten from the state)
     launch_records(d, e->main);
     int rrc = rebin(e);
     if (rrc) return rrc;
@@ -1722,12 +1725,80 @@ int upload_all(csf_engine *e) {
     return CSF_OK;
 }
 
+// A rank of a sharded run integrates only its own block of slots: its fp64 copy of the other blocks goes stale with the first
+// tick.  Before the host may change the population - the road users of SUMO co-simulation arrive and leave on every rank's copy
+// alike, intersection.py:458-634 - every rank needs every block's state as it is now: one broadcast per rank, array and row,
+// grouped into one collective call (a rare call: a few hundred small pieces); the members of a loopback group copy them from
+// each other.  Every rank has to make the same population calls in the same order (they are collective from here on).
+template <class F>
+static int each_slot_array(csf_engine *e, F &&f) {                // f(base pointer, bytes per element, rows): the arrays download_all reads
+    const int hl = e->d.hist_len;
+    int rc;
+#define ARR(buf, rows) if ((rc = f((char *)e->buf.p, sizeof(*e->buf.p), (int)(rows)))) return rc;
+    ARR(s, STATE_ROWS) ARR(znp, 3) ARR(hx, hl) ARR(hy, hl) ARR(lti, 5) ARR(ppsi, 1) ARR(F, 6)
+    ARR(ptr, 1) ARR(ti, 1) ARR(dgood, 1) ARR(znav, 1) ARR(zrid, 1) ARR(status, 1)
+#undef ARR
+    return CSF_OK;
+}
+
+static int gather_population(csf_engine *e) {
+    if (e->state_all_current) return CSF_OK;
+    const size_t cap = (size_t)e->cap;
+    if (e->loopback) {                                             // for every member of the group at once (they tick in step)
+        const int world = (int)e->group.size();
+        for (csf_engine *dst : e->group) {
+            for (int r = 0; r < world; r++) {
+                csf_engine *src = e->group[(size_t)r];
+                if (src == dst) continue;
+                const int64_t lo = src->d.lo, hi = src->d.hi;
+                if (hi <= lo) continue;
+                // (the two engines hold the same arrays: walk them in step)
+                std::vector<char *> from, to;
+                std::vector<size_t> elem;
+                std::vector<int> rows;
+                each_slot_array(src, [&](char *p, size_t el, int rw) -> int { from.push_back(p); elem.push_back(el); rows.push_back(rw); return CSF_OK; });
+                each_slot_array(dst, [&](char *p, size_t, int) -> int { to.push_back(p); return CSF_OK; });
+                for (size_t k = 0; k < from.size(); k++)
+                    for (int row = 0; row < rows[k]; row++)
+                        HIPCHK(dst, hipMemcpyAsync(to[k] + ((size_t)row * cap + (size_t)lo) * elem[k], from[k] + ((size_t)row * cap + (size_t)lo) * elem[k],
+                                                   (size_t)(hi - lo) * elem[k], hipMemcpyDeviceToDevice, e->main));
+            }
+        }
+        for (csf_engine *m : e->group) m->state_all_current = true;
+        return CSF_OK;
+    }
+    if (e->world > 1 && e->nccl) {
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        if (e->comm) HIPCHK(e, hipStreamSynchronize(e->comm));
+        const int64_t shard = e->d.n_pad / e->world;
+        NCCLCHK(e, g_rccl.GroupStart());
+        int rc = each_slot_array(e, [&](char *p, size_t el, int rows) -> int {
+            for (int row = 0; row < rows; row++)
+                for (int r = 0; r < e->world; r++) {
+                    const int64_t lo = std::min<int64_t>(e->d.n, (int64_t)r * shard), hi = std::min<int64_t>(e->d.n, lo + shard);
+                    if (hi <= lo) continue;
+                    char *at = p + ((size_t)row * cap + (size_t)lo) * el;
+                    NCCLCHK(e, g_rccl.Broadcast(at, at, (size_t)(hi - lo) * el, ncclChar, r, e->nccl, e->main));
+                }
+            return CSF_OK;
+        });
+        NCCLCHK(e, g_rccl.GroupEnd());
+        if (rc) return rc;
+        HIPCHK(e, hipStreamSynchronize(e->main));
+    }
+    e->state_all_current = true;                                   // (one rank: every block is its own)
+    return CSF_OK;
+}
+
 int prepare_mutation(csf_engine *e) {
     // a rank integrates only its own block: its fp64 copy of the other blocks goes stale with the first tick, and an
-    // upload would rebuild their records from it
-    if ((e->world > 1 || e->loopback) && e->device_ahead)
-        return fail(e, CSF_E_STATE, "a sharded population cannot be changed from the host once ticks have run");
-    int rc = download_all(e);
+    // upload would rebuild their records from it - so the blocks are gathered first (gather_population)
+    int rc;
+    if ((e->world > 1 || e->loopback || e->nccl) && e->device_ahead) {
+        if ((rc = flush_pending(e))) return rc;
+        if ((rc = gather_population(e))) return rc;
+    }
+    rc = download_all(e);
     if (rc) return rc;
     e->dirty = true;
     return CSF_OK;
@@ -2100,7 +2171,6 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!s0 || !v_desired))) return fail(e, CSF_E_ARG, "csf_add_agents: bad arguments");
     if ((int64_t)e->order.size() + n > e->cap_user) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap_user);
-    if (e->world > 1 && e->nccl) return fail(e, CSF_E_STATE, "population is frozen once the shard communicator exists");
     if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
     Dev &d = e->d;
@@ -2226,7 +2296,6 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
 int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && !idx)) return fail(e, CSF_E_ARG, "csf_remove_agents: bad arguments");
-    if (e->world > 1 && e->nccl) return fail(e, CSF_E_STATE, "population is frozen once the shard communicator exists");
     HIPCHK(e, hipSetDevice(e->device));
     const int64_t pop = (int64_t)e->order.size();
     std::vector<uint8_t> kill((size_t)pop, 0);

@@ -110,7 +110,10 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
  * the queues when full); no download, no upload; the binned order is renewed when ticks x arrivals since the last renewal
  * reaches a few thousand.  The capacity holds up to 4096 extra slots for this.  on == 0: every change goes through the host
  * mirror (download, edit, upload, re-sort), which is also what sharded engines and engines with the history ring do.
- * The population order seen by every other entry point is the same either way. */
+ * The population order seen by every other entry point is the same either way.
+ * On a sharded run (csf_comm_init) the population calls, csf_push_state and csf_set_integrator_state are COLLECTIVE: every rank
+ * makes the same calls in the same order; before the first change after a tick the ranks exchange the fp64 state of their blocks
+ * (a rank integrates only its own), and the next tick starts from the upload with new shard bounds. */
 int csf_set_incremental(csf_engine *e, int32_t on);
 
 /* Vehicle.setDestinations (vehicle.py:606-647) for n agents: CSR (offsets[n+1], xyz_stop[sum,3]);

@@ -437,10 +437,70 @@ def test_sharded_engine_loopback(amd, monkeypatch, model, world, n, binned):
     for m in members:
         lo, hi = m.shard_range()
         assert (m.status()[lo:hi] == 0).all()
-        with pytest.raises(Exception):
-            m.push_state([0], s[:1])                        # a sharded population is frozen on the host side
     for m in members[::-1]:
         m.close()
+
+
+@pytest.mark.parametrize("model,world,n", [("twod", 3, 3001), ("invpend", 2, 1100), ("twod", 2, 6000)])
+def test_population_changes_on_a_sharded_engine(amd, monkeypatch, model, world, n):
+    """Road users arriving and leaving on a sharded run (the SUMO seam of intersection.py:458-634 on several ranks): every rank
+    makes the same calls; before the first one the ranks exchange their blocks' fp64 state (a rank integrates its own block
+    only - csf_engine.hip: gather_population; here the loopback group's copies), then every rank changes its host mirror alike
+    and the next tick starts from the upload, with new shard bounds.  Against the unsharded engine making the same calls:
+    departures, arrivals with queues, a pushed state, desired speeds - positions, integrator states, pointers."""
+    monkeypatch.setenv("CSF_REBIN_TICKS", "32")
+    box = 110.0 if n < 5000 else 160.0
+    s0, off, dq = population(n + 200, box, seed=9)
+    dq3 = dq.reshape(-1, 4, 3)
+    ns = orc.N_STATES[MODELS[model]]
+    pool = np.zeros((n + 200, ns)); pool[:, :4] = s0[:, :4]
+    cap = n + 200
+
+    def make():
+        e = amd.Engine(amd.pod(model), cap)
+        e.add_agents(pool[:n], 5.0)
+        e.set_dest_queue(np.arange(n), np.arange(n + 1) * 4, dq3[:n].reshape(-1, 3), reset=True)
+        return e
+
+    ref = make()
+    members = [make() for _ in range(world)]
+    amd.Engine.loopback_group(members)
+    ref.step(6)
+    amd.Engine.step_group(members, 6)
+    rng = np.random.default_rng(3)
+    count, fresh = n, n
+    for rnd in range(3):
+        kill = np.sort(rng.choice(count, 25 + 10 * rnd, replace=False))
+        k = 30 + 20 * rnd
+        new = np.arange(fresh, fresh + k); fresh += k
+        pushed = ref.state()[:2].copy(); pushed[:, 0] += 0.5
+        for e in [ref] + members:                               # the same calls on every rank
+            e.remove_agents(kill)
+            e.add_agents(pool[new], 4.0)
+            e.set_dest_queue(np.arange(count - kill.size, count - kill.size + k), np.arange(k + 1) * 4, dq3[new].reshape(-1, 3), reset=True)
+            e.set_v_desired(np.arange(5), np.full(5, 3.0 + rnd))
+            e.push_state([0, 1], pushed)
+        count += k - kill.size
+        size = -(-(-(-count // world)) // 64) * 64
+        ref.step(9)
+        amd.Engine.step_group(members, 9)
+        for r, m in enumerate(members):
+            assert m.n == count and m.shard_range() == (min(count, r * size), min(count, (r + 1) * size))
+        got, F = gather_blocks(members)
+        want = ref.state()
+        assert got.shape == want.shape == (count, ns)
+        # (nine ticks from a common state: the same terms in another fp32 summation order)
+        np.testing.assert_allclose(got[:, :2], want[:, :2], rtol=0, atol=2e-5, err_msg=f"round {rnd}")
+        np.testing.assert_allclose(got[:, 3], want[:, 3], rtol=0, atol=2e-4)
+        ptr = np.zeros(count, dtype=np.int64)
+        for m in members:
+            lo, hi = m.shard_range()
+            ptr[lo:hi] = m.state(with_nav=True)[1][lo:hi]
+            assert (m.status()[lo:hi] == 0).all()
+        np.testing.assert_array_equal(ptr, ref.state(with_nav=True)[1])
+    for m in members[::-1]:
+        m.close()
+    ref.close()
 
 
 def test_loopback_first_tick_matches_unsharded_closely(amd):

@@ -402,6 +402,15 @@ def test_single_rank_communicator_path(amd):
     assert e.shard_range() == (0, n)
     e.step(40)
     np.testing.assert_array_equal(e.state(), ref.state())
+    # the population changes with the communicator in place (every rank would make the same calls: csf_engine.hip gather_population)
+    for eng in (ref, e):
+        eng.remove_agents(np.arange(100, 140))
+        eng.add_agents(s0[:25] + np.array([0.3, 0.2, 0.0, 0.0, 0.0]), 4.0)
+        eng.set_dest_queue(np.arange(n - 40, n - 15), np.arange(26) * 4, dq.reshape(-1, 4, 3)[:25].reshape(-1, 3), reset=True)
+        eng.step(12)
+    assert e.n == ref.n == n - 15 and e.shard_range() == (0, n - 15)
+    # (the unsharded engine takes arrivals on the device, this one through its host mirror: other slots, another summation order)
+    np.testing.assert_allclose(e.state(), ref.state(), rtol=0, atol=1e-4)
 
 
 @pytest.mark.parametrize("rpb", [8, 16, 32])
