@@ -172,6 +172,7 @@ void launch_small_tick(const Dev &d, int n_ticks, hipStream_t st, hipEvent_t t0,
     case CSF_TWOD: CSF_SMALL(CSF_TWOD); break;
     case CSF_INVPEND: CSF_SMALL(CSF_INVPEND); break;
     case CSF_PLANARBIKE: CSF_SMALL(CSF_PLANARBIKE); break;
+    case CSF_BALANCINGRIDER: CSF_SMALL(CSF_BALANCINGRIDER); break;
     default: CSF_SMALL(CSF_PLANARPOINT); break;
     }
 #undef CSF_SMALL

@@ -2918,7 +2918,7 @@ static bool small_fused_ok(const csf_engine *e) {
     const Dev &d = e->d;
     const int m = d.p.model;
     return e->knobs.fused_small != 0 && e->knobs.pair_variant < 0 && d.n >= 1 && d.n <= SMALL_MAX && d.n_live == d.n &&
-           e->classes.size() == 1 && m != CSF_UNCONTROLLED && m != CSF_BALANCINGRIDER && small_road_ok(d) &&
+           e->classes.size() == 1 && m != CSF_UNCONTROLLED && small_road_ok(d) &&
            e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && d.hist == nullptr && e->profile <= 0 &&
            d.atrace == nullptr && d.lo == 0 && d.hi == d.n && e->pend.empty() && !e->dirty;
 }

@@ -38,7 +38,8 @@
 namespace csf {
 
 // waves of a workgroup: twelve where the per-agent code of the vehicle class leaves room for three waves per SIMD (168 registers),
-// else eight - one workgroup per CU either way, and one more wave per SIMD on the pair sums
+// else eight (InvPendulum; the BalancingRider's per-agent chain is longer still and its one-launch tick was measured no faster than
+// two launches - 16.4 against 15.6 us at 1 024 riders -: csf_engine.hip keeps that class on two launches) - one workgroup per CU either way, and one more wave per SIMD on the pair sums
 __host__ __device__ constexpr int mid_waves(int model) { return model == CSF_INVPEND ? 8 : 12; }
 constexpr int MID_GROUP_MAX = 32;             // road users (slots) of a group at most
 constexpr int MID_ITEMS_MAX = 384;            // (receiver set, source batch) items of a group at most: 12 KB of partial sums

@@ -23,10 +23,9 @@ def run(tag, model, n, box, env):
     for k, v in env.items():
         os.environ[k] = v
     s0, off, dq = synthetic_population(n, box, reach=REACH)
-    if model == "invpend":
-        s0 = np.c_[s0, np.zeros(n)]
-    elif model == "planarpoint":
-        s0 = s0[:, :4]
+    from cyclistsocialforce_amd import _ffi, engine as _engine
+    width = _ffi.N_STATES[_engine.MODEL_IDS[model]]
+    s0 = np.c_[s0, np.zeros((n, max(0, width - s0.shape[1])))][:, :width]
     e = Engine(parameters.default_pod(model), n)
     e.add_agents(s0, 5.0)
     e.set_dest_queue(np.arange(n), off, dq, reset=True)
