@@ -105,7 +105,7 @@ struct Knobs {
     int pair_variant = -1;                    // CSF_PAIR_VARIANT (-1: by population size)
     int64_t rebin_ticks = 64;                 // CSF_REBIN_TICKS: ticks between two re-binnings (1 .. 120; the tests that step 40 - 48 ticks "across a re-binning" pin 32)
     int fused_mid = 1;                        // CSF_FUSED_MID=0: mid-size populations take a pair launch and a per-agent launch per tick (csf_mid.hip: one launch)
-    int mid_below = 2176;                     // CSF_MID_BELOW: ... for populations smaller than this
+    int mid_below = 0;                        // CSF_MID_BELOW: ... for populations smaller than this (0: by vehicle class, mid_below_for)
     int mid_group = 0;                        // CSF_MID_GROUP: road users per workgroup of it, 4 / 8 / 16 / 32 (0: about one workgroup per CU)
     int fused_small = 1;                      // CSF_FUSED_SMALL=0: a handful of road users take the general path too (csf_agent.hip: small_tick_kernel)
     int segments = -1;                        // CSF_SEGMENTS
@@ -142,7 +142,7 @@ struct Knobs {
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
         fused_small = geti("CSF_FUSED_SMALL", 1);
         fused_mid = geti("CSF_FUSED_MID", 1);
-        mid_below = geti("CSF_MID_BELOW", 2176);
+        mid_below = geti("CSF_MID_BELOW", 0);
         mid_group = geti("CSF_MID_GROUP", 0);
         rebin_ticks = std::max(1, std::min(120, geti("CSF_REBIN_TICKS", 64)));
         segments = geti("CSF_SEGMENTS", -1);
@@ -2764,9 +2764,18 @@ static int calibrate_comm_stream_body(csf_engine *e) {
 // ---- mid-size populations: the whole tick in one launch (csf_mid.hip) --------------------------------------------------
 // One device, one parameter set, the plain all-pairs kernel's range (below PLAIN_BELOW road users; up to SMALL_MAX the one-wave
 // kernel is faster still), nothing that wants the two kernels apart (time stamps per kernel, wave traces, pair counters).
+// Where two launches take over again (tools/mid_rate.py, profiles/r5_v2_models_mid_rate.jsonl; microseconds per tick, one launch /
+// two): the classes with twelve waves per workgroup and the cull-first pair sums win up to ~2 100 road users (2 048: TwoD 20.9 /
+// 22.0, PlanarPoint 20.6 / 21.7), the InvPendulum (eight waves) and the Bicycle field (four receivers per item, no cull) only
+// to ~1 300 (1 024: 18.2 / 19.2 and 13.7 / 14.0; 2 048: 29.2 / 26.0 and 20.0 / 17.5).
+static int64_t mid_below_for(const csf_engine *e) {
+    if (e->knobs.mid_below > 0) return e->knobs.mid_below;
+    return e->d.p.model == CSF_INVPEND || e->d.p.model == CSF_BICYCLE ? 1280 : 2176;
+}
+
 static bool mid_fused_ok(const csf_engine *e) {
     const Dev &d = e->d;
-    return e->knobs.fused_mid != 0 && e->knobs.pair_variant < 0 && d.pair_variant == 1 && d.n_live > 1 && d.n_live < e->knobs.mid_below && e->classes.size() == 1 &&
+    return e->knobs.fused_mid != 0 && e->knobs.pair_variant < 0 && d.pair_variant == 1 && d.n_live > 1 && d.n_live < mid_below_for(e) && e->classes.size() == 1 &&
            d.p.model != CSF_UNCONTROLLED && d.p.model != CSF_BALANCINGRIDER && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && e->profile <= 0 &&
            d.trace == nullptr && d.pair_count == nullptr && d.lo == 0 && d.hi == d.n && e->segs.empty() && e->state_all_current &&
            d.src_beg == 0 && d.n_src / 64 * 8 <= 384;                  // (csf_mid.hip: MID_ITEMS_MAX items of the largest group)
