@@ -343,6 +343,7 @@ struct csf_engine {
     // largest |coordinate| relative to the scene origin at the last upload (road users, prescribed trajectories, arrivals
     // since), and the integration steps since - nobody moves farther than t_s * v_max per step
     double coord_bound0 = 0.0;
+    double *bound_pin = nullptr;     // pinned: where the positions land when that bound is measured again (set_fov_band)
     int64_t moves = 0;
     int64_t small_ticks = 0;         // ticks run by the one-wave kernel (csf_small_ticks)
     int64_t slab_rewrites = 0;       // compact_slab calls (upload_queues sizes the slab by them)
@@ -544,9 +545,12 @@ int set_fov_band(csf_engine *e) {
     Dev &d = e->d;
     const double u = 5.9604644775390625e-8;
     if (e->bound_stale) {   // (single device: every slot's state is here)
-        std::vector<double> xy(2 * (size_t)e->cap);
+        // (through a pinned buffer: the first copy into pageable memory of a process costs ~9 ms - the runtime sets its staging
+        // path up - and a population that is only ever stepped met it here, in the middle of a run: tick 4 096 of config 2)
+        if (!e->bound_pin) HIPCHK(e, hipHostMalloc((void **)&e->bound_pin, 2 * (size_t)e->cap * sizeof(double), hipHostMallocDefault));   // (csf_create made it)
+        HIPCHK(e, hipMemcpyAsync(e->bound_pin, e->s.p, 2 * (size_t)e->cap * sizeof(double), hipMemcpyDeviceToHost, e->main));
         HIPCHK(e, hipStreamSynchronize(e->main));
-        HIPCHK(e, hipMemcpy(xy.data(), e->s.p, xy.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const double *xy = e->bound_pin;
         double cb = e->coord_bound0;
         for (int32_t a : e->order) {
             const double bx = std::fabs(xy[(size_t)a] - d.ox), by = std::fabs(xy[(size_t)e->cap + (size_t)a] - d.oy);
@@ -920,6 +924,7 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->edge_head.alloc(cap));
     e->pend_spawn_at.assign(cap, -1);
     e->holes.recent_at.assign(cap, -1);
+    if (!e->bound_pin) HIPCHK(e, hipHostMalloc((void **)&e->bound_pin, 2 * (size_t)cap * sizeof(double), hipHostMallocDefault));
     e->pend_requeue_at.assign(cap, -1);
     e->pend_retire_at.assign(cap, -1);
     e->dev_alive.assign(cap, 0);
@@ -2121,6 +2126,7 @@ int csf_destroy(csf_engine *e) {
     e->ptab.release(); e->pctab.release(); e->pbtab.release(); e->cls.release();
     e->sort_vals.release(); e->rlist.release(); e->sort_keys.release(); e->sort_keys_out.release(); e->sort_tmp.release();
     if (e->snap_host) (void)hipHostFree(e->snap_host);
+    if (e->bound_pin) (void)hipHostFree(e->bound_pin);
     if (e->holes.pos) (void)hipHostFree(e->holes.pos);
     if (e->holes.bnd) (void)hipHostFree(e->holes.bnd);
     if (e->holes.ev) (void)hipEventDestroy(e->holes.ev);
