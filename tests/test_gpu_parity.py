@@ -13,7 +13,7 @@ from oracle import csf_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-MODELS = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3}
+MODELS = {"bicycle": 0, "twod": 1, "invpend": 2, "planarpoint": 3, "planarbike": 4, "balancingrider": 6}
 
 
 @pytest.fixture(scope="module")

@@ -54,11 +54,15 @@ def crowd(n, seed, box=14.0):
                                                ("invpend", 6, 0, None), ("planarpoint", 8, 1, 2.0), ("planarpoint", 3, 0, None),
                                                ("twod", 16, 0, None), ("twod", 13, 1, 2.0), ("invpend", 16, 0, 4.0), ("planarpoint", 11, 0, None), ("twod", 16, 0, 4.0),
                                                ("twod", 32, 0, None), ("planarpoint", 27, 1, 2.0), ("invpend", 32, 0, None), ("invpend", 32, 0, 4.0), ("twod", 19, 0, 4.0),
-                                               ("bicycle", 7, 0, None), ("bicycle", 32, 1, None), ("bicycle", 12, 0, 4.0)])
+                                               ("bicycle", 7, 0, None), ("bicycle", 32, 1, None), ("bicycle", 12, 0, 4.0),
+                                               ("balancingrider", 5, 0, None), ("balancingrider", 14, 1, 2.5), ("balancingrider", 32, 0, None)])
 def test_small_crowds_vs_oracle(amd, model, n, rule, hfov):
     """a dense handful (14 m box: every pair matters, fields of view cut through the crowd), forces every tick for 30 ticks,
     trajectories over 400 - against the oracle, and against the engine's general path"""
-    x, y, psi, v, off, dq = crowd(n, seed=10 * n + rule, box=14.0 if n <= 8 else (22.0 if n <= 16 else 30.0))
+    box = 14.0 if n <= 8 else (22.0 if n <= 16 else 30.0)
+    if model == "balancingrider":
+        box *= 2.0             # (the pole placement's gains grow as a rider is slowed to walking pace: tests/test_gpu_balancingrider.py)
+    x, y, psi, v, off, dq = crowd(n, seed=10 * n + rule, box=box)
     s0 = np.zeros((n, orc.N_STATES[MODELS[model]])); s0[:, 0] = x; s0[:, 1] = y; s0[:, 2] = psi; s0[:, 3] = v
     over = {} if hfov is None else {"hfov": hfov}
     e = make_engine(amd, model, s0, 5.0, off, dq, rule, **over)
