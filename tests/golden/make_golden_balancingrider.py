@@ -248,6 +248,29 @@ def main():
     out["dense_off"] = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
     out["dense_dq"] = np.vstack([v.destqueue for v in vs])
     out["dense_S"] = run(vs, 200)
+    # (6) three riders on the road of scenarios/curve-scenario.py: the road edges' forces (intersection.py:226-242) on this class
+    segs = mg.curve_road()
+    verts, roff, F0, sg = mg.road_arrays(segs)
+    vs = []
+    for k, (x, y) in enumerate(((0.5, -19.0), (-0.8, -16.0), (1.0, -12.0))):
+        b = rv.BalancingRiderBicycle((x, y, np.pi / 2, 4.0, 0.0, 0.0, 0.0, 0.0), id=f"r{k}")
+        dxs, dys = segs.get_destinations_from_segments()
+        b.setDestinations(dxs, dys)
+        vs.append(b)
+    out["road_s0"] = np.array([v.s for v in vs])
+    out["road_vdes"] = np.array([v.params.v_desired_default for v in vs])
+    out["road_off"] = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
+    out["road_dq"] = np.vstack([v.destqueue for v in vs])
+    for v in vs:
+        v.drawing = mg._NoDrawing()
+    ins = ri.SocialForceIntersection(vs, road_elements=[segs])
+    S = np.zeros((31, 3, 8)); S[0] = np.array([v.s for v in vs])
+    for tk in range(300):
+        ins.step()
+        if (tk + 1) % 10 == 0:
+            S[(tk + 1) // 10] = np.array([v.s for v in vs])
+    out["road_S"] = S
+    out["road_verts"], out["road_roff"], out["road_F0"], out["road_sigma"] = verts, roff, F0, sg
     np.savez(os.path.join(HERE, "balancingrider.npz"), **out)
     print("wrote balancingrider.npz:", {k: np.shape(v) for k, v in out.items()})
 

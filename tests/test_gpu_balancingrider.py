@@ -288,3 +288,21 @@ def test_golden_populations_through_the_one_wave_kernel(amd, golden, tag):
             np.testing.assert_allclose(got[:, 2:], S[k][:, 2:], rtol=0, atol=2e-3, err_msg=f"sample {k}")
         assert e.small_ticks() == 10 * (S.shape[0] - 1) and (e.status() == 0).all()
         e.close()
+
+
+@pytest.mark.parametrize("path", [pytest.param("one wave", marks=pytest.mark.auto_variant), "two launches"])
+def test_riders_between_road_edges_against_the_reference(amd, golden, path):
+    """three riders on the curve scenario's road (1 530 vertices of eight edges): the road term of intersection.py:853-857 on this
+    class, 300 ticks of the literal reference - in the one-wave kernel (the road staged in LDS) and on the general path"""
+    g = golden("balancingrider")
+    S = g["road_S"]
+    e = make_engine(amd, "balancingrider", g["road_s0"], g["road_vdes"], g["road_off"], g["road_dq"])
+    e.set_road(g["road_roff"], g["road_verts"], g["road_F0"], g["road_sigma"])
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    for k in range(1, S.shape[0]):
+        e.step(10)
+        got = e.state()
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"sample {k}")
+        np.testing.assert_allclose(got[:, 2:], S[k][:, 2:], rtol=0, atol=2e-3, err_msg=f"sample {k}")
+    assert (e.status() == 0).all() and (e.small_ticks() == 300) == (path == "one wave")
+    e.close()

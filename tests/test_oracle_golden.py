@@ -356,3 +356,15 @@ def test_balancingrider_population_trajectories(golden, tag):
     for k in range(1, S.shape[0]):
         pop.step(10)
         np.testing.assert_allclose(pop.state(), S[k], rtol=0, atol=1e-9, err_msg=f"sample {k}")
+
+
+def test_balancingrider_between_road_edges(golden):
+    """three riders on the road of scenarios/curve-scenario.py through the literal SocialForceIntersection.step with road_elements
+    (intersection.py:226-242, 853-857): 300 ticks, every tenth state"""
+    g = golden("balancingrider")
+    pop = orc.Population(orc.default_params("balancingrider"), g["road_s0"], g["road_vdes"], g["road_off"], g["road_dq"])
+    pop.set_road(g["road_roff"], g["road_verts"], g["road_F0"], g["road_sigma"])
+    S = g["road_S"]
+    for k in range(1, S.shape[0]):
+        pop.step(10)
+        np.testing.assert_allclose(pop.state(), S[k], rtol=0, atol=1e-9, err_msg=f"sample {k}")
