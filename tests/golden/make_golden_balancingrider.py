@@ -271,6 +271,21 @@ def main():
             S[(tk + 1) // 10] = np.array([v.s for v in vs])
     out["road_S"] = S
     out["road_verts"], out["road_roff"], out["road_F0"], out["road_sigma"] = verts, roff, F0, sg
+    # (7) the reference's DEFAULT demo: demoCSFstandalone.py -m balancingrider (:101-118, 144-146) - three riders, t = 7 s
+    vs = []
+    for ident, s0_, vd, dx_, dy_ in (("a", (-23 + 17, 0, 0, 5, 0, 0, 0, 0), 4.5, (35, 64, 65), (0, 0, 0)),
+                                      ("b", (0 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), 5.0, (15, 15, 15), (20, 49, 50)),
+                                      ("c", (-2 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), 5.0, (13, 13, 13), (20, 49, 50))):
+        b = rv.BalancingRiderBicycle(s0_, id=ident, saveForces=True)
+        b.params.v_desired_default = vd
+        b.setDestinations(dx_, dy_)
+        vs.append(b)
+    out["stddemo_s0"] = np.array([v.s for v in vs])
+    out["stddemo_vdes"] = np.array([v.params.v_desired_default for v in vs])
+    out["stddemo_off"] = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
+    out["stddemo_dq"] = np.vstack([v.destqueue for v in vs])
+    out["stddemo_S"] = run(vs, 700)
+    out["stddemo_F"] = np.array([v.force for v in vs])
     np.savez(os.path.join(HERE, "balancingrider.npz"), **out)
     print("wrote balancingrider.npz:", {k: np.shape(v) for k, v in out.items()})
 

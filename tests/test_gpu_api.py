@@ -500,6 +500,55 @@ def test_scripts_written_against_the_reference_package_name(golden):
             del sys.modules[k]
 
 
+def test_the_reference_default_demo_with_balancing_riders(golden):
+    """`python demo/demoCSFstandalone.py` as the reference ships it runs -m balancingrider: three BalancingRiderBicycles, t = 7 s
+    (:101-118, 144-146).  The same constructor calls, intersection and Scenario.run through the package with the reference's
+    name (compat/), against the literal reference's own run of it."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "compat"))
+    try:
+        from cyclistsocialforce.intersection import SocialForceIntersection
+        from cyclistsocialforce.scenario import Scenario
+        from cyclistsocialforce.vehicle import BalancingRiderBicycle as bike_type
+
+        class DemoScenario(Scenario):
+            def __init__(self):
+                bike1 = bike_type((-23 + 17, 0, 0, 5, 0, 0, 0, 0), id="a", saveForces=True)
+                bike1.params.v_desired_default = 4.5
+                bike2 = bike_type((0 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), id="b", saveForces=True)
+                bike2.params.v_desired_default = 5.0
+                bike3 = bike_type((-2 + 15, -20, np.pi / 2, 5, 0, 0, 0, 0), id="c", saveForces=True)
+                bike3.params.v_desired_default = 5.0
+                bike1.setDestinations((35, 64, 65), (0, 0, 0))
+                bike2.setDestinations((15, 15, 15), (20, 49, 50))
+                bike3.setDestinations((13, 13, 13), (20, 49, 50))
+                self.intersection = SocialForceIntersection((bike1, bike2, bike3), activate_sumo_cosimulation=False)
+                Scenario.__init__(self, self._step_func, verbose=False)
+
+            def _step_func(self):
+                self.intersection.step()
+
+        scn = DemoScenario()
+        scn.run(7)
+        g = golden("balancingrider")
+        S = g["stddemo_S"]
+        bikes = scn.intersection.vehicles
+        got = np.array([v.s for v in bikes])
+        assert got.shape == (3, 8) and all(v.i == 700 for v in bikes)
+        np.testing.assert_allclose(got[:, :2], S[-1][:, :2], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(got[:, 2:], S[-1][:, 2:], rtol=0, atol=2e-3)
+        for k, v in enumerate(bikes):
+            np.testing.assert_allclose(v.traj[:2, 10:701:10].T, S[1:, k, :2], rtol=0, atol=2e-4)      # vehicle.traj history
+            np.testing.assert_allclose(v.force, g["stddemo_F"][k], rtol=0, atol=2e-3)
+    finally:
+        sys.path.remove(os.path.join(root, "compat"))
+        for k in [k for k in sys.modules if k == "cyclistsocialforce" or k.startswith("cyclistsocialforce.")]:
+            del sys.modules[k]
+
+
 def test_uncontrolled_vehicle_in_an_intersection(golden):
     """UncontrolledVehicle through the drop-in classes (vehicle.py:920-988): cyclists, a car on a prescribed trajectory and a
     parked one in ONE SocialForceIntersection, constructed as the reference's users would - against the trajectories the

@@ -346,10 +346,11 @@ def test_balancingrider_gains_and_steps_against_the_reference(golden):
         np.testing.assert_allclose(pop.state()[0], S[t + 1], rtol=0, atol=1e-10, err_msg=f"step {t}")
 
 
-@pytest.mark.parametrize("tag", ["demo", "dense"])
+@pytest.mark.parametrize("tag", ["demo", "dense", "stddemo"])
 def test_balancingrider_population_trajectories(golden, tag):
     """three and sixteen BalancingRiderBicycles through the literal SocialForceIntersection.step (TwoD field, direct-approach
-    destination force, vehicle.py:1953-1990): 300 / 200 ticks, every tenth state"""
+    destination force, vehicle.py:1953-1990): 300 / 200 ticks, every tenth state; stddemo: the reference's DEFAULT demo,
+    demoCSFstandalone.py -m balancingrider, 700 ticks"""
     g = golden("balancingrider")
     pop = orc.Population(orc.default_params("balancingrider"), g[f"{tag}_s0"], g[f"{tag}_vdes"], g[f"{tag}_off"], g[f"{tag}_dq"])
     S = g[f"{tag}_S"]
