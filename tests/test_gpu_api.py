@@ -424,7 +424,8 @@ def test_sumo_cosimulation_loop_against_the_reference(golden):
     print(f"SUMO loop vs the reference: {mk} moveToXY calls, worst position deviation {worst:.1e} m")
 
 
-def test_animated_demo_on_agg_canvas(tmp_path):
+@pytest.mark.parametrize("cls", ["twod", "balancingrider"])
+def test_animated_demo_on_agg_canvas(tmp_path, cls):
     """the reference's demo with animate=True (demo/demoCSFstandalone.py:120-156) - drawings created on
     the first tick, refreshed from the read-back of every tick, blitted by Scenario, histories plotted afterwards."""
     import matplotlib
@@ -433,7 +434,9 @@ def test_animated_demo_on_agg_canvas(tmp_path):
 
     fig, ax = plt.subplots(1, 1)
     ax.set_xlim(0, 30); ax.set_ylim(-10, 20)
-    bikes = demo_bikes(TwoDBicycle)
+    from cyclistsocialforce_amd.vehicle import BalancingRiderBicycle
+
+    bikes = demo_bikes(TwoDBicycle if cls == "twod" else BalancingRiderBicycle)      # (the demo's default class: eight states)
     ins = SocialForceIntersection(bikes, animate=True, axes=ax)
     scn = Scenario(ins.step, t_r=0, verbose=False, animate=True, axes=ax)
     scn.run(1.0)
