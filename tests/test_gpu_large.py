@@ -1040,13 +1040,17 @@ def test_random_population_calls_device_path_vs_host_mirror(amd, monkeypatch, se
             raise AssertionError(f"call {it} ({op}): {int(outside.sum())} road users differ; |A - B| = {dpos:.1e} m, {dang:.1e} rad, "
                                  f"{dvel:.1e} m/s; worst: road user {r} of {n}, state {c}: {A[r]} vs {B[r]}; calls so far: {history}")
     print(f"  after the last call: |A - B| = {dpos:.1e} m, {dang:.1e} rad, {dvel:.1e} m/s, {int(outside.sum())} road users outside the tight band")
+    holes = engines[0].holes_taken()
     for e in engines:
         assert np.isfinite(e.state()).all()
         bits = np.unique(e.status() & ~np.uint32(1))               # (random queues may end a spline: CSF_ST_SPLINE only)
         assert (bits == 0).all(), bits
         e.close()
-    print(f"  calls: {counts}; {n} road users at the end")
+    print(f"  calls: {counts}; {n} road users at the end; arrivals in leavers' slots: {holes}")
     assert min(counts.values()) > 0
+    # one parameter set, binned: some arrivals found the slot of a road user who had left nearby (csf_engine.hip: HoleIndex) -
+    # the sequence above ran through that path as well
+    assert holes > 0 or sets > 1 or n0 < 1024
 
 
 def test_arrival_bursts_beyond_the_sentinel_tail(amd):
