@@ -13,11 +13,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cyclistsocialforce_amd.intersection import SocialForceIntersection  # noqa: E402
 from cyclistsocialforce_amd.scenario import Scenario  # noqa: E402
-from cyclistsocialforce_amd.vehicle import (Bicycle, InvPendulumBicycle, PlanarBicycle, PlanarPointBicycle,  # noqa: E402
-                                            TwoDBicycle)
+from cyclistsocialforce_amd.vehicle import (BalancingRiderBicycle, Bicycle, InvPendulumBicycle, PlanarBicycle,  # noqa: E402
+                                            PlanarPointBicycle, TwoDBicycle)
 
-MODELS = {"2d": TwoDBicycle, "planartwowheel": Bicycle, "invpendulum": InvPendulumBicycle,
-          "planarpoint": PlanarPointBicycle, "planarbike": PlanarBicycle}
+MODELS = {"balancingrider": BalancingRiderBicycle, "2d": TwoDBicycle, "planartwowheel": Bicycle, "invpendulum": InvPendulumBicycle,
+          "planarpoint": PlanarPointBicycle, "planarbike": PlanarBicycle}      # (balancingrider: the reference demo's default)
 
 
 class Demo(Scenario):
