@@ -202,11 +202,21 @@ __device__ __forceinline__ void window_at(const Spline<M> &s, double u, Window &
     int si = 0;  // interior knots <= u; u = 1 falls into the last span (fpbspl / splev convention)
 #pragma unroll
     for (int j = 0; j < M - 4; j++) si += (u >= s.t[4 + j]) ? 1 : 0;
+    // The knots as opaque register values: left as members of `s`, the compiler turns the chain of selects below into ONE
+    // load from a selected address - and keeps the knot vector in scratch memory for it (184 bytes per lane in every kernel
+    // that holds this planner, a store and a dependent load of ~1 us on the destination force's chain).  (The allocation
+    // itself costs a launch nothing - tools/graph_gap_ubench.hip, mode 8 - the traffic does.)
+    double tk[M + 4];
+#pragma unroll
+    for (int j = 0; j < M + 4; j++) {
+        tk[j] = s.t[j];
+        asm volatile("" : "+v"(tk[j]));
+    }
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-        double v = s.t[1 + q];
+        double v = tk[1 + q];
 #pragma unroll
-        for (int c = 1; c <= M - 4; c++) v = (si == c) ? s.t[1 + q + c] : v;
+        for (int c = 1; c <= M - 4; c++) v = (si == c) ? tk[1 + q + c] : v;
         w.k[q] = v;
     }
 #pragma unroll

@@ -290,7 +290,7 @@ def test_golden_populations_through_the_one_wave_kernel(amd, golden, tag):
         e.close()
 
 
-@pytest.mark.parametrize("path", [pytest.param("one wave", marks=pytest.mark.auto_variant), "two launches"])
+@pytest.mark.parametrize("path", [pytest.param("one wave", marks=pytest.mark.auto_variant), pytest.param("two launches", marks=pytest.mark.cull_variant)])
 def test_riders_between_road_edges_against_the_reference(amd, golden, path):
     """three riders on the curve scenario's road (1 530 vertices of eight edges): the road term of intersection.py:853-857 on this
     class, 300 ticks of the literal reference - in the one-wave kernel (the road staged in LDS) and on the general path"""

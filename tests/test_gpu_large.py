@@ -1050,7 +1050,10 @@ def test_random_population_calls_device_path_vs_host_mirror(amd, monkeypatch, se
     assert min(counts.values()) > 0
     # one parameter set, binned: some arrivals found the slot of a road user who had left nearby (csf_engine.hip: HoleIndex) -
     # the sequence above ran through that path as well
-    assert holes > 0 or sets > 1 or n0 < 1024
+    import os
+
+    binned = os.environ.get("CSF_PAIR_VARIANT") == "0" or n0 >= 3072          # (the plain kernel of small populations has no binned order)
+    assert holes > 0 or sets > 1 or not binned
 
 
 def test_arrival_bursts_beyond_the_sentinel_tail(amd):
