@@ -197,7 +197,7 @@ struct Window {
     double x[4], y[4];
 };
 
-template <int M>
+template <int M, bool KREG>
 __device__ __forceinline__ void window_at(const Spline<M> &s, double u, Window &w) {
     int si = 0;  // interior knots <= u; u = 1 falls into the last span (fpbspl / splev convention)
 #pragma unroll
@@ -205,19 +205,31 @@ __device__ __forceinline__ void window_at(const Spline<M> &s, double u, Window &
     // The knots as opaque register values: left as members of `s`, the compiler turns the chain of selects below into ONE
     // load from a selected address - and keeps the knot vector in scratch memory for it (184 bytes per lane in every kernel
     // that holds this planner, a store and a dependent load of ~1 us on the destination force's chain).  (The allocation
-    // itself costs a launch nothing - tools/graph_gap_ubench.hip, mode 8 - the traffic does.)
-    double tk[M + 4];
+    // itself costs a launch nothing - tools/graph_gap_ubench.hip, mode 8 - the traffic does.)  KREG: where the planner is on a
+    // tick's critical path - the one-launch tick and the one-wave kernel: config 2 13.2 -> 13.0 us; the per-agent kernel of large
+    // populations is one wave per CU with other latencies to hide behind and ran 0.3 us FASTER with the load (8.4 against 8.7).
+    if constexpr (KREG) {
+        double tk[M + 4];
 #pragma unroll
-    for (int j = 0; j < M + 4; j++) {
-        tk[j] = s.t[j];
-        asm volatile("" : "+v"(tk[j]));
-    }
+        for (int j = 0; j < M + 4; j++) {
+            tk[j] = s.t[j];
+            asm volatile("" : "+v"(tk[j]));
+        }
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        double v = tk[1 + q];
+        for (int q = 0; q < 6; q++) {
+            double v = tk[1 + q];
 #pragma unroll
-        for (int c = 1; c <= M - 4; c++) v = (si == c) ? tk[1 + q + c] : v;
-        w.k[q] = v;
+            for (int c = 1; c <= M - 4; c++) v = (si == c) ? tk[1 + q + c] : v;
+            w.k[q] = v;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            double v = s.t[1 + q];
+#pragma unroll
+            for (int c = 1; c <= M - 4; c++) v = (si == c) ? s.t[1 + q + c] : v;
+            w.k[q] = v;
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -344,10 +356,10 @@ __device__ __forceinline__ bool spline_fit(Spline<M> &s, const double (&px)[M], 
     return true;
 }
 
-template <int M>
+template <int M, bool KREG>
 __device__ __forceinline__ void spline_pos(const Spline<M> &s, double u, double &X, double &Y) {
     Window w;
-    window_at(s, u, w);
+    window_at<M, KREG>(s, u, w);
     double N3[4], N2[3], N1[2];
     basis(w.k, u, N3, N2, N1);
     X = N3[0] * w.x[0] + N3[1] * w.x[1] + N3[2] * w.x[2] + N3[3] * w.x[3];
@@ -355,11 +367,11 @@ __device__ __forceinline__ void spline_pos(const Spline<M> &s, double u, double 
 }
 
 // position, first and second derivative at u (splev with der = 0, 1, 2)
-template <int M>
+template <int M, bool KREG>
 __device__ __forceinline__ void spline_all(const Spline<M> &s, double u, double &X, double &Y, double &dX,
                                            double &dY, double &ddX, double &ddY) {
     Window w;
-    window_at(s, u, w);
+    window_at<M, KREG>(s, u, w);
     double N3[4], N2[3], N1[2];
     basis(w.k, u, N3, N2, N1);
     X = N3[0] * w.x[0] + N3[1] * w.x[1] + N3[2] * w.x[2] + N3[3] * w.x[3];
@@ -385,7 +397,7 @@ __device__ __forceinline__ void spline_all(const Spline<M> &s, double u, double 
 }
 
 // vehicle.py:1494-1558 once the M control points are known
-template <int M>
+template <int M, bool KREG>
 __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const double (&px)[M], const double (&py)[M], bool last,
                              double vd, double &fx, double &fy) {
     const int nS = 20, ipred = 3, ipredlast = 5;              // :1446-1448
@@ -401,7 +413,7 @@ __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const doubl
         double best = INFINITY;
         for (int k = 0; k < nS; k++) {
             double X, Y;
-            spline_pos(s, k == nS - 1 ? 1.0 : (double)k / (nS - 1), X, Y);
+            spline_pos<M, KREG>(s, k == nS - 1 ? 1.0 : (double)k / (nS - 1), X, Y);
             const double dd = (X - g.x) * (X - g.x) + (Y - g.y) * (Y - g.y);
             if (dd < best) {
                 best = dd;
@@ -414,8 +426,8 @@ __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const doubl
         const double ui = i == nS - 1 ? 1.0 : (double)i / (nS - 1);
         const double up = iprev == nS - 1 ? 1.0 : (double)iprev / (nS - 1);
         double X0, Y0, X1, Y1, dX, dY, ddX, ddY;
-        spline_all(s, ui, X0, Y0, dX, dY, ddX, ddY);
-        spline_pos(s, up, X1, Y1);
+        spline_all<M, KREG>(s, ui, X0, Y0, dX, dY, ddX, ddY);
+        spline_pos<M, KREG>(s, up, X1, Y1);
         const double sp = qsqrt(dX * dX + dY * dY);
         const double R = sp * sp * sp / fabs(dX * ddY - dY * ddX);  // :1532-1537
         const double thetacomf = 10 * (2 * PI / 360);         // :1541
@@ -431,6 +443,7 @@ __device__ __forceinline__ void spline_force(const Dev &d, Agent &g, const doubl
 }
 
 // vehicle.py:1416-1558
+template <bool KREG>
 __device__ __forceinline__ void twod_dest(const Dev &d, Agent &g, double &fx, double &fy) {
     update_destination(d, g);                                 // :1451
     double ddest, vd = update_nav(d, g, ddest);               // :1452
@@ -453,26 +466,26 @@ __device__ __forceinline__ void twod_dest(const Dev &d, Agent &g, double &fx, do
         if (cnt == 2) {
             const double px[4] = {h1x, h0x, g.rx[0], g.rx[1]};
             const double py[4] = {h1y, h0y, g.ry[0], g.ry[1]};
-            spline_force<4>(d, g, px, py, false, vd, fx, fy);
+            spline_force<4, KREG>(d, g, px, py, false, vd, fx, fy);
         } else if (cnt == 3) {
             const double px[5] = {h1x, h0x, g.rx[0], g.rx[1], g.rx[2]};
             const double py[5] = {h1y, h0y, g.ry[0], g.ry[1], g.ry[2]};
-            spline_force<5>(d, g, px, py, false, vd, fx, fy);
+            spline_force<5, KREG>(d, g, px, py, false, vd, fx, fy);
         } else {
             const double px[6] = {h1x, h0x, g.rx[0], g.rx[1], g.rx[2], g.rx[3]};
             const double py[6] = {h1y, h0y, g.ry[0], g.ry[1], g.ry[2], g.ry[3]};
-            spline_force<6>(d, g, px, py, false, vd, fx, fy);
+            spline_force<6, KREG>(d, g, px, py, false, vd, fx, fy);
         }
     } else {                                                  // :1486-1492: last leg, three trajectory points
         const int hm = d.hist_len - 1;
         const int back = max(0, g.ti - d.back);
         const double px[4] = {d.hx[(int64_t)(back & hm) * d.cap + g.a], h1x, h0x, g.rx[0]};
         const double py[4] = {d.hy[(int64_t)(back & hm) * d.cap + g.a], h1y, h0y, g.ry[0]};
-        spline_force<4>(d, g, px, py, true, vd, fx, fy);
+        spline_force<4, KREG>(d, g, px, py, true, vd, fx, fy);
     }
 }
 
-template <int MODEL>
+template <int MODEL, bool KREG>
 __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, double &fy) {
     if (MODEL == CSF_UNCONTROLLED) fx = 0, fy = 0;            // vehicle.py:987-988
     else if (MODEL == CSF_BICYCLE) direct_approach(d, g, fx, fy);  // vehicle.py:1189-1194
@@ -481,7 +494,7 @@ __device__ __forceinline__ void dest_force(const Dev &d, Agent &g, double &fx, d
         direct_approach(d, g, fx, fy);
     } else {
         if (MODEL == CSF_PLANARPOINT || MODEL == CSF_PLANARBIKE) update_destination(d, g);  // Vehicle.calcDestinationForce :295-297
-        twod_dest(d, g, fx, fy);
+        twod_dest<KREG>(d, g, fx, fy);
     }
 }
 
@@ -1078,7 +1091,7 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     stamp(1);
     double fdx, fdy;
     if (phases & PH_DEST) {
-        dest_force<MODEL>(d, g, fdx, fdy);
+        dest_force<MODEL, FUSED || MID != 0>(d, g, fdx, fdy);
         d.F[2 * cap + a] = fdx;
         d.F[3 * cap + a] = fdy;
         d.ptr[a] = g.ptr;
