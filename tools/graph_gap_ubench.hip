@@ -23,14 +23,16 @@ struct Big {            // a kernel argument block of the engine's size (csf_dev
     float pad[320];
 };
 
-// MODE bits: 1 the argument block is read, 2 a scratch array (dynamic index: 192 bytes per lane in scratch memory), 4 60 KB of LDS
+// MODE bits: 1 the argument block is read, 2 / 8 a scratch array (208 bytes per lane) touched by every lane / one lane per workgroup,
+// 4 / 16 60 KB of LDS touched by every lane (with a barrier) / by one lane
 template <int MODE>
 __global__ __launch_bounds__(768) void busy_kernel(const float *in, float *out, int busy_ticks, Big big) {
     constexpr bool BIG = (MODE & 1) != 0;
-    __shared__ float lds[(MODE & 4) ? 15000 : 1];
+    __shared__ float lds[(MODE & (4 | 16)) ? 15000 : 1];
     float stack[48];
 
     if (MODE & 4) lds[threadIdx.x] = in[threadIdx.x];
+    if ((MODE & 16) && threadIdx.x == 0) lds[blockIdx.x & 1023] = in[0];      // (60 KB allocated, one word touched)
     const unsigned long long t0 = wall_clock64();
     float v = in[(blockIdx.x * 64 + (threadIdx.x & 63)) & 16383];
     // (scratch memory, 208 bytes per lane allocated: MODE 2 - every lane touches two of its words; MODE 8 - one lane per workgroup does)
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(768) void busy_kernel(const float *in, float *out, 
     if ((MODE & 2) || ((MODE & 8) && threadIdx.x == 0)) v += stack[(int)(v * 1e-9f + (float)(threadIdx.x % 48)) % 48] + stack[(threadIdx.x + 7) % 48];   // (read back inside the busy time)
     while ((long long)(wall_clock64() - t0) < busy_ticks) v = v * 1.0000001f + 1e-9f;     // (100 MHz: 100 ticks per microsecond)
     if (MODE & 4) { __syncthreads(); v += lds[(threadIdx.x * 7) % 15000]; }
+    if ((MODE & 16) && threadIdx.x == 0) v += lds[blockIdx.x & 1023];
     if (BIG) v += big.pad[threadIdx.x & 255] + big.pad[319];       // (read: first from its last line, as a struct's late members are)
     if (threadIdx.x < 64) out[blockIdx.x * 64 + threadIdx.x] = v;
 }
@@ -65,6 +68,7 @@ int main(int argc, char **argv) {
         case 1: hipLaunchKernelGGL(busy_kernel<1>, dim3(256), dim3(768), 0, st, src, dst, busy, big); break;
         case 2: hipLaunchKernelGGL(busy_kernel<2>, dim3(256), dim3(768), 0, st, src, dst, busy, big); break;
         case 4: hipLaunchKernelGGL(busy_kernel<4>, dim3(256), dim3(768), 0, st, src, dst, busy, big); break;
+        case 16: hipLaunchKernelGGL(busy_kernel<16>, dim3(256), dim3(768), 0, st, src, dst, busy, big); break;
         case 8: hipLaunchKernelGGL(busy_kernel<8>, dim3(256), dim3(768), 0, st, src, dst, busy, big); break;
         case 7: hipLaunchKernelGGL(busy_kernel<7>, dim3(256), dim3(768), 0, st, src, dst, busy, big); break;
         default: hipLaunchKernelGGL(busy_kernel<0>, dim3(256), dim3(768), 0, st, src, dst, busy, big); break;
