@@ -12,7 +12,7 @@ Rank 0 prints ONE JSON line.  The CPU oracle is used only for the `cpu_baseline`
 What the line reports beside `value`:
   roofline      the dominant kernel (the all-pairs kernel) against the fp32 vector peak: 100 op-equivalents per pair
                  x the pairs the launch actually EVALUATES (counted on the device, csf_count_pairs:
-                pairs masked by the field of view are evaluated neither here nor by the reference) / the kernel's mean
+                pairs masked by the field of view are evaluated neither here nor by the reference) / the kernel's MEDIAN
                 duration from HIP events on its own stream over the timed region.  `traffic` is the HBM bytes per launch
                 from the committed rocprofv3 --pmc passes of this kernel, `hbm_frac` the physical HBM fraction.
   algorithmic   SURVEY.md §8(d)'s byte/flop rates over ALL N x n_loc pairs (what BASELINE.json's "HBM GB/s fraction" is
@@ -274,6 +274,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     samples = eng.profile_samples()
+    stats = eng.profile_stats()                                # (median / min / max per kernel: before the reset below)
     prof = eng.profile_kernels()
     eng.profile(0)
     if dist is not None:
@@ -292,8 +293,9 @@ def main():
     # every rank's own figures (kernel times incl. the all-gather, the stream order its communicator chose, the pairs one launch
     # of its receiver block evaluates): a scaling curve then explains itself
     order, cal = eng.comm_stream_order()
+    med = lambda k: (stats[k]["median"] if stats.get(k) else 0.0)   # noqa: E731  (microseconds; 0: not launched / not sampled)
     mine = {"rank": rank, "receivers": [int(lo), int(hi)],
-            "kernels_us": {k: (ms * 1e3 / max(c, 1)) for k, (ms, c) in prof.items()},
+            "kernels_us": {k: med(k) for k in prof}, "kernels_us_stats": stats,
             "pairs_evaluated": evaluated, "comm_stream": order, "comm_calibration_us": cal}
     ranks = [mine]
     if dist is not None:
@@ -302,8 +304,11 @@ def main():
     if rank == 0:
         value = n * args.steps / dt
         n_loc = hi - lo
-        mean_s = {k: ms * 1e-3 / max(c, 1) for k, (ms, c) in prof.items()}     # mean duration of each kernel
-        pair_s, road_s, agent_s, launches = mean_s["pair"], mean_s["road"], mean_s["agent"], prof["pair"][1]
+        # MEDIAN duration of each kernel over its sampled launches (round 6; the means stay beside them in `kernels_us_stats`:
+        # one launch of ~40 that meets a clock step or a re-binning's tail moves a mean by per cents, a median not at all)
+        mean_s = {k: ms * 1e-3 / max(c, 1) for k, (ms, c) in prof.items()}
+        med_s = {k: med(k) * 1e-6 for k in prof}
+        pair_s, road_s, agent_s, launches = med_s["pair"], med_s["road"], med_s["agent"], prof["pair"][1]
         pairs_all = float(n) * n_loc
         alg_bytes = 16.0 * n * n_loc + 8.0 * n_loc          # source records consumed + partial sums written
         traffic, traffic_src = measured_traffic(kernel) if (world == 1 and n == 16384 and args.model == "twod") else (None, None)
@@ -312,7 +317,8 @@ def main():
                     f"batches of sources beyond {rfar:.1f} m skipped: together they add < 2^-24 f_0 to a receiver "
                     f"(DESIGN.md D8; CSF_FAR_EPS=0 evaluates every pair)")
         roof = {"bound": "valu", "kernel": kernel, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "launch_us": pair_s * 1e6, "launches_sampled": int(launches), "pairs_evaluated": evaluated,
+                "launch_us": pair_s * 1e6, "launch_us_is": "median of the sampled launches", "launch_us_mean": mean_s["pair"] * 1e6,
+                "launches_sampled": int(launches), "pairs_evaluated": evaluated,
                 "pairs_all": pairs_all, "traffic": traffic, "traffic_source": traffic_src}
         if evaluated is not None and pair_s > 0:
             ops = OPS_PER_PAIR * evaluated + OPS_PER_TEST * work["tested"]
@@ -321,7 +327,7 @@ def main():
             roof["field_only_frac"] = OPS_PER_PAIR * evaluated / pair_s / 1e12 / VALU_PEAK_TFLOPS   # crediting the field alone
             roof["work_per_launch"] = dict(work, op_equivalents=ops)
             roof["note"] = ("(100 fp32 op-equivalents x pairs evaluated + 25 x sources tested per lane) by one launch "
-                            "(device counters) / mean kernel duration; the stream of source records is served from "
+                            "(device counters) / median kernel duration; the stream of source records is served from "
                             "LDS/L2, HBM is not the roof (hbm_frac)")
         else:
             roof["achieved"] = roof["frac"] = None
@@ -350,8 +356,10 @@ def main():
             "dispersed": dispersed,
             "roofline": roof,
             "kernels_us": {"pair": pair_s * 1e6, "road": road_s * 1e6, "agent": agent_s * 1e6,
-                           "all_gather": mean_s["gather"] * 1e6, "tick": dt / args.steps * 1e6,
+                           "all_gather": med_s["gather"] * 1e6, "tick": dt / args.steps * 1e6,
+                           "are": "medians over the sampled launches (kernels_us_stats: median, min, max, mean, n); tick: wall time / steps",
                            "sampled_launches": {k: c for k, (_, c) in prof.items()}},
+            "kernels_us_stats": stats,
             "algorithmic": {"bytes_per_launch": alg_bytes, "GBps": alg_bytes / pair_s / 1e9 if pair_s > 0 else None,
                             "x_hbm_peak": alg_bytes / pair_s / 1e9 / HBM_PEAK_GBS if pair_s > 0 else None,
                             "pairs_per_s": pairs_all / pair_s if pair_s > 0 else None,

@@ -28,7 +28,9 @@ SYMBOLS = (
     "csf_count_pairs", "csf_comm_init_loopback", "csf_step_group", "csf_untracked", "csf_update_destination",
     "csf_update_nav_state", "csf_set_dest_pointer", "csf_set_incremental", "csf_set_script", "csf_near_dropped", "csf_comm_stream_order", "csf_small_ticks", "csf_step_get_tick",
     "csf_get_integrator_state", "csf_set_integrator_state", "csf_mid_ticks", "csf_holes_taken",
+    "csf_create_v", "csf_params_size", "csf_profile_samples_of",
 )
+ABI_VERSION = 9
 
 
 class Params(C.Structure):
@@ -77,6 +79,10 @@ def load():
     vp, i32, i64, dp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
     L.csf_create.restype = vp
     L.csf_create.argtypes = [C.POINTER(Params), i64, i32]
+    L.csf_create_v.restype = vp
+    L.csf_create_v.argtypes = [C.POINTER(Params), C.c_size_t, i32, i64, i32]
+    L.csf_params_size.restype = C.c_size_t
+    L.csf_params_size.argtypes = []
     L.csf_destroy.argtypes = [vp]
     L.csf_last_error.restype = C.c_char_p
     L.csf_last_error.argtypes = [vp]
@@ -119,6 +125,7 @@ def load():
     pd = C.POINTER(C.c_double)
     L.csf_profile_kernels.argtypes = [vp, pd, C.POINTER(i64)]
     L.csf_profile_samples.argtypes = [vp, dp, i64, C.POINTER(i64)]
+    L.csf_profile_samples_of.argtypes = [vp, i32, dp, i64, C.POINTER(i64)]
     L.csf_count_pairs.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_char_p)]   # int64 counts[4]
     L.csf_comm_init_loopback.argtypes = [C.POINTER(vp), i32]
     L.csf_step_group.argtypes = [C.POINTER(vp), i32, i64]
@@ -136,7 +143,10 @@ def load():
     L.csf_holes_taken.argtypes = [vp, C.POINTER(i64)]
     L.csf_get_integrator_state.argtypes = [vp, dp, dp, vp]
     L.csf_set_integrator_state.argtypes = [vp, i64, vp, dp, dp, vp]
-    if L.csf_abi_version() != 8:
-        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected 8")
+    if L.csf_abi_version() != ABI_VERSION:
+        raise EngineError(f"libcsf_hip.so has ABI {L.csf_abi_version()}, expected {ABI_VERSION}")
+    if L.csf_params_size() != C.sizeof(Params):
+        raise EngineError(f"csf_params: the library's has {L.csf_params_size()} bytes, this binding's {C.sizeof(Params)} "
+                          "(include/csf.h and _ffi.Params are out of step)")
     _lib = L
     return L

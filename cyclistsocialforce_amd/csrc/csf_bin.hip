@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void clist_kernel(const Dev d, const float4 *t
             const float d2 = ex * ex + ey * ey;
             near = d2 <= rr * rr;
             if (!near && far != nullptr && fabsf(tc.x) < 1e14f)     // (a tile of nothing but sentinels adds nothing)
-                tail += (float)d.clist_tile * __expf(-kappa * fmaxf(sqrtf(d2) * 0.9999f - tc.z - gc.z - move, 0.0f));
+                tail += (float)d.clist_tile * __expf(-kappa * fmaxf(sqrtf(d2) * 0.9999f - tc.z - gc.z - 2.0f * move, 0.0f));   // (BOTH sides move until the next re-binning, as in `reach`)
         }
         const unsigned long long m = __ballot(near);
         if (near) {

@@ -271,7 +271,7 @@ constexpr int SMALL_ROAD_MAX = 2048;   // road vertices (padded) the one-wave ke
 void launch_small_tick(const Dev &d, int n_ticks, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 // csf_mid.hip: one tick of a mid-size population (plain pair sums + per-agent tick) in one launch; d.rec_w / recg_w / rec2_w /
 // src64_w point at the halves of the double buffers this tick does not read, d.mid_group = slots per workgroup
-void launch_mid_tick(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+bool launch_mid_tick(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 const char *pair_kernel_name(const Dev &d);           // the kernel launch_pair() takes for this engine
 void launch_records(const Dev &d, hipStream_t st);  // rebuild fp32 records from the fp64 state
 // csf_get_tick: row-major state [n, ns], Fx [n], Fy [n] (doubles), destination pointers [n] (int32), navigation state

@@ -390,7 +390,7 @@ struct csf_engine {
     double prof_ms[4] = {0, 0, 0, 0};   // pair, road, agent, gather
     int64_t prof_cnt[4] = {0, 0, 0, 0}; // launches behind each sum
     int64_t prof_ticks = 0;             // sampled ticks issued (the kernels beside the pair kernel are timed on every 8th)
-    std::vector<float> prof_pair_us;    // per sampled launch (at most PROF_KEEP of them)
+    std::vector<float> prof_us[4];      // per sampled launch and kernel - pair, road, per-agent, all-gather - (at most PROF_KEEP of each)
 };
 
 namespace {
@@ -1383,9 +1383,13 @@ int rebin(csf_engine *e) {
             d.clist = e->clist.p;
             d.ccount = e->ccount.p;
             if (tighten) {
+                // (into the pinned buffer csf_create made for the coordinate bound - cap >= 64 doubles; the stream is waited for
+                // right below, so the two uses cannot meet: a runtime's first copy into PAGEABLE memory cost 9 ms in mid-run)
                 unsigned st[2] = {0u, 0u};
-                HIPCHK(e, hipMemcpyAsync(st, e->far_stat.p, sizeof st, hipMemcpyDeviceToHost, e->main));
+                if (!e->bound_pin) HIPCHK(e, hipHostMalloc((void **)&e->bound_pin, 2 * (size_t)e->cap * sizeof(double), hipHostMallocDefault));
+                HIPCHK(e, hipMemcpyAsync(e->bound_pin, e->far_stat.p, sizeof st, hipMemcpyDeviceToHost, e->main));
                 HIPCHK(e, hipStreamSynchronize(e->main));
+                std::memcpy(st, e->bound_pin, sizeof st);
                 float tail;
                 std::memcpy(&tail, &st[1], sizeof tail);
                 const double eps = e->knobs.far_eps, met = std::min<double>((double)st[0], (double)d.n) + (double)TAIL_SLOTS;   // (+ arrivals until then)
@@ -1732,9 +1736,8 @@ int upload_all(csf_engine *e) {
 
 // A rank of a sharded run integrates only its own block of slots: its fp64 copy of the other blocks goes stale with the first
 // tick.  Before the host may change the population - the road users of SUMO co-simulation arrive and leave on every rank's copy
-// alike, intersection.py:458-634 - every rank needs every block's state as it is now: one broadcast per rank, array and row,
-// grouped into one collective call (a rare call: a few hundred small pieces); the members of a loopback group copy them from
-// each other.  Every rank has to make the same population calls in the same order (they are collective from here on).
+// alike, intersection.py:458-634 - every rank needs every block's state as it is now: one all-gather per array on packed blocks
+// (gather_population; a rare call); the members of a loopback group copy them from each other.  Every rank has to make the same population calls in the same order (they are collective from here on).
 template <class F>
 static int each_slot_array(csf_engine *e, F &&f) {                // f(base pointer, bytes per element, rows): the arrays download_all reads
     const int hl = e->d.hist_len;
@@ -1747,51 +1750,85 @@ static int each_slot_array(csf_engine *e, F &&f) {                // f(base poin
 }
 
 static int gather_population(csf_engine *e) {
-    if (e->state_all_current) return CSF_OK;
-    const size_t cap = (size_t)e->cap;
-    if (e->loopback) {                                             // for every member of the group at once (they tick in step)
-        const int world = (int)e->group.size();
-        for (csf_engine *dst : e->group) {
-            for (int r = 0; r < world; r++) {
-                csf_engine *src = e->group[(size_t)r];
-                if (src == dst) continue;
-                const int64_t lo = src->d.lo, hi = src->d.hi;
-                if (hi <= lo) continue;
-                // (the two engines hold the same arrays: walk them in step)
-                std::vector<char *> from, to;
-                std::vector<size_t> elem;
-                std::vector<int> rows;
-                each_slot_array(src, [&](char *p, size_t el, int rw) -> int { from.push_back(p); elem.push_back(el); rows.push_back(rw); return CSF_OK; });
-                each_slot_array(dst, [&](char *p, size_t, int) -> int { to.push_back(p); return CSF_OK; });
-                for (size_t k = 0; k < from.size(); k++)
-                    for (int row = 0; row < rows[k]; row++)
-                        HIPCHK(dst, hipMemcpyAsync(to[k] + ((size_t)row * cap + (size_t)lo) * elem[k], from[k] + ((size_t)row * cap + (size_t)lo) * elem[k],
-                                                   (size_t)(hi - lo) * elem[k], hipMemcpyDeviceToDevice, e->main));
-            }
-        }
-        for (csf_engine *m : e->group) m->state_all_current = true;
+    // One exchange per ARRAY (thirteen in all), on equal blocks: a rank packs the rows of its own block - strided by the capacity -
+    // into its place of a staging buffer ([rank][row][shard]: the in-place layout of ncclAllGather, the collective every tick
+    // already uses), and unpacks the others' behind the call.  The members of a loopback group pack and unpack with the same code
+    // and copy the packed blocks from each other where a real run calls the collective; a communicator of ONE rank takes the path
+    // too (its all-gather is a copy onto itself) - so what the tests on one device cannot reach is the collective call alone.
+    // (Until round 6: one ncclBroadcast per rank, array and ROW in one group - ~2 300 calls at 8 ranks with the ring's 128
+    // columns - on a branch no test could enter.)
+    const bool rehearse = e->nccl && e->world == 1 && !e->loopback;
+    if (e->state_all_current && !rehearse) return CSF_OK;
+    std::vector<csf_engine *> mem;
+    if (e->loopback) mem.assign(e->group.begin(), e->group.end());
+    else if (e->nccl) mem.push_back(e);
+    if (mem.empty()) {                                             // (one device, no communicator: every block is its own)
+        e->state_all_current = true;
         return CSF_OK;
     }
-    if (e->world > 1 && e->nccl) {
-        HIPCHK(e, hipStreamSynchronize(e->main));
-        if (e->comm) HIPCHK(e, hipStreamSynchronize(e->comm));
-        const int64_t shard = e->d.n_pad / e->world;
-        NCCLCHK(e, g_rccl.GroupStart());
-        int rc = each_slot_array(e, [&](char *p, size_t el, int rows) -> int {
-            for (int row = 0; row < rows; row++)
-                for (int r = 0; r < e->world; r++) {
-                    const int64_t lo = std::min<int64_t>(e->d.n, (int64_t)r * shard), hi = std::min<int64_t>(e->d.n, lo + shard);
-                    if (hi <= lo) continue;
-                    char *at = p + ((size_t)row * cap + (size_t)lo) * el;
-                    NCCLCHK(e, g_rccl.Broadcast(at, at, (size_t)(hi - lo) * el, ncclChar, r, e->nccl, e->main));
-                }
-            return CSF_OK;
-        });
-        NCCLCHK(e, g_rccl.GroupEnd());
-        if (rc) return rc;
-        HIPCHK(e, hipStreamSynchronize(e->main));
+    const int world = e->loopback ? (int)mem.size() : e->world;
+    const size_t cap = (size_t)e->cap;
+    const int64_t shard = e->d.n_pad / world;
+    if (shard <= 0 || shard * world != e->d.n_pad) return fail(e, CSF_E_STATE, "shard layout: %lld slots do not split over %d ranks", (long long)e->d.n_pad, world);
+    for (csf_engine *m : mem) {
+        if (m->cap != e->cap || m->d.n_pad != e->d.n_pad || m->d.n != e->d.n) return fail(e, CSF_E_STATE, "the ranks of a group hold different populations");
+        HIPCHK(m, hipStreamSynchronize(m->main));
+        if (m->comm) HIPCHK(m, hipStreamSynchronize(m->comm));
     }
-    e->state_all_current = true;                                   // (one rank: every block is its own)
+    struct Arr { char *p; size_t el; int rows; };
+    std::vector<std::vector<Arr>> arrs(mem.size());
+    for (size_t i = 0; i < mem.size(); i++)
+        each_slot_array(mem[i], [&](char *p, size_t el, int rows) -> int { arrs[i].push_back({p, el, rows}); return CSF_OK; });
+    std::vector<DevBuf<char>> stage(mem.size());
+    auto block = [&](int r, int64_t &lo, int64_t &hi) { lo = std::min<int64_t>(e->d.n, (int64_t)r * shard), hi = std::min<int64_t>(e->d.n, lo + shard); };
+    int rc = CSF_OK;
+    auto body = [&]() -> int {
+        for (size_t k = 0; k < arrs[0].size(); k++) {
+            const size_t el = arrs[0][k].el;
+            const int rows = arrs[0][k].rows;
+            if (rows <= 0) continue;
+            const size_t blk = (size_t)rows * (size_t)shard * el;  // bytes of one rank's packed block
+            int64_t lo, hi;
+            for (size_t i = 0; i < mem.size(); i++) {              // pack: own block, rows made contiguous
+                csf_engine *m = mem[i];
+                HIPCHK(m, stage[i].reserve(blk * (size_t)world));
+                block(m->rank, lo, hi);
+                if (hi > lo)
+                    HIPCHK(m, hipMemcpy2DAsync(stage[i].p + (size_t)m->rank * blk, (size_t)shard * el, arrs[i][k].p + (size_t)lo * el, cap * el,
+                                               (size_t)(hi - lo) * el, (size_t)rows, hipMemcpyDeviceToDevice, m->main));
+            }
+            if (e->loopback) {                                     // the "all-gather" of a group on one device
+                for (size_t i = 0; i < mem.size(); i++)
+                    for (size_t j = 0; j < mem.size(); j++)
+                        if (i != j)
+                            HIPCHK(mem[i], hipMemcpyAsync(stage[i].p + (size_t)mem[j]->rank * blk, stage[j].p + (size_t)mem[j]->rank * blk, blk,
+                                                          hipMemcpyDeviceToDevice, e->main));
+            } else {
+                NCCLCHK(e, g_rccl.AllGather(stage[0].p + (size_t)e->rank * blk, stage[0].p, blk, ncclChar, e->nccl, e->main));
+            }
+            for (size_t i = 0; i < mem.size(); i++) {              // unpack: everybody else's block
+                csf_engine *m = mem[i];
+                for (int r = 0; r < world; r++) {
+                    if (r == m->rank) continue;
+                    block(r, lo, hi);
+                    if (hi > lo)
+                        HIPCHK(m, hipMemcpy2DAsync(arrs[i][k].p + (size_t)lo * el, cap * el, stage[i].p + (size_t)r * blk, (size_t)shard * el,
+                                                   (size_t)(hi - lo) * el, (size_t)rows, hipMemcpyDeviceToDevice, m->main));
+                }
+            }
+        }
+        return CSF_OK;
+    };
+    rc = body();
+    hipError_t sr = hipSuccess;
+    for (csf_engine *m : mem) {                                    // (before the staging buffers go)
+        hipError_t r1 = hipStreamSynchronize(m->main);
+        if (sr == hipSuccess) sr = r1;
+    }
+    for (auto &b : stage) b.release();
+    if (rc) return rc;
+    HIPCHK(e, sr);
+    for (csf_engine *m : mem) m->state_all_current = true;
     return CSF_OK;
 }
 
@@ -1993,7 +2030,7 @@ int prof_resolve_one(csf_engine *e) {
         HIPCHK(e, hipEventElapsedTime(&ms, sl.ev[2 * k], sl.ev[2 * k + 1]));
         e->prof_ms[k] += ms;
         e->prof_cnt[k]++;
-        if (k == 0 && e->prof_pair_us.size() < PROF_KEEP) e->prof_pair_us.push_back(ms * 1e3f);
+        if (e->prof_us[k].size() < PROF_KEEP) e->prof_us[k].push_back(ms * 1e3f);
     }
     e->prof_resolved++;
     return CSF_OK;
@@ -2083,6 +2120,18 @@ csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t dev
     if (alloc_all(e) != CSF_OK) return bail("allocation");
     set_shard(e);
     return e;
+}
+
+size_t csf_params_size(void) { return sizeof(csf_params); }
+
+csf_engine *csf_create_v(const csf_params *params, size_t params_size, int32_t abi_version, int64_t n_capacity, int32_t device) {
+    // before anything is read from `params`: a hand-declared struct of another ABI is shorter (or longer) than ours
+    if (params_size != sizeof(csf_params) || abi_version != CSF_ABI_VERSION) {
+        fail(nullptr, CSF_E_ABI, "csf_create_v: the caller's csf_params has %zu bytes and ABI %d, this library's has %zu bytes and ABI %d "
+             "(include/csf.h: field order and size are ABI)", params_size, (int)abi_version, sizeof(csf_params), (int)CSF_ABI_VERSION);
+        return nullptr;
+    }
+    return csf_create(params, n_capacity, device);
 }
 
 int csf_destroy(csf_engine *e) {
@@ -2797,6 +2846,13 @@ static int mid_sync(csf_engine *e) {
         HIPCHK(e, e->rec2_alt.alloc(e->rec2.n));
         HIPCHK(e, e->src64_a.alloc(3 * (size_t)e->cap));
         HIPCHK(e, e->src64_b.alloc(3 * (size_t)e->cap));
+        // the permanent sentinel (alloc_all: the last record, no slot's; the padding of the class-segmented order points at it)
+        // exists in BOTH halves: after an odd number of one-launch ticks d.rec is the other half, and a population that then
+        // outgrows this path would read (0, 0, 0, 0) - a road user at the origin - where its order is padded
+        HIPCHK(e, hipMemcpyAsync(e->rec_alt.p + e->sent_slot, e->rec.p + e->sent_slot, sizeof(float4), hipMemcpyDeviceToDevice, e->main));
+        HIPCHK(e, hipMemcpyAsync(e->rec2_alt.p + e->sent_slot, e->rec2.p + e->sent_slot, sizeof(float2), hipMemcpyDeviceToDevice, e->main));
+        if ((size_t)e->sent_slot < e->recg.n)
+            HIPCHK(e, hipMemcpyAsync(e->recg_alt.p + e->sent_slot, e->recg.p + e->sent_slot, sizeof(float4), hipMemcpyDeviceToDevice, e->main));
     }
     float4 *rec_o = d.rec == e->rec.p ? e->rec_alt.p : e->rec.p, *recg_o = d.recg == e->recg.p ? e->recg_alt.p : e->recg.p;
     float2 *rec2_o = d.rec2 == e->rec2.p ? e->rec2_alt.p : e->rec2.p;
@@ -2809,10 +2865,10 @@ static int mid_sync(csf_engine *e) {
     return CSF_OK;
 }
 
+// (behind bounds_before_pair - the re-binning: new origins of the precise records, and a new d.n_src, which the gate reads)
 static int enqueue_mid_tick(csf_engine *e) {
     Dev &d = e->d;
     int rc;
-    if ((rc = bounds_before_pair(e))) return rc;              // (the re-binning: new origins of the precise records)
     if ((rc = set_fov_band(e))) return rc;
     if (!e->mid_synced && (rc = mid_sync(e))) return rc;
     if (d.nv > 0) launch_road(d, e->main);
@@ -2832,7 +2888,8 @@ static int enqueue_mid_tick(csf_engine *e) {
         while (G < 32 && (d.hi - d.lo + G - 1) / G > 256) G *= 2;
     }
     dd.mid_group = G;
-    launch_mid_tick(dd, e->main);
+    // (nothing has traded places yet: a refused launch leaves the engine where it was)
+    if (!launch_mid_tick(dd, e->main)) return fail(e, CSF_E_STATE, "the one-launch tick does not take this population (%lld sources, groups of %d)", (long long)d.n_src, G);
     HIPCHK(e, hipGetLastError());
     // the halves trade places: what the launch wrote is what every later launch reads
     d.rec = d.rec_w = rec_o;
@@ -2850,7 +2907,15 @@ static int enqueue_mid_tick(csf_engine *e) {
 //   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)
 static int enqueue_tick(csf_engine *e) {
     Dev &d = e->d;
-    if (mid_fused_ok(e)) return enqueue_mid_tick(e);
+    bool bounds_done = false;
+    if (mid_fused_ok(e)) {
+        // the re-binning inside may move d.n_src past what the one-launch tick takes: ask again behind it, and carry on with
+        // two launches (the bounds are in place) rather than lose the tick
+        int rcb = bounds_before_pair(e);
+        if (rcb) return rcb;
+        bounds_done = true;
+        if (mid_fused_ok(e)) return enqueue_mid_tick(e);
+    }
     e->mid_synced = false;
     const bool sharded = e->world > 1 || e->nccl != nullptr || e->loopback;  // a 1-rank communicator rehearses the sharded path
     int rc = CSF_OK;
@@ -2864,7 +2929,7 @@ static int enqueue_tick(csf_engine *e) {
         launch_agent(d, PH_DEST, e->main);
         if ((rc = wait_gather(e))) return rc;
     }
-    if ((rc = bounds_before_pair(e))) return rc;
+    if (!bounds_done && (rc = bounds_before_pair(e))) return rc;
     // sharded: the other ranks' records arrived in index order; a coalesced tile fill from the binned copy saves the
     // pair kernel 5 - 7 us at every shard size, the copy costs ~3 us
     if (sharded && d.recs_valid && e->ticks_since_rebin > 1) {
@@ -3557,7 +3622,7 @@ int csf_profile_kernels(csf_engine *e, double ms[4], int64_t launches[4]) {
     e->last_gather_ms = e->prof_ms[3];
     for (int k = 0; k < 4; k++) e->prof_ms[k] = 0, e->prof_cnt[k] = 0;
     e->prof_ticks = 0;
-    e->prof_pair_us.clear();
+    for (auto &v : e->prof_us) v.clear();
     return CSF_OK;
 }
 
@@ -3572,16 +3637,22 @@ int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *
     return CSF_OK;
 }
 
-int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_t *n_samples) {
-    if (!e || !n_samples || capacity < 0 || (capacity > 0 && !pair_us)) return e ? fail(e, CSF_E_ARG, "csf_profile_samples: bad arguments") : CSF_E_ARG;
+int csf_profile_samples_of(csf_engine *e, int32_t kernel, double *us, int64_t capacity, int64_t *n_samples) {
+    if (!e || !n_samples || capacity < 0 || (capacity > 0 && !us) || kernel < 0 || kernel > 3)
+        return e ? fail(e, CSF_E_ARG, "csf_profile_samples_of: bad arguments") : CSF_E_ARG;
     int rc = csf_sync(e);
     if (rc) return rc;
     while (e->prof_resolved < e->prof_issued)
         if ((rc = prof_resolve_one(e))) return rc;
-    const int64_t n = std::min<int64_t>(capacity, (int64_t)e->prof_pair_us.size());
-    for (int64_t k = 0; k < n; k++) pair_us[k] = e->prof_pair_us[(size_t)k];
+    const std::vector<float> &v = e->prof_us[kernel];
+    const int64_t n = std::min<int64_t>(capacity, (int64_t)v.size());
+    for (int64_t k = 0; k < n; k++) us[k] = v[(size_t)k];
     *n_samples = n;
     return CSF_OK;
+}
+
+int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_t *n_samples) {
+    return csf_profile_samples_of(e, 0, pair_us, capacity, n_samples);
 }
 
 int csf_count_pairs(csf_engine *e, int64_t counts[4], const char **kernel_name) {

@@ -356,9 +356,10 @@ __global__ __launch_bounds__(mid_waves(MODEL) * WAVE) void mid_tick_kernel(const
     }
 }
 
-void launch_mid_tick(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
-    if (d.hi <= d.lo || d.mid_group < RPW || d.mid_group > MID_GROUP_MAX || d.mid_group % RPW != 0) return;
-    if ((d.mid_group / RPW) * ((d.n_src - d.src_beg) >> 6) > MID_ITEMS_MAX) return;   // (csf_engine.hip: mid_fused_ok asks before)
+// false: nothing was launched (a shape this kernel is not built for) - the caller must not count the tick as taken
+bool launch_mid_tick(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
+    if (d.hi <= d.lo || d.mid_group < RPW || d.mid_group > MID_GROUP_MAX || d.mid_group % RPW != 0) return false;
+    if ((d.mid_group / RPW) * ((d.n_src - d.src_beg) >> 6) > MID_ITEMS_MAX) return false;   // (csf_engine.hip: mid_fused_ok asks before)
     const dim3 g((unsigned)((d.hi - d.lo + d.mid_group - 1) / d.mid_group));
     const bool p2r = d.p.priority_rule == CSF_P2R;
 #define CSF_MID(MODEL)                                                                                            \
@@ -372,6 +373,7 @@ void launch_mid_tick(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1)
     default: CSF_MID(CSF_PLANARPOINT); break;
     }
 #undef CSF_MID
+    return true;
 }
 
 }  // namespace csf

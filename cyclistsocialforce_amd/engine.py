@@ -36,7 +36,7 @@ class Engine:
         self.params = params
         self.model = int(params.model)
         self.ns = N_STATES[self.model]
-        h = self._lib.csf_create(C.byref(params), int(capacity), int(device))
+        h = self._lib.csf_create_v(C.byref(params), C.sizeof(params), _ffi.ABI_VERSION, int(capacity), int(device))
         if not h:
             raise EngineError(self._lib.csf_last_error(None).decode())
         self._h = C.c_void_p(h)
@@ -406,12 +406,23 @@ class Engine:
         self._ck(self._lib.csf_profile_kernels(self._h, ms, cnt))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(("pair", "road", "agent", "gather"))}
 
-    def profile_samples(self, capacity=65536):
-        """pair-kernel microseconds of every sampled launch since the last reset (does not reset)"""
+    def profile_samples(self, capacity=65536, kernel="pair"):
+        """microseconds of every sampled launch of `kernel` (pair, road, agent, gather) since the last reset (does not reset)"""
         out = np.zeros(int(capacity))
         n = C.c_int64(0)
-        self._ck(self._lib.csf_profile_samples(self._h, _ptr(out), int(capacity), C.byref(n)))
+        which = {"pair": 0, "road": 1, "agent": 2, "gather": 3}[kernel]
+        self._ck(self._lib.csf_profile_samples_of(self._h, which, _ptr(out), int(capacity), C.byref(n)))
         return out[: n.value].copy()
+
+    def profile_stats(self):
+        """{kernel: {"median", "min", "max", "mean", "n"}} in microseconds over the sampled launches since the last reset -
+        call BEFORE profile_kernels(), which resets.  Medians: one launch that met a clock step moves a mean of forty."""
+        out = {}
+        for k in ("pair", "road", "agent", "gather"):
+            v = self.profile_samples(kernel=k)
+            out[k] = None if v.size == 0 else {"median": float(np.median(v)), "min": float(v.min()), "max": float(v.max()),
+                                               "mean": float(v.mean()), "n": int(v.size)}
+        return out
 
     def count_pairs(self, detail=False):
         """(pair evaluations of one launch on the current snapshot or None, name of the engine's pair kernel); with

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CSF_ABI_VERSION 8
+#define CSF_ABI_VERSION 9
 
 /* rider models — vehicle.py:990 (Bicycle), :1292 (TwoDBicycle), :1651 (InvPendulumBicycle),
  * :1991 (PlanarPointBicycle), :2031 (PlanarBicycle); :920 (UncontrolledVehicle: follows a prescribed trajectory
@@ -42,7 +42,8 @@ enum csf_status_code {
     CSF_E_DEVICE = -2,   /* no usable HIP device / HIP runtime error */
     CSF_E_CAPACITY = -3, /* more agents than the engine was created for */
     CSF_E_STATE = -4,    /* call not valid in the current engine state */
-    CSF_E_COMM = -5      /* RCCL error */
+    CSF_E_COMM = -5,     /* RCCL error */
+    CSF_E_ABI = -6       /* the caller's csf_params (size) or ABI version is not this library's: csf_create_v */
 };
 
 /* per-agent status bits reported by csf_status() (reference: exceptions / prints) */
@@ -87,6 +88,13 @@ typedef struct csf_engine csf_engine;
 /* SocialForceIntersection.__init__ (intersection.py:259-330): an empty population of one vehicle
  * class on HIP device `device`.  `n_capacity` bounds the number of agents.  Returns NULL on failure. */
 csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t device);
+/* The same for a caller that is NOT compiled against this header (ABI 9) - a ctypes / cffi binding declares csf_params by hand,
+ * and a struct that has fallen behind the header (members were inserted in ABI 8) would make csf_create read `model` from
+ * whatever lies behind the caller's memory.  csf_create_v refuses - NULL, csf_last_error(NULL) names both figures, nothing is
+ * read from `params` - unless params_size == csf_params_size() and abi_version == csf_abi_version().  Bindings call this one;
+ * csf_params_size() is what sizeof(csf_params) was when the library was built. */
+csf_engine *csf_create_v(const csf_params *params, size_t params_size, int32_t abi_version, int64_t n_capacity, int32_t device);
+size_t csf_params_size(void);
 int csf_destroy(csf_engine *e);
 const char *csf_last_error(const csf_engine *e);
 int32_t csf_abi_version(void);
@@ -113,7 +121,9 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
  * The population order seen by every other entry point is the same either way.
  * On a sharded run (csf_comm_init) the population calls, csf_push_state and csf_set_integrator_state are COLLECTIVE: every rank
  * makes the same calls in the same order; before the first change after a tick the ranks exchange the fp64 state of their blocks
- * (a rank integrates only its own), and the next tick starts from the upload with new shard bounds. */
+ * (a rank integrates only its own: one all-gather per state array on packed blocks), and the next tick starts from the upload with
+ * new shard bounds.  The contract is the collective's: a call that only SOME ranks make blocks those ranks inside the exchange until
+ * the others make it too - guard rank-dependent edits (e.g. a conditional push of vehicle.s) with the same condition on every rank. */
 int csf_set_incremental(csf_engine *e, int32_t on);
 
 /* Vehicle.setDestinations (vehicle.py:606-647) for n agents: CSR (offsets[n+1], xyz_stop[sum,3]);
@@ -282,6 +292,9 @@ int csf_profile_read(csf_engine *e, double *pair_ms, double *agent_ms, int64_t *
  * kept) WITHOUT resetting. */
 int csf_profile_kernels(csf_engine *e, double ms[4], int64_t launches[4]);
 int csf_profile_samples(csf_engine *e, double *pair_us, int64_t capacity, int64_t *n_samples);
+/* ... of any of the four (ABI 9): kernel = 0 pair, 1 road, 2 per-agent, 3 all-gather - what a median needs (a mean of ~40 sampled
+ * launches is moved by one launch that met a re-binning or a clock step; bench.py and tools/ report median, min and max). */
+int csf_profile_samples_of(csf_engine *e, int32_t kernel, double *us, int64_t capacity, int64_t *n_samples);
 /* What ONE launch of the pair kernel on the current snapshot does (the roofline of bench.py is computed from it):
  *   counts[0]  pair evaluations - calls of the force field vehicle.py:1560-1648 for a (source, receiver) pair, after the
  *              mask of intersection.py:690-745, the far-field cull and the per-pair reach test;

@@ -192,3 +192,50 @@ def test_undecidable_pairs_on_the_one_launch_path(amd):
         assert max(np.abs(fx - ofx).max(), np.abs(fy - ofy).max()) < 1e-4 * scale, t
         anchor(e, pop)                                         # (the planted geometry is rounding-sensitive by construction)
     assert e.mid_ticks() == 12 and e.near_dropped() == 0
+
+
+def test_population_outgrows_the_one_launch_tick_on_the_other_half_of_its_records(amd, monkeypatch):
+    """An ODD number of one-launch ticks leaves the records in the second half of the double buffer; the population then grows
+    past the plain kernels' range with a second parameter set, and the class-segmented order pads its runs with the permanent
+    sentinel record - which has to exist in that half too (a zero record there is a road user at the scene's origin)."""
+    monkeypatch.setenv("CSF_SEGMENTS", "1")
+    rng = np.random.default_rng(3)
+    n0, n1, box = 600, 3300, 170.0
+    pods = [amd.pod("twod"), amd.pod("twod", hfov=1.2 * np.pi, f_0=10.0, sigma_0=0.6)]
+
+    def people(n):
+        s = np.zeros((n, 5))
+        s[:, 0] = rng.uniform(0.3 * box, box, n); s[:, 1] = rng.uniform(0.3 * box, box, n)     # (nobody near the origin but a phantom)
+        s[:, 2] = rng.uniform(-np.pi, np.pi, n); s[:, 3] = rng.uniform(3, 4.8, n)
+        d = np.array([40.0, 79.0, 80.0])
+        dq = np.zeros((n, 4, 3))
+        dq[:, 0, 0] = s[:, 0]; dq[:, 0, 1] = s[:, 1]
+        dq[:, 1:, 0] = s[:, 0, None] + d[None, :] * np.cos(s[:, 2])[:, None]
+        dq[:, 1:, 1] = s[:, 1, None] + d[None, :] * np.sin(s[:, 2])[:, None]
+        return s, dq.reshape(-1, 3)
+
+    s0, dq0 = people(n0)
+    e = amd.Engine(pods[0], 4096)
+    e.add_agents(s0, 4.5)
+    e.set_dest_queue(np.arange(n0), np.arange(n0 + 1) * 4, dq0, reset=True)
+    e.step(3)
+    assert e.mid_ticks() == 3
+    s1, dq1 = people(n1 - n0)
+    e.set_param_classes(pods)
+    e.add_agents(s1, 4.5)
+    e.set_dest_queue(np.arange(n0, n1), np.arange(n1 - n0 + 1) * 4, dq1, reset=True)
+    cls = (np.arange(n1) % 2).astype(np.int32)
+    e.set_agent_class(np.arange(n1), cls)
+    e.step(2)
+    assert e.mid_ticks() == 3 and e.count_pairs()[1] == "pair_cull_kernel"
+    st = e.state()
+    e.calc_forces()
+    fdx, fdy, frx, fry = e.force_parts()
+    recv = np.arange(0, n1, 3)
+    classes = [orc.Params.from_buffer_copy(bytes(p)) for p in pods]
+    ox, oy = orc.column_sums(classes, st[:, 0], st[:, 1], st[:, 2], st[:, 3], recv, cls=cls.astype(np.uint8))
+    lim, mag = np.hypot(fdx[recv], fdy[recv]), np.hypot(ox, oy)
+    sc = np.where(mag > lim, lim / np.maximum(mag, 1e-300), 1.0)
+    err = max(np.abs(frx[recv] - ox * sc).max(), np.abs(fry[recv] - oy * sc).max()) / max(np.hypot(ox * sc, oy * sc).max(), 1.0)
+    assert err < 1e-4 and (e.status() == 0).all(), err
+    e.close()

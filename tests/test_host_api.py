@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _ffi.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.csf_abi_version() == 8
+    assert lib.csf_abi_version() == 9
     assert ctypes.sizeof(_ffi.Params) == 576
 
 
