@@ -26,6 +26,49 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     agent_body<MODEL, HET, false>(d, phases, a, tr, ka_lines, 0.0, 0.0);
 }
 
+// The per-agent tick BESIDE the pair launch that feeds it (csf_dev.h: chase_cnt; csf_engine.hip: enqueue_chase_tick): the same
+// code with the sums waited for between the destination-force phase and the rest (agent_body<.., MID = 3>).
+template <int MODEL>
+__global__ __launch_bounds__(256) void agent_chase_kernel(const Dev d) {
+    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev)>();
+    const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t *const tr = d.atrace ? d.atrace + 8 * ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+    if (tr != nullptr && (threadIdx.x & 63) == 0) tr[0] = wall_clock64();
+    agent_body<MODEL, false, false, 3>(d, PH_DEST | PH_COMBINE | PH_INTEGRATE, a, tr, ka_lines, 0.0, 0.0);
+}
+
+// One wave that holds the per-agent launch behind it (same stream) back until `want` pair workgroups are through: launched at once the
+// 256 per-agent waves would sit on their registers for the whole pair launch and cost it a workgroup per CU.
+__global__ __launch_bounds__(64) void chase_gate_kernel(const unsigned *through, unsigned want, unsigned *gave_up) {
+    if (threadIdx.x != 0) return;
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(through, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        if (++spins > CHASE_SPIN_LIMIT) {
+            atomicAdd(gave_up, 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
+    if (d.hi <= d.lo || d.chase_cnt == nullptr || d.n_classes > 1) return false;
+    const dim3 g((unsigned)((d.hi - d.lo + 63) / 64)), b(64);
+    switch (d.p.model) {
+    case CSF_TWOD: break;
+    case CSF_INVPEND: break;
+    case CSF_PLANARPOINT: break;
+    default: return false;
+    }
+    hipLaunchKernelGGL(chase_gate_kernel, dim3(1), dim3(64), 0, st, d.chase_misc, d.chase_gate, d.chase_misc + 1);
+    switch (d.p.model) {
+    case CSF_TWOD: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_TWOD>), g, b, 0, st, t0, t1, 0, d); break;
+    case CSF_INVPEND: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_INVPEND>), g, b, 0, st, t0, t1, 0, d); break;
+    default: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_PLANARPOINT>), g, b, 0, st, t0, t1, 0, d); break;
+    }
+    return true;
+}
+
 // ---- a handful of road users: the whole tick in one wave, any number of ticks in one launch ---------------------------------
 // The reference's own scenarios (three cyclists at a crossing, scenarios/*.py; BASELINE config 1) are latency, not work: a pair
 // launch and a per-agent launch of 5 - 6 us each, nearly all of it launch, teardown and first round trips.  Up to

@@ -978,7 +978,7 @@ __device__ __forceinline__ void write_record(const Dev &d, const csf_params &p, 
     d.recg_w[a] = g;
     if (d.recs_valid) {
         const int32_t p = place >= 0 ? place : d.pos[a];      // (the per-agent kernel asks for it with its first loads)
-        d.recs[p] = g;
+        d.recs_w[p] = g;
         if (d.recv_binned) {                                   // (large populations only: csf_dev.h recb)
             const float2 bo = d.borg[p >> 6];
             d.recb[p] = make_float4(q.x + (o.x - bo.x), q.y + (o.y - bo.y), q.z, q.w);
@@ -1030,7 +1030,8 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     // trip to memory that every other load of the kernel would wait behind
     if (d.n_live != d.n && !d.alive[a]) return;
     const int64_t cap = d.cap;
-    constexpr bool IN = MID == 2, OUT = MID == 1, SUMS_GIVEN = FUSED || MID == 2;
+    constexpr bool CHASE = MID == 3;                          // beside the pair launch (csf_dev.h: chase_cnt): the sums are waited for
+    constexpr bool IN = MID == 2 || CHASE, OUT = MID == 1, SUMS_GIVEN = FUSED || MID == 2;
     constexpr bool PLANNER = MODEL != CSF_BICYCLE && MODEL != CSF_UNCONTROLLED;   // (the models whose planner reads the ring)
     constexpr int PRE = 16;
     Agent g;
@@ -1062,7 +1063,7 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     // clamped addresses: a guarded load is a branch with its own wait.
 #pragma unroll
     for (int c = 0; c < PRE; c++) pp[c] = make_float2(0.f, 0.f);
-    if (!SUMS_GIVEN) {                                         // (eight chunks is the single-device split: the other eight loads
+    if (!SUMS_GIVEN && !CHASE) {                               // (eight chunks is the single-device split: the other eight loads
 #pragma unroll                                                 //  would only queue in front of everything asked for after them)
         for (int c = 0; c < PRE / 2; c++) pp[c] = d.part[(int64_t)min(c, d.n_split - 1) * cap + a];
         if (d.n_split > PRE / 2) {
@@ -1086,12 +1087,12 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     if (PLANNER && (phases & PH_DEST)) load_ring(d, g);
     // pairs of this receiver that the pair kernel could not decide within fp32 rounding of a field-of-view edge wait in a ring
     // (csf_dev.h: EdgeRec): bit 31 of the status word says so - a few dozen road users of a large population, per tick
-    const bool edge_pending = !FUSED && (phases & PH_COMBINE) && (g.st & CSF_ST_EDGE) != 0u;
+    bool edge_pending = !FUSED && !CHASE && (phases & PH_COMBINE) && (g.st & CSF_ST_EDGE) != 0u;   // (CHASE: asked behind the wait)
     if (edge_pending) g.st &= ~CSF_ST_EDGE;
     stamp(1);
     double fdx, fdy;
     if (phases & PH_DEST) {
-        dest_force<MODEL, FUSED || MID != 0>(d, g, fdx, fdy);
+        dest_force<MODEL, FUSED || MID == 1 || MID == 2>(d, g, fdx, fdy);
         d.F[2 * cap + a] = fdx;
         d.F[3 * cap + a] = fdy;
         d.ptr[a] = g.ptr;
@@ -1100,10 +1101,47 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
         d.znp[cap + a] = g.zd0;
         d.znp[2 * cap + a] = g.zd1;
     } else {
-        fdx = d.F[2 * cap + a];
-        fdy = d.F[3 * cap + a];
+        // (unconditional - a guarded load is a branch with its own wait -, from a row the view has: csf_replay_forces hands a view of
+        // two rows, and this phase's result is not used there)
+        fdx = d.F[(int64_t)min(2, d.F_rows - 1) * cap + a];
+        fdy = d.F[(int64_t)min(3, d.F_rows - 1) * cap + a];
     }
     stamp(2);
+    if (CHASE) {
+        // The pair launch that forms this wave's sums is still running.  Every pair workgroup ends with: write-through stores of its
+        // partial sums, s_waitcnt, one agent-scope add to the counter of the 64 slots it serves; here one poll loop (an sc1 load,
+        // an s_sleep between polls), then sc1 loads of the sums, the status words and the hand-over entries.  A wait that does not
+        // end gives up after CHASE_SPIN_LIMIT polls and says so (csf_sync turns that into an error): the grid always drains.
+        const int64_t w = (a - d.lo) >> 6;                     // (wave-uniform: one wave = 64 consecutive slots)
+        const int64_t left = (d.hi - d.lo) - (w << 6);
+        const unsigned groups = (unsigned)((min((int64_t)64, left) + d.rpb - 1) / d.rpb);   // pair workgroups per source chunk that serve this wave
+        const unsigned want = d.chase_round * (unsigned)d.n_split * groups;
+        const unsigned *cnt = d.chase_cnt + w;
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            if (++spins > CHASE_SPIN_LIMIT) {
+                if ((threadIdx.x & 63) == 0) atomicAdd(&d.chase_misc[1], 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        stamp(3);
+        g.st |= ld_pub<true>(&d.status[a]) & CSF_ST_EDGE;      // (set by pair workgroups since the first load: an atomic OR)
+        edge_pending = (g.st & CSF_ST_EDGE) != 0u;
+        g.st &= ~CSF_ST_EDGE;
+#pragma unroll
+        for (int c = 0; c < PRE / 2; c++) {
+            const unsigned long long u = ld_pub<true>((const unsigned long long *)&d.part[(int64_t)min(c, d.n_split - 1) * cap + a]);
+            pp[c] = make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+        }
+        if (d.n_split > PRE / 2) {
+#pragma unroll
+            for (int c = PRE / 2; c < PRE; c++) {
+                const unsigned long long u = ld_pub<true>((const unsigned long long *)&d.part[(int64_t)min(c, d.n_split - 1) * cap + a]);
+                pp[c] = make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+            }
+        }
+    }
     double Fx, Fy;
     if (phases & PH_COMBINE) {
         double rx = 0, ry = 0;

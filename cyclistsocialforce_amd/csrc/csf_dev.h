@@ -222,7 +222,8 @@ struct Dev {
     const int32_t *rg_start;   // [nx ny + 1] first vertex of every cell (row-major)
     const float *rg_c;         // [nx ny][2][64] coefficients c_ab of sum_ab c_ab T_a(xi) T_b(eta), x and y component
 
-    double *F;         // [6][cap] Fx, Fy, Fdest_x, Fdest_y, Frep_x, Frep_y
+    double *F;         // [F_rows][cap] Fx, Fy, Fdest_x, Fdest_y, Frep_x, Frep_y
+    int32_t F_rows;    // 6; 2 in the view of csf_replay_forces (Fx, Fy of one recorded tick): loads clamp their row to F_rows - 1
     uint32_t *status;
 
     // The fused tick of mid-size populations (csf_mid.hip: one launch = pair sums + per-agent tick): a receiver group's per-agent
@@ -234,6 +235,19 @@ struct Dev {
     const double *src64;      // [3][cap] (x, y, psi) of every slot as the pair kernels' hand-overs read them: s itself, or the snapshot
     double *src64_w;          // fused tick: the snapshot the per-agent phase leaves for the next tick (NULL otherwise)
     int32_t mid_group;        // fused tick: road users (slots) per workgroup: 4, 8, 16 or 32
+    // The per-agent launch INSIDE the pair launch's drain (round 6; csf_engine.hip: enqueue_chase_tick).  At the headline size the
+    // pair launch spends its last ~24 us with most CUs idle while the per-agent kernel (8 us + two launch gaps) waits behind it; a
+    // group of 64 road users needs only ITS partial sums.  The per-agent kernel runs on the engine's second stream beside the
+    // pair launch: a one-wave gate kernel in front of it holds it back until most pair workgroups are through, then every wave
+    // runs its destination-force phase at once, waits for the arrival counter of its 64 slots (bumped by one lane of every pair
+    // workgroup behind its write-through stores: MI355X_MICROARCH.md, hand-offs with sc1 stores / agent-scope atomic add / sc1
+    // load poll), reads the sums with agent-scope loads and carries on.  Next tick's records go to the other halves of the
+    // double buffers the one-launch tick already uses (+ recs_w), the fp64 positions of hand-overs come from the snapshot.
+    float4 *recs_w;           // where write_record puts the binned copy: recs itself, or the other half
+    unsigned *chase_cnt;      // [ceil(n_loc / 64)] arrivals per group of 64 slots since the counters were cleared; NULL: no chase
+    unsigned *chase_misc;     // [0] pair workgroups through since then (the gate's counter), [1] waits that gave up (an error)
+    uint32_t chase_round;     // ticks since then, this one included: a group is complete at chase_round x (source chunks x pair groups of it)
+    uint32_t chase_gate;      // the gate opens at this many pair workgroups through
 
     const int32_t *replay_len;  // csf_replay_forces: per-agent number of ticks (NULL = all), and the tick within
     int64_t replay_tick;        // the replay
@@ -264,6 +278,9 @@ constexpr int RG_NODES = 8;     // Chebyshev nodes per direction
 void launch_road_far(const Dev &d, const short2 *vcell, double *samples, hipStream_t st);
 void launch_road_grid(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// the whole per-agent tick beside the pair launch that feeds it (Dev::chase_cnt), behind its gate; false: not built for this class
+bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+constexpr unsigned CHASE_SPIN_LIMIT = 1u << 18;   // polls (each behind an s_sleep: ~0.3 s in all) before a wait gives up - every wave exits
 // csf_agent.hip: up to SMALL_MAX road users of one TwoD-field class, n_ticks whole ticks in one launch of one wave (the rounding
 // bands of the launch: csf_engine.hip set_fov_band)
 constexpr int SMALL_MAX = 32;

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <limits>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -68,6 +69,14 @@ struct Rccl {
     }
 } g_rccl;
 
+// CSF_DEBUG_POISON=1 (read at the first csf_create of the process): a debugging aid for loads whose safety is a property of the
+// caller's allocation.  Every device buffer gets a red zone of POISON_GUARD bytes of 0xFF behind it (NaN as float or double, -1 as an
+// integer: a load that runs past the end meets poison instead of a neighbour's data or a fault), the slots behind the population and
+// the records no slot owns are poisoned instead of zeroed (upload_all, alloc_all) - a kernel whose RESULT depends on any of them
+// shows NaN in the suite.  DESIGN.md section 3 lists the loads that are unconditional by design.
+bool g_poison = false;
+constexpr size_t POISON_GUARD = 1 << 16;
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -76,9 +85,18 @@ struct DevBuf {
         release();
         n = count;
         if (count == 0) return hipSuccess;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        const size_t guard = g_poison ? POISON_GUARD : 0;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T) + guard);
         // the clear runs on the NULL stream, which the engine's non-blocking streams do not wait for: finish it here
         if (e == hipSuccess) e = hipMemset(p, 0, count * sizeof(T));
+        if (e == hipSuccess && guard) e = hipMemset((char *)p + count * sizeof(T), 0xFF, guard);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        return e;
+    }
+    // CSF_DEBUG_POISON: elements [from, n) become 0xFF bytes
+    hipError_t poison_from(size_t from) {
+        if (!g_poison || !p || from >= n) return hipSuccess;
+        hipError_t e = hipMemset(p + from, 0xFF, (n - from) * sizeof(T));
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         return e;
     }
@@ -135,10 +153,14 @@ struct Knobs {
             int fr = 0, fw = 1;
             if (sscanf(v, "%d/%d", &fr, &fw) == 2 && fw > 1 && fr >= 0 && fr < fw) fake_rank = fr, fake_world = fw;
         }
-        nsplit = geti("CSF_NSPLIT", 0);
-        dyn_recv = geti("CSF_DYN_RECV", -1);
-        rpb = geti("CSF_RPB", 0);
-        wide = geti("CSF_WIDE", -1);
+        // launch-shape knobs whose A/B is settled (every setting but the default measured slower): honoured only
+        // with CSF_EXPERT=1, so that a stray variable cannot change the product's grid
+        const bool expert = geti("CSF_EXPERT", 0) != 0;
+        auto gete = [&](const char *name, int dflt) { return expert ? geti(name, dflt) : dflt; };
+        nsplit = gete("CSF_NSPLIT", 0);
+        dyn_recv = gete("CSF_DYN_RECV", -1);
+        rpb = gete("CSF_RPB", 0);
+        wide = gete("CSF_WIDE", -1);
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
         fused_small = geti("CSF_FUSED_SMALL", 1);
         fused_mid = geti("CSF_FUSED_MID", 1);
@@ -149,7 +171,7 @@ struct Knobs {
         recv_binned = geti("CSF_RECV_BINNED", -1);
         clist = geti("CSF_CLIST", 1);
         far_tight = geti("CSF_FAR_TIGHT", 1);
-        seg_grid = geti("CSF_SEG_GRID", 1);
+        seg_grid = gete("CSF_SEG_GRID", 1);
         rebin_churn = std::max(1, geti("CSF_REBIN_CHURN", 4000));
         hole_reuse = geti("CSF_HOLE_REUSE", 1);
         if (const char *v = getenv("CSF_HOLE_DIST")) hole_dist = atof(v);
@@ -887,6 +909,14 @@ int alloc_all(csf_engine *e) {
     HIPCHK(e, e->recs.alloc(nrec));
     HIPCHK(e, e->recg.alloc(nrec));
     HIPCHK(e, e->recb.alloc(nrec));
+    if (g_poison) {   // records that no slot owns: NaN instead of (0, 0, 0, 0), which is a road user at the scene's origin
+        const float4 sent = make_float4(1e15f, 1e15f, 1.0f, 0.0f);
+        const float2 sent2 = make_float2(0.0f, 1.0f);
+        HIPCHK(e, e->rec.poison_from(0)); HIPCHK(e, e->rec2.poison_from(0)); HIPCHK(e, e->recs.poison_from(0));
+        HIPCHK(e, e->recs2.poison_from(0)); HIPCHK(e, e->recg.poison_from(0)); HIPCHK(e, e->recb.poison_from(0));
+        HIPCHK(e, hipMemcpy(e->rec.p + nrec - 1, &sent, sizeof sent, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->rec2.p + nrec - 1, &sent2, sizeof sent2, hipMemcpyHostToDevice));
+    }
     HIPCHK(e, e->borg.alloc(nrec / 64 + 1));
     HIPCHK(e, e->bnd.alloc(nrec / 64));
     HIPCHK(e, e->bnd2.alloc(nrec / 64));
@@ -947,6 +977,7 @@ int alloc_all(csf_engine *e) {
     d.dgood = e->dgood.p;
     d.ppsi = e->ppsi.p;
     d.F = e->F.p;
+    d.F_rows = 6;
     d.status = e->status.p;
     d.part = e->part.p;
     d.froad = e->froad.p;
@@ -1626,6 +1657,14 @@ int upload_all(csf_engine *e) {
     }
     HIPCHK(e, hipMemcpy(e->alive.p, e->h_alive.data(), e->h_alive.size(), hipMemcpyHostToDevice));
     e->dev_alive = e->h_alive;
+    if (g_poison) {   // the slots behind the population (no road user, no sentinel duty but the record): NaN, not zero
+        const double qnan = std::numeric_limits<double>::quiet_NaN();
+        auto fill = [&](std::vector<double> &v) {
+            const size_t rows = v.size() / (size_t)e->cap;
+            for (size_t r = 0; r < rows; r++) std::fill(v.begin() + r * e->cap + n, v.begin() + (r + 1) * e->cap, qnan);
+        };
+        fill(e->h_s); fill(e->h_vdes); fill(e->h_znp); fill(e->h_hx); fill(e->h_hy); fill(e->h_lti); fill(e->h_ppsi); fill(e->h_F);
+    }
 #define H2D(vec, buf) HIPCHK(e, hipMemcpy(buf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
     H2D(e->h_s, e->s);
     H2D(e->h_vdes, e->vdes);
@@ -2095,6 +2134,7 @@ csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t dev
         fail(nullptr, CSF_E_DEVICE, "hipSetDevice(%d) failed", device);
         return nullptr;
     }
+    if (const char *pv = getenv("CSF_DEBUG_POISON")) g_poison = atoi(pv) != 0;   // (before the first allocation)
     csf_engine *e = new csf_engine();
     e->device = device;
     e->cap_user = n_capacity;
@@ -3151,10 +3191,9 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
     const int64_t chunk = std::min<int64_t>(n_ticks, 256);
     DevBuf<double> fbuf, hbuf;
     DevBuf<int32_t> lbuf;
-    // (+ 4 rows: the per-agent kernel asks for the destination-force rows F[2], F[3] of its view unconditionally - a guarded
-    // load would be a branch with its own wait -, which for the last tick of a chunk lie behind the chunk's forces)
-    HIPCHK(e, fbuf.alloc(((size_t)chunk * 2 + 4) * (size_t)cap));
-    HIPCHK(e, hipMemsetAsync(fbuf.p + (size_t)chunk * 2 * (size_t)cap, 0, 4 * (size_t)cap * sizeof(double), e->main));
+    // (the per-agent kernel asks for the destination-force rows F[2], F[3] of its view unconditionally - a guarded load would be
+    // a branch with its own wait; the view says how many rows it has, Dev::F_rows, and the kernel clamps the row: no padding)
+    HIPCHK(e, fbuf.alloc((size_t)chunk * 2 * (size_t)cap));
     const int64_t n_samples = n_ticks / stride;
     if (states_out && n_samples > 0) HIPCHK(e, hbuf.alloc((size_t)n_samples * (size_t)n * (size_t)e->d.ns));
     if (lengths) {
@@ -3162,6 +3201,7 @@ int csf_replay_forces(csf_engine *e, int64_t n_ticks, const double *Fx, const do
         HIPCHK(e, hipMemcpy(lbuf.p, lengths, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     Dev dd = e->d;                       // a view of the engine with replay forces and a private history ring
+    dd.F_rows = 2;                       // (the view holds Fx, Fy of one tick: the kernel clamps its row index - csf_dev.h)
     dd.replay_len = lengths ? lbuf.p : nullptr;
     dd.hist = (states_out && n_samples > 0) ? hbuf.p : nullptr;
     dd.hist_stride = stride;

@@ -124,18 +124,29 @@ __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int3
     }
     const unsigned at = atomicAdd(d.edge_n, 1u) % EDGE_CAP;
     EdgeRec *const o = d.edge + at;          // (member by member: a local EdgeRec went through scratch memory)
-    o->xi = xi;
-    o->yi = yi;
-    o->psi = psi;
-    o->hfov = hfov;
-    o->fx = fx;
-    o->fy = fy;
-    o->fx2 = fx2;
-    o->fy2 = fy2;
-    o->recv = a_recv;
-    o->stamp = d.edge_stamp;
-    o->flags = (int32_t)((seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC));
-    o->next = atomicExch(&d.edge_head[a_recv], (int)at + 1);
+    const int32_t fl = (int32_t)((seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC));
+    const int32_t nx = atomicExch(&d.edge_head[a_recv], (int)at + 1);
+    if (d.chase_cnt != nullptr) {            // read by a per-agent wave of another XCD within this launch: write-through stores
+#define CSF_ST_PUB(member, value) __hip_atomic_store(&o->member, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+        CSF_ST_PUB(xi, xi); CSF_ST_PUB(yi, yi); CSF_ST_PUB(psi, psi); CSF_ST_PUB(hfov, hfov);
+        CSF_ST_PUB(fx, fx); CSF_ST_PUB(fy, fy); CSF_ST_PUB(fx2, fx2); CSF_ST_PUB(fy2, fy2);
+        CSF_ST_PUB(recv, a_recv); CSF_ST_PUB(stamp, d.edge_stamp); CSF_ST_PUB(flags, fl); CSF_ST_PUB(next, nx);
+#undef CSF_ST_PUB
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the entry before the bit that announces it
+    } else {
+        o->xi = xi;
+        o->yi = yi;
+        o->psi = psi;
+        o->hfov = hfov;
+        o->fx = fx;
+        o->fy = fy;
+        o->fx2 = fx2;
+        o->fy2 = fy2;
+        o->recv = a_recv;
+        o->stamp = d.edge_stamp;
+        o->flags = fl;
+        o->next = nx;
+    }
     atomicOr(&d.status[a_recv], CSF_ST_EDGE);
 }
 

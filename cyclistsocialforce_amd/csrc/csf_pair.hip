@@ -634,11 +634,29 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         }
     }
     if (DYN) {
+        const unsigned *const chase = cold_args().chase_cnt;   // (uniform; NULL but for the launches the per-agent kernel runs beside)
+        if (chase != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over stores have landed (edge_handover)
         __syncthreads();
         const int te = (wave << 6) | lane;     // (threadIdx.x, not kept alive across the kernel)
         if (te < RPB) {
             const int64_t a = ragent[te];
-            if (a >= 0) d.part[(int64_t)(d.part_base + by) * d.cap + a] = make_float2(racc[0][te], racc[1][te]);
+            if (a >= 0) {
+                float2 *const dst = &d.part[(int64_t)(d.part_base + by) * d.cap + a];
+                if (chase != nullptr) {        // write-through: another XCD's per-agent wave reads it within this launch
+                    const unsigned long long u = (unsigned long long)__float_as_uint(racc[0][te]) | ((unsigned long long)__float_as_uint(racc[1][te]) << 32);
+                    __hip_atomic_store((unsigned long long *)dst, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    *dst = make_float2(racc[0][te], racc[1][te]);
+                }
+            }
+        }
+        if (chase != nullptr && wave == 0) {   // (the sums are this wave's stores: RPB <= 64)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                const Dev &dc = cold_args();
+                atomicAdd(&dc.chase_cnt[((int64_t)blockIdx.x * RPB) >> 6], 1u);   // the 64 slots this workgroup's receivers lie in
+                atomicAdd(&dc.chase_misc[0], 1u);                                  // (the gate of the per-agent launch)
+            }
         }
     } else {
         reduce_store(d, j0, lane, ax, ay, &ragent[wave * RPW]);

@@ -143,7 +143,11 @@ def run(key, ticks=None, plain=False):
 if __name__ == "__main__":
     args = sys.argv[1:]
     plain = "--plain" in args
-    ticks = int(args[args.index("--ticks") + 1]) if "--ticks" in args else None
+    ticks = None
+    if "--ticks" in args:
+        k = args.index("--ticks")
+        ticks = int(args[k + 1])
+        del args[k:k + 2]                               # (its value is not a config number)
     which = [a for a in args if a in CONFIGS] or ["2", "3", "4", "5"]
     for key in which:
         run(key, ticks, plain)
