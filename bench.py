@@ -289,6 +289,11 @@ def main():
     work, kernel = eng.count_pairs(detail=True)     # one extra launch on the final snapshot, outside the timed region
     evaluated = None if work is None else work["evaluated"]
     win1 = window_state(eng) if world == 1 else None
+    # the per-agent launch beside the pair launch (include/csf.h: csf_chase_ticks): what the scratch engine measured on its warm-up
+    # ticks (16 ticks each way), and how many ticks of the timed engine took that order
+    cal = scratch.chase_calibration()
+    side_by_side = {"decided": {1: "side by side", -1: "in turn", 0: "not measured"}[cal[0]], "measured_us_per_tick": {"in_turn": cal[1][0], "side_by_side": cal[1][1]},
+                    "timed_engine": {"decided": eng.chase_calibration()[0], "ticks_side_by_side": int(eng.chase_ticks()), "ticks": int(eng.tick)}}
     scratch.close()
     # every rank's own figures (kernel times incl. the all-gather, the stream order its communicator chose, the pairs one launch
     # of its receiver block evaluates): a scaling curve then explains itself
@@ -353,6 +358,7 @@ def main():
             "build_id": build_id(),
             "ranks": ranks,
             "timed_window": {"start": win0, "end": win1},
+            "per_agent_launch": side_by_side,
             "dispersed": dispersed,
             "roofline": roof,
             "kernels_us": {"pair": pair_s * 1e6, "road": road_s * 1e6, "agent": agent_s * 1e6,

@@ -28,7 +28,7 @@ SYMBOLS = (
     "csf_count_pairs", "csf_comm_init_loopback", "csf_step_group", "csf_untracked", "csf_update_destination",
     "csf_update_nav_state", "csf_set_dest_pointer", "csf_set_incremental", "csf_set_script", "csf_near_dropped", "csf_comm_stream_order", "csf_small_ticks", "csf_step_get_tick",
     "csf_get_integrator_state", "csf_set_integrator_state", "csf_mid_ticks", "csf_holes_taken",
-    "csf_create_v", "csf_params_size", "csf_profile_samples_of",
+    "csf_create_v", "csf_params_size", "csf_profile_samples_of", "csf_chase_ticks", "csf_chase_calibration",
 )
 ABI_VERSION = 9
 
@@ -141,6 +141,8 @@ def load():
     L.csf_step_get_tick.argtypes = [vp, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
     L.csf_mid_ticks.argtypes = [vp, C.POINTER(i64)]
     L.csf_holes_taken.argtypes = [vp, C.POINTER(i64)]
+    L.csf_chase_ticks.argtypes = [vp, C.POINTER(i64)]
+    L.csf_chase_calibration.argtypes = [vp, C.POINTER(i32), dp]
     L.csf_get_integrator_state.argtypes = [vp, dp, dp, vp]
     L.csf_set_integrator_state.argtypes = [vp, i64, vp, dp, dp, vp]
     if L.csf_abi_version() != ABI_VERSION:

@@ -29,18 +29,27 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
 // The per-agent tick BESIDE the pair launch that feeds it (csf_dev.h: chase_cnt; csf_engine.hip: enqueue_chase_tick): the same
 // code with the sums waited for between the destination-force phase and the rest (agent_body<.., MID = 3>).
 template <int MODEL>
-__global__ __launch_bounds__(256) void agent_chase_kernel(const Dev d) {
-    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev)>();
+// (`phases` is an argument, always all three: with a constant the compiler contracts the fp64 chains of some rider classes differently, and the
+// two paths must agree to the last bit)
+__global__ __launch_bounds__(256) void agent_chase_kernel(const Dev d, const int phases) {
+    const uint32_t ka_lines = kernarg_touch<(int)sizeof(Dev) + 4>();
     const int64_t a = d.lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t *const tr = d.atrace ? d.atrace + 8 * ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
     if (tr != nullptr && (threadIdx.x & 63) == 0) tr[0] = wall_clock64();
-    agent_body<MODEL, false, false, 3>(d, PH_DEST | PH_COMBINE | PH_INTEGRATE, a, tr, ka_lines, 0.0, 0.0);
+    unsigned long long *const ck = d.chase_clock ? d.chase_clock + 8 * d.chase_slot : nullptr;
+    if (ck != nullptr && (threadIdx.x & 63) == 0) atomicMin(ck + 4, (unsigned long long)wall_clock64());
+    agent_body<MODEL, false, false, 3>(d, phases, a, tr, ka_lines, 0.0, 0.0);
+    if (ck != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) atomicMax(ck + 6, (unsigned long long)wall_clock64());
+    }
 }
 
 // One wave that holds the per-agent launch behind it (same stream) back until `want` pair workgroups are through: launched at once the
 // 256 per-agent waves would sit on their registers for the whole pair launch and cost it a workgroup per CU.
-__global__ __launch_bounds__(64) void chase_gate_kernel(const unsigned *through, unsigned want, unsigned *gave_up) {
+__global__ __launch_bounds__(64) void chase_gate_kernel(const unsigned *through, unsigned want, unsigned *gave_up, unsigned long long *ck) {
     if (threadIdx.x != 0) return;
+    if (ck != nullptr) ck[2] = wall_clock64();
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(through, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
         if (++spins > CHASE_SPIN_LIMIT) {
@@ -49,6 +58,7 @@ __global__ __launch_bounds__(64) void chase_gate_kernel(const unsigned *through,
         }
         __builtin_amdgcn_s_sleep(32);
     }
+    if (ck != nullptr) ck[3] = wall_clock64();
 }
 
 bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
@@ -60,11 +70,13 @@ bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t 
     case CSF_PLANARPOINT: break;
     default: return false;
     }
-    hipLaunchKernelGGL(chase_gate_kernel, dim3(1), dim3(64), 0, st, d.chase_misc, d.chase_gate, d.chase_misc + 1);
+    const int ph = PH_DEST | PH_COMBINE | PH_INTEGRATE;
+    hipLaunchKernelGGL(chase_gate_kernel, dim3(1), dim3(64), 0, st, d.chase_misc, d.chase_gate, d.chase_misc + 1,
+                       d.chase_clock ? d.chase_clock + 8 * d.chase_slot : nullptr);
     switch (d.p.model) {
-    case CSF_TWOD: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_TWOD>), g, b, 0, st, t0, t1, 0, d); break;
-    case CSF_INVPEND: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_INVPEND>), g, b, 0, st, t0, t1, 0, d); break;
-    default: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_PLANARPOINT>), g, b, 0, st, t0, t1, 0, d); break;
+    case CSF_TWOD: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_TWOD>), g, b, 0, st, t0, t1, 0, d, ph); break;
+    case CSF_INVPEND: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_INVPEND>), g, b, 0, st, t0, t1, 0, d, ph); break;
+    default: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_PLANARPOINT>), g, b, 0, st, t0, t1, 0, d, ph); break;
     }
     return true;
 }

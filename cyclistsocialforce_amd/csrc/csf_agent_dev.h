@@ -1126,6 +1126,7 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
             __builtin_amdgcn_s_sleep(16);
         }
         stamp(3);
+        if (d.chase_clock != nullptr && (threadIdx.x & 63) == 0) atomicMax(d.chase_clock + 8 * d.chase_slot + 5, (unsigned long long)wall_clock64());
         g.st |= ld_pub<true>(&d.status[a]) & CSF_ST_EDGE;      // (set by pair workgroups since the first load: an atomic OR)
         edge_pending = (g.st & CSF_ST_EDGE) != 0u;
         g.st &= ~CSF_ST_EDGE;

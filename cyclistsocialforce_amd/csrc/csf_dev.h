@@ -248,6 +248,9 @@ struct Dev {
     unsigned *chase_misc;     // [0] pair workgroups through since then (the gate's counter), [1] waits that gave up (an error)
     uint32_t chase_round;     // ticks since then, this one included: a group is complete at chase_round x (source chunks x pair groups of it)
     uint32_t chase_gate;      // the gate opens at this many pair workgroups through
+    uint32_t chase_slot;               // ... row of this tick in it
+    unsigned long long *chase_clock;   // CSF_CHASE_CLOCK (tools/chase_clock.py): [128 ticks][8] wall_clock64 stamps - pair: first start, last end;
+                                       // gate: entry, exit; per-agent: first entry, last past its wait, last end - else NULL
 
     const int32_t *replay_len;  // csf_replay_forces: per-agent number of ticks (NULL = all), and the tick within
     int64_t replay_tick;        // the replay
@@ -444,7 +447,7 @@ __device__ __forceinline__ float4 box_circle(float x0, float x1, float y0, float
 
 // bounding circle of batch b (64 records in perm order), computed by one wave: centre (scene coordinates) and radius of
 // the bounding box's circumcircle, grown by `margin`
-__device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, float margin, float4 *out) {
+__device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, float margin, float4 *out, bool pub = false) {
     // scene coordinates of the batch's records: the binned copy, or (without it) offset + origin of the slot
     float4 q;
     if (d.recs_valid) {
@@ -464,7 +467,16 @@ __device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, 
         y0 = fminf(y0, __shfl_xor(y0, o2, 64));
         y1 = fmaxf(y1, __shfl_xor(y1, o2, 64));
     }
-    if (lane == 0) out[b] = box_circle(x0, x1, y0, y1, margin);
+    if (lane == 0) {
+        const float4 c = box_circle(x0, x1, y0, y1, margin);
+        if (pub) {   // write-through (csf_dev.h: chase_cnt): the NEXT pair launch, on the other stream, may start before this launch's end-of-kernel write-back
+            unsigned long long *o = (unsigned long long *)&out[b];
+            __hip_atomic_store(o, (unsigned long long)__float_as_uint(c.x) | ((unsigned long long)__float_as_uint(c.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(o + 1, (unsigned long long)__float_as_uint(c.z) | ((unsigned long long)__float_as_uint(c.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            out[b] = c;
+        }
+    }
 }
 
 

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -125,6 +126,9 @@ struct Knobs {
     int fused_mid = 1;                        // CSF_FUSED_MID=0: mid-size populations take a pair launch and a per-agent launch per tick (csf_mid.hip: one launch)
     int mid_below = 0;                        // CSF_MID_BELOW: ... for populations smaller than this (0: by vehicle class, mid_below_for)
     int mid_group = 0;                        // CSF_MID_GROUP: road users per workgroup of it, 4 / 8 / 16 / 32 (0: about one workgroup per CU)
+    int chase = 1;                            // CSF_CHASE: 0 the per-agent launch behind the pair launch, 2 beside it (enqueue_chase_tick), 1 [default] whichever the engine measures faster on its first stretch of eligible ticks
+    std::string chase_clock;                  // CSF_CHASE_CLOCK=<file>
+    int chase_gate_pct = 85;                  // CSF_CHASE_GATE: per cent of the pair workgroups through before the per-agent kernel is let go
     int fused_small = 1;                      // CSF_FUSED_SMALL=0: a handful of road users take the general path too (csf_agent.hip: small_tick_kernel)
     int segments = -1;                        // CSF_SEGMENTS
     int seg_grid = 1;                         // CSF_SEG_GRID=0: one launch per parameter set (class-segmented order) instead of one grid
@@ -162,6 +166,9 @@ struct Knobs {
         rpb = gete("CSF_RPB", 0);
         wide = gete("CSF_WIDE", -1);
         pair_variant = geti("CSF_PAIR_VARIANT", -1);
+        chase = geti("CSF_CHASE", 1);
+        if (const char *v = getenv("CSF_CHASE_CLOCK")) chase_clock = v;
+        chase_gate_pct = std::max(0, std::min(100, geti("CSF_CHASE_GATE", 85)));
         fused_small = geti("CSF_FUSED_SMALL", 1);
         fused_mid = geti("CSF_FUSED_MID", 1);
         mid_below = geti("CSF_MID_BELOW", 0);
@@ -336,6 +343,23 @@ struct csf_engine {
     DevBuf<double> src64_a, src64_b;
     bool mid_synced = false, mid_cur_is_a = true;
     int64_t mid_ticks = 0;
+    // the per-agent launch beside the pair launch (enqueue_chase_tick): the binned copy's other half, the arrival counters
+    // ([groups of 64 slots]) and the gate's / the error word, whether the last tick took this path (the two streams then have to
+    // meet before anything else runs), ticks since the counters were cleared, which stream the next pair launch goes to
+    DevBuf<float4> recs_alt;
+    DevBuf<unsigned> chase_cnt, chase_misc;
+    DevBuf<unsigned long long> chase_clock;   // CSF_CHASE_CLOCK=<file>: stamps of the last 64 side-by-side ticks, written at csf_destroy
+    bool chase_prev = false;
+    uint32_t chase_round = 0;
+    int chase_parity = 0;
+    int64_t chase_ticks = 0, chase_checked = 0;
+    // CSF_CHASE=1: decided by measurement, once per engine (chase_take): twice 12 ticks in turn and 12 side by side, bracketed by events on the
+    // main stream - whether the two streams got hardware queues of their own is the runtime's business, and without them the
+    // side-by-side tick is the slower one
+    int chase_state = 0;                // 0 undecided, 1 side by side, -1 in turn
+    int cal_phase = 0, cal_left = 0;    // 0 idle, 1 .. 4 the stretches (odd: in turn, even: side by side), 5 waiting for the last event
+    hipEvent_t cal_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double chase_cal_us[2] = {0.0, 0.0};
     DevBuf<float2> borg;
     DevBuf<float2> rvo;          // origins of the road-vertex tiles
     DevBuf<int32_t> pos;
@@ -991,6 +1015,13 @@ int alloc_all(csf_engine *e) {
     d.rec_w = d.rec;
     d.recg_w = d.recg;
     d.rec2_w = d.rec2;
+    d.recs_w = d.recs;
+    d.chase_cnt = nullptr;
+    d.chase_misc = nullptr;
+    d.chase_round = 0;
+    d.chase_gate = 0;
+    d.chase_clock = nullptr;
+    d.chase_slot = 0;
     d.src64 = e->s.p;
     d.src64_w = nullptr;
     d.mid_group = 0;
@@ -2071,6 +2102,17 @@ int prof_resolve_one(csf_engine *e) {
         e->prof_cnt[k]++;
         if (e->prof_us[k].size() < PROF_KEEP) e->prof_us[k].push_back(ms * 1e3f);
     }
+    // CSF_CHASE_CLOCK (measurement aid, every tick sampled): the dispatch time stamps of consecutive ticks against each other - pair end ->
+    // per-agent start / end, per-agent end -> the next tick's pair start (the previous slot of the pool is still intact)
+    if (!e->knobs.chase_clock.empty() && sl.pair && sl.agent && e->prof_resolved > 0) {
+        csf_engine::ProfSlot &pv = e->prof_pool[(e->prof_resolved - 1) % PROF_SLOTS];
+        float a = 0, b = 0, c = 0, d2 = 0;
+        if (pv.pair && pv.agent && hipEventElapsedTime(&a, pv.ev[1], pv.ev[4]) == hipSuccess && hipEventElapsedTime(&b, pv.ev[1], pv.ev[5]) == hipSuccess &&
+            hipEventElapsedTime(&c, pv.ev[5], sl.ev[0]) == hipSuccess && hipEventElapsedTime(&d2, pv.ev[0], sl.ev[0]) == hipSuccess)
+            fprintf(stderr, "CHASE_EVENTS agent_start_after_pair_end %.2f agent_end_after_pair_end %.2f next_pair_start_after_agent_end %.2f period %.2f\n",
+                    a * 1e3, b * 1e3, c * 1e3, d2 * 1e3);
+        (void)hipGetLastError();
+    }
     e->prof_resolved++;
     return CSF_OK;
 }
@@ -2154,7 +2196,16 @@ csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t dev
     if (hipStreamCreateWithFlags(&e->main, hipStreamNonBlocking) != hipSuccess) return bail("stream");
     e->main_hold = std::make_shared<csf_engine::StreamHold>();
     e->main_hold->s = e->main;
-    if (hipStreamCreateWithFlags(&e->comm, hipStreamNonBlocking) != hipSuccess) return bail("stream");
+    {   // The second stream from ANOTHER priority level: the runtime hands streams of one level out over a small pool of hardware
+        // queues (four by default), and two streams that share a queue serialise - the per-agent kernel beside the pair launch
+        // (enqueue_chase_tick) then runs behind it after all, with a third launch on top (measured: 120 against 115 us per tick with
+        // two engines in one process; 111 with queues of their own).  Priority levels have pools of their own.
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // (numerically lower = higher priority)
+        if (hi < lo && hipStreamCreateWithPriority(&e->comm, hipStreamNonBlocking, hi) != hipSuccess) e->comm = nullptr;
+        (void)hipGetLastError();
+        if (!e->comm && hipStreamCreateWithFlags(&e->comm, hipStreamNonBlocking) != hipSuccess) return bail("stream");
+    }
     if (hipEventCreateWithFlags(&e->ev_integ, hipEventDisableTiming) != hipSuccess) return bail("event");
     if (hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming) != hipSuccess) return bail("event");
     if (alloc_all(e) != CSF_OK) return bail("allocation");
@@ -2179,6 +2230,17 @@ int csf_destroy(csf_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->main) (void)hipStreamSynchronize(e->main);
     if (e->comm) (void)hipStreamSynchronize(e->comm);
+    if (e->chase_clock.p) {
+        std::vector<unsigned long long> h(128 * 8);
+        if (hipMemcpy(h.data(), e->chase_clock.p, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(e->knobs.chase_clock.c_str(), "wb")) {
+                fwrite(h.data(), sizeof(h[0]), h.size(), f);
+                fwrite(&e->chase_ticks, sizeof e->chase_ticks, 1, f);
+                fclose(f);
+            }
+        }
+        e->chase_clock.release();
+    }
     if (e->atrace.p) {  // CSF_TRACE_AGENT=<file>: the stamps of the last per-agent launch
         std::vector<uint64_t> h(e->atrace.n);
         if (hipMemcpy(h.data(), e->atrace.p, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -2203,10 +2265,13 @@ int csf_destroy(csf_engine *e) {
     for (auto &sl : e->prof_pool)
         for (hipEvent_t ev : sl.ev)
             if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->cal_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->ev_integ) (void)hipEventDestroy(e->ev_integ);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     e->s.release(); e->vdes.release(); e->q.release(); e->znp.release(); e->hx.release(); e->hy.release();
     e->rec_alt.release(); e->recg_alt.release(); e->rec2_alt.release(); e->src64_a.release(); e->src64_b.release();
+    e->recs_alt.release(); e->chase_cnt.release(); e->chase_misc.release();
     e->lti.release(); e->ppsi.release(); e->script.release(); e->sbeg.release(); e->slen.release(); e->F.release(); e->hist.release(); e->qbeg.release(); e->qlen.release(); e->alive.release(); e->order_dev.release();
     e->ptr.release(); e->ti.release(); e->dgood.release(); e->znav.release(); e->zrid.release();
     e->status.release(); e->rec.release(); e->rv.release(); e->rvo.release(); e->rg_v.release(); e->rg_start.release(); e->rg_c.release(); e->kat4.release(); e->rec2.release(); e->recs2.release();
@@ -2886,6 +2951,7 @@ static int mid_sync(csf_engine *e) {
         HIPCHK(e, e->rec2_alt.alloc(e->rec2.n));
         HIPCHK(e, e->src64_a.alloc(3 * (size_t)e->cap));
         HIPCHK(e, e->src64_b.alloc(3 * (size_t)e->cap));
+        HIPCHK(e, e->recs_alt.alloc(e->recs.n));
         // the permanent sentinel (alloc_all: the last record, no slot's; the padding of the class-segmented order points at it)
         // exists in BOTH halves: after an odd number of one-launch ticks d.rec is the other half, and a population that then
         // outgrows this path would read (0, 0, 0, 0) - a road user at the origin - where its order is padded
@@ -2899,6 +2965,10 @@ static int mid_sync(csf_engine *e) {
     HIPCHK(e, hipMemcpyAsync(rec_o, d.rec, (size_t)d.n_pad * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
     HIPCHK(e, hipMemcpyAsync(recg_o, d.recg, std::min((size_t)d.n_pad, e->recg.n) * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
     if (d.has_bike) HIPCHK(e, hipMemcpyAsync(rec2_o, d.rec2, (size_t)d.n_pad * sizeof(float2), hipMemcpyDeviceToDevice, e->main));
+    if (d.recs_valid) {   // (the binned copy: the tiles of the cull-first kernel - enqueue_chase_tick)
+        float4 *recs_o = d.recs == e->recs.p ? e->recs_alt.p : e->recs.p;
+        HIPCHK(e, hipMemcpyAsync(recs_o, d.recs, (size_t)d.n_pad * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
+    }
     double *cur = e->mid_cur_is_a ? e->src64_a.p : e->src64_b.p;
     HIPCHK(e, hipMemcpyAsync(cur, e->s.p, 3 * (size_t)e->cap * sizeof(double), hipMemcpyDeviceToDevice, e->main));
     e->mid_synced = true;
@@ -2943,10 +3013,198 @@ static int enqueue_mid_tick(csf_engine *e) {
     return CSF_OK;
 }
 
+// ---- the per-agent launch inside the pair launch's drain (csf_dev.h: chase_cnt) ---------------------------------------------------
+// At the headline size the pair launch idles most CUs for its last ~24 us while the per-agent launch (8 us + two launch gaps) waits
+// behind it.  Here the two run side by side on the engine's two streams, which trade places every tick:
+//   tick t:      P: pair(t)                      Q: gate(t) - agent(t)     [agent(t) waits, per 64 slots, for pair(t)'s arrivals]
+//   tick t + 1:  Q: pair(t + 1)  (behind agent(t): every record is in place)      P: gate(t + 1) - agent(t + 1)  (behind pair(t))
+// No event between the streams in steady state: a kernel only ever waits (on the device) for one that was enqueued BEFORE it, on
+// a stream whose earlier work does not wait for it - so whatever the runtime maps the streams to, the grid drains (mapped to one
+// hardware queue the launches simply serialise).  Next tick's records go to the other halves of the double buffers, hand-overs
+// read the fp64 snapshot of the tick's start (as in csf_mid.hip).  The streams meet (two events) when the path is left.
+static bool chase_ok(const csf_engine *e, int64_t ticks_left) {
+    const Dev &d = e->d;
+    if (e->knobs.chase == 0) return false;
+    const int m = d.p.model;
+    if (m != CSF_TWOD && m != CSF_INVPEND && m != CSF_PLANARPOINT) return false;
+    const bool rebin_now = e->ticks_since_rebin + e->moved_unbinned >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= e->knobs.rebin_churn;
+    return e->classes.size() == 1 && d.n_classes == 1 && d.pair_variant == 0 && d.classify && d.recs_valid && !d.recv_binned && d.dyn_recv &&
+           (d.rpb == 32 || d.rpb == 16 || d.rpb == 8) && d.n_split <= 8 && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 &&
+           d.nv == 0 && d.hist == nullptr && d.pair_count == nullptr && e->segs.empty() && e->state_all_current &&   // (wave traces allowed: tools/chase_timeline.py)
+           e->pend.empty() && !rebin_now && !e->bound_stale && e->bounds_fresh && d.n_live > 1 && d.lo == 0 && d.hi == d.n && d.replay_len == nullptr &&
+           e->comm != nullptr && (e->chase_prev || ticks_left >= 4);
+}
+
+static int chase_join(csf_engine *e);
+
+// What an engine measured holds for the next engine of the same kind in this process (same device, same rider class, same size to a
+// factor of two): bench.py's timed engine takes over what its scratch engine found, and a caller that steps a few ticks per call
+// - too few for a measurement of its own - is served by an earlier one.  0: nothing measured yet.
+static std::atomic<int> g_chase_found[8][8][32];
+static std::atomic<int> *chase_found_slot(const csf_engine *e) {
+    int b = 0;
+    for (int64_t n = std::max<int64_t>(e->d.n, 1); n > 1 && b < 31; n >>= 1) b++;
+    return &g_chase_found[e->device & 7][e->d.p.model & 7][b];
+}
+
+constexpr int CHASE_CAL = 12;   // ticks per stretch of the measurement: in turn, side by side, in turn, side by side
+
+// the measurement's last event has been reached: decide
+static void chase_cal_resolve(csf_engine *e, bool wait) {
+    if (e->cal_phase != 5) return;
+    if (wait ? hipEventSynchronize(e->cal_ev[4]) != hipSuccess : hipEventQuery(e->cal_ev[4]) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    float t[4] = {0, 0, 0, 0};
+    bool ok = true;
+    for (int k = 0; k < 4; k++) ok = ok && hipEventElapsedTime(&t[k], e->cal_ev[k], e->cal_ev[k + 1]) == hipSuccess;
+    if (ok) {
+        e->chase_cal_us[0] = (double)(t[0] + t[2]) * 1e3 / (2 * CHASE_CAL);
+        e->chase_cal_us[1] = (double)(t[1] + t[3]) * 1e3 / (2 * CHASE_CAL);
+        // (both side-by-side stretches faster than the in-turn stretch in front of them, and by a per cent in all: a clock that is
+        // still ramping up, or one slow launch, does not decide)
+        e->chase_state = (t[1] < t[0] && t[3] < t[2] && t[1] + t[3] < 0.99f * (t[0] + t[2])) ? 1 : -1;
+        chase_found_slot(e)->store(e->chase_state);
+    }
+    (void)hipGetLastError();
+    e->cal_phase = 0;
+}
+
+// this tick beside the pair launch?  (CSF_CHASE=1: drives the one-off measurement)
+static bool chase_take(csf_engine *e, int64_t ticks_left) {
+    if (!chase_ok(e, ticks_left)) {
+        if (e->cal_phase >= 1 && e->cal_phase <= 4) e->cal_phase = 0;        // (a stretch cut short measures nothing: start over later)
+        return false;
+    }
+    if (e->knobs.chase >= 2 || e->chase_state == 1) return true;
+    if (e->chase_state == -1) return false;
+    if (e->cal_phase == 0) {
+        const int found = chase_found_slot(e)->load();                     // an earlier engine of this kind has measured
+        if (found != 0) {
+            e->chase_state = found;
+            return found == 1;
+        }
+        // all four stretches inside this call and before the next re-binning, on warm clocks (a fresh process finds the device in a
+        // low power state: its first ~200 ticks run up to 1.7 x slower and speed up as they go), nothing else sampled
+        const int64_t until_rebin = e->knobs.rebin_ticks - (e->ticks_since_rebin + e->moved_unbinned), need = 4 * CHASE_CAL + 2;
+        if (ticks_left < need || until_rebin < need || e->ticks_since_rebin < 1 || e->profile > 0 || e->d.tick < 192) return false;
+        for (hipEvent_t &ev : e->cal_ev)
+            if (!ev && hipEventCreate(&ev) != hipSuccess) return false;
+        if (hipEventRecord(e->cal_ev[0], e->main) != hipSuccess) return false;
+        e->cal_phase = 1;
+        e->cal_left = CHASE_CAL;
+    }
+    if (e->cal_phase == 5) {
+        chase_cal_resolve(e, false);
+        return e->chase_state == 1;
+    }
+    if (e->cal_left == 0) {                                                // a stretch is complete: its closing event, the next stretch
+        if ((e->cal_phase % 2 == 0 && chase_join(e) != CSF_OK) || hipEventRecord(e->cal_ev[e->cal_phase], e->main) != hipSuccess) {
+            e->cal_phase = 0;
+            return false;
+        }
+        e->cal_phase++;
+        e->cal_left = CHASE_CAL;
+        if (e->cal_phase == 5) return false;                               // (this tick in turn; the decision when the last event is reached)
+    }
+    e->cal_left--;
+    return e->cal_phase % 2 == 0;
+}
+
+// the two streams meet: whatever follows runs on the main stream alone
+static int chase_join(csf_engine *e) {
+    if (!e->chase_prev) return CSF_OK;
+    HIPCHK(e, hipEventRecord(e->ev_gather, e->comm));
+    HIPCHK(e, hipStreamWaitEvent(e->main, e->ev_gather, 0));
+    HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
+    HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
+    e->chase_prev = false;
+    return CSF_OK;
+}
+
+static int enqueue_chase_tick(csf_engine *e, csf_engine::ProfSlot *ps, csf_engine::ProfSlot *po) {
+    Dev &d = e->d;
+    int rc;
+    if ((rc = bounds_before_pair(e))) return rc;                 // (chase_ok: no re-binning, circles in place - nothing is launched)
+    if ((rc = set_fov_band(e))) return rc;
+    const size_t nw = (size_t)((d.hi - d.lo + 63) / 64);
+    if (!e->chase_prev) {                                         // entering: the second stream behind everything so far, counters cleared
+        HIPCHK(e, e->chase_cnt.reserve(nw + 64));
+        HIPCHK(e, e->chase_misc.reserve(64));
+        if (!e->mid_synced && (rc = mid_sync(e))) return rc;
+        HIPCHK(e, hipMemsetAsync(e->chase_cnt.p, 0, e->chase_cnt.n * sizeof(unsigned), e->main));
+        HIPCHK(e, hipMemsetAsync(e->chase_misc.p, 0, sizeof(unsigned), e->main));   // (the gate's counter; the error word stays)
+        HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
+        HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
+        e->chase_round = 0;
+        e->chase_parity = 0;
+    }
+    hipStream_t P = e->chase_parity ? e->comm : e->main, Q = e->chase_parity ? e->main : e->comm;
+    float4 *rec_o = d.rec == e->rec.p ? e->rec_alt.p : e->rec.p, *recg_o = d.recg == e->recg.p ? e->recg_alt.p : e->recg.p;
+    float4 *recs_o = d.recs == e->recs.p ? e->recs_alt.p : e->recs.p;
+    float2 *rec2_o = d.rec2 == e->rec2.p ? e->rec2_alt.p : e->rec2.p;
+    double *cur = e->mid_cur_is_a ? e->src64_a.p : e->src64_b.p, *nxt = e->mid_cur_is_a ? e->src64_b.p : e->src64_a.p;
+    const int64_t groups = (d.hi - d.lo + d.rpb - 1) / d.rpb, wgs = groups * d.n_split;
+    e->chase_round++;
+    Dev dd = d;
+    dd.rec_w = rec_o;
+    dd.recg_w = recg_o;
+    dd.rec2_w = rec2_o;
+    dd.recs_w = recs_o;
+    dd.src64 = cur;
+    dd.src64_w = nxt;
+    dd.chase_cnt = e->chase_cnt.p;
+    dd.chase_misc = e->chase_misc.p;
+    dd.chase_round = e->chase_round;
+    dd.chase_clock = nullptr;
+    if (!e->knobs.chase_clock.empty()) {   // (a ring of 128 ticks, initialised once: the tool reads fewer than that)
+        if (e->chase_clock.n == 0) {
+            HIPCHK(e, e->chase_clock.alloc(128 * 8));
+            std::vector<unsigned long long> init(128 * 8, 0ull);
+            for (int r = 0; r < 128; r++) init[8 * r + 0] = init[8 * r + 4] = ~0ull;       // (minima start high)
+            HIPCHK(e, hipMemcpy(e->chase_clock.p, init.data(), init.size() * sizeof(init[0]), hipMemcpyHostToDevice));
+        }
+        dd.chase_clock = e->chase_clock.p;
+        dd.chase_slot = (uint32_t)(e->chase_ticks & 127);
+    }
+    // (cumulative: the counter is cleared when the path is entered)
+    dd.chase_gate = (uint32_t)((int64_t)(e->chase_round - 1) * wgs + wgs * e->knobs.chase_gate_pct / 100);
+    launch_pair(dd, P, ps ? ps->ev[0] : nullptr, ps ? ps->ev[1] : nullptr);
+    if (ps) ps->pair = true;
+    bounds_after_pair(e, true);
+    if (!launch_agent_chase(dd, Q, po ? po->ev[4] : nullptr, po ? po->ev[5] : nullptr))
+        return fail(e, CSF_E_STATE, "the per-agent kernel beside the pair launch is not built for vehicle class %d", (int)d.p.model);
+    if (po) po->agent = true;
+    HIPCHK(e, hipGetLastError());
+    // the halves trade places: what the launch wrote is what every later launch reads
+    d.rec = d.rec_w = rec_o;
+    d.recg = d.recg_w = recg_o;
+    d.rec2 = d.rec2_w = rec2_o;
+    d.recs = d.recs_w = recs_o;
+    e->mid_cur_is_a = !e->mid_cur_is_a;
+    e->chase_parity ^= 1;
+    e->chase_prev = true;
+    e->chase_ticks++;
+    e->moves++;
+    d.tick++;
+    return CSF_OK;
+}
+
 //   main:  agent(DEST) - wait(ev_gather) - bounds - pair - road - agent(COMBINE|INTEGRATE) - record(ev_integ)
 //   comm:  wait(ev_integ) - all-gather(records) - record(ev_gather)
-static int enqueue_tick(csf_engine *e) {
+static int enqueue_tick(csf_engine *e, int64_t ticks_left = 1) {
     Dev &d = e->d;
+    if (chase_take(e, ticks_left)) {                              // the per-agent launch beside the pair launch (large populations)
+        int rcp = CSF_OK;
+        csf_engine::ProfSlot *ps = prof_slot(e, &rcp);
+        if (rcp) return rcp;
+        return enqueue_chase_tick(e, ps, (ps && ((e->prof_ticks++ % 8 == 0) || !e->knobs.chase_clock.empty())) ? ps : nullptr);
+    }
+    {
+        int rcj = chase_join(e);
+        if (rcj) return rcj;
+    }
     bool bounds_done = false;
     if (mid_fused_ok(e)) {
         // the re-binning inside may move d.n_src past what the one-launch tick takes: ask again behind it, and carry on with
@@ -3099,9 +3357,11 @@ static int step_impl(csf_engine *e, int64_t n_ticks, bool want_snap, bool *snapp
         return CSF_OK;
     }
     for (int64_t t = 0; t < n_ticks; t++) {
-        rc = enqueue_tick(e);
+        rc = enqueue_tick(e, n_ticks - t);
         if (rc) return rc;
     }
+    if ((rc = chase_join(e))) return rc;                          // (every other entry point works on the main stream alone)
+    if (e->cal_phase >= 1 && e->cal_phase <= 4) e->cal_phase = 0;  // (a measurement does not span calls)
     if (n_ticks > 0) e->device_ahead = true;
     return CSF_OK;
 }
@@ -3119,6 +3379,30 @@ int csf_sync(csf_engine *e) {
     // right: no abort any more, and no gain - SocialForceIntersection.step() 37 / 54 us per tick at N = 3 / 1 024 against 32 / 48)
     HIPCHK(e, hipStreamSynchronize(e->main));
     HIPCHK(e, hipStreamSynchronize(e->comm));
+    chase_cal_resolve(e, true);
+    if (e->chase_ticks != e->chase_checked) {   // did a wait of the side-by-side tick give up? (csf_dev.h: CHASE_SPIN_LIMIT - it never has)
+        e->chase_checked = e->chase_ticks;
+        if (!e->bound_pin) HIPCHK(e, hipHostMalloc((void **)&e->bound_pin, 2 * (size_t)e->cap * sizeof(double), hipHostMallocDefault));
+        HIPCHK(e, hipMemcpyAsync(e->bound_pin, e->chase_misc.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, e->main));
+        HIPCHK(e, hipStreamSynchronize(e->main));
+        unsigned gave_up = 0;
+        std::memcpy(&gave_up, e->bound_pin, sizeof gave_up);
+        if (gave_up != 0)
+            return fail(e, CSF_E_DEVICE, "%u waits of the per-agent kernel beside the pair launch gave up: the states since are not a simulation (CSF_CHASE=0 takes the two launches in turn)", gave_up);
+    }
+    return CSF_OK;
+}
+
+int csf_chase_ticks(const csf_engine *e, int64_t *n_ticks) {
+    if (!e || !n_ticks) return CSF_E_ARG;
+    *n_ticks = e->chase_ticks;
+    return CSF_OK;
+}
+
+int csf_chase_calibration(const csf_engine *e, int32_t *side_by_side, double us_per_tick[2]) {
+    if (!e) return CSF_E_ARG;
+    if (side_by_side) *side_by_side = e->knobs.chase >= 2 ? 1 : e->knobs.chase == 0 ? -1 : e->chase_state;
+    if (us_per_tick) us_per_tick[0] = e->chase_cal_us[0], us_per_tick[1] = e->chase_cal_us[1];
     return CSF_OK;
 }
 

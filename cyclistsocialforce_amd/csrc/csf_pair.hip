@@ -114,6 +114,8 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     int64_t ibeg, iend;
     source_chunk(d, ibeg, iend, by);
     const uint64_t t_start = d.trace ? wall_clock64() : 0;
+    if (cold_args().chase_clock != nullptr && lane == 0 && wave == 0)      // (measurement aid: when did this launch's first wave start?)
+        atomicMin(cold_args().chase_clock + 8 * cold_args().chase_slot + 0, (unsigned long long)wall_clock64());
     float2 og = make_float2(0.f, 0.f);   // BINR: origin of the workgroup (uniform: scalar loads), else the scene's
     if (BINR) {
         const int64_t jg = d.lo + (int64_t)blockIdx.x * RPB;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     // batch): a separate launch per tick would cost more in launch gaps than in work
     if (CLASSIFY && d.bnd_next != nullptr && by == 0) {
         for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * CW + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * CW)
-            batch_circle(d, b, lane, d.bnd_margin, d.bnd_next);
+            batch_circle(d, b, lane, d.bnd_margin, d.bnd_next, d.chase_cnt != nullptr);
     }
 
     float ax[RPW], ay[RPW];     // the receivers themselves stay in LDS (rrec); one at a time is held in registers
@@ -656,6 +658,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
                 const Dev &dc = cold_args();
                 atomicAdd(&dc.chase_cnt[((int64_t)blockIdx.x * RPB) >> 6], 1u);   // the 64 slots this workgroup's receivers lie in
                 atomicAdd(&dc.chase_misc[0], 1u);                                  // (the gate of the per-agent launch)
+                if (dc.chase_clock != nullptr) atomicMax(dc.chase_clock + 8 * dc.chase_slot + 1, (unsigned long long)wall_clock64());
             }
         }
     } else {

@@ -455,6 +455,19 @@ class Engine:
         self._ck(self._lib.csf_mid_ticks(self._h, C.byref(v)))
         return v.value
 
+    def chase_ticks(self):
+        """ticks whose per-agent launch ran beside the pair launch (include/csf.h: csf_chase_ticks)"""
+        v = C.c_int64()
+        self._ck(self._lib.csf_chase_ticks(self._h, C.byref(v)))
+        return v.value
+
+    def chase_calibration(self):
+        """(1 side by side / -1 in turn / 0 not measured yet, [us per tick in turn, side by side]) - include/csf.h: csf_chase_calibration"""
+        st = C.c_int32()
+        us = np.zeros(2)
+        self._ck(self._lib.csf_chase_calibration(self._h, C.byref(st), _ptr(us)))
+        return st.value, us.tolist()
+
     def holes_taken(self):
         """arrivals that took the slot of a road user who had left from nearby (include/csf.h: csf_holes_taken)"""
         v = C.c_int64()

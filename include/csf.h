@@ -332,6 +332,18 @@ int csf_small_ticks(const csf_engine *e, int64_t *n_ticks);
  * one grid, the group's last workgroup to finish its sums carrying on with the road users; the next tick's records go to the
  * other half of a double buffer.  CSF_FUSED_MID=0, a pinned CSF_PAIR_VARIANT or per-kernel profiling keep the two launches. */
 int csf_mid_ticks(const csf_engine *e, int64_t *n_ticks);
+/* Ticks whose per-agent launch ran BESIDE the pair launch that feeds it (ABI 9).  From a few thousand road users
+ * of one TwoD-field class on one device, a tick of csf_step(e, n >= 4) is a pair launch on one of the engine's two streams and the
+ * per-agent kernel on the other: every wave runs its destination-force phase (vehicle.py:1416-1558) at once and takes up the column
+ * sums of its 64 road users (intersection.py:841-862) as soon as the pair workgroups that form them have arrived, while the rest of the
+ * pair launch drains; the next tick's records go to the other half of a double buffer.  Bit-identical to the two launches in turn.
+ * Per-tick calls, re-binning ticks, roads, history, shards and several parameter sets take the launches in turn.
+ * Whether it pays depends on the runtime giving the engine's two streams hardware queues of their own (two streams on one queue
+ * serialise, and the tick is then a launch LONGER): unless CSF_CHASE=0 (never) or 2 (always) says otherwise, an engine times twice 12 ticks
+ * each way on its first eligible stretch after tick 192 (warm clocks) and keeps the faster - engines of the same kind created later in the process take the finding over - csf_chase_calibration: side_by_side 1 / -1 / 0 (not measured yet),
+ * us_per_tick = {in turn, side by side} (0 when nothing was measured).  Both ways give the same states. */
+int csf_chase_ticks(const csf_engine *e, int64_t *n_ticks);
+int csf_chase_calibration(const csf_engine *e, int32_t *side_by_side, double us_per_tick[2]);
 
 /* Arrivals that took the slot of a road user who had left from nearby (ABI 8).  Under traffic - road users arriving and leaving
  * every tick, intersection.py:458-634 - a slot freed inside a batch of the binned order is handed to the next arrival that starts
