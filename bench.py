@@ -208,8 +208,12 @@ def main():
     # (profiles/r2_tick_sequence.json).  A SCRATCH engine (the same population, unsharded, on this rank's device) runs the
     # untimed pre-roll - about 0.1 s of ticks - and the W warm-up ticks, and is thrown away; the population the line names
     # is then created afresh and timed from its first ticks (`timed_window.start.tick`).
-    scratch = populate()
-    eng = populate()
+    if os.environ.get("CSF_BENCH_SWAP") == "1":                   # (measurement aid: which engine is created first)
+        eng = populate()
+        scratch = populate()
+    else:
+        scratch = populate()
+        eng = populate()
     if world > 1:
         shard_engine(eng, dist, rank, world)
     elif rehearse:
@@ -239,6 +243,8 @@ def main():
     # of the driver's 20-step command (five launches: their spread is 2 %).  (The event pool is created here, not in front of
     # the timed region.)
     every = max(1, min(16, args.steps // 5))
+    if os.environ.get("CSF_BENCH_SAMPLE_EVERY"):              # (measurement aid: what do the time stamps themselves cost?)
+        every = int(os.environ["CSF_BENCH_SAMPLE_EVERY"])
     eng.profile(every)
     eng.step(first)
     fence()

@@ -283,6 +283,11 @@ void launch_road_grid(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hip
 void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 // the whole per-agent tick beside the pair launch that feeds it (Dev::chase_cnt), behind its gate; false: not built for this class
 bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void preload_chase_kernels();
+void launch_chase_scratch_warm(unsigned *out, hipStream_t st);
+// the other halves of the double buffers <- this tick's, the arrival counters (cnt, through: may be NULL) cleared: one launch
+void launch_chase_sync(const Dev &d, float4 *rec_o, float4 *recg_o, float4 *recs_o, float2 *rec2_o, double *cur, int64_t nrecg, unsigned *cnt,
+                       int64_t ncnt, unsigned *through, hipStream_t st);
 constexpr unsigned CHASE_SPIN_LIMIT = 1u << 18;   // polls (each behind an s_sleep: ~0.3 s in all) before a wait gives up - every wave exits
 // csf_agent.hip: up to SMALL_MAX road users of one TwoD-field class, n_ticks whole ticks in one launch of one wave (the rounding
 // bands of the launch: csf_engine.hip set_fov_band)

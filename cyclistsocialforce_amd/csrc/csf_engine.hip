@@ -349,17 +349,19 @@ struct csf_engine {
     DevBuf<float4> recs_alt;
     DevBuf<unsigned> chase_cnt, chase_misc;
     DevBuf<unsigned long long> chase_clock;   // CSF_CHASE_CLOCK=<file>: stamps of the last 64 side-by-side ticks, written at csf_destroy
-    bool chase_prev = false;
+    bool dirty_layout_for_warm() const { return dirty || !segs.empty() || classes.size() != 1; }   // (the warm pair launch of chase_alloc takes the plain single-set launch)
+    bool chase_prev = false, chase_resume = false;   // resume: the counters and halves are those of the last side-by-side tick (mid_synced says nothing else wrote records since)
     uint32_t chase_round = 0;
     int chase_parity = 0;
     int64_t chase_ticks = 0, chase_checked = 0;
-    // CSF_CHASE=1: decided by measurement, once per engine (chase_take): twice 12 ticks in turn and 12 side by side, bracketed by events on the
+    // CSF_CHASE=1: decided by measurement, once per engine (chase_take): three periods between re-binnings - in turn, side by side, in turn -, bracketed by events on the
     // main stream - whether the two streams got hardware queues of their own is the runtime's business, and without them the
     // side-by-side tick is the slower one
     int chase_state = 0;                // 0 undecided, 1 side by side, -1 in turn
-    int cal_phase = 0, cal_left = 0;    // 0 idle, 1 .. 4 the stretches (odd: in turn, even: side by side), 5 waiting for the last event
-    hipEvent_t cal_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int cal_phase = 0;                  // 0 idle, 1 .. 3 the periods (in turn, side by side, in turn), 4 waiting for the last event
+    hipEvent_t cal_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double chase_cal_us[2] = {0.0, 0.0};
+    int64_t cal_ticks[3] = {0, 0, 0};   // ticks of every period of the measurement
     DevBuf<float2> borg;
     DevBuf<float2> rvo;          // origins of the road-vertex tiles
     DevBuf<int32_t> pos;
@@ -438,6 +440,10 @@ struct csf_engine {
     int64_t prof_ticks = 0;             // sampled ticks issued (the kernels beside the pair kernel are timed on every 8th)
     std::vector<float> prof_us[4];      // per sampled launch and kernel - pair, road, per-agent, all-gather - (at most PROF_KEEP of each)
 };
+
+// (defined with the side-by-side tick, used by upload_all)
+static bool chase_shape(const csf_engine *e);
+static int chase_alloc(csf_engine *e);
 
 namespace {
 
@@ -1801,6 +1807,12 @@ int upload_all(csf_engine *e) {
     HIPCHK(e, hipStreamSynchronize(e->main));
     e->gather_pending = false;
     e->dirty = false;
+    // what the side-by-side tick needs beside these arrays (enqueue_chase_tick): allocated here, where the host waits anyway - an
+    // allocation synchronises, and the first such tick may lie inside a region somebody is timing
+    if (chase_shape(e)) {
+        int rcc = chase_alloc(e);
+        if (rcc) return rcc;
+    }
     return CSF_OK;
 }
 
@@ -2233,7 +2245,10 @@ int csf_destroy(csf_engine *e) {
     if (e->chase_clock.p) {
         std::vector<unsigned long long> h(128 * 8);
         if (hipMemcpy(h.data(), e->chase_clock.p, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *f = fopen(e->knobs.chase_clock.c_str(), "wb")) {
+            static std::atomic<int> g_clock_files{0};     // (one file per engine of the process, in the order they are destroyed)
+            const int fk = g_clock_files.fetch_add(1);
+            const std::string path = fk == 0 ? e->knobs.chase_clock : e->knobs.chase_clock + "." + std::to_string(fk);
+            if (FILE *f = fopen(path.c_str(), "wb")) {
                 fwrite(h.data(), sizeof(h[0]), h.size(), f);
                 fwrite(&e->chase_ticks, sizeof e->chase_ticks, 1, f);
                 fclose(f);
@@ -2942,35 +2957,40 @@ static bool mid_fused_ok(const csf_engine *e) {
 }
 
 // the other halves of the double buffers <- this tick's records (sentinels of free and padding slots included) and state
-static int mid_sync(csf_engine *e) {
-    Dev &d = e->d;
+// the second halves of the double buffers (allocations synchronise: never inside something that is being timed)
+static int alt_alloc(csf_engine *e) {
     const size_t nrec = e->rec.n;
-    if (e->rec_alt.n < nrec) {
-        HIPCHK(e, e->rec_alt.alloc(nrec));
-        HIPCHK(e, e->recg_alt.alloc(e->recg.n));
-        HIPCHK(e, e->rec2_alt.alloc(e->rec2.n));
-        HIPCHK(e, e->src64_a.alloc(3 * (size_t)e->cap));
-        HIPCHK(e, e->src64_b.alloc(3 * (size_t)e->cap));
-        HIPCHK(e, e->recs_alt.alloc(e->recs.n));
-        // the permanent sentinel (alloc_all: the last record, no slot's; the padding of the class-segmented order points at it)
-        // exists in BOTH halves: after an odd number of one-launch ticks d.rec is the other half, and a population that then
-        // outgrows this path would read (0, 0, 0, 0) - a road user at the origin - where its order is padded
-        HIPCHK(e, hipMemcpyAsync(e->rec_alt.p + e->sent_slot, e->rec.p + e->sent_slot, sizeof(float4), hipMemcpyDeviceToDevice, e->main));
-        HIPCHK(e, hipMemcpyAsync(e->rec2_alt.p + e->sent_slot, e->rec2.p + e->sent_slot, sizeof(float2), hipMemcpyDeviceToDevice, e->main));
-        if ((size_t)e->sent_slot < e->recg.n)
-            HIPCHK(e, hipMemcpyAsync(e->recg_alt.p + e->sent_slot, e->recg.p + e->sent_slot, sizeof(float4), hipMemcpyDeviceToDevice, e->main));
+    if (e->rec_alt.n >= nrec) return CSF_OK;
+    HIPCHK(e, e->rec_alt.alloc(nrec));
+    HIPCHK(e, e->recg_alt.alloc(e->recg.n));
+    HIPCHK(e, e->rec2_alt.alloc(e->rec2.n));
+    HIPCHK(e, e->src64_a.alloc(3 * (size_t)e->cap));
+    HIPCHK(e, e->src64_b.alloc(3 * (size_t)e->cap));
+    HIPCHK(e, e->recs_alt.alloc(e->recs.n));
+    // the permanent sentinel (alloc_all: the last record, no slot's; the padding of the class-segmented order points at it)
+    // exists in BOTH halves: after an odd number of one-launch ticks d.rec is the other half, and a population that then
+    // outgrows this path would read (0, 0, 0, 0) - a road user at the origin - where its order is padded
+    HIPCHK(e, hipMemcpyAsync(e->rec_alt.p + e->sent_slot, e->rec.p + e->sent_slot, sizeof(float4), hipMemcpyDeviceToDevice, e->main));
+    HIPCHK(e, hipMemcpyAsync(e->rec2_alt.p + e->sent_slot, e->rec2.p + e->sent_slot, sizeof(float2), hipMemcpyDeviceToDevice, e->main));
+    if ((size_t)e->sent_slot < e->recg.n)
+        HIPCHK(e, hipMemcpyAsync(e->recg_alt.p + e->sent_slot, e->recg.p + e->sent_slot, sizeof(float4), hipMemcpyDeviceToDevice, e->main));
+    return CSF_OK;
+}
+
+static int mid_sync(csf_engine *e, unsigned *cnt = nullptr, int64_t ncnt = 0, unsigned *through = nullptr) {
+    Dev &d = e->d;
+    {
+        int rca = alt_alloc(e);
+        if (rca) return rca;
     }
     float4 *rec_o = d.rec == e->rec.p ? e->rec_alt.p : e->rec.p, *recg_o = d.recg == e->recg.p ? e->recg_alt.p : e->recg.p;
+    float4 *recs_o = d.recs == e->recs.p ? e->recs_alt.p : e->recs.p;
     float2 *rec2_o = d.rec2 == e->rec2.p ? e->rec2_alt.p : e->rec2.p;
-    HIPCHK(e, hipMemcpyAsync(rec_o, d.rec, (size_t)d.n_pad * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
-    HIPCHK(e, hipMemcpyAsync(recg_o, d.recg, std::min((size_t)d.n_pad, e->recg.n) * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
-    if (d.has_bike) HIPCHK(e, hipMemcpyAsync(rec2_o, d.rec2, (size_t)d.n_pad * sizeof(float2), hipMemcpyDeviceToDevice, e->main));
-    if (d.recs_valid) {   // (the binned copy: the tiles of the cull-first kernel - enqueue_chase_tick)
-        float4 *recs_o = d.recs == e->recs.p ? e->recs_alt.p : e->recs.p;
-        HIPCHK(e, hipMemcpyAsync(recs_o, d.recs, (size_t)d.n_pad * sizeof(float4), hipMemcpyDeviceToDevice, e->main));
-    }
     double *cur = e->mid_cur_is_a ? e->src64_a.p : e->src64_b.p;
-    HIPCHK(e, hipMemcpyAsync(cur, e->s.p, 3 * (size_t)e->cap * sizeof(double), hipMemcpyDeviceToDevice, e->main));
+    // (one launch: six copy / fill calls cost a launch and its gap each, once per re-binning)
+    launch_chase_sync(d, rec_o, recg_o, recs_o, rec2_o, cur, (int64_t)std::min((size_t)d.n_pad, e->recg.n), cnt, ncnt, through, e->main);
+    HIPCHK(e, hipGetLastError());
+    if (cnt == nullptr) e->chase_resume = false;                  // (the one-launch tick's call: the arrival counters are as they were)
     e->mid_synced = true;
     return CSF_OK;
 }
@@ -3022,12 +3042,25 @@ static int enqueue_mid_tick(csf_engine *e) {
 // a stream whose earlier work does not wait for it - so whatever the runtime maps the streams to, the grid drains (mapped to one
 // hardware queue the launches simply serialise).  Next tick's records go to the other halves of the double buffers, hand-overs
 // read the fp64 snapshot of the tick's start (as in csf_mid.hip).  The streams meet (two events) when the path is left.
-static bool chase_ok(const csf_engine *e, int64_t ticks_left) {
+static bool rebin_due(const csf_engine *e) {   // (bounds_before_pair's condition: this tick renews the binned order, on the main stream)
+    return e->ticks_since_rebin + e->moved_unbinned >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= e->knobs.rebin_churn;
+}
+
+// could ticks of this engine take the path at all (what does not change from tick to tick)?
+static bool chase_shape(const csf_engine *e) {
+    const Dev &d = e->d;
+    const int m = d.p.model;
+    return e->knobs.chase != 0 && (m == CSF_TWOD || m == CSF_INVPEND || m == CSF_PLANARPOINT) && e->classes.size() == 1 && d.pair_variant == 0 && d.classify &&
+           !d.recv_binned && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && d.nv == 0 && d.hist == nullptr && e->comm != nullptr;
+}
+
+// everything but "no re-binning this tick"
+static bool chase_eligible(const csf_engine *e, int64_t ticks_left) {
     const Dev &d = e->d;
     if (e->knobs.chase == 0) return false;
     const int m = d.p.model;
     if (m != CSF_TWOD && m != CSF_INVPEND && m != CSF_PLANARPOINT) return false;
-    const bool rebin_now = e->ticks_since_rebin + e->moved_unbinned >= e->knobs.rebin_ticks || e->ticks_since_rebin * e->churn >= e->knobs.rebin_churn;
+    const bool rebin_now = false;
     return e->classes.size() == 1 && d.n_classes == 1 && d.pair_variant == 0 && d.classify && d.recs_valid && !d.recv_binned && d.dyn_recv &&
            (d.rpb == 32 || d.rpb == 16 || d.rpb == 8) && d.n_split <= 8 && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 &&
            d.nv == 0 && d.hist == nullptr && d.pair_count == nullptr && e->segs.empty() && e->state_all_current &&   // (wave traces allowed: tools/chase_timeline.py)
@@ -3035,7 +3068,38 @@ static bool chase_ok(const csf_engine *e, int64_t ticks_left) {
            e->comm != nullptr && (e->chase_prev || ticks_left >= 4);
 }
 
+static bool chase_ok(const csf_engine *e, int64_t ticks_left) { return !rebin_due(e) && chase_eligible(e, ticks_left); }
+
 static int chase_join(csf_engine *e);
+static int alt_alloc(csf_engine *e);
+
+// what the side-by-side tick needs beside the engine's arrays (allocations synchronise: before a measurement, not inside it)
+static int chase_alloc(csf_engine *e) {
+    const size_t nw = (size_t)((e->d.hi - e->d.lo + 63) / 64);
+    HIPCHK(e, e->chase_cnt.reserve(nw + 64));
+    if (e->chase_misc.n == 0) {
+        HIPCHK(e, e->chase_misc.reserve(64));
+        // once per engine: the runtime makes a stream's hardware queue when the stream is first used, and loads a kernel's code when it
+        // is first asked for - a hundred microseconds and more each, which would land in the first side-by-side tick (and, for a
+        // caller who times twenty ticks, in the figure)
+        HIPCHK(e, hipMemsetAsync(e->chase_misc.p, 0, 64 * sizeof(unsigned), e->comm));
+        preload_chase_kernels();
+        // ... and a queue gets its scratch memory when a kernel that spills is first dispatched on it: one pair launch that hands
+        // nothing over (as csf_count_pairs's: partial sums and next tick's circles are written again by the tick's own launch)
+        // and a kernel that asks for the per-agent kernels' bytes per lane, on the second stream
+        if (e->d.n_live > 1 && e->d.hi > e->d.lo && !e->dirty_layout_for_warm()) {
+            Dev dw = e->d;
+            dw.edge = nullptr;
+            dw.pair_count = nullptr;
+            dw.trace = nullptr;
+            launch_pair(dw, e->comm);
+        }
+        launch_chase_scratch_warm(e->chase_misc.p, e->comm);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->comm));
+    }
+    return alt_alloc(e);
+}
 
 // What an engine measured holds for the next engine of the same kind in this process (same device, same rider class, same size to a
 // factor of two): bench.py's timed engine takes over what its scratch engine found, and a caller that steps a few ticks per call
@@ -3047,78 +3111,84 @@ static std::atomic<int> *chase_found_slot(const csf_engine *e) {
     return &g_chase_found[e->device & 7][e->d.p.model & 7][b];
 }
 
-constexpr int CHASE_CAL = 12;   // ticks per stretch of the measurement: in turn, side by side, in turn, side by side
-
 // the measurement's last event has been reached: decide
 static void chase_cal_resolve(csf_engine *e, bool wait) {
-    if (e->cal_phase != 5) return;
-    if (wait ? hipEventSynchronize(e->cal_ev[4]) != hipSuccess : hipEventQuery(e->cal_ev[4]) != hipSuccess) {
+    if (e->cal_phase != 4) return;
+    if (wait ? hipEventSynchronize(e->cal_ev[3]) != hipSuccess : hipEventQuery(e->cal_ev[3]) != hipSuccess) {
         (void)hipGetLastError();
         return;
     }
-    float t[4] = {0, 0, 0, 0};
+    float t[3] = {0, 0, 0};
     bool ok = true;
-    for (int k = 0; k < 4; k++) ok = ok && hipEventElapsedTime(&t[k], e->cal_ev[k], e->cal_ev[k + 1]) == hipSuccess;
+    for (int k = 0; k < 3; k++) ok = ok && hipEventElapsedTime(&t[k], e->cal_ev[k], e->cal_ev[k + 1]) == hipSuccess && e->cal_ticks[k] > 0;
     if (ok) {
-        e->chase_cal_us[0] = (double)(t[0] + t[2]) * 1e3 / (2 * CHASE_CAL);
-        e->chase_cal_us[1] = (double)(t[1] + t[3]) * 1e3 / (2 * CHASE_CAL);
-        // (both side-by-side stretches faster than the in-turn stretch in front of them, and by a per cent in all: a clock that is
-        // still ramping up, or one slow launch, does not decide)
-        e->chase_state = (t[1] < t[0] && t[3] < t[2] && t[1] + t[3] < 0.99f * (t[0] + t[2])) ? 1 : -1;
+        for (int k = 0; k < 3; k++) t[k] = t[k] * 1e3f / (float)e->cal_ticks[k];        // microseconds per tick of every period
+        e->chase_cal_us[0] = 0.5 * (double)(t[0] + t[2]);
+        e->chase_cal_us[1] = (double)t[1];
+        // (the side-by-side period against the MEAN of the in-turn periods on either side of it: a clock that is still ramping up
+        // cancels; by a per cent, so that noise does not decide)
+        e->chase_state = t[1] < 0.99f * 0.5f * (t[0] + t[2]) ? 1 : -1;
         chase_found_slot(e)->store(e->chase_state);
     }
     (void)hipGetLastError();
     e->cal_phase = 0;
 }
 
-// this tick beside the pair launch?  (CSF_CHASE=1: drives the one-off measurement)
+// This tick beside the pair launch?  CSF_CHASE=1 drives the one-off measurement: three whole periods between re-binnings - in turn, side
+// by side, in turn -, each from its re-binning tick to the next, so that what entering and leaving the side-by-side path costs once
+// per period (the halves made equal, the streams meeting) is part of what is compared.
 static bool chase_take(csf_engine *e, int64_t ticks_left) {
-    if (!chase_ok(e, ticks_left)) {
-        if (e->cal_phase >= 1 && e->cal_phase <= 4) e->cal_phase = 0;        // (a stretch cut short measures nothing: start over later)
-        return false;
-    }
-    if (e->knobs.chase >= 2 || e->chase_state == 1) return true;
-    if (e->chase_state == -1) return false;
+    const bool ok = chase_ok(e, ticks_left);
+    if (e->knobs.chase != 1 || e->chase_state != 0) return ok && (e->knobs.chase >= 2 || e->chase_state == 1);
     if (e->cal_phase == 0) {
         const int found = chase_found_slot(e)->load();                     // an earlier engine of this kind has measured
         if (found != 0) {
             e->chase_state = found;
-            return found == 1;
+            return ok && found == 1;
         }
-        // all four stretches inside this call and before the next re-binning, on warm clocks (a fresh process finds the device in a
-        // low power state: its first ~200 ticks run up to 1.7 x slower and speed up as they go), nothing else sampled
-        const int64_t until_rebin = e->knobs.rebin_ticks - (e->ticks_since_rebin + e->moved_unbinned), need = 4 * CHASE_CAL + 2;
-        if (ticks_left < need || until_rebin < need || e->ticks_since_rebin < 1 || e->profile > 0 || e->d.tick < 192) return false;
-        for (hipEvent_t &ev : e->cal_ev)
-            if (!ev && hipEventCreate(&ev) != hipSuccess) return false;
-        if (hipEventRecord(e->cal_ev[0], e->main) != hipSuccess) return false;
-        e->cal_phase = 1;
-        e->cal_left = CHASE_CAL;
     }
-    if (e->cal_phase == 5) {
+    if (e->cal_phase == 4) {
         chase_cal_resolve(e, false);
-        return e->chase_state == 1;
+        return ok && e->chase_state == 1;
     }
-    if (e->cal_left == 0) {                                                // a stretch is complete: its closing event, the next stretch
-        if ((e->cal_phase % 2 == 0 && chase_join(e) != CSF_OK) || hipEventRecord(e->cal_ev[e->cal_phase], e->main) != hipSuccess) {
+    if (rebin_due(e) && chase_eligible(e, ticks_left)) {                   // a period ends, the next begins (this tick: the launches in turn)
+        if (e->cal_phase == 0) {
+            // three periods inside this call, on clocks that have had time to come up (a fresh process finds the device in a low
+            // power state: its first few hundred ticks run up to 1.7 x slower and speed up as they go), nothing else sampled
+            if (ticks_left < 3 * e->knobs.rebin_ticks + 2 || e->d.tick < 256 || e->profile > 0) return false;
+            for (hipEvent_t &ev : e->cal_ev)
+                if (!ev && hipEventCreate(&ev) != hipSuccess) return false;
+            if (chase_alloc(e) != CSF_OK) return false;                     // (now, not inside the side-by-side period)
+            if (hipEventRecord(e->cal_ev[0], e->main) != hipSuccess) return false;
+            e->cal_phase = 1;
+            for (int64_t &c : e->cal_ticks) c = 0;
+        } else {
+            if ((e->cal_phase == 2 && chase_join(e) != CSF_OK) || hipEventRecord(e->cal_ev[e->cal_phase], e->main) != hipSuccess) {
+                e->cal_phase = 0;
+                return false;
+            }
+            e->cal_phase++;
+        }
+        if (e->cal_phase <= 3) e->cal_ticks[e->cal_phase - 1]++;
+        return false;
+    }
+    if (e->cal_phase >= 1 && e->cal_phase <= 3) {
+        if (!ok) {                                                          // (something else got in the way: start over later)
             e->cal_phase = 0;
             return false;
         }
-        e->cal_phase++;
-        e->cal_left = CHASE_CAL;
-        if (e->cal_phase == 5) return false;                               // (this tick in turn; the decision when the last event is reached)
+        e->cal_ticks[e->cal_phase - 1]++;
+        return e->cal_phase == 2;
     }
-    e->cal_left--;
-    return e->cal_phase % 2 == 0;
+    return false;
 }
 
 // the two streams meet: whatever follows runs on the main stream alone
 static int chase_join(csf_engine *e) {
     if (!e->chase_prev) return CSF_OK;
+    // (one event: the main stream behind the second; the second stream is put behind the main one when the path is entered again)
     HIPCHK(e, hipEventRecord(e->ev_gather, e->comm));
     HIPCHK(e, hipStreamWaitEvent(e->main, e->ev_gather, 0));
-    HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
-    HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
     e->chase_prev = false;
     return CSF_OK;
 }
@@ -3128,17 +3198,19 @@ static int enqueue_chase_tick(csf_engine *e, csf_engine::ProfSlot *ps, csf_engin
     int rc;
     if ((rc = bounds_before_pair(e))) return rc;                 // (chase_ok: no re-binning, circles in place - nothing is launched)
     if ((rc = set_fov_band(e))) return rc;
-    const size_t nw = (size_t)((d.hi - d.lo + 63) / 64);
-    if (!e->chase_prev) {                                         // entering: the second stream behind everything so far, counters cleared
-        HIPCHK(e, e->chase_cnt.reserve(nw + 64));
-        HIPCHK(e, e->chase_misc.reserve(64));
-        if (!e->mid_synced && (rc = mid_sync(e))) return rc;
-        HIPCHK(e, hipMemsetAsync(e->chase_cnt.p, 0, e->chase_cnt.n * sizeof(unsigned), e->main));
-        HIPCHK(e, hipMemsetAsync(e->chase_misc.p, 0, sizeof(unsigned), e->main));   // (the gate's counter; the error word stays)
+    if (!e->chase_prev) {                                         // entering: the second stream behind everything so far
+        if ((rc = chase_alloc(e))) return rc;
+        // Nothing but side-by-side ticks since the halves were made equal (the last call ended with such ticks and nothing ran in
+        // between): counters, round and stream parity carry on, and entering costs one event.  Else one launch makes the halves
+        // equal and clears the arrival counters and the gate's counter (the error word stays).
+        if (!e->mid_synced || !e->chase_resume) {
+            if ((rc = mid_sync(e, e->chase_cnt.p, (int64_t)e->chase_cnt.n, e->chase_misc.p))) return rc;
+            e->chase_round = 0;
+            e->chase_parity = 0;
+        }
+        e->chase_resume = true;
         HIPCHK(e, hipEventRecord(e->ev_integ, e->main));
         HIPCHK(e, hipStreamWaitEvent(e->comm, e->ev_integ, 0));
-        e->chase_round = 0;
-        e->chase_parity = 0;
     }
     hipStream_t P = e->chase_parity ? e->comm : e->main, Q = e->chase_parity ? e->main : e->comm;
     float4 *rec_o = d.rec == e->rec.p ? e->rec_alt.p : e->rec.p, *recg_o = d.recg == e->recg.p ? e->recg_alt.p : e->recg.p;
@@ -3361,7 +3433,7 @@ static int step_impl(csf_engine *e, int64_t n_ticks, bool want_snap, bool *snapp
         if (rc) return rc;
     }
     if ((rc = chase_join(e))) return rc;                          // (every other entry point works on the main stream alone)
-    if (e->cal_phase >= 1 && e->cal_phase <= 4) e->cal_phase = 0;  // (a measurement does not span calls)
+    if (e->cal_phase >= 1 && e->cal_phase <= 3) e->cal_phase = 0;  // (a measurement does not span calls)
     if (n_ticks > 0) e->device_ahead = true;
     return CSF_OK;
 }

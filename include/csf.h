@@ -339,8 +339,9 @@ int csf_mid_ticks(const csf_engine *e, int64_t *n_ticks);
  * pair launch drains; the next tick's records go to the other half of a double buffer.  Bit-identical to the two launches in turn.
  * Per-tick calls, re-binning ticks, roads, history, shards and several parameter sets take the launches in turn.
  * Whether it pays depends on the runtime giving the engine's two streams hardware queues of their own (two streams on one queue
- * serialise, and the tick is then a launch LONGER): unless CSF_CHASE=0 (never) or 2 (always) says otherwise, an engine times twice 12 ticks
- * each way on its first eligible stretch after tick 192 (warm clocks) and keeps the faster - engines of the same kind created later in the process take the finding over - csf_chase_calibration: side_by_side 1 / -1 / 0 (not measured yet),
+ * serialise, and the tick is then a launch LONGER): unless CSF_CHASE=0 (never) or 2 (always) says otherwise, an engine times three whole periods
+ * between re-binnings (64 ticks each: in turn, side by side, in turn) in its first call of 200 ticks or more after tick 256 (clocks that
+ * have come up; the mean of the two in-turn periods cancels what is left of the ramp) and keeps the faster - engines of the same kind created later in the process take the finding over - csf_chase_calibration: side_by_side 1 / -1 / 0 (not measured yet),
  * us_per_tick = {in turn, side by side} (0 when nothing was measured).  Both ways give the same states. */
 int csf_chase_ticks(const csf_engine *e, int64_t *n_ticks);
 int csf_chase_calibration(const csf_engine *e, int32_t *side_by_side, double us_per_tick[2]);

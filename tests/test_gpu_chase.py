@@ -104,14 +104,14 @@ def test_side_by_side_ticks_between_other_calls(amd, monkeypatch):
 
 
 def test_the_engine_measures_which_order_is_faster(amd, monkeypatch):
-    """CSF_CHASE=1 (the default): twice 12 ticks each way on the first eligible stretch after tick 192, then the faster order - the states are the in-turn engine's
+    """CSF_CHASE=1 (the default): three periods between re-binnings - in turn, side by side, in turn -, then the faster order - the states are the in-turn engine's
     whatever it decides"""
     n, box = 16384, 200.0
     s0, off, dq = crowd(n, box, 2, 5)
     a = engine(amd, monkeypatch, 0, "twod", s0, off, dq)
     b = engine(amd, monkeypatch, 1, "twod", s0, off, dq)
     for e in (a, b):
-        e.step(10); e.step(190); e.step(120)
+        e.step(10); e.step(250); e.step(400)
     same(a, b)
     decided, us = b.chase_calibration()
     assert decided in (1, -1), decided

@@ -27,8 +27,20 @@ for m in modes:
     e.add_agents(s0, 5.0)
     e.set_dest_queue(np.arange(16384), off, dq, reset=True)
     engines.append(e)
+if "--profiled-bystander" in sys.argv:      # bench.py: the timed engine has its event pool and has run its first ticks before the scratch engine runs
+    os.environ["CSF_CHASE"] = "0"
+    by = Engine(parameters.default_pod("twod"), 16384)
+    by.add_agents(s0, 5.0)
+    by.set_dest_queue(np.arange(16384), off, dq, reset=True)
+    by.profile(16)
+    by.step(8, sync=True)
+    if "--torch" in sys.argv:
+        torch.cuda.synchronize()
 for e in engines:
-    e.step(200, sync=True)
+    e.step(8, sync=True)
+    if "--window-state" in sys.argv:          # bench.py: window_state(scratch) - a read-back and the counting launch - before the warm-up
+        e.state(); e.count_pairs(detail=True)
+    e.step(192, sync=True)
 for r in range(3):
     row = []
     for m, e in zip(modes, engines):
