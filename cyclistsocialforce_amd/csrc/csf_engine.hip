@@ -3051,7 +3051,7 @@ static bool chase_shape(const csf_engine *e) {
     const Dev &d = e->d;
     const int m = d.p.model;
     return e->knobs.chase != 0 && (m == CSF_TWOD || m == CSF_INVPEND || m == CSF_PLANARPOINT) && e->classes.size() == 1 && d.pair_variant == 0 && d.classify &&
-           !d.recv_binned && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 && d.nv == 0 && d.hist == nullptr && e->comm != nullptr;
+           !d.recv_binned && e->world == 1 && !e->nccl && !e->loopback && d.nv == 0 && d.hist == nullptr && e->comm != nullptr;   // (CSF_FAKE_SHARD: a rank's block of receivers, for tools/fake_shard.py)
 }
 
 // everything but "no re-binning this tick"
@@ -3062,9 +3062,10 @@ static bool chase_eligible(const csf_engine *e, int64_t ticks_left) {
     if (m != CSF_TWOD && m != CSF_INVPEND && m != CSF_PLANARPOINT) return false;
     const bool rebin_now = false;
     return e->classes.size() == 1 && d.n_classes == 1 && d.pair_variant == 0 && d.classify && d.recs_valid && !d.recv_binned && d.dyn_recv &&
-           (d.rpb == 32 || d.rpb == 16 || d.rpb == 8) && d.n_split <= 8 && e->world == 1 && !e->nccl && !e->loopback && e->knobs.fake_world <= 1 &&
+           (d.rpb == 32 || d.rpb == 16 || d.rpb == 8) && d.n_split <= 16 && e->world == 1 && !e->nccl && !e->loopback &&
            d.nv == 0 && d.hist == nullptr && d.pair_count == nullptr && e->segs.empty() && e->state_all_current &&   // (wave traces allowed: tools/chase_timeline.py)
-           e->pend.empty() && !rebin_now && !e->bound_stale && e->bounds_fresh && d.n_live > 1 && d.lo == 0 && d.hi == d.n && d.replay_len == nullptr &&
+           e->pend.empty() && !rebin_now && !e->bound_stale && e->bounds_fresh && d.n_live > 1 && d.hi > d.lo && (d.lo & 63) == 0 && d.replay_len == nullptr &&
+           ((d.lo == 0 && d.hi == d.n) || e->knobs.fake_world > 1) &&
            e->comm != nullptr && (e->chase_prev || ticks_left >= 4);
 }
 

@@ -314,7 +314,8 @@ class PlanarBicycleParameters(BicycleParameters):
 
 
 # The bicycle of BalancingRiderBicycleParameters' default (parameters.py:16, 1217): the Balance Assist v1 bicycle with an average
-# rider, as data/bicycleparams/balanceassist_bikeparams.py lists it (derived there from Moore's BicycleParameters data, BSD-2).
+# rider, as data/bicycleparams/balanceassist_bikeparams.py lists it (derived there from Moore's BicycleParameters data; BSD-2-Clause,
+# Copyright (c) 2011-2025 BicycleParameters Authors: the licence text is in THIRD_PARTY_NOTICES.md at the root of this repository).
 balanceassistv1_with_averagerider = dict(
     IBxx=16.136560964517308, IBxz=-2.5375819134691833, IByy=18.98228436804581, IBzz=4.308368614306412, IFxx=0.0995, IFyy=0.1902,
     IHxx=0.2984, IHxz=-0.038, IHyy=0.257, IHzz=0.0566, IRxx=0.1023, IRyy=0.1887, c=0.042, g=9.81, lam=0.255,

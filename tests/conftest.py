@@ -16,6 +16,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "cull_variant: written around the cull-first kernel (its counters, its name): pinned even with CSF_TEST_AUTO_VARIANT=1")
 
 
+def pytest_generate_tests(metafunc):
+    """Every GPU test against the reference's golden vectors runs TWICE in one pass of the suite: with the cull-first kernel pinned
+    (below) and on the engine's own choice of kernels for its population - the one-wave kernel, the one-launch tick, the plain
+    kernels -, which is what a drop-in user of those population sizes gets.  (Tests that are marked `auto_variant` or `cull_variant`,
+    or that pin a kernel themselves, keep their single run.)"""
+    fn = metafunc.function
+    marks = {m.name for m in metafunc.definition.iter_markers()}
+    if "golden" in fn.__name__ and "gpu" in marks and not ({"auto_variant", "cull_variant"} & marks) and "kernel_choice" not in metafunc.fixturenames:
+        metafunc.fixturenames.append("kernel_choice")
+        metafunc.parametrize("kernel_choice", ["cull-first", "own-choice"])
+
+
+@pytest.fixture
+def kernel_choice(request):
+    return getattr(request, "param", "cull-first")
+
+
 @pytest.fixture(autouse=True)
 def _cull_kernel_at_every_size(request, monkeypatch):
     """The engine picks the plain all-pairs kernel below ~3 000 road users and the cull-first kernel above
@@ -23,6 +40,9 @@ def _cull_kernel_at_every_size(request, monkeypatch):
     classification, queue and far-field cull - so the suite pins that kernel; tests marked `auto_variant` (and every test
     that sets CSF_PAIR_VARIANT itself) run with the engine's own choice."""
     if "auto_variant" in request.keywords or "CSF_PAIR_VARIANT" in os.environ:
+        return
+    cs = getattr(request.node, "callspec", None)
+    if cs is not None and cs.params.get("kernel_choice") == "own-choice":
         return
     # CSF_TEST_AUTO_VARIANT=1: the whole suite on the engine's own choice, but for the tests written around the cull-first kernel
     if os.environ.get("CSF_TEST_AUTO_VARIANT") != "1" or "cull_variant" in request.keywords:

@@ -291,4 +291,9 @@ def main():
 
 
 if __name__ == "__main__":
+    # (the reference's PoleModel makes an output directory "pole-modeling" under the working directory when it is loaded,
+    # controlbehavior.py:1079-1082: let that happen in a scratch directory, not in the repository)
+    import tempfile
+
+    os.chdir(tempfile.mkdtemp(prefix="csf_golden_"))
     main()
