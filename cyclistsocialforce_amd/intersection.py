@@ -185,6 +185,8 @@ class SocialForceIntersection:
         self._zn = None           # znav [capacity, 3]; vehicle.znav are row views
         self._fx = self._fy = None
         self._have_force = False
+        self._hooked = False      # some vehicle carries a custom rep_force_func / dest_force_func: forces are formed on the host (_hooked_forces)
+        self._field_engines = {}  # ... engines for the class fields of the others, by parameter set
         self._ti = None           # vehicle.i [capacity]
         self._traj = None         # vehicle.traj, stored [traj_len, rows, n_states] (a tick writes one contiguous slab);
                                   # vehicle.traj are transposed views [n_states, traj_len]
@@ -279,8 +281,7 @@ class SocialForceIntersection:
         if v._owner is not None and v._owner is not self:
             raise RuntimeError(f"vehicle {v.id} already belongs to another intersection")
         if v.dest_force_func is not None or v.rep_force_func is not None:
-            raise NotImplementedError(f"vehicle {v.id} carries a custom dest_force_func / rep_force_func: the population "
-                                      "engine evaluates the class's own force functions for every agent")
+            self._hooked = True                                        # (this population's forces are formed on the host: _hooked_forces)
         if v._solo is not None:
             v._solo.close()
             v._solo = None
@@ -734,10 +735,70 @@ class SocialForceIntersection:
     def calc_forces(self):
         """intersection.py:747-864: total force on every road user from the current snapshot."""
         e = self._push_mutations()
+        if self._hooked and self.n_bikes > 0:
+            fx, fy = self._hooked_forces(e)
+            n = len(self.vehicles)
+            self._fx[:n], self._fy[:n] = fx, fy
+            self._have_force = True
+            self._log_forces(fx, fy)
+            return fx, fy
         fx, fy = e.calc_forces()
         self._pull(forces=True, advance=0)
         self._log_forces(fx, fy)
         return fx, fy
+
+    # ------------------------------------------------------------------ custom per-vehicle force hooks (vehicle.py:194-204, 250-299)
+    def _field_engine(self, v):
+        """an engine of the vehicle's class and parameter set, for its field alone (csf_pair_force: vehicle.py:1560-1648 /
+        1054-1147 with THAT set's constants - the population's own engine evaluates set 0's)"""
+        pod = v._pod(PRIORITY_RULES.get(self.priority_rule, 0))
+        key = bytes(pod)
+        eng = self._field_engines.get(key)
+        if eng is None:
+            from .engine import Engine
+
+            eng = self._field_engines[key] = Engine(pod, 1)
+        return eng
+
+    def _hooked_forces(self, e):
+        """calc_forces() of a population in which some vehicle carries a custom `rep_force_func` / `dest_force_func`
+        (intersection.py:797-862, statement by statement): the hooks are the caller's Python, everything else comes from the
+        engine's single-function entry points - csf_dest_force (queue pointer, navigation state, the class's destination force),
+        csf_untracked (the mask), csf_pair_force (the class's field of one source at the receivers that track it) -, the column
+        sum, the clamp and the road term are NumPy as in the reference.  O(n) device calls per tick: for the handful of road users
+        scenarios with hooks have (the reference's own tick is slower still)."""
+        from .utils import limitMagnitude
+
+        n = self.n_bikes
+        fdx, fdy = e.dest_force()                                  # :799 for every class force; advances the queues as the reference does
+        self._pull(forces=False, advance=0)                        # vehicle.s / dest / destpointer as the hooks expect to find them
+        S = self._S[:n]
+        X, Y, PSI = S[:, 0].copy(), S[:, 1].copy(), S[:, 2].copy()
+        for i, v in enumerate(self.vehicles):
+            if v.dest_force_func is not None:                      # vehicle.py:295-297 (updateDestination has run: csf_dest_force)
+                fdx[i], fdy[i] = v.dest_force_func(v)
+        fx, fy = fdx.copy(), fdy.copy()
+        if n > 1:
+            U = e.untracked()                                      # [source, receiver], True: not considered (:690-745)
+            Fx, Fy = np.zeros((n, n)), np.zeros((n, n))
+            for i, v in enumerate(self.vehicles):
+                trk = ~U[i]
+                if not trk.any():
+                    continue
+                if v.rep_force_func is not None:                   # :814-820
+                    fxi, fyi = v.rep_force_func(v, X[trk], Y[trk], PSI[trk])
+                elif getattr(v.params, "f_0", 1.0) == 0.0 and v.MODEL != 0:
+                    continue                                       # vehicle.py:1592-1593
+                else:
+                    fxi, fyi = self._field_engine(v).pair_force(np.r_[S[i, :3], S[i, 3]], X[trk], Y[trk], PSI[trk])
+                Fx[i, trk], Fy[i, trk] = fxi, fyi                  # :822-823
+            frx, fry = limitMagnitude(Fx.sum(axis=0), Fy.sum(axis=0), np.sqrt(fdx ** 2 + fdy ** 2))   # :841-845
+            fx, fy = frx + fdx, fry + fdy
+        for el in self.road_elements:                              # :854-857
+            fxe, fye = el.calcRepulsiveForce(X[:, None], Y[:, None])
+            fx = fx + np.asarray(fxe).ravel()
+            fy = fy + np.asarray(fye).ravel()
+        return np.ascontiguousarray(fx, dtype=float), np.ascontiguousarray(fy, dtype=float)
 
     def step(self):
         """intersection.py:866-896: one simulation tick of the whole population."""
@@ -746,7 +807,12 @@ class SocialForceIntersection:
                 if v.drawing is None:
                     v.add_drawing(self.ax, animated=True, **self.bicycle_drawing_kwargs)
         self.is_first_step = False
-        if self.n_bikes > 0:
+        if self.n_bikes > 0 and self._hooked:
+            e = self._push_mutations()
+            fx, fy = self._hooked_forces(e)                        # intersection.py:889
+            e.apply_forces(fx, fy)                                 # :891-892: every vehicle.step(Fx[i], Fy[i])
+            self._pull(forces=True, advance=1)                     # :894
+        elif self.n_bikes > 0:
             self._push_mutations()
             self._pull(forces=True, advance=1, step=1)
         self.hist_n_vecs.append(self.n_bikes)
@@ -754,6 +820,10 @@ class SocialForceIntersection:
     def step_n(self, n_ticks, pull=True):
         """n_ticks ticks with no per-tick host work (the benchmark path).  `traj` receives only the final
         state; enable the engine's device-side history for dense trajectories."""
+        if self._hooked and self.n_bikes > 0:                     # (custom force hooks: the forces of every tick are formed on the host)
+            for _ in range(int(n_ticks)):
+                self.step()
+            return
         if self.n_bikes > 0 and n_ticks > 0:
             e = self._push_mutations()
             e.step(int(n_ticks))

@@ -32,8 +32,10 @@ class Vehicle:
     def __init__(self, s0, id="unknown", route=(), saveForces=False, params=None, dest_force_func=None,
                  rep_force_func=None):
         # per-vehicle hooks (vehicle.py:56, 194-204, 225-234): None selects the class's own force functions, which run
-        # on the GPU.  A custom callable is honoured by the single-vehicle methods below (it is the caller's Python
-        # code); a population engine evaluates one field for all its agents and refuses vehicles that carry one.
+        # on the GPU.  A custom callable is the caller's Python code: honoured by the single-vehicle methods below, and inside
+        # a SocialForceIntersection by a tick that forms the forces on the host from the engine's pieces (intersection.py of
+        # this package: _hooked_forces) - meant for the handful of road users such scenarios have.
+        self._owner = None
         self.dest_force_func = dest_force_func
         self.rep_force_func = rep_force_func
         if self.MODEL is None:
@@ -80,6 +82,27 @@ class Vehicle:
         self._solo_synced = False
         self._queue_dirty = True
         self._s_shadow = self.s.copy()
+
+    # hooks may be assigned at any time (the reference's are plain attributes): the intersection that holds the vehicle is told
+    @property
+    def rep_force_func(self):
+        return self._rep_force_func
+
+    @rep_force_func.setter
+    def rep_force_func(self, f):
+        self._rep_force_func = f
+        if f is not None and self._owner is not None:
+            self._owner._hooked = True
+
+    @property
+    def dest_force_func(self):
+        return self._dest_force_func
+
+    @dest_force_func.setter
+    def dest_force_func(self, f):
+        self._dest_force_func = f
+        if f is not None and self._owner is not None:
+            self._owner._hooked = True
 
     # ------------------------------------------------------------------ mirrored scalars
     # Inside a SocialForceIntersection these live in the intersection's bulk arrays (one device read-back per tick
@@ -217,6 +240,12 @@ class Vehicle:
         """vehicle.py:250-279 / 1560-1648: force this vehicle exerts on road users at (x, y, psi)."""
         if self.rep_force_func is not None:
             return self.rep_force_func(self, x, y, psi)
+        return self.class_field(x, y, psi)
+
+    def class_field(self, x, y, psi):
+        """The field of the vehicle's CLASS whatever hook it carries - what the reference's classes reach by calling
+        `TwoDBicycle.calcRepulsiveForce(vehicle, x, y, psi)` unbound (vehicle.py:982, 1987, 2024, 2069): a hook that scales or
+        reshapes its class's own field calls this."""
         if getattr(self.params, "f_0", 1.0) == 0.0 and self.MODEL != _ffi.BICYCLE:
             return 0.0, 0.0                                            # vehicle.py:1592-1593
         x = np.atleast_1d(np.asarray(x, dtype=float)).ravel()

@@ -514,6 +514,38 @@ def gen_trajectories():
 
 
 # ----------------------------------------------------------------------------
+# (9b) custom per-vehicle force hooks inside a population — vehicle.py:194-204, 250-299
+# ----------------------------------------------------------------------------
+def hook_strong_field(veh, x, y, psi):
+    """a repulsive-force hook: 2.5 x the TwoD field the class would exert (vehicle.py:1560-1648, called unbound as the
+    reference's own classes do: vehicle.py:2024)"""
+    fx, fy = rv.TwoDBicycle.calcRepulsiveForce(veh, x, y, psi)
+    return 2.5 * fx, 2.5 * fy
+
+
+def hook_constant_pull(veh):
+    """a destination-force hook that looks at the vehicle: a pull of 3.5 towards (30, 30) + a lateral bias"""
+    dx, dy = 30.0 - veh.s[0], 30.0 - veh.s[1]
+    r = np.hypot(dx, dy)
+    return 3.5 * dx / r + 0.4, 3.5 * dy / r - 0.2
+
+
+def gen_hooks():
+    """Seven PlanarPointBicycles (the class whose forces go through Vehicle's hook dispatch, vehicle.py:2024-2025) in 18 m: vehicle 1
+    exerts a stronger field, vehicle 3 follows its own destination force, vehicle 5 has both hooks; 150 ticks."""
+    rng = np.random.default_rng(4242)
+    vs = random_population(rng, "planarpoint", 7, 18.0)
+    vs[1].rep_force_func = hook_strong_field
+    vs[3].dest_force_func = hook_constant_pull
+    vs[5].rep_force_func = hook_strong_field
+    vs[5].dest_force_func = hook_constant_pull
+    s0, vdes, off, dq = pop_arrays(vs)
+    S, Ft = run_population(vs, 150, every=10)
+    ptr = np.array([v.destpointer for v in vs])
+    save("hooks", s0=s0, vdes=vdes, off=off, dq=dq, S=S, F=Ft, ptr=ptr, rep_hook=np.array([1, 5]), dest_hook=np.array([3, 5]))
+
+
+# ----------------------------------------------------------------------------
 # (10) helpers — utils.py:56-86, 124-227
 # ----------------------------------------------------------------------------
 def gen_utils():
@@ -863,10 +895,10 @@ def gen_uncontrolled():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero", "mixed", "sumo", "uncontrolled"]
+    which = sys.argv[1:] or ["pair", "masks", "control", "dest", "pp", "road", "traj", "utils", "yawstep", "planarbike", "hetero", "mixed", "sumo", "uncontrolled", "hooks"]
     gens = {"pair": gen_pair_fields, "masks": gen_masks_and_totals, "control": gen_control_move,
             "dest": gen_dest_force, "pp": gen_planarpoint_steps, "road": gen_road,
             "traj": gen_trajectories, "utils": gen_utils, "yawstep": gen_invpend_yawstep,
-            "planarbike": gen_planarbike, "hetero": gen_hetero, "mixed": gen_mixed, "sumo": gen_sumo_seam, "uncontrolled": gen_uncontrolled}
+            "planarbike": gen_planarbike, "hetero": gen_hetero, "mixed": gen_mixed, "sumo": gen_sumo_seam, "uncontrolled": gen_uncontrolled, "hooks": gen_hooks}
     for w in which:
         gens[w]()

@@ -611,3 +611,47 @@ def test_uncontrolled_vehicle_trajectory_rewritten_while_running():
     assert j == i + 7
     np.testing.assert_allclose(car.s[:4], car.traj[:4, j], rtol=0, atol=1e-12)
     assert abs(car.s[1] - 2.75) < 1e-12
+
+
+def test_custom_force_hooks_inside_a_population_against_the_reference(golden):
+    """vehicle.py:194-204, 250-299: `rep_force_func` / `dest_force_func` of single vehicles inside a SocialForceIntersection.  The
+    literal reference ran seven PlanarPointBicycles of which one exerts 2.5 x its class's field, one follows its own destination force
+    and one does both (tests/golden/make_golden.py: gen_hooks); the mirror forms such a population's forces on the host from the
+    engine's pieces (csf_dest_force, csf_untracked, csf_pair_force, csf_apply_forces) and must land on the same trajectory."""
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import PlanarPointBicycle
+
+    g = golden("hooks")
+    s0, vdes, off, dq, S, F = (g[k] for k in ("s0", "vdes", "off", "dq", "S", "F"))
+
+    def strong_field(veh, x, y, psi):
+        fx, fy = veh.class_field(x, y, psi)      # (the reference's hook calls TwoDBicycle.calcRepulsiveForce(veh, ...) unbound)
+        return 2.5 * np.asarray(fx), 2.5 * np.asarray(fy)
+
+    def constant_pull(veh):
+        dx, dy = 30.0 - veh.s[0], 30.0 - veh.s[1]
+        r = np.hypot(dx, dy)
+        return 3.5 * dx / r + 0.4, 3.5 * dy / r - 0.2
+
+    vs = []
+    for a in range(s0.shape[0]):
+        v = PlanarPointBicycle(tuple(s0[a]), id=str(a))
+        v.params.v_desired_default = float(vdes[a])
+        rows = dq[off[a] + 1:off[a + 1]]
+        v.setDestinations(rows[:, 0], rows[:, 1], rows[:, 2])
+        vs.append(v)
+    for a in g["rep_hook"]:
+        vs[int(a)].rep_force_func = strong_field
+    ins = SocialForceIntersection(vs)
+    for a in g["dest_hook"]:
+        vs[int(a)].dest_force_func = constant_pull           # (assigned after the vehicle joined: the intersection is told)
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    for k in range(1, S.shape[0]):
+        for _ in range(10):
+            ins.step()
+        got = np.array([v.s for v in vs])
+        np.testing.assert_allclose(got[:, :2], S[k][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"sample {k}")
+        np.testing.assert_allclose(np.array([v.force for v in vs]), F[k - 1], rtol=0, atol=2e-3 * max(np.abs(F[k - 1]).max(), 1.0))
+    assert [v.destpointer for v in vs] == list(g["ptr"]) and all(len(v.F) == 150 for v in vs)
+    # the same population without hooks takes the engine's own tick and lands elsewhere (the hooks did act)
+    assert np.abs(S[-1][:, :2] - S[0][:, :2]).max() > 1.0

@@ -222,10 +222,14 @@ def test_parameter_sets_of_an_intersection():
     many = [TwoDBicycle((k, 30, 0, 5, 0), id=f"m{k}", params=P.InvPendulumBicycleParameters(f_0=1.0 + 0.01 * k)) for k in range(257)]
     with pytest.raises(NotImplementedError, match="256"):
         ins._param_classes(many)
+    # a vehicle with a custom force hook may join (vehicle.py:194-204): the intersection then forms its forces on the host
     hooked = TwoDBicycle((0, 15, 0, 5, 0), id="h2", dest_force_func=lambda v: (0.0, 0.0))
-    with pytest.raises(NotImplementedError, match="dest_force_func"):
-        ins.add_road_user(hooked)
-    assert hooked.calcDestinationForce.__self__ is hooked and hooked._owner is None
+    assert not ins._hooked
+    ins.add_road_user(hooked)
+    assert ins._hooked and hooked._owner is ins
+    late = SocialForceIntersection((TwoDBicycle((0, 0, 0, 5, 0), id="l"),))
+    late.vehicles[0].rep_force_func = lambda v, x, y, psi: (0.0 * x, 0.0 * y)     # (assigned after joining: the intersection is told)
+    assert late._hooked
 
 
 def test_shard_bounds_cover_the_population():
