@@ -187,6 +187,7 @@ class SocialForceIntersection:
         self._have_force = False
         self._hooked = False      # some vehicle carries a custom rep_force_func / dest_force_func: forces are formed on the host (_hooked_forces)
         self._field_engines = {}  # ... engines for the class fields of the others, by parameter set
+        self._stoch, self._stoch_for, self._stoch_epoch = [], -1, 0   # riders with stochastic_control_behavior (cache)
         self._ti = None           # vehicle.i [capacity]
         self._traj = None         # vehicle.traj, stored [traj_len, rows, n_states] (a tick writes one contiguous slab);
                                   # vehicle.traj are transposed views [n_states, traj_len]
@@ -280,6 +281,7 @@ class SocialForceIntersection:
             raise TypeError("road users must be cyclistsocialforce_amd.vehicle.Vehicle objects")
         if v._owner is not None and v._owner is not self:
             raise RuntimeError(f"vehicle {v.id} already belongs to another intersection")
+        self._stoch_for = -1
         if v.dest_force_func is not None or v.rep_force_func is not None:
             self._hooked = True                                        # (this population's forces are formed on the host: _hooked_forces)
         if v._solo is not None:
@@ -377,6 +379,7 @@ class SocialForceIntersection:
 
     def _remove(self, idx):
         idx = sorted(set(idx))
+        self._stoch_for = -1
         for k in idx:
             if not 0 <= k < len(self.vehicles):
                 raise IndexError(f"no road user {k}")
@@ -747,6 +750,31 @@ class SocialForceIntersection:
         self._log_forces(fx, fy)
         return fx, fy
 
+    # ------------------------------------------------------------------ riders whose poles are drawn anew as their speed changes
+    def _stochastic_riders(self):
+        """the BalancingRiderBicycles with `stochastic_control_behavior=True` (parameters.py:1380-1396); cached until the population changes"""
+        if self._stoch_for != len(self.vehicles) + self._stoch_epoch:
+            self._stoch = [v for v in self.vehicles if getattr(v.params, "stochastic_control_behavior", False)]
+            self._stoch_for = len(self.vehicles) + self._stoch_epoch
+        return self._stoch
+
+    def _resample_poles(self, riders, fx, fy):
+        """BalancingRiderDynamics.step up to its gains (dynamics.py:617-647, 677-682), on the host, for the riders whose poles are
+        drawn: the speed step (P controller, clamped acceleration, clamped speed - what the device is about to do with the same
+        force), and where the speed changes `params.update_control_params((v_new + v) / 2)`, which draws new poles once the speed
+        has moved 0.8333 m/s since the last draw.  In vehicle order: the draws come off one generator.  The tick is split for
+        this - forces, draws, then the integration with the forces (csf_calc_forces / csf_apply_forces) - so that a rider steps
+        with the poles the reference would have given it in THAT tick."""
+        n = len(self.vehicles)
+        v_now = self._S[:n, 3]
+        for r in riders:
+            i, p = r._index, r.params
+            vd = np.sqrt(fx[i] ** 2 + fy[i] ** 2)
+            a = min(max(p.k_p_v * (vd - v_now[i]), p.a_max[0]), p.a_max[1])
+            v_new = min(max(v_now[i] + p.t_s * a, p.v_max_riding[0]), p.v_max_riding[1])
+            if v_new != v_now[i]:
+                p.update_control_params((v_new + v_now[i]) / 2)
+
     # ------------------------------------------------------------------ custom per-vehicle force hooks (vehicle.py:194-204, 250-299)
     def _field_engine(self, v):
         """an engine of the vehicle's class and parameter set, for its field alone (csf_pair_force: vehicle.py:1560-1648 /
@@ -807,9 +835,16 @@ class SocialForceIntersection:
                 if v.drawing is None:
                     v.add_drawing(self.ax, animated=True, **self.bicycle_drawing_kwargs)
         self.is_first_step = False
-        if self.n_bikes > 0 and self._hooked:
+        stochastic = self.n_bikes > 0 and self._stochastic_riders()
+        if self.n_bikes > 0 and (self._hooked or stochastic):
             e = self._push_mutations()
-            fx, fy = self._hooked_forces(e)                        # intersection.py:889
+            if self._hooked:
+                fx, fy = self._hooked_forces(e)                    # intersection.py:889
+            else:
+                fx, fy = e.calc_forces()
+            if stochastic:
+                self._resample_poles(stochastic, fx, fy)
+                e = self._push_mutations()                         # (a new draw is a new parameter set of its rider)
             e.apply_forces(fx, fy)                                 # :891-892: every vehicle.step(Fx[i], Fy[i])
             self._pull(forces=True, advance=1)                     # :894
         elif self.n_bikes > 0:
@@ -820,7 +855,7 @@ class SocialForceIntersection:
     def step_n(self, n_ticks, pull=True):
         """n_ticks ticks with no per-tick host work (the benchmark path).  `traj` receives only the final
         state; enable the engine's device-side history for dense trajectories."""
-        if self._hooked and self.n_bikes > 0:                     # (custom force hooks: the forces of every tick are formed on the host)
+        if self.n_bikes > 0 and (self._hooked or self._stochastic_riders()):   # (custom force hooks, drawn poles: every tick passes the host)
             for _ in range(int(n_ticks)):
                 self.step()
             return

@@ -381,11 +381,18 @@ class BalancingRiderBicycleParameters(BicycleParameters):
         self.controlparam_polemodel_component = controlparam_polemodel_component
         self.polefuns = None
         if poles is None and gains is None:                            # :1309-1316
-            if stochastic_control_behavior:
-                raise NotImplementedError("stochastic_control_behavior: poles sampled anew from the mixture as the speed changes "
-                                          "(parameters.py:1391-1396) - the engine takes the component mean over speed")
             self.controlparam_fix = False
-            if controlparam_filename in polemodel.MEAN_FUNCTIONS:
+            self.polesampler = None
+            if stochastic_control_behavior:
+                # parameters.py:1391-1396: the poles are SAMPLED from the pole model's mixture, conditioned on the speed, whenever
+                # the speed has moved by controlparam_resampling_speedthresh since the last draw.  The draws are the host's
+                # (polemodel.PoleSampler, on NumPy's global generator like the reference); the device holds the drawn poles as
+                # constants until the next draw (to_pod).
+                self.polesampler = polemodel.PoleSampler(controlparam_filename)
+                self.poles = None
+                self.gains = None
+                self.v_last_update = -10000
+            elif controlparam_filename in polemodel.MEAN_FUNCTIONS:
                 self.polefuns = polemodel.MEAN_FUNCTIONS[controlparam_filename]
             else:                                                      # a model file of the caller's: its path
                 import os
@@ -394,7 +401,7 @@ class BalancingRiderBicycleParameters(BicycleParameters):
                     raise FileNotFoundError(f"Couldn't find Balancing Rider Control Behavior model {controlparam_filename}. "
                                             f"Available models are: {sorted(polemodel.MEAN_FUNCTIONS)} (or the path of a model file)")
                 self.polefuns = polemodel.component_mean_functions(controlparam_filename)
-            if controlparam_polemodel_component >= self.polefuns.shape[0]:
+            if not stochastic_control_behavior and controlparam_polemodel_component >= self.polefuns.shape[0]:
                 raise ValueError(f"Balancing Rider Control Behavior model {controlparam_filename} has only {self.polefuns.shape[0]} "
                                  f"components but controlparam_polemodel_component is set to {controlparam_polemodel_component}!")
             self.v_last_update = -10000
@@ -425,6 +432,11 @@ class BalancingRiderBicycleParameters(BicycleParameters):
         if not self.controlparam_fix:
             from . import polemodel
 
+            if self.stochastic_control_behavior:                       # :1391-1396
+                if np.abs(v - self.v_last_update) > self.controlparam_resampling_speedthresh:
+                    self.poles = self.polesampler.sample(float(v))
+                    self.v_last_update = v
+                return
             self.poles = polemodel.poles_at(self.polefuns[self.controlparam_polemodel_component], v)
             self.v_last_update = v
 
@@ -453,6 +465,11 @@ class BalancingRiderBicycleParameters(BicycleParameters):
                 raise ValueError("BalancingRider gains: five (k_phi, k_delta, k_phidot, k_deltadot, k_psi)")
             p.br_gains = (_ffi.C.c_double * 5)(*g)
             p.br_mode = 2
+        elif self.stochastic_control_behavior:                         # the poles of the last draw, until the next one
+            if self.poles is None:
+                raise ValueError("stochastic_control_behavior: no poles drawn yet (BalancingRiderBicycle.__init__ draws the first, dynamics.py:306)")
+            pl = np.asarray(self.poles, dtype=complex).flatten()
+            fun[:, 0] = [pl[0].real, pl[1].real, abs(pl[1].imag), pl[3].real, abs(pl[3].imag)]
         else:
             fun = np.asarray(self.polefuns[self.controlparam_polemodel_component], dtype=float)
         p.br_pole_fun = (_ffi.C.c_double * 10)(*fun.ravel())

@@ -100,6 +100,102 @@ def component_mean_functions(model, speeds=None):
     return out
 
 
+class PoleSampler:
+    """`PoleModel.sample_poles(n_samples=1, X_given=v)` of the reference (controlbehavior.py:1414-1469 -> :1337-1412 -> :536-570 ->
+    :478-533 -> sklearn's GaussianMixture.sample): ONE draw of the five poles from the model's mixture conditioned on the speed.
+
+    The chain, statement for statement: the speed through the preprocessing pipeline (Yeo-Johnson, scaler; the log-shift leaves
+    the speed column alone); every component conditioned on it (mean, covariance, weight x its marginal density at the speed, the
+    weights normalised); sklearn's sample(1): `multinomial(1, weights)` picks the component, `multivariate_normal(mean, cov, k)`
+    draws from it - both on `rng`; back through the pipeline (scaler, Yeo-Johnson inverse, log-shift inverse); a draw that the
+    inverse transform cannot represent is drawn again; (p0_real, p1_real, p1_imag, p2_real, p2_imag) -> [p0, p1, conj p1, p2, conj p2].
+
+    rng: the reference's mixtures carry random_state=None, i.e. they draw from NumPy's GLOBAL generator; `rng=None` does the same
+    (np.random.multinomial / multivariate_normal), so `np.random.seed(s)` in front of the same sequence of calls gives the
+    reference's numbers (tests/test_host_api.py, against tests/golden/balancingrider_stochastic.npz).  Any object with those two
+    methods (numpy.random.RandomState, numpy.random.Generator) may be passed for a stream of one's own.
+
+    One deviation: a draw with a pole in the right half plane is drawn again here; the reference means to (ensure_stable) but its
+    loop assigns a tuple into the pole array and raises (controlbehavior.py:1462-1463)."""
+
+    def __init__(self, model):
+        from . import polemodel_data
+
+        if isinstance(model, (str, os.PathLike)) and os.path.basename(str(model)) in polemodel_data.MIXTURES and not os.path.exists(str(model)):
+            model = polemodel_data.MIXTURES[os.path.basename(str(model))]
+        elif isinstance(model, (str, os.PathLike)):
+            import yaml
+
+            with open(model) as fh:
+                y = yaml.safe_load(fh)
+            gm, pp = y["gmm_data"], y["preprocessing_pipeline"]
+            lt = pp.get("log_transform_params", {}) if pp.get("log_transform") else {}
+            model = {"features": list(y["presets"]["features"]), "means": gm["means"], "covariances": gm["covariances"], "weights": gm["weights"],
+                     "lambdas": pp["power_transform_params"]["lambdas"], "scaler_mean": pp["standard_scaler_params"]["mean"],
+                     "scaler_scale": pp["standard_scaler_params"]["scale"], "log_features": [int(i) for i in lt.get("log_transform_features", [])],
+                     "log_a": np.array(lt.get("a", [])).reshape(-1).tolist(), "log_sign": np.array(lt.get("sign", [])).reshape(-1).tolist()}
+        if list(model["features"]) != list(FEATURES):
+            raise NotImplementedError("only the Balancing Rider feature set ImRe5GivenV (speed + one real pole + two complex pairs)")
+        self.mu = np.array(model["means"], dtype=float)
+        self.cov = np.array(model["covariances"], dtype=float)
+        self.pi = np.array(model["weights"], dtype=float).ravel()
+        self.lam = np.array(model["lambdas"], dtype=float)
+        self.mean = np.array(model["scaler_mean"], dtype=float)
+        self.scale = np.array(model["scaler_scale"], dtype=float)
+        self.logf = [int(i) for i in model["log_features"]]
+        self.log_a = np.array(model["log_a"], dtype=float)
+        self.log_sign = np.array(model["log_sign"], dtype=float)
+
+    def conditional(self, v):
+        """(weights, means [K, 5], covariances [K, 5, 5]) of the mixture conditioned on the speed (controlbehavior.py:478-533)"""
+        vt = (_yeo_johnson(np.array([float(v)]), self.lam[0])[0] - self.mean[0]) / self.scale[0]
+        K = self.mu.shape[0]
+        w, mc, cc = np.zeros(K), np.zeros((K, 5)), np.zeros((K, 5, 5))
+        for k in range(K):
+            var = self.cov[k, 0, 0]
+            c = self.cov[k, 1:, 0]
+            mc[k] = self.mu[k, 1:] + c / var * (vt - self.mu[k, 0])
+            cc[k] = self.cov[k, 1:, 1:] - np.outer(c, c) / var
+            w[k] = self.pi[k] * np.exp(-0.5 * (vt - self.mu[k, 0]) ** 2 / var) / np.sqrt(2 * np.pi * var)
+        w = w / w.sum()
+        if np.any(w == 0.0):                                           # (:525-528)
+            w[w == 0.0] = np.finfo(float).eps * K
+            w = w / w.sum()
+        return w, mc, cc
+
+    def _back(self, x):
+        """a drawn feature vector back through the pipeline (controlbehavior.py:961-985)"""
+        raw = np.empty(5)
+        with np.errstate(all="ignore"):
+            for f in range(5):
+                raw[f] = _yeo_johnson_inverse(np.array([x[f] * self.scale[f + 1] + self.mean[f + 1]]), self.lam[f + 1])[0]
+            for j, f in enumerate(self.logf):
+                raw[f - 1] = (np.exp(raw[f - 1]) + self.log_a[j]) * self.log_sign[j]
+        return raw
+
+    def sample(self, v, rng=None):
+        rng = np.random if rng is None else rng
+        w, mc, cc = self.conditional(v)
+
+        def draw():                                                    # sklearn.mixture.GaussianMixture.sample(1), covariance_type "full"
+            counts = rng.multinomial(1, w)
+            x = np.vstack([rng.multivariate_normal(mc[k], cc[k], int(counts[k])) for k in range(len(w))])
+            return x[0]
+
+        for _ in range(1000):
+            raw = self._back(draw())
+            for _ in range(101):                                       # (:1377-1394: outside the inverse transform's range: draw again)
+                if np.all(np.isfinite(raw)):
+                    break
+                raw = self._back(draw())
+            else:
+                raise RuntimeError("Sampling error!")
+            poles = [complex(raw[0]), complex(raw[1], raw[2]), complex(raw[1], -raw[2]), complex(raw[3], raw[4]), complex(raw[3], -raw[4])]
+            if all(p.real <= 0 for p in poles):                        # ensure_stable (see the class docstring)
+                return np.array(poles)
+        raise TimeoutError("Couldn't find stable poles after 1000 draws!")
+
+
 def poles_at(fun, v):
     """the five poles at speed v from one component's lines (parameters.py:1400-1409): p0 real, two conjugate pairs"""
     f = fun[:, 0] + fun[:, 1] * float(v)

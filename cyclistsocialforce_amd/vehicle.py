@@ -506,3 +506,7 @@ class BalancingRiderBicycle(Vehicle):
 
     def __init__(self, s0, **kwargs):
         Vehicle.__init__(self, s0, **kwargs)
+        # dynamics.py:306: the rider's first gains are placed at the start speed - with stochastic_control_behavior that is the first
+        # draw from the pole model (in the order the vehicles are made, on NumPy's global generator: parameters.py:1391-1396)
+        if getattr(self.params, "stochastic_control_behavior", False):
+            self.params.update_control_params(float(self._s[3]))

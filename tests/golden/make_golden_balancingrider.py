@@ -290,10 +290,91 @@ def main():
     print("wrote balancingrider.npz:", {k: np.shape(v) for k, v in out.items()})
 
 
+def main_stochastic():
+    """`stochastic_control_behavior=True` (parameters.py:1380-1396): a rider's poles are SAMPLED from its pole model's mixture,
+    conditioned on the speed, whenever the speed has moved 0.8333 m/s since the last draw (controlbehavior.py:1337-1469, 536-570,
+    478-533).  The draws come from NumPy's global generator (the mixtures carry random_state=None), so `np.random.seed` pins them.
+    Writes balancingrider_stochastic.npz and the mixtures' numbers the host restatement samples from
+    (cyclistsocialforce_amd/polemodel_data.py: data of the reference's model files, MIT, see THIRD_PARTY_NOTICES.md)."""
+    import yaml
+
+    rp, rd, rv, ri, mg = _install()
+    out, tables = {}, {}
+    for fname in ("BR0_ImRe5GivenV_pole-model-params.yaml", "BR1_ImRe5GivenV_pole-model-params.yaml"):
+        tag = fname[:3]
+        with open(os.path.join(REF_SRC, "cyclistsocialforce", "data", "balancingriderparams", fname)) as fh:
+            m = yaml.safe_load(fh)
+        gm, pp = m["gmm_data"], m["preprocessing_pipeline"]
+        tables[fname] = {"features": list(m["presets"]["features"]), "means": gm["means"], "covariances": gm["covariances"], "weights": gm["weights"],
+                         "lambdas": pp["power_transform_params"]["lambdas"], "scaler_mean": pp["standard_scaler_params"]["mean"],
+                         "scaler_scale": pp["standard_scaler_params"]["scale"],
+                         "log_features": [int(i) for i in pp["log_transform_params"]["log_transform_features"]] if pp.get("log_transform") else [],
+                         "log_a": np.array(pp["log_transform_params"]["a"]).reshape(-1).tolist() if pp.get("log_transform") else [],
+                         "log_sign": np.array(pp["log_transform_params"]["sign"]).reshape(-1).tolist() if pp.get("log_transform") else []}
+        p = rp.BalancingRiderBicycleParameters(controlparam_filename=fname, stochastic_control_behavior=True)
+        rng = np.random.default_rng(3)
+        vs = rng.uniform(1.2, 6.5, 60)
+        np.random.seed(1234)
+        poles = []
+        for v in vs:
+            pl, _ = p.polemodel.sample_poles(n_samples=1, X_given=float(v))
+            poles.append(pl.flatten())
+        out[f"draws_{tag}_v"] = vs
+        out[f"draws_{tag}_poles"] = np.array(poles)
+    # a population: five riders, each with its OWN parameter object (the draws interleave in vehicle order), 400 ticks
+    def population(n, box, seed, fname):
+        rng = np.random.default_rng(seed)
+        vs = []
+        for k in range(n):
+            x, y, psi, v = rng.uniform(0, box), rng.uniform(0, box), rng.uniform(-np.pi, np.pi), rng.uniform(2.0, 5.5)
+            prm = rp.BalancingRiderBicycleParameters(controlparam_filename=fname, stochastic_control_behavior=True)
+            prm.v_desired_default = float(rng.uniform(2.5, 6.0))
+            b = rv.BalancingRiderBicycle((x, y, psi, v, 0.0, 0.0, 0.0, 0.0), id=f"s{k}", params=prm)
+            d = np.array([15.0, 40.0, 80.0])
+            b.setDestinations(x + d * np.cos(psi), y + d * np.sin(psi))
+            vs.append(b)
+        return vs
+
+    for tag, fname, n, box, seed in (("pop1", "BR1_ImRe5GivenV_pole-model-params.yaml", 5, 16.0, 8), ("pop0", "BR0_ImRe5GivenV_pole-model-params.yaml", 3, 12.0, 9)):
+        np.random.seed(77)
+        vs = population(n, box, seed, fname)
+        for v in vs:
+            v.drawing = mg._NoDrawing()
+        out[f"{tag}_s0"] = np.array([v.s for v in vs])
+        out[f"{tag}_vdes"] = np.array([v.params.v_desired_default for v in vs])
+        out[f"{tag}_off"] = np.cumsum([0] + [v.destqueue.shape[0] for v in vs])
+        out[f"{tag}_dq"] = np.vstack([v.destqueue for v in vs])
+        out[f"{tag}_poles0"] = np.array([np.asarray(v.params.poles, dtype=complex).flatten() for v in vs])     # drawn by the constructors
+        ins = ri.SocialForceIntersection(vs)
+        ticks = 400
+        S = np.zeros((ticks // 10 + 1, n, 8)); S[0] = np.array([v.s for v in vs])
+        P = np.zeros((ticks, n, 5), dtype=complex)
+        for tk in range(ticks):
+            ins.step()
+            P[tk] = np.array([np.asarray(v.params.poles, dtype=complex).flatten() for v in vs])
+            if (tk + 1) % 10 == 0:
+                S[(tk + 1) // 10] = np.array([v.s for v in vs])
+        out[f"{tag}_S"], out[f"{tag}_poles"] = S, P
+        print(tag, "resamplings per rider:", [(int((np.abs(np.diff(P[:, k, 0])) > 0).sum())) for k in range(n)])
+    np.savez(os.path.join(HERE, "balancingrider_stochastic.npz"), **out)
+    with open(os.path.join(HERE, "..", "..", "cyclistsocialforce_amd", "polemodel_data.py"), "w") as fh:
+        fh.write('"""The Gaussian mixtures of the reference\'s Balancing Rider pole models (data/balancingriderparams/*.yaml: means, covariances and weights\n'
+                 'in the space behind the preprocessing pipeline, and the pipeline\'s parameters) - DATA of chris-konrad/cyclistsocialforce (MIT licence,\n'
+                 'Copyright 2025 Christoph M. Konrad: THIRD_PARTY_NOTICES.md), written by tests/golden/make_golden_balancingrider.py stochastic.\n'
+                 'polemodel.py samples from them (stochastic_control_behavior=True)."""\n\nMIXTURES = ')
+        import pprint
+        fh.write(pprint.pformat(tables, width=150, compact=True))
+        fh.write("\n")
+    print("wrote balancingrider_stochastic.npz:", {k: np.shape(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     # (the reference's PoleModel makes an output directory "pole-modeling" under the working directory when it is loaded,
     # controlbehavior.py:1079-1082: let that happen in a scratch directory, not in the repository)
     import tempfile
 
     os.chdir(tempfile.mkdtemp(prefix="csf_golden_"))
-    main()
+    if sys.argv[1:] == ["stochastic"]:
+        main_stochastic()
+    else:
+        main()

@@ -2,6 +2,8 @@
 Whipple-Carvallo bicycle under full-state feedback whose gains follow the rider's speed, stepped with the implicit midpoint
 rule - against the literal reference (tests/golden/balancingrider.npz, make_golden_balancingrider.py) and against the oracle,
 alone, in crowds, mixed with the other vehicle classes, and through the host mirror's classes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -306,3 +308,43 @@ def test_riders_between_road_edges_against_the_reference(amd, golden, path):
         np.testing.assert_allclose(got[:, 2:], S[k][:, 2:], rtol=0, atol=2e-3, err_msg=f"sample {k}")
     assert (e.status() == 0).all() and (e.small_ticks() == 300) == (path == "one wave")
     e.close()
+
+
+@pytest.mark.auto_variant
+@pytest.mark.parametrize("tag,fname", [("pop1", "BR1_ImRe5GivenV_pole-model-params.yaml"), ("pop0", "BR0_ImRe5GivenV_pole-model-params.yaml")])
+def test_riders_whose_poles_are_drawn_anew_against_the_reference(tag, fname):
+    """`stochastic_control_behavior=True` (parameters.py:1380-1396): every rider draws its poles from its pole model's mixture when
+    it is made and again whenever its speed has moved 0.8333 m/s - from NumPy's global generator, so that np.random.seed(77) in front of
+    the same construction gives the mirror the reference's draws, tick for tick (the tick is split: forces, draws on the host, then
+    the integration - cyclistsocialforce_amd/intersection.py: _resample_poles).  400 ticks of the literal reference
+    (tests/golden/make_golden_balancingrider.py stochastic): the poles of every rider after every tick, the trajectory."""
+    from cyclistsocialforce_amd import parameters as P
+    from cyclistsocialforce_amd.intersection import SocialForceIntersection
+    from cyclistsocialforce_amd.vehicle import BalancingRiderBicycle
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "balancingrider_stochastic.npz"))
+    s0, vdes, off, dq, S, Pl = (g[f"{tag}_{k}"] for k in ("s0", "vdes", "off", "dq", "S", "poles"))
+    np.random.seed(77)
+    vs = []
+    for a in range(s0.shape[0]):
+        prm = P.BalancingRiderBicycleParameters(controlparam_filename=fname, stochastic_control_behavior=True)
+        prm.v_desired_default = float(vdes[a])
+        b = BalancingRiderBicycle(tuple(s0[a]), id=f"s{a}", params=prm)
+        rows = dq[off[a] + 1:off[a + 1]]
+        b.setDestinations(rows[:, 0], rows[:, 1], rows[:, 2])
+        vs.append(b)
+    np.testing.assert_allclose(np.array([v.params.poles for v in vs]), g[f"{tag}_poles0"], rtol=1e-10, atol=1e-11)   # the constructors' draws
+    ins = SocialForceIntersection(vs)
+    extent = max(np.ptp(S[..., 0]), np.ptp(S[..., 1]), 1.0)
+    draws = 0
+    for tk in range(Pl.shape[0]):
+        before = [np.array(v.params.poles) for v in vs]
+        ins.step()
+        now = np.array([v.params.poles for v in vs])
+        draws += sum(not np.array_equal(x, y) for x, y in zip(before, now))
+        np.testing.assert_allclose(now, Pl[tk], rtol=1e-6, atol=1e-7, err_msg=f"poles after tick {tk + 1}")   # (a draw is conditioned on the speed, which carries the fp32 pair sums: 4e-9)
+        if (tk + 1) % 10 == 0:
+            got = np.array([v.s for v in vs])
+            np.testing.assert_allclose(got[:, :2], S[(tk + 1) // 10][:, :2], rtol=0, atol=1e-4 * extent, err_msg=f"tick {tk + 1}")
+            np.testing.assert_allclose(got[:, 3], S[(tk + 1) // 10][:, 3], rtol=0, atol=2e-3)
+    assert draws >= 3, draws          # (the reference drew anew 5 / 3 times in these runs: the test would be empty without)

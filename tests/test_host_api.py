@@ -443,5 +443,50 @@ def test_balancingrider_parameters_follow_the_reference(golden):
     assert list(fixed.br_pole_fun) == [-8.0, 0.0, -1.0, 0.0, 2.0, 0.0, -2.0, 0.0, 6.0, 0.0] and fixed.br_mode == 0
     gained = parameters.BalancingRiderBicycleParameters(gains=(-10.0, 2.0, -7.0, -0.1, -7.0)).to_pod(6)
     assert gained.br_mode == 2 and list(gained.br_gains) == [-10.0, 2.0, -7.0, -0.1, -7.0]
-    with pytest.raises(NotImplementedError):
-        parameters.BalancingRiderBicycleParameters(stochastic_control_behavior=True)
+    assert parameters.BalancingRiderBicycleParameters(stochastic_control_behavior=True).polesampler is not None   # (round 6: built)
+
+
+def test_pole_sampler_draws_what_the_reference_draws():
+    """stochastic_control_behavior (parameters.py:1380-1396): polemodel.PoleSampler against 60 consecutive
+    `PoleModel.sample_poles(1, X_given=v)` of the literal reference per model file, both on NumPy's global generator behind
+    np.random.seed(1234) (tests/golden/make_golden_balancingrider.py stochastic)."""
+    from cyclistsocialforce_amd import polemodel
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "balancingrider_stochastic.npz"))
+    for tag, fname in (("BR0", "BR0_ImRe5GivenV_pole-model-params.yaml"), ("BR1", "BR1_ImRe5GivenV_pole-model-params.yaml")):
+        smp = polemodel.PoleSampler(fname)
+        np.random.seed(1234)
+        got = np.array([smp.sample(v) for v in g[f"draws_{tag}_v"]])
+        ref = g[f"draws_{tag}_poles"]
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12)
+        assert (got.real <= 0).all() and np.allclose(got[:, 1], np.conj(got[:, 2])) and np.allclose(got[:, 3], np.conj(got[:, 4]))
+        # a stream of one's own: a RandomState gives the same numbers as the global generator it mirrors, a Generator others
+        a = np.array([smp.sample(3.0, rng=np.random.RandomState(5)) for _ in range(2)])
+        np.random.seed(5)
+        b = smp.sample(3.0)
+        assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], b)
+        assert not np.array_equal(smp.sample(3.0, rng=np.random.default_rng(5)), b)
+
+
+def test_stochastic_rider_parameters():
+    """parameters.py:1380-1396: the first draw at construction, a new one only once the speed has moved 0.8333 m/s since the last;
+    the POD carries the drawn poles as constants"""
+    from cyclistsocialforce_amd import parameters as P
+    from cyclistsocialforce_amd.vehicle import BalancingRiderBicycle
+
+    np.random.seed(3)
+    prm = P.BalancingRiderBicycleParameters(stochastic_control_behavior=True)
+    assert prm.poles is None
+    with pytest.raises(ValueError, match="no poles drawn"):
+        prm.to_pod(6)
+    b = BalancingRiderBicycle((0, 0, 0, 4.0, 0, 0, 0, 0), params=prm)
+    first = np.array(prm.poles)
+    assert first.shape == (5,) and prm.v_last_update == 4.0 and b.params is prm
+    prm.update_control_params(4.5)
+    assert np.array_equal(prm.poles, first) and prm.v_last_update == 4.0            # within the threshold: the poles stay
+    prm.update_control_params(4.9)
+    assert not np.array_equal(prm.poles, first) and prm.v_last_update == 4.9
+    pod = prm.to_pod(6)
+    fun = np.array(pod.br_pole_fun).reshape(5, 2)
+    pl = np.asarray(prm.poles)
+    assert pod.br_mode == 0 and (fun[:, 1] == 0).all() and np.allclose(fun[:, 0], [pl[0].real, pl[1].real, abs(pl[1].imag), pl[3].real, abs(pl[3].imag)])
