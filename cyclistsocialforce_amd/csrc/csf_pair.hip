@@ -1082,7 +1082,10 @@ void launch_road(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
     if (d.hi <= d.lo || d.nv == 0) return;
     if (d.rg_nx > 0) {     // a large, static network: near field summed, far field interpolated (csf_road.hip)
         Dev dd = d;        // receivers in binned order where this device bins and integrates every slot
-        dd.rg_by_place = d.recs_valid && !d.seg_keys && d.rlist == nullptr && d.lo == 0 && d.hi == d.n;
+        dd.rg_by_place = (d.recs_valid && !d.seg_keys && d.rlist == nullptr && d.lo == 0 && d.hi == d.n) ? 1 : 0;
+        // (a rank's block: its receivers sorted by place - round 6: in slot order a rank's road term took 2.8 x its share, the
+        // neighbours of a wave no longer sharing their cells' vertices in cache)
+        if (!dd.rg_by_place && d.recs_valid && !d.seg_keys && d.rlist != nullptr && d.recv_binned) dd.rg_by_place = 2;
         launch_road_grid(dd, st, t0, t1);
         return;
     }

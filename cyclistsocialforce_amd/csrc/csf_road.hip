@@ -135,7 +135,9 @@ template <int NP>
 __global__ __launch_bounds__(BLOCK) void road_grid_kernel(const Dev d) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t jend = d.rg_by_place ? d.n_pad : d.hi;
+    // rg_by_place: 0 the block's slots in turn; 1 every place of the binned order (whole population); 2 the places of THIS rank's
+    // receivers in ascending order (Dev::rlist: a shard whose receivers are taken in binned order) - neighbours in a wave either way
+    const int64_t jend = d.rg_by_place == 1 ? d.n_pad : d.rg_by_place == 2 ? d.hi - d.lo : d.hi;
     const int64_t j0 = (d.rg_by_place ? 0 : d.lo) + ((int64_t)blockIdx.x * WPB + wave) * RPW;
     if (j0 >= jend) return;
     const float w = d.rg_w, hw = 0.5f * w, iw = 1.0f / w;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(BLOCK) void road_grid_kernel(const Dev d) {
 #pragma unroll
     for (int u = 0; u < RPW; u++) {
         const int64_t j = j0 + u < jend ? j0 + u : jend - 1;
-        const int32_t a = d.rg_by_place ? d.perm[j] : (int32_t)j;
+        const int32_t a = d.rg_by_place == 1 ? d.perm[j] : d.rg_by_place == 2 ? d.perm[d.rlist[j]] : (int32_t)j;
         const float4 q = d.rec[a];
         const float2 o = d.rorg[a];
         const bool ok = j0 + u < jend && rec_is_real(q) && a >= d.lo && a < d.hi;
@@ -250,7 +252,7 @@ static void far_launch(const Dev &d, const short2 *vcell, double *samples, hipSt
 }
 template <int NP>
 static void grid_launch(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
-    const int64_t m = d.rg_by_place ? d.n_pad : d.hi - d.lo;
+    const int64_t m = d.rg_by_place == 1 ? d.n_pad : d.hi - d.lo;
     hipExtLaunchKernelGGL(road_grid_kernel<NP>, dim3((unsigned)((m + WPB * RPW - 1) / (WPB * RPW))), dim3(BLOCK), 0, st, t0, t1, 0, d);
 }
 

@@ -49,7 +49,7 @@ if solo >= 0:                                              # one engine only (tw
         e.step(ticks, sync=True)
         print(json.dumps({"CSF_CHASE": solo, "solo": True, "round": r, "tick_us": (time.perf_counter() - t0) / ticks * 1e6, "side_by_side_ticks": e.chase_ticks()}), flush=True)
     sys.exit(0)
-a, b = make(0), make(1)
+a, b = make(0), make(2)
 for k in range(0, check, 50):
     a.step(min(50, check - k), sync=True)
     b.step(min(50, check - k), sync=True)
