@@ -28,7 +28,7 @@ SYMBOLS = (
     "csf_count_pairs", "csf_comm_init_loopback", "csf_step_group", "csf_untracked", "csf_update_destination",
     "csf_update_nav_state", "csf_set_dest_pointer", "csf_set_incremental", "csf_set_script", "csf_near_dropped", "csf_comm_stream_order", "csf_small_ticks", "csf_step_get_tick",
     "csf_get_integrator_state", "csf_set_integrator_state", "csf_mid_ticks", "csf_holes_taken",
-    "csf_create_v", "csf_params_size", "csf_profile_samples_of", "csf_chase_ticks", "csf_chase_calibration",
+    "csf_create_v", "csf_params_size", "csf_profile_samples_of", "csf_chase_ticks", "csf_chase_calibration", "csf_replace_agents",
 )
 ABI_VERSION = 9
 
@@ -89,6 +89,7 @@ def load():
     L.csf_abi_version.restype = i32
     L.csf_add_agents.argtypes = [vp, i64, dp, dp]
     L.csf_remove_agents.argtypes = [vp, i64, vp]
+    L.csf_replace_agents.argtypes = [vp, i64, vp, i64, dp, dp, vp, dp]
     L.csf_set_dest_queue.argtypes = [vp, i64, vp, vp, dp, i32]
     L.csf_set_road_vertices.argtypes = [vp, i32, vp, dp, dp, dp]
     L.csf_set_params.argtypes = [vp, C.POINTER(Params)]

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -354,6 +355,9 @@ struct csf_engine {
     DevBuf<unsigned> chase_cnt, chase_misc;
     DevBuf<unsigned long long> chase_clock;   // CSF_CHASE_CLOCK=<file>: stamps of the last 64 side-by-side ticks, written at csf_destroy
     bool dirty_layout_for_warm() const { return dirty || !segs.empty() || classes.size() != 1; }   // (the warm pair launch of chase_alloc takes the plain single-set launch)
+    // CSF_TIME_POP=1 (measurement aid): nanoseconds inside the population calls, by part, printed at csf_destroy
+    bool time_pop = false;
+    int64_t tp_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_calls = 0;
     std::vector<int32_t> remove_sorted;   // csf_remove_agents: the listed indices sorted, when the caller's are not
     bool chase_prev = false, chase_resume = false;   // resume: the counters and halves are those of the last side-by-side tick (mid_synced says nothing else wrote records since)
     uint32_t chase_round = 0;
@@ -2200,6 +2204,7 @@ csf_engine *csf_create(const csf_params *params, int64_t n_capacity, int32_t dev
     // every SoA array - fresh slots are handed out up to n_pad (csf_add_agents)
     e->cap = (e->cap + 63) / 64 * 64;
     e->knobs.read();
+    e->time_pop = getenv("CSF_TIME_POP") != nullptr;
     e->d.p = *params;
     derive_consts(e);
     auto bail = [&](const char *what) {
@@ -2244,6 +2249,10 @@ int csf_destroy(csf_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->main) (void)hipStreamSynchronize(e->main);
     if (e->comm) (void)hipStreamSynchronize(e->comm);
+    if (e->time_pop && e->tp_calls > 0)
+        fprintf(stderr, "CSF_TIME_POP per call (us): remove: loop %.1f (of it holes_add %.1f) compaction %.1f | add: slots %.1f (of it holes_take %.1f) fill %.1f | queues %.1f  [%lld calls]\n",
+                e->tp_ns[0] / 1e3 / e->tp_calls, e->tp_ns[1] / 1e3 / e->tp_calls, e->tp_ns[2] / 1e3 / e->tp_calls, e->tp_ns[3] / 1e3 / e->tp_calls,
+                e->tp_ns[4] / 1e3 / e->tp_calls, e->tp_ns[5] / 1e3 / e->tp_calls, e->tp_ns[6] / 1e3 / e->tp_calls, (long long)e->tp_calls);
     if (e->chase_clock.p) {
         std::vector<unsigned long long> h(128 * 8);
         if (hipMemcpy(h.data(), e->chase_clock.p, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -2344,9 +2353,20 @@ static void side_state(csf_engine *e, size_t a, const csf_params &p) {
     e->h_ppsi[a] = s[2 * cap];                                   // dynamics.py:828, 987-993
 }
 
-int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired) {
+// q_off / q_rows: NULL (every new road user gets the one-row queue of vehicle.py:183-185) or the destination queues the arrivals
+// START with, CSR - what csf_add_agents followed by csf_set_dest_queue(reset = 1) on the new road users leaves, in one pass
+// over them (csf_replace_agents)
+static int add_agents_impl(csf_engine *e, int64_t n, const double *s0, const double *v_desired, const int64_t *q_off, const double *q_rows) {
     if (!e) return CSF_E_ARG;
     if (n < 0 || (n > 0 && (!s0 || !v_desired))) return fail(e, CSF_E_ARG, "csf_add_agents: bad arguments");
+    int64_t q_total = 0;
+    if (q_off != nullptr) {
+        if (!q_rows) return fail(e, CSF_E_ARG, "csf_replace_agents: queue offsets without rows");
+        for (int64_t k = 0; k < n; k++) {
+            if (q_off[k + 1] <= q_off[k]) return fail(e, CSF_E_ARG, "csf_replace_agents: an arrival's destination queue must have a row");
+        }
+        q_total = n > 0 ? q_off[n] - q_off[0] : 0;
+    }
     if ((int64_t)e->order.size() + n > e->cap_user) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap_user);
     if (n == 0) return CSF_OK;
     HIPCHK(e, hipSetDevice(e->device));
@@ -2355,8 +2375,8 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     // collected for the device when its copy is current, the new slots have a place in the binned order (slot < n_pad)
     // and the start rows fit behind the queues already in the slab
     bool patch = can_patch_device(e) && d.n + (n - reuse) <= d.n_pad;
-    if (patch && e->q_top + (int64_t)(e->pend.rows.size() / 3) + n > d.qcap) {
-        int rc = compact_slab(e, n);
+    if (patch && e->q_top + (int64_t)(e->pend.rows.size() / 3) + std::max(n, q_total) > d.qcap) {
+        int rc = compact_slab(e, std::max(n, q_total));
         if (rc) return rc;
     }
     if (!patch) {
@@ -2370,12 +2390,21 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
     // loop that fills them - the loop's time was cache misses, 55 us per tick with 819 arrivals), then the road users
     std::vector<int32_t> &slot_of = e->add_slots;
     slot_of.resize((size_t)n);
+    const auto ta0 = std::chrono::steady_clock::now();
+    int64_t ta_holes = 0;
     for (int64_t k = 0; k < n; k++) {
         int64_t a;
         bool tail = true;
         int32_t hole = -1;
-        if (patch && e->tail_tracked && e->knobs.hole_reuse && !e->free_recent.empty() && holes_ready(e))
-            hole = holes_take(e, s0[k * ns], s0[k * ns + 1]);      // the slot of a road user that left from around here
+        if (patch && e->tail_tracked && e->knobs.hole_reuse && !e->free_recent.empty() && holes_ready(e)) {
+            if (e->time_pop) {
+                const auto h0 = std::chrono::steady_clock::now();
+                hole = holes_take(e, s0[k * ns], s0[k * ns + 1]);
+                ta_holes += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count();
+            } else {
+                hole = holes_take(e, s0[k * ns], s0[k * ns + 1]);      // the slot of a road user that left from around here
+            }
+        }
         if (hole >= 0) {
             a = hole;
             tail = false;
@@ -2404,11 +2433,15 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         __builtin_prefetch(&e->h_cls[(size_t)a], 1);
         __builtin_prefetch(&e->sidx[(size_t)a], 1);
     }
+    const auto ta1 = std::chrono::steady_clock::now();
     for (int64_t k = 0; k < n; k++) {
         const int64_t a = slot_of[(size_t)k];
         const double *s = s0 + k * ns;
         e->h_vdes[a] = v_desired[k];
-        e->h_q[a].assign({s[0], s[1], 0.0});                     // vehicle.py:183-185
+        const double *qr = q_off ? q_rows + 3 * q_off[k] : nullptr;         // its queue: given, or the start row (vehicle.py:183-185)
+        const int32_t qn = q_off ? (int32_t)(q_off[k + 1] - q_off[k]) : 1;
+        if (qr) e->h_q[a].assign(qr, qr + 3 * (size_t)qn);
+        else e->h_q[a].assign({s[0], s[1], 0.0});
         e->h_alive[a] = 1;
         e->h_cls[a] = 0;
         e->order.push_back((int32_t)a);
@@ -2423,14 +2456,15 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
             drop_pending_requeue(e, (size_t)a);                  // (defensive: a retirement has dropped it already)
             SpawnRec r;
             r.slot = (int32_t)a;
-            r.qlen = 1;
+            r.qlen = qn;
             r.qbeg = (int64_t)(e->pend.rows.size() / 3);
             for (int c = 0; c < STATE_ROWS; c++) r.s[c] = c < ns ? s[c] : 0.0;
             e->coord_bound0 = std::max({e->coord_bound0, std::fabs(s[0] - d.ox), std::fabs(s[1] - d.oy)});   // (set_fov_band)
             r.vdes = v_desired[k];
             r.cls = 0;
             r.pad = 0;
-            e->pend.rows.insert(e->pend.rows.end(), {s[0], s[1], 0.0});
+            if (qr) e->pend.rows.insert(e->pend.rows.end(), qr, qr + 3 * (size_t)qn);
+            else e->pend.rows.insert(e->pend.rows.end(), {s[0], s[1], 0.0});
             e->sidx[(size_t)a].spawn = (int32_t)e->pend.spawn.size();
             e->pend.spawn.push_back(r);
             continue;
@@ -2446,6 +2480,11 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         side_state(e, (size_t)a, p);
         for (int c = 0; c < 6; c++) e->h_F[c * cap + a] = 0.0;
         e->h_status[a] = 0;
+    }
+    if (e->time_pop) {
+        e->tp_ns[3] += std::chrono::duration_cast<std::chrono::nanoseconds>(ta1 - ta0).count();
+        e->tp_ns[4] += ta_holes;
+        e->tp_ns[5] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ta1).count();
     }
     d.n_live = (int64_t)e->order.size();
     e->order_dirty = true;
@@ -2466,6 +2505,20 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
         }
     }
     return CSF_OK;
+}
+
+int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_desired) { return add_agents_impl(e, n, s0, v_desired, nullptr, nullptr); }
+
+int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
+
+int csf_replace_agents(csf_engine *e, int64_t n_leave, const int32_t *idx_leave, int64_t n_arrive, const double *s0, const double *v_desired,
+                       const int64_t *q_offsets, const double *q_rows) {
+    if (!e) return CSF_E_ARG;
+    if (n_leave < 0 || n_arrive < 0 || (n_arrive > 0 && (!q_offsets || !q_rows))) return fail(e, CSF_E_ARG, "csf_replace_agents: bad arguments");
+    if ((int64_t)e->order.size() - n_leave + n_arrive > e->cap_user) return fail(e, CSF_E_CAPACITY, "capacity %lld exceeded", (long long)e->cap_user);
+    int rc = n_leave > 0 ? csf_remove_agents(e, n_leave, idx_leave) : CSF_OK;
+    if (rc) return rc;
+    return n_arrive > 0 ? add_agents_impl(e, n_arrive, s0, v_desired, q_offsets, q_rows) : CSF_OK;
 }
 
 int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
@@ -2496,6 +2549,8 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         int rc = prepare_mutation(e);
         if (rc) return rc;
     }
+    const auto tp0 = std::chrono::steady_clock::now();
+    int64_t tp_holes = 0;
     for (int64_t k = 0; k < n; k++) {
         const int32_t a = e->order[(size_t)lst[k]];
         e->h_alive[(size_t)a] = 0;
@@ -2505,7 +2560,15 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         e->sidx[(size_t)a].recent = (int32_t)e->free_recent.size();
         e->free_recent.push_back(a);
         if (!patch) continue;
-        if (e->tail_tracked && e->knobs.hole_reuse) holes_add(e, a);
+        if (e->tail_tracked && e->knobs.hole_reuse) {
+            if (e->time_pop) {
+                const auto h0 = std::chrono::steady_clock::now();
+                holes_add(e, a);
+                tp_holes += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count();
+            } else {
+                holes_add(e, a);
+            }
+        }
         drop_pending_requeue(e, (size_t)a);                      // a queue collected for the road user that leaves
         if (e->sidx[(size_t)a].spawn >= 0) {                  // added and removed within one batch: never reaches the device
             const int32_t at = e->sidx[(size_t)a].spawn;
@@ -2519,6 +2582,7 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
         e->sidx[(size_t)a].retire = (int32_t)e->pend.retire.size();
         e->pend.retire.push_back(a);
     }
+    const auto tp1 = std::chrono::steady_clock::now();
     {   // the remaining road users keep their relative order: the blocks between two leavers move down
         int32_t *o = e->order.data();
         int64_t w = lst[0];
@@ -2528,6 +2592,12 @@ int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx) {
             w += to - from;
         }
         e->order.resize((size_t)w);
+    }
+    if (e->time_pop) {
+        e->tp_ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(tp1 - tp0).count();
+        e->tp_ns[1] += tp_holes;
+        e->tp_ns[2] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tp1).count();
+        e->tp_calls++;
     }
     e->d.n_live = (int64_t)e->order.size();
     e->order_dirty = true;

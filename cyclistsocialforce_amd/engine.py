@@ -75,6 +75,23 @@ class Engine:
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         self._ck(self._lib.csf_remove_agents(self._h, idx.size, _ptr(idx)))
 
+    def replace_agents(self, leave, s0, v_desired, offsets, xyz_stop):
+        """One traffic step (include/csf.h: csf_replace_agents): road users `leave` (indices) go, the rows of s0 join behind the rest
+        with destination queues (offsets [n + 1], xyz_stop [sum, 3]).  Arrays that are already contiguous and of the right type
+        are passed as they are."""
+        leave = np.ascontiguousarray(leave, dtype=np.int32)
+        s0 = np.asarray(s0, dtype=np.float64).reshape(-1, max(np.shape(s0)[-1] if np.ndim(s0) == 2 else self.ns, 1))
+        if s0.size and s0.shape[1] < self.ns:
+            raise ValueError(f"s0 must be [n, >={self.ns}]")
+        s0 = _f64(s0[:, : self.ns])
+        n = s0.shape[0]
+        vd = _f64(np.broadcast_to(np.asarray(v_desired, dtype=np.float64), (n,)))
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        rows = _f64(xyz_stop)
+        if off.size != n + 1 or rows.size != 3 * (int(off[-1]) if n else 0):
+            raise ValueError("offsets [n + 1] and xyz_stop [offsets[-1], 3] must describe one queue per arrival")
+        self._ck(self._lib.csf_replace_agents(self._h, leave.size, _ptr(leave), n, _ptr(s0), _ptr(vd), _ptr(off), _ptr(rows)))
+
     def set_dest_queue(self, agents, offsets, xyz_stop, reset=False):
         agents = np.ascontiguousarray(agents, dtype=np.int32)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

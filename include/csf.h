@@ -110,6 +110,14 @@ int csf_add_agents(csf_engine *e, int64_t n, const double *s0, const double *v_d
  * population, any order; the remaining agents keep their relative order. */
 int csf_remove_agents(csf_engine *e, int64_t n, const int32_t *idx);
 
+/* One traffic step in one call (ABI 9): the listed road users leave (as csf_remove_agents), n_arrive new ones join behind the remaining
+ * ones (as csf_add_agents) and START with the given destination queues (CSR, at least one row each: what csf_set_dest_queue with
+ * reset = 1 on the new road users would leave) - what SUMO co-simulation does every step (scenario.py:376-466: find_entered_exited,
+ * remove_road_users_by_id, add_road_user + its route).  The same population and order as the three calls; one pass over the arrivals
+ * instead of two, no start-row queue that is replaced at once. */
+int csf_replace_agents(csf_engine *e, int64_t n_leave, const int32_t *idx_leave, int64_t n_arrive, const double *s0, const double *v_desired,
+                       const int64_t *q_offsets, const double *q_rows);
+
 /* How csf_add_agents / csf_remove_agents / csf_set_dest_queue reach the device once ticks have run (the per-tick arrivals
  * and departures of SUMO co-simulation, intersection.py:429-453, 458-634; scenario.py:376-466).  on != 0 (default): the
  * calls only record what to do, and the next device call applies the batch with one small launch - a removed road user

@@ -1376,3 +1376,57 @@ def test_config5_1048576_planarpoint_with_road_5_ticks(amd):
         assert err < 1e-4 and rerr < 1e-4, (k, err, rerr)
     assert (e.status() == 0).all() and np.isfinite(st).all()
     e.close()
+
+
+@pytest.mark.parametrize("incremental", [True, False])
+def test_one_traffic_step_in_one_call(amd, incremental):
+    """csf_replace_agents (leave + arrive + the arrivals' destination queues in one call; scenario.py:376-466 does the three every SUMO step)
+    against csf_remove_agents + csf_add_agents + csf_set_dest_queue(reset = 1): the same population in the same order with the same states,
+    to the last bit, over rounds of departures (listed in any order, with repeats) and arrivals - on the device-side path and through the
+    host mirror."""
+    rng = np.random.default_rng(5)
+    n0, cap, box = 5000, 8192, 150.0
+
+    def people(n):
+        s = np.zeros((n, 5))
+        s[:, 0] = rng.uniform(0, box, n); s[:, 1] = rng.uniform(0, box, n); s[:, 2] = rng.uniform(-np.pi, np.pi, n); s[:, 3] = rng.uniform(3, 5.5, n)
+        k = rng.integers(2, 6, n)                                      # queues of 2 ... 5 rows
+        off = np.r_[0, np.cumsum(k)]
+        rows = np.zeros((off[-1], 3))
+        for a in range(n):
+            d = np.cumsum(rng.uniform(15, 45, k[a]))
+            rows[off[a]:off[a + 1], 0] = s[a, 0] + d * np.cos(s[a, 2]); rows[off[a]:off[a + 1], 1] = s[a, 1] + d * np.sin(s[a, 2])
+        return s, off, rows
+
+    s0, off0, rows0 = people(n0)
+    engines = []
+    for _ in range(2):
+        e = amd.Engine(amd.pod("twod"), cap)
+        e.set_incremental(incremental)
+        e.add_agents(s0, 4.5)
+        e.set_dest_queue(np.arange(n0), off0, rows0, reset=True)
+        engines.append(e)
+    a, b = engines
+    for rnd in range(8):
+        for e in engines:
+            e.step(3)
+        n = a.n
+        leave = rng.choice(n, int(rng.integers(20, 200)), replace=True).astype(np.int32)      # any order, with repeats
+        m = int(rng.integers(0, 200)) if rnd != 3 else 0                                       # (one round without arrivals)
+        s, off, rows = people(max(m, 1))
+        s, off, rows = s[:m], off[: m + 1], rows[: off[m]]
+        vd = rng.uniform(3.5, 5.5, m)
+        a.remove_agents(np.unique(leave))
+        if m:
+            a.add_agents(s, vd)
+            a.set_dest_queue(np.arange(a.n - m, a.n), off, rows, reset=True)
+        b.replace_agents(leave, s, vd, off, rows)
+        assert a.n == b.n
+        for e in engines:
+            e.step(2)
+        sa, pa, za, _ = a.state(with_nav=True); sb, pb, zb, _ = b.state(with_nav=True)
+        assert np.array_equal(sa, sb) and np.array_equal(pa, pb) and np.array_equal(za, zb), rnd
+    assert (a.status() == 0).all() and (b.status() == 0).all()
+    with pytest.raises(Exception, match="must have a row"):
+        b.replace_agents([], s0[:2], 4.5, [0, 0, 2], rows0[:2])
+    a.close(); b.close()

@@ -29,7 +29,8 @@ new_s = [np.ascontiguousarray(pool[i]) for i in news]
 new_q = [np.ascontiguousarray(pdq[i].reshape(-1, 3)) for i in news]
 tail = np.arange(n - k, n, dtype=np.int32)
 qoff = np.arange(k + 1, dtype=np.int64) * 4
-for label, inc, churn in (("static", True, False), ("incremental", True, True), ("host_mirror", False, True)):
+vd5 = np.full(k, 5.0)
+for label, inc, churn in (("static", True, False), ("incremental", True, True), ("one_call", True, True), ("host_mirror", False, True)):
     t_run = ticks if label != "host_mirror" else max(20, ticks // 20)
     e = Engine(parameters.default_pod("twod"), n)
     e.set_incremental(inc)
@@ -41,9 +42,12 @@ for label, inc, churn in (("static", True, False), ("incremental", True, True), 
     for t in range(t_run):
         if churn and k:
             c0 = time.perf_counter()
-            e.remove_agents(kills[t])
-            e.add_agents(new_s[t], 5.0)
-            e.set_dest_queue(tail, qoff, new_q[t], reset=True)
+            if label == "one_call":                                    # csf_replace_agents: leave + arrive + queues in one call
+                e.replace_agents(kills[t], new_s[t], vd5, qoff, new_q[t])
+            else:
+                e.remove_agents(kills[t])
+                e.add_agents(new_s[t], 5.0)
+                e.set_dest_queue(tail, qoff, new_q[t], reset=True)
             calls += time.perf_counter() - c0
         e.step(1)
     e.sync()
@@ -53,4 +57,5 @@ for label, inc, churn in (("static", True, False), ("incremental", True, True), 
                   "healthy": healthy}
     e.close()
 out["incremental_over_static"] = out["incremental"]["us_per_tick"] / out["static"]["us_per_tick"]
+out["one_call_over_static"] = out["one_call"]["us_per_tick"] / out["static"]["us_per_tick"]
 print(json.dumps(out))
