@@ -1108,17 +1108,33 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     }
     stamp(2);
     if (CHASE) {
-        // The pair launch that forms this wave's sums is still running.  Every pair workgroup ends with: write-through stores of its
-        // partial sums, s_waitcnt, one agent-scope add to the counter of the 64 slots it serves; here one poll loop (an sc1 load,
-        // an s_sleep between polls), then sc1 loads of the sums, the status words and the hand-over entries.  A wait that does not
-        // end gives up after CHASE_SPIN_LIMIT polls and says so (csf_sync turns that into an error): the grid always drains.
-        const int64_t w = (a - d.lo) >> 6;                     // (wave-uniform: one wave = 64 consecutive slots)
-        const int64_t left = (d.hi - d.lo) - (w << 6);
-        const unsigned groups = (unsigned)((min((int64_t)64, left) + d.rpb - 1) / d.rpb);   // pair workgroups per source chunk that serve this wave
-        const unsigned want = d.chase_round * (unsigned)d.n_split * groups;
-        const unsigned *cnt = d.chase_cnt + w;
+        // The pair launch that forms this wave's sums is still running.  Every pair workgroup ends with ONE write-through store per
+        // receiver - its partial sum and the tick's tag in one 16-byte granule - and neither waits nor signals; here a poll loop over
+        // the lanes' own granules (agent-scope loads, an s_sleep between polls), then the status words and the hand-over entries.  A
+        // wait that does not end gives up after CHASE_SPIN_LIMIT polls and says so (csf_sync turns that into an error): the grid always drains.
+        // every lane polls the granules of ITS road user - (x, y, tag, 0), one per source chunk, each written by one store of the pair
+        // workgroup that formed it - until every lane of the wave has all of this tick's
+        const uint32_t tag = d.chase_tag;
+        const int nsp = d.n_split;
         unsigned spins = 0;
-        while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        for (;;) {
+            bool mine = true;
+            v4f_t g8[8];
+            ld_granules16_x8(&d.part4[a], cap, nsp < 8 ? nsp : 8, g8);
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                pp[c] = make_float2(g8[c].x, g8[c].y);
+                mine = mine && (c >= nsp || __float_as_uint(g8[c].z) == tag);
+            }
+            if (nsp > 8) {                                             // (more than eight source chunks: a second batch)
+                ld_granules16_x8(&d.part4[(int64_t)8 * cap + a], cap, nsp - 8, g8);
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    pp[8 + c] = make_float2(g8[c].x, g8[c].y);
+                    mine = mine && (8 + c >= nsp || __float_as_uint(g8[c].z) == tag);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(!mine) == 0ull) break;
             if (++spins > CHASE_SPIN_LIMIT) {
                 if ((threadIdx.x & 63) == 0) atomicAdd(&d.chase_misc[1], 1u);
                 break;
@@ -1130,18 +1146,6 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
         g.st |= ld_pub<true>(&d.status[a]) & CSF_ST_EDGE;      // (set by pair workgroups since the first load: an atomic OR)
         edge_pending = (g.st & CSF_ST_EDGE) != 0u;
         g.st &= ~CSF_ST_EDGE;
-#pragma unroll
-        for (int c = 0; c < PRE / 2; c++) {
-            const unsigned long long u = ld_pub<true>((const unsigned long long *)&d.part[(int64_t)min(c, d.n_split - 1) * cap + a]);
-            pp[c] = make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-        }
-        if (d.n_split > PRE / 2) {
-#pragma unroll
-            for (int c = PRE / 2; c < PRE; c++) {
-                const unsigned long long u = ld_pub<true>((const unsigned long long *)&d.part[(int64_t)min(c, d.n_split - 1) * cap + a]);
-                pp[c] = make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-            }
-        }
     }
     double Fx, Fy;
     if (phases & PH_COMBINE) {

@@ -245,6 +245,10 @@ struct Dev {
     // double buffers the one-launch tick already uses (+ recs_w), the fp64 positions of hand-overs come from the snapshot.
     float4 *recs_w;           // where write_record puts the binned copy: recs itself, or the other half
     unsigned *chase_cnt;      // [ceil(n_loc / 64)] arrivals per group of 64 slots since the counters were cleared; NULL: no chase
+    float4 *part4;            // [MAX_SPLIT][cap] the partial sums of such a launch as 16-byte granules (x, y, tag, 0), each written by ONE
+                              // write-through store: the per-agent wave polls the granules of its road users until every tag is this
+                              // tick's (chase_tag) - the producer neither waits for its stores nor signals (NULL: the counters above)
+    uint32_t chase_tag;       // ... this tick's tag: never 0, never repeated while old granules can still be read
     unsigned *chase_misc;     // [0] pair workgroups through since then (the gate's counter), [1] waits that gave up (an error)
     uint32_t chase_round;     // ticks since then, this one included: a group is complete at chase_round x (source chunks x pair groups of it)
     uint32_t chase_gate;      // the gate opens at this many pair workgroups through
@@ -386,6 +390,23 @@ template <bool PUB, class T>
 __device__ __forceinline__ T ld_pub(const T *p) {
     if (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
+}
+
+// 16-byte granules handed from a workgroup to a wave of another kernel within a launch (csf_dev.h: part4): ONE write-through store, ONE
+// agent-scope load - data and tag travel together, so no ordering between separate accesses is needed (MI355X_MICROARCH.md: granules)
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_granule16(float4 *p, float x, float y, float z, float w) {
+    const v4f_t v = {x, y, z, w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// eight of them asked for at once, one wait: the values are operands of the wait, so that nothing that uses them moves in front of it
+__device__ __forceinline__ void ld_granules16_x8(const float4 *p, int64_t stride, int n, v4f_t (&g)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float4 *q = p + (int64_t)(c < n ? c : n - 1) * stride;       // (clamped: the duplicates are not looked at)
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(g[c]) : "v"(q) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7])::"memory");
 }
 
 // utils.py:124-139

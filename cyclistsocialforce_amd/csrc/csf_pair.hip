@@ -643,23 +643,21 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         if (te < RPB) {
             const int64_t a = ragent[te];
             if (a >= 0) {
-                float2 *const dst = &d.part[(int64_t)(d.part_base + by) * d.cap + a];
-                if (chase != nullptr) {        // write-through: another XCD's per-agent wave reads it within this launch
-                    const unsigned long long u = (unsigned long long)__float_as_uint(racc[0][te]) | ((unsigned long long)__float_as_uint(racc[1][te]) << 32);
-                    __hip_atomic_store((unsigned long long *)dst, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (chase != nullptr) {
+                    // a per-agent wave of another XCD reads it within this launch: ONE 16-byte write-through store, the tick's tag
+                    // beside the sums - nobody waits for it here and nobody signals (a wave that waited for its stores before an
+                    // arrival counter kept its workgroup's slot ~1.5 us longer: + 2 us on the launch)
+                    const Dev &dc = cold_args();
+                    st_granule16(&dc.part4[(int64_t)(d.part_base + by) * d.cap + a], racc[0][te], racc[1][te], __uint_as_float(dc.chase_tag), 0.0f);
                 } else {
-                    *dst = make_float2(racc[0][te], racc[1][te]);
+                    d.part[(int64_t)(d.part_base + by) * d.cap + a] = make_float2(racc[0][te], racc[1][te]);
                 }
             }
         }
-        if (chase != nullptr && wave == 0) {   // (the sums are this wave's stores: RPB <= 64)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                const Dev &dc = cold_args();
-                atomicAdd(&dc.chase_cnt[((int64_t)blockIdx.x * RPB) >> 6], 1u);   // the 64 slots this workgroup's receivers lie in
-                atomicAdd(&dc.chase_misc[0], 1u);                                  // (the gate of the per-agent launch)
-                if (dc.chase_clock != nullptr) atomicMax(dc.chase_clock + 8 * dc.chase_slot + 1, (unsigned long long)wall_clock64());
-            }
+        if (chase != nullptr && wave == 0 && lane == 0) {
+            const Dev &dc = cold_args();
+            atomicAdd(&dc.chase_misc[0], 1u);                                      // (the gate of the per-agent launch: a count, no hand-off)
+            if (dc.chase_clock != nullptr) atomicMax(dc.chase_clock + 8 * dc.chase_slot + 1, (unsigned long long)wall_clock64());
         }
     } else {
         reduce_store(d, j0, lane, ax, ay, &ragent[wave * RPW]);
