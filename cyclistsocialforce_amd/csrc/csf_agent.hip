@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void agent_kernel(const Dev d, const int phase
     agent_body<MODEL, HET, false>(d, phases, a, tr, ka_lines, 0.0, 0.0);
 }
 
-// The per-agent tick BESIDE the pair launch that feeds it (csf_dev.h: chase_cnt; csf_engine.hip: enqueue_chase_tick): the same
+// The per-agent tick BESIDE the pair launch that feeds it (csf_dev.h: part4; engine/tick.inc: enqueue_chase_tick): the same
 // code with the sums waited for between the destination-force phase and the rest (agent_body<.., MID = 3>).
 template <int MODEL>
 // (`phases` is an argument, always all three: with a constant the compiler contracts the fp64 chains of some rider classes differently, and the
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void chase_gate_kernel(const unsigned *through,
 }
 
 __global__ void chase_sync_kernel(const Dev d, float4 *rec_o, float4 *recg_o, float4 *recs_o, float2 *rec2_o, double *cur, int64_t nrecg,
-                                  unsigned *cnt, int64_t ncnt, unsigned *through);
+                                  unsigned *through);
 
 // (a hardware queue gets its scratch memory when a kernel that needs some is first dispatched on it - the per-agent kernels spill ~200 bytes
 // per lane: this one asks for as much, on the stream that has not run them yet)
@@ -92,7 +92,7 @@ void preload_chase_kernels() {
 }
 
 bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t t1) {
-    if (d.hi <= d.lo || d.chase_cnt == nullptr || d.n_classes > 1) return false;
+    if (d.hi <= d.lo || d.part4 == nullptr || d.n_classes > 1) return false;
     const dim3 g((unsigned)((d.hi - d.lo + 63) / 64)), b(64);
     switch (d.p.model) {
     case CSF_TWOD: break;
@@ -386,10 +386,10 @@ void launch_records(const Dev &d, hipStream_t st) {
     hipLaunchKernelGGL(records_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);
 }
 
-// The other halves of the double buffers <- this tick's records and fp64 positions, and the arrival counters cleared: what six
+// The other halves of the double buffers <- this tick's records and fp64 positions, and the gate's counter cleared: what five
 // copy / fill calls did when the side-by-side tick was entered (once per re-binning: a launch and its gap each), in one launch.
 __global__ void chase_sync_kernel(const Dev d, float4 *rec_o, float4 *recg_o, float4 *recs_o, float2 *rec2_o, double *cur, int64_t nrecg,
-                                  unsigned *cnt, int64_t ncnt, unsigned *through) {
+                                  unsigned *through) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d.n_pad) {
         rec_o[i] = d.rec[i];
@@ -398,15 +398,14 @@ __global__ void chase_sync_kernel(const Dev d, float4 *rec_o, float4 *recg_o, fl
         if (d.has_bike) rec2_o[i] = d.rec2[i];
     }
     if (i < 3 * d.cap) cur[i] = d.s[i];
-    if (cnt != nullptr && i < ncnt) cnt[i] = 0u;
     if (through != nullptr && i == 0) *through = 0u;
 }
 
-void launch_chase_sync(const Dev &d, float4 *rec_o, float4 *recg_o, float4 *recs_o, float2 *rec2_o, double *cur, int64_t nrecg, unsigned *cnt,
-                       int64_t ncnt, unsigned *through, hipStream_t st) {
-    const int64_t n = std::max<int64_t>(std::max<int64_t>(d.n_pad, 3 * d.cap), ncnt);
+void launch_chase_sync(const Dev &d, float4 *rec_o, float4 *recg_o, float4 *recs_o, float2 *rec2_o, double *cur, int64_t nrecg, unsigned *through,
+                       hipStream_t st) {
+    const int64_t n = std::max<int64_t>(d.n_pad, 3 * d.cap);
     if (n <= 0) return;
-    hipLaunchKernelGGL(chase_sync_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, rec_o, recg_o, recs_o, rec2_o, cur, nrecg, cnt, ncnt, through);
+    hipLaunchKernelGGL(chase_sync_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, rec_o, recg_o, recs_o, rec2_o, cur, nrecg, through);
 }
 
 // ---- population changes on the device ---------------------------------------------------------------------------------

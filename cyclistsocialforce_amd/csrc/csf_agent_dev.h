@@ -1030,7 +1030,7 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
     // trip to memory that every other load of the kernel would wait behind
     if (d.n_live != d.n && !d.alive[a]) return;
     const int64_t cap = d.cap;
-    constexpr bool CHASE = MID == 3;                          // beside the pair launch (csf_dev.h: chase_cnt): the sums are waited for
+    constexpr bool CHASE = MID == 3;                          // beside the pair launch (csf_dev.h: part4): the sums are waited for
     constexpr bool IN = MID == 2 || CHASE, OUT = MID == 1, SUMS_GIVEN = FUSED || MID == 2;
     constexpr bool PLANNER = MODEL != CSF_BICYCLE && MODEL != CSF_UNCONTROLLED;   // (the models whose planner reads the ring)
     constexpr int PRE = 16;

@@ -239,18 +239,16 @@ struct Dev {
     // pair launch spends its last ~24 us with most CUs idle while the per-agent kernel (8 us + two launch gaps) waits behind it; a
     // group of 64 road users needs only ITS partial sums.  The per-agent kernel runs on the engine's second stream beside the
     // pair launch: a one-wave gate kernel in front of it holds it back until most pair workgroups are through, then every wave
-    // runs its destination-force phase at once, waits for the arrival counter of its 64 slots (bumped by one lane of every pair
-    // workgroup behind its write-through stores: MI355X_MICROARCH.md, hand-offs with sc1 stores / agent-scope atomic add / sc1
-    // load poll), reads the sums with agent-scope loads and carries on.  Next tick's records go to the other halves of the
+    // runs its destination-force phase at once, polls the tagged granules of its road users' partial sums (part4 below: written
+    // through by the pair workgroups, nobody waits, nobody signals - MI355X_MICROARCH.md: granules) and carries on.  Next tick's records go to the other halves of the
     // double buffers the one-launch tick already uses (+ recs_w), the fp64 positions of hand-overs come from the snapshot.
     float4 *recs_w;           // where write_record puts the binned copy: recs itself, or the other half
-    unsigned *chase_cnt;      // [ceil(n_loc / 64)] arrivals per group of 64 slots since the counters were cleared; NULL: no chase
-    float4 *part4;            // [MAX_SPLIT][cap] the partial sums of such a launch as 16-byte granules (x, y, tag, 0), each written by ONE
+    float4 *part4;            // [16][cap] the partial sums of such a launch as 16-byte granules (x, y, tag, 0), each written by ONE
                               // write-through store: the per-agent wave polls the granules of its road users until every tag is this
-                              // tick's (chase_tag) - the producer neither waits for its stores nor signals (NULL: the counters above)
+                              // tick's (chase_tag) - the producer neither waits for its stores nor signals.  NULL: an ordinary launch
     uint32_t chase_tag;       // ... this tick's tag: never 0, never repeated while old granules can still be read
-    unsigned *chase_misc;     // [0] pair workgroups through since then (the gate's counter), [1] waits that gave up (an error)
-    uint32_t chase_round;     // ticks since then, this one included: a group is complete at chase_round x (source chunks x pair groups of it)
+    unsigned *chase_misc;     // [0] pair workgroups through since it was cleared (the gate's counter), [1] waits that gave up (an error)
+    uint32_t chase_round;     // ticks since the through-counter was cleared, this one included
     uint32_t chase_gate;      // the gate opens at this many pair workgroups through
     uint32_t chase_slot;               // ... row of this tick in it
     unsigned long long *chase_clock;   // CSF_CHASE_CLOCK (tools/chase_clock.py): [128 ticks][8] wall_clock64 stamps - pair: first start, last end;
@@ -285,13 +283,13 @@ constexpr int RG_NODES = 8;     // Chebyshev nodes per direction
 void launch_road_far(const Dev &d, const short2 *vcell, double *samples, hipStream_t st);
 void launch_road_grid(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void launch_agent(const Dev &d, int phases, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
-// the whole per-agent tick beside the pair launch that feeds it (Dev::chase_cnt), behind its gate; false: not built for this class
+// the whole per-agent tick beside the pair launch that feeds it (Dev::part4), behind its gate; false: not built for this class
 bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void preload_chase_kernels();
 void launch_chase_scratch_warm(unsigned *out, hipStream_t st);
-// the other halves of the double buffers <- this tick's, the arrival counters (cnt, through: may be NULL) cleared: one launch
-void launch_chase_sync(const Dev &d, float4 *rec_o, float4 *recg_o, float4 *recs_o, float2 *rec2_o, double *cur, int64_t nrecg, unsigned *cnt,
-                       int64_t ncnt, unsigned *through, hipStream_t st);
+// the other halves of the double buffers <- this tick's, the gate's counter (through: may be NULL) cleared: one launch
+void launch_chase_sync(const Dev &d, float4 *rec_o, float4 *recg_o, float4 *recs_o, float2 *rec2_o, double *cur, int64_t nrecg, unsigned *through,
+                       hipStream_t st);
 constexpr unsigned CHASE_SPIN_LIMIT = 1u << 18;   // polls (each behind an s_sleep: ~0.3 s in all) before a wait gives up - every wave exits
 // csf_agent.hip: up to SMALL_MAX road users of one TwoD-field class, n_ticks whole ticks in one launch of one wave (the rounding
 // bands of the launch: csf_engine.hip set_fov_band)
@@ -495,7 +493,7 @@ __device__ __forceinline__ void batch_circle(const Dev &d, int64_t b, int lane, 
     }
     if (lane == 0) {
         const float4 c = box_circle(x0, x1, y0, y1, margin);
-        if (pub) {   // write-through (csf_dev.h: chase_cnt): the NEXT pair launch, on the other stream, may start before this launch's end-of-kernel write-back
+        if (pub) {   // write-through (csf_dev.h: part4): the NEXT pair launch, on the other stream, may start before this launch's end-of-kernel write-back
             unsigned long long *o = (unsigned long long *)&out[b];
             __hip_atomic_store(o, (unsigned long long)__float_as_uint(c.x) | ((unsigned long long)__float_as_uint(c.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(o + 1, (unsigned long long)__float_as_uint(c.z) | ((unsigned long long)__float_as_uint(c.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

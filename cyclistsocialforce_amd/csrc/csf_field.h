@@ -126,7 +126,7 @@ __device__ __forceinline__ void edge_handover(const Dev &d, int32_t a_recv, int3
     EdgeRec *const o = d.edge + at;          // (member by member: a local EdgeRec went through scratch memory)
     const int32_t fl = (int32_t)((seen ? EDGE_SEEN : 0) | (side ? EDGE_SIDE : 0) | (d.state_current ? 0 : EDGE_HEADING_REC));
     const int32_t nx = atomicExch(&d.edge_head[a_recv], (int)at + 1);
-    if (d.chase_cnt != nullptr) {            // read by a per-agent wave of another XCD within this launch: write-through stores
+    if (d.part4 != nullptr) {            // read by a per-agent wave of another XCD within this launch: write-through stores
 #define CSF_ST_PUB(member, value) __hip_atomic_store(&o->member, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
         CSF_ST_PUB(xi, xi); CSF_ST_PUB(yi, yi); CSF_ST_PUB(psi, psi); CSF_ST_PUB(hfov, hfov);
         CSF_ST_PUB(fx, fx); CSF_ST_PUB(fy, fy); CSF_ST_PUB(fx2, fx2); CSF_ST_PUB(fy2, fy2);

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
     // batch): a separate launch per tick would cost more in launch gaps than in work
     if (CLASSIFY && d.bnd_next != nullptr && by == 0) {
         for (int64_t b = (d.src_beg >> 6) + (int64_t)blockIdx.x * CW + wave; b * WAVE < d.n_src; b += (int64_t)gridDim.x * CW)
-            batch_circle(d, b, lane, d.bnd_margin, d.bnd_next, d.chase_cnt != nullptr);
+            batch_circle(d, b, lane, d.bnd_margin, d.bnd_next, d.part4 != nullptr);
     }
 
     float ax[RPW], ay[RPW];     // the receivers themselves stay in LDS (rrec); one at a time is held in registers
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(CW * WAVE, CSF_CULL_WAVES) void pair_cull_kernel(co
         }
     }
     if (DYN) {
-        const unsigned *const chase = cold_args().chase_cnt;   // (uniform; NULL but for the launches the per-agent kernel runs beside)
+        const float4 *const chase = cold_args().part4;   // (uniform; NULL but for the launches the per-agent kernel runs beside)
         if (chase != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over stores have landed (edge_handover)
         __syncthreads();
         const int te = (wave << 6) | lane;     // (threadIdx.x, not kept alive across the kernel)
