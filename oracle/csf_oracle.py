@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "libcsf_oracle.so")
+# CSF_ORACLE_LIB: another build of the same source (oracle/Makefile: `make asan` - AddressSanitizer + UBSan on the CPU)
+LIB = os.environ.get("CSF_ORACLE_LIB") or os.path.join(HERE, "libcsf_oracle.so")
 
 BICYCLE, TWOD, INVPEND, PLANARPOINT, PLANARBIKE, UNCONTROLLED, BALANCINGRIDER = 0, 1, 2, 3, 4, 5, 6
 MODEL_IDS = {"bicycle": BICYCLE, "twod": TWOD, "invpend": INVPEND, "planarpoint": PLANARPOINT, "planarbike": PLANARBIKE,
@@ -139,6 +140,8 @@ def default_params(model, priority_rule=0, **overrides):
 
 def build(force=False):
     src = os.path.join(HERE, "csf_oracle.c")
+    if os.environ.get("CSF_ORACLE_LIB"):
+        return LIB
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libcsf_oracle.so"])
     return LIB
