@@ -7,7 +7,7 @@ and must hold the same states bit for bit - a refused call has no side effect.  
 
 NOT in the table, because the ABI accepts them by design: csf_destroy(NULL) (as free(NULL)); read-backs whose output pointers are all
 NULL (each is optional); an index listed twice in csf_remove_agents (sorted and made unique); csf_comm_init(id = NULL) for a world of
-one; and numbers that are not numbers - a NaN position, speed, destination, force or road vertex is DATA: the reference takes it too,
+one; lengths beyond n_ticks in csf_replay_forces (the sequence ends with the call); and numbers that are not numbers - a NaN position, speed, destination, force or road vertex is DATA: the reference takes it too,
 and it comes back as CSF_ST_NAN in csf_status (tests/test_gpu_parity.py).  A NaN inside csf_params is refused."""
 import ctypes as C
 import json
@@ -97,7 +97,6 @@ calls = [
     ("csf_add_agents", (victim, -1, ptr(s1), ptr(f64(1)))), ("csf_add_agents", (victim, CAP, ptr(f64(CAP, NS)), ptr(f64(CAP)))),   # beyond the capacity
     ("csf_add_agents", (victim, 1, None, ptr(f64(1)))), ("csf_remove_agents", (victim, -3, ptr(good_idx))), ("csf_remove_agents", (victim, 1, None)),
     ("csf_step", (victim, -1)), ("csf_enable_history", (victim, 0, 16)), ("csf_enable_history", (victim, 1, -2)),
-    ("csf_get_history", (victim, 0, 4, ptr(f64(4, N, NS)))),                                           # no history enabled
     ("csf_profile_samples_of", (victim, 9, ptr(f64(8)), 8, C.byref(i64v))), ("csf_profile_samples_of", (victim, 0, None, 8, C.byref(i64v))),
     ("csf_profile_samples", (victim, ptr(f64(8)), -1, C.byref(i64v))),
     # indices out of range, twice the same, negative
@@ -146,6 +145,32 @@ L.csf_create_v.restype = C.c_void_p
 L.csf_create_v.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int64, C.c_int32]
 L.csf_create.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
 
+# ---- wrong in its context: the victim has a history ring of 8 samples (stride 2) from here on, the twin too -------------------
+for h in (victim, twin):
+    assert L.csf_enable_history(h, 2, 8) == 0 and L.csf_step(h, 6) == 0          # three samples recorded
+eng2 = make()                                   # a third engine, one road user short: for groups that are no groups
+assert L.csf_remove_agents(eng2, 1, ptr(i32a(N - 1))) == 0
+grp_same = (C.c_void_p * 2)(victim, victim)
+grp_null = (C.c_void_p * 2)(victim, None)
+grp_diff = (C.c_void_p * 2)(victim, eng2)       # (the members of a group hold the same population)
+calls += [
+    ("csf_get_history", (victim, -1, 2, ptr(f64(2, N, NS)))), ("csf_get_history", (victim, 0, 50, ptr(f64(50, N, NS)))),       # more than was recorded
+    ("csf_get_history", (victim, 2, 5, ptr(f64(5, N, NS)))), ("csf_get_history", (victim, 0, -1, ptr(f64(1, N, NS)))), ("csf_get_history", (victim, 0, 2, None)),
+    ("csf_enable_history", (victim, 2, 0)), ("csf_get_history", (eng2, 0, 1, ptr(f64(1, N, NS)))),                             # no history there
+    ("csf_comm_init_loopback", (grp_same, 2)), ("csf_comm_init_loopback", (grp_null, 2)), ("csf_comm_init_loopback", (grp_diff, 2)),
+    ("csf_comm_init_loopback", (grp_diff, 0)), ("csf_comm_init_loopback", (grp_diff, -2)),
+    ("csf_step_group", (grp_diff, 2, 1)),                                        # no group was formed
+    ("csf_replay_forces", (victim, 2, ptr(f64(2, N)), ptr(f64(2, N)), ptr(i32a(*([-1] * N))), 0, 1, None)),
+    ("csf_replay_forces", (victim, 2, ptr(f64(2, N)), ptr(f64(2, N)), None, 0, -1, ptr(f64(2, N, NS)))),   # a stride below zero with somewhere to write
+    ("csf_set_script", (victim, 1, ptr(good_idx), ptr(i64a(0, 2)), ptr(f64(2, 4)))),                      # not an UncontrolledVehicle
+    ("csf_replace_agents", (victim, 1, ptr(i32a(N)), 0, None, None, None, None)),
+    ("csf_replace_agents", (victim, 0, None, 1, ptr(s1), ptr(f64(1)), ptr(i64a(0, 0)), ptr(f64(1, 3)))),    # an arrival without a queue row
+    ("csf_replace_agents", (victim, 0, None, 1, ptr(s1), ptr(f64(1)), None, None)),
+    ("csf_replace_agents", (victim, 0, None, CAP, ptr(f64(CAP, NS)), ptr(f64(CAP)), ptr(i64a(*range(CAP + 1))), ptr(f64(CAP, 3)))),   # beyond the capacity
+    ("csf_replace_agents", (victim, 0, None, 2, ptr(f64(2, NS)), ptr(f64(2)), ptr(i64a(0, 2, 1)), ptr(f64(2, 3)))),
+    ("csf_replace_agents", (victim, -1, ptr(good_idx), 0, None, None, None, None)),
+]
+
 accepted, silent = [], []
 only = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else None     # (to find the call behind a crash: its number)
 for k, (name, args) in enumerate(calls):
@@ -167,13 +192,14 @@ for k, (name, args) in enumerate(calls):
         silent.append([k, name])
 
 # the engine that was called names still works, and holds what its twin holds
-for h in (victim, twin):
+for h in (victim, twin, eng2):
     assert L.csf_step(h, 7) == 0 and L.csf_sync(h) == 0, L.csf_last_error(h)
 sv, st = state(victim), state(twin)
 same = bool(all(np.array_equal(a, b) for a, b in zip(sv[:3], st[:3])) and sv[3] == st[3])
 flags = np.zeros(N, np.uint32)
 L.csf_status(victim, ptr(flags))
 print(json.dumps({"calls": len(calls), "accepted": accepted, "silent": silent, "same_as_twin": same, "finite": bool(np.isfinite(sv[0]).all()),
-                  "status_flags": int((flags != 0).sum()), "tick": sv[3], "agents": int(L.csf_num_agents(victim))}))
+                  "status_flags": int((flags != 0).sum()), "tick": sv[3], "eng2_tick": state(eng2)[3], "agents": int(L.csf_num_agents(victim))}))
 L.csf_destroy(victim)
 L.csf_destroy(twin)
+L.csf_destroy(eng2)
