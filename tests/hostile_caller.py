@@ -138,7 +138,8 @@ calls = [
     # creation: no parameters, a struct of another size, another ABI, no capacity, a device that is not there
     ("csf_create_v", (None, C.sizeof(pod), _ffi.ABI_VERSION, CAP, 0)), ("csf_create_v", (C.byref(pod), C.sizeof(pod) - 8, _ffi.ABI_VERSION, CAP, 0)),
     ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION - 1, CAP, 0)), ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION, 0, 0)),
-    ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION, -5, 0)), ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION, CAP, 4096)),
+    ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION, -5, 0)), ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION, 1 << 62, 0)),
+    ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION, (1 << 30) + 1, 0)), ("csf_create_v", (C.byref(pod), C.sizeof(pod), _ffi.ABI_VERSION, CAP, 4096)),
     ("csf_create_v", (C.byref(pod_model), C.sizeof(pod), _ffi.ABI_VERSION, CAP, 0)), ("csf_create", (None, CAP, 0)),
 ]
 L.csf_create_v.restype = C.c_void_p
