@@ -43,7 +43,9 @@ enum csf_status_code {
     CSF_E_CAPACITY = -3, /* more agents than the engine was created for */
     CSF_E_STATE = -4,    /* call not valid in the current engine state */
     CSF_E_COMM = -5,     /* RCCL error */
-    CSF_E_ABI = -6       /* the caller's csf_params (size) or ABI version is not this library's: csf_create_v */
+    CSF_E_ABI = -6,      /* the caller's csf_params (size) or ABI version is not this library's: csf_create_v */
+    CSF_E_HOST = -7      /* the host ran out of memory (or another C++ exception was caught at the boundary: none crosses it);
+                          * the engine is good for csf_last_error and csf_destroy only */
 };
 
 /* per-agent status bits reported by csf_status() (reference: exceptions / prints) */

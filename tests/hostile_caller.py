@@ -113,6 +113,7 @@ calls = [
     ("csf_set_dest_queue", (victim, 1, ptr(i32a(N)), ptr(i64a(0, 1)), ptr(f64(1, 3)), 1)),
     ("csf_set_dest_queue", (victim, 2, ptr(i32a(0, 1)), ptr(i64a(0, 2, 1)), ptr(f64(2, 3)), 1)),
     ("csf_set_dest_queue", (victim, 1, ptr(good_idx), ptr(i64a(0, 0)), ptr(f64(1, 3)), 1)),
+    ("csf_set_dest_queue", (victim, 1, ptr(good_idx), ptr(i64a(0, 1 << 60)), ptr(f64(1, 3)), 1)),     # more rows than a vector can hold: refused, or caught at the boundary
     ("csf_set_dest_queue", (victim, 1, ptr(good_idx), ptr(i64a(0, 1)), None, 1)), ("csf_set_dest_queue", (victim, 1, ptr(good_idx), None, ptr(f64(1, 3)), 1)),
     # road: offsets that run backwards, an edge of one vertex ... none, a NaN coordinate, a negative exponent base
     ("csf_set_road_vertices", (victim, 1, ptr(i64a(2, 0)), ptr(f64(2, 2)), ptr(np.full(1, .05)), ptr(np.full(1, 3.0)))),
