@@ -310,6 +310,20 @@ void launch_segment_perm(const Dev &d, const int32_t *sorted_slots, const SegTab
     if (m > 0) hipLaunchKernelGGL(segment_perm_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d, sorted_slots, tab);
 }
 
+// slot -> place and the circles of the batches, for the host (csf_engine.hip: holes_request): written by lanes, straight into mapped
+// host memory - no copy command in the stream
+__global__ void export_places_kernel(const int32_t *__restrict__ pos, const float4 *__restrict__ bnd, int32_t *__restrict__ hpos,
+                                     float4 *__restrict__ hbnd, int64_t np, int64_t nb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) hpos[i] = pos[i];
+    if (i < nb) hbnd[i] = bnd[i];
+}
+
+void launch_export_places(const Dev &d, int32_t *hpos, float4 *hbnd, int64_t np, int64_t nb, hipStream_t st) {
+    if (np <= 0) return;
+    hipLaunchKernelGGL(export_places_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, d.pos, d.bnd, hpos, hbnd, np, nb);
+}
+
 void launch_identity_perm(const Dev &d, hipStream_t st) {
     if (d.n_pad <= 0) return;
     hipLaunchKernelGGL(identity_perm_kernel, dim3((unsigned)((d.n_pad + 255) / 256)), dim3(256), 0, st, d);

@@ -317,6 +317,7 @@ void launch_segment_perm(const Dev &d, const int32_t *sorted_slots, const SegTab
 int launch_rebin(const Dev &d, uint32_t *keys, uint32_t *keys_out, int32_t *vals, void *tmp, size_t tmp_bytes,
                  hipStream_t st);
 void launch_identity_perm(const Dev &d, hipStream_t st);
+void launch_export_places(const Dev &d, int32_t *hpos, float4 *hbnd, int64_t np, int64_t nb, hipStream_t st);
 // pos[] and recs[] from perm[] and rec[]; from_exchange: the records of the other ranks' blocks are taken from the exchange
 // records that have just arrived (Dev::xbuf) and written to rec / reclo / rec2 on the way
 void launch_sorted_copy(const Dev &d, hipStream_t st, bool from_exchange = false);
