@@ -49,13 +49,14 @@ __global__ __launch_bounds__(256) void agent_chase_kernel(const Dev d, const int
 
 // One wave that holds the per-agent launch behind it (same stream) back until `want` pair workgroups are through: launched at once the
 // 256 per-agent waves would sit on their registers for the whole pair launch and cost it a workgroup per CU.
-__global__ __launch_bounds__(64) void chase_gate_kernel(const unsigned *through, unsigned want, unsigned *gave_up, unsigned long long *ck) {
+__global__ __launch_bounds__(64) void chase_gate_kernel(const unsigned *through, unsigned want, unsigned *gave_up, unsigned *gave_up_host, unsigned long long *ck) {
     if (threadIdx.x != 0) return;
     if (ck != nullptr) ck[2] = wall_clock64();
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(through, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
         if (++spins > CHASE_SPIN_LIMIT) {
             atomicAdd(gave_up, 1u);
+            if (gave_up_host != nullptr) __hip_atomic_store(gave_up_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         __builtin_amdgcn_s_sleep(32);
@@ -101,7 +102,7 @@ bool launch_agent_chase(const Dev &d, hipStream_t st, hipEvent_t t0, hipEvent_t 
     default: return false;
     }
     const int ph = PH_DEST | PH_COMBINE | PH_INTEGRATE;
-    hipLaunchKernelGGL(chase_gate_kernel, dim3(1), dim3(64), 0, st, d.chase_misc, d.chase_gate, d.chase_misc + 1,
+    hipLaunchKernelGGL(chase_gate_kernel, dim3(1), dim3(64), 0, st, d.chase_misc, d.chase_gate, d.chase_misc + 1, d.chase_err,
                        d.chase_clock ? d.chase_clock + 8 * d.chase_slot : nullptr);
     switch (d.p.model) {
     case CSF_TWOD: hipExtLaunchKernelGGL((agent_chase_kernel<CSF_TWOD>), g, b, 0, st, t0, t1, 0, d, ph); break;

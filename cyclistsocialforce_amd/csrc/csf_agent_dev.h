@@ -1136,7 +1136,10 @@ __device__ __forceinline__ void agent_body(const Dev &d, const int phases, const
             }
             if (__builtin_amdgcn_ballot_w64(!mine) == 0ull) break;
             if (++spins > CHASE_SPIN_LIMIT) {
-                if ((threadIdx.x & 63) == 0) atomicAdd(&d.chase_misc[1], 1u);
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&d.chase_misc[1], 1u);
+                    if (d.chase_err != nullptr) __hip_atomic_store(d.chase_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 break;
             }
             __builtin_amdgcn_s_sleep(16);

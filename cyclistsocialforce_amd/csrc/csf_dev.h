@@ -248,6 +248,7 @@ struct Dev {
                               // tick's (chase_tag) - the producer neither waits for its stores nor signals.  NULL: an ordinary launch
     uint32_t chase_tag;       // ... this tick's tag: never 0, never repeated while old granules can still be read
     unsigned *chase_misc;     // [0] pair workgroups through since it was cleared (the gate's counter), [1] waits that gave up (an error)
+    unsigned *chase_err;      // ... and the word of MAPPED HOST memory a wait that gives up sets to 1: csf_sync reads it without a copy
     uint32_t chase_round;     // ticks since the through-counter was cleared, this one included
     uint32_t chase_gate;      // the gate opens at this many pair workgroups through
     uint32_t chase_slot;               // ... row of this tick in it
