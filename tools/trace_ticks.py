@@ -2,7 +2,8 @@
 """What runs between two pair launches?  From a rocprofv3 kernel trace (*_kernel_trace.csv): the ticks (pair launch to pair launch) are
 grouped by their SEQUENCE of kernels; for the commonest sequences, per kernel the median start relative to the pair launch's start and
 the median duration, then the median gap to the next pair launch and the tick.  Copies the runtime enqueues (memcpy / fill kernels) show
-up as kernels too.      tools/trace_ticks.py TRACE.csv [pair-kernel-substring] [--from K] [--top 3]"""
+up as kernels too.      tools/trace_ticks.py TRACE.csv [pair-kernel-substring] [--from K] [--top 3] [--list N]
+--list N: the last N ticks one by one instead - the period and every kernel's start (relative to the pair launch's start) and duration."""
 import collections
 import csv
 import statistics
@@ -11,7 +12,8 @@ import sys
 args = sys.argv[1:]
 top = int(args[args.index("--top") + 1]) if "--top" in args else 3
 first = int(args[args.index("--from") + 1]) if "--from" in args else 0
-pos = [a for k, a in enumerate(args) if not a.startswith("--") and (k == 0 or args[k - 1] not in ("--top", "--from"))]
+listn = int(args[args.index("--list") + 1]) if "--list" in args else 0
+pos = [a for k, a in enumerate(args) if not a.startswith("--") and (k == 0 or args[k - 1] not in ("--top", "--from", "--list"))]
 key = pos[1] if len(pos) > 1 else "pair_cull_kernel"
 rows = []
 with open(pos[0], newline="") as fh:
@@ -28,6 +30,11 @@ def short(name):
     return name[:58]
 
 
+if listn:
+    for a, b in list(zip(starts[:-1], starts[1:]))[-listn:]:
+        t0 = rows[a][0]
+        print(f"{(rows[b][0] - t0) / 1e3:8.1f} us  " + "  ".join(f"{short(rows[k][2])[:24]}@{(rows[k][0] - t0) / 1e3:.1f}+{(rows[k][1] - rows[k][0]) / 1e3:.1f}[q{rows[k][3]}]" for k in range(a, b)))
+    sys.exit(0)
 ticks = collections.defaultdict(list)
 for a, b in zip(starts[:-1], starts[1:]):
     seq = tuple(short(rows[k][2]) for k in range(a, b))
