@@ -1,4 +1,4 @@
-"""Host time of the three population calls and of csf_step per tick at 5 % churn (N = 16 384), then the kernels' own times over 100 such ticks (GPU box)."""
+"""Host time of the three population calls and of csf_step per tick at 5 % churn (N = 16 384; another fraction as the first argument), then the kernels' own times over 100 such ticks (GPU box)."""
 import os, sys, time, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from bench import synthetic_population
 from cyclistsocialforce_amd import parameters
 from cyclistsocialforce_amd.engine import Engine
-n, box, ticks, frac = 16384, 200.0, 600, 0.05
+n, box, ticks, frac = 16384, 200.0, 600, float(sys.argv[1]) if len(sys.argv) > 1 else 0.05
 s0, off, dq = synthetic_population(n, box)
 pool, _, pdq = synthetic_population(8 * n, box, seed=1)
 pdq = pdq.reshape(-1, 4, 3)
